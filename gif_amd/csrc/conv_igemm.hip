@@ -1,0 +1,380 @@
+// fp32 MFMA implicit-GEMM "gather" convolution for gfx950 (NHWC).
+//
+// One kernel serves every dense contraction of the G/D step that maps input pixels to output pixels:
+//   * conv2d forward, stride 1/2           (F.conv2d in ModulatedConv2d / EqualConv2d / NoiseInjection,
+//                                           stylegan2_common_layers.py:345, :339, :176, :405-414)
+//   * conv_transpose2d == data gradient    (F.conv_transpose2d stylegan2_common_layers.py:330 and autograd's dgrad);
+//                                           stride 2 is run as 4 output-parity phases, each a DENSE gather over
+//                                           the taps of that parity, so no MFMA work is spent on inserted zeros.
+// GEMM view: M = B*Hp*Wp output pixels of the phase sub-grid, N = Cout, K = taps * Cin.
+//   A[m,k] = in_scale[b,ci] * x[b, oy'*is + dy_t, ox'*is + dx_t, ci]   (NHWC: ci contiguous => float4 loads)
+//   B[k,n] = wp[t][n][ci]                                              (packed, ci contiguous)
+// The reference's per-sample weights (groups=batch) are never materialised: modulation is the in_scale on A,
+// demodulation the out_scale in the epilogue (conv(x*s, W)*d, algebraically identical).
+//
+// Tiling: 256 threads = 4 waves; v_mfma_f32_32x32x2_f32 (exact fp32, 157 TF peak).  A and B tiles are staged
+// through LDS K-contiguous with a +4-float row pad (odd number of 16-B slots => conflict-free ds_read_b128),
+// double buffered, global loads for step s+1 are issued before the MFMAs of step s.
+// Lane (i = lane&31, h = lane>>5) feeds A[i][k] / B[k][i] with k = 8*kk + 4*h + t for MFMA t of group kk: the
+// same K permutation on both operands, so one ds_read_b128 per 32-row tile yields the operands of 4 MFMAs.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kMaxTaps = 9;
+
+struct GatherParams {
+    const float* x;
+    const float* wp;
+    float* y;
+    const float* in_scale;
+    const float* out_scale;
+    const float* bias;
+    const float* residual;
+    int B, Hi, Wi, Ci;  // input tensor
+    int Ho, Wo, Co;     // output tensor
+    int Hp, Wp;         // output sub-grid of this launch
+    int os, ooy, oox;   // output pixel = (oy'*os + ooy, ox'*os + oox)
+    int is;             // input  pixel = (oy'*is + dy[t], ox'*is + dx[t])
+    int ntaps;
+    int dy[kMaxTaps], dx[kMaxTaps], widx[kMaxTaps];
+    int RP, CP;  // packed weight rows (>= Co, multiple of BN) / cols (>= Ci, multiple of BK)
+    int act;
+    float slope, gain;
+    int M;  // B*Hp*Wp
+    int tiles_m, tiles_n;
+};
+
+// XCD-aware, bijective block remap (cdna guide T1): consecutive logical tiles share an XCD's L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int nx = 8;
+    int xcd = bid % nx, idx = bid / nx;
+    int q = nwg / nx, r = nwg % nx;
+    int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
+__global__ void __launch_bounds__(256) conv_gather_mfma(const GatherParams p) {
+    constexpr int THREADS = 256;
+    constexpr int LD = BK + 4;  // padded LDS row (floats)
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int MT = WM / 32, NT = WN / 32;
+    constexpr int F4_ROW = BK / 4;  // float4 per tile row
+    constexpr int A_F4 = BM * F4_ROW, B_F4 = BN * F4_ROW;
+    constexpr int A_IT = (A_F4 + THREADS - 1) / THREADS, B_IT = (B_F4 + THREADS - 1) / THREADS;
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+    static_assert(A_F4 % THREADS == 0 || A_F4 < THREADS, "A tile / thread mapping");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                 // [2][BM][LD]
+    float* Bs = smem + 2 * BM * LD;   // [2][BN][LD]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int HWp = p.Hp * p.Wp;
+
+    // ---- per-thread A rows (fixed over the K loop)
+    int a_iy0[A_IT], a_ix0[A_IT], a_b[A_IT];
+    bool a_ok[A_IT];
+    int a_row[A_IT], a_c4[A_IT];
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+        int q = tid + it * THREADS;
+        int row = q / F4_ROW, c4 = q % F4_ROW;
+        a_row[it] = row;
+        a_c4[it] = c4;
+        int m = m0 + row;
+        bool ok = (q < A_F4) && (m < p.M);
+        int mm = ok ? m : 0;
+        int b = mm / HWp;
+        int r = mm - b * HWp;
+        int oy = r / p.Wp, ox = r - oy * p.Wp;
+        a_b[it] = b;
+        a_iy0[it] = oy * p.is;
+        a_ix0[it] = ox * p.is;
+        a_ok[it] = ok;
+    }
+
+    float4 a_reg[A_IT], b_reg[B_IT];
+    const int ksteps_c = p.CP / BK;
+    const int nsteps = p.ntaps * ksteps_c;
+
+    auto load_global = [&](int step) {
+        const int t = step / ksteps_c;
+        const int kc = (step - t * ksteps_c) * BK;
+        const int dy = p.dy[t], dx = p.dx[t];
+        const float* wt = p.wp + ((size_t)p.widx[t] * p.RP + n0) * p.CP + kc;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            int iy = a_iy0[it] + dy, ix = a_ix0[it] + dx;
+            int ch = kc + a_c4[it] * 4;
+            bool ok = a_ok[it] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi && ch < p.Ci;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) {
+                v = *reinterpret_cast<const float4*>(p.x + (((size_t)a_b[it] * p.Hi + iy) * p.Wi + ix) * p.Ci + ch);
+                if (p.in_scale) {
+                    float4 s = *reinterpret_cast<const float4*>(p.in_scale + (size_t)a_b[it] * p.Ci + ch);
+                    v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
+                }
+            }
+            a_reg[it] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            int q = tid + it * THREADS;
+            if (B_F4 % THREADS == 0 || q < B_F4) {
+                int row = q / F4_ROW, c4 = q % F4_ROW;
+                b_reg[it] = *reinterpret_cast<const float4*>(wt + (size_t)row * p.CP + c4 * 4);
+            }
+        }
+    };
+    auto store_lds = [&](int buf) {
+        float* Ab = As + buf * BM * LD;
+        float* Bb = Bs + buf * BN * LD;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            int q = tid + it * THREADS;
+            if (A_F4 % THREADS == 0 || q < A_F4)
+                *reinterpret_cast<float4*>(Ab + a_row[it] * LD + a_c4[it] * 4) = a_reg[it];
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            int q = tid + it * THREADS;
+            if (B_F4 % THREADS == 0 || q < B_F4) {
+                int row = q / F4_ROW, c4 = q % F4_ROW;
+                *reinterpret_cast<float4*>(Bb + row * LD + c4 * 4) = b_reg[it];
+            }
+        }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_global(0);
+    store_lds(0);
+    __syncthreads();
+
+    int cur = 0;
+    for (int step = 0; step < nsteps; ++step) {
+        const bool more = step + 1 < nsteps;
+        if (more) load_global(step + 1);
+
+        const float* Ab = As + cur * BM * LD + (wm0 + li) * LD + lh * 4;
+        const float* Bb = Bs + cur * BN * LD + (wn0 + li) * LD + lh * 4;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            float4 av[MT], bv[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) av[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LD + kk * 8);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bv[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LD + kk * 8);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    float a = t == 0 ? av[i].x : t == 1 ? av[i].y : t == 2 ? av[i].z : av[i].w;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        float b = t == 0 ? bv[j].x : t == 1 ? bv[j].y : t == 2 ? bv[j].z : bv[j].w;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (more) store_lds(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (m >= p.M) continue;
+            int b = m / HWp;
+            int rr = m - b * HWp;
+            int oy = rr / p.Wp, ox = rr - oy * p.Wp;
+            size_t opix = ((size_t)b * p.Ho + (oy * p.os + p.ooy)) * p.Wo + (ox * p.os + p.oox);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                int n = n0 + wn0 + j * 32 + li;
+                if (n >= p.Co) continue;
+                float v = acc[i][j][r];
+                if (p.out_scale) v *= p.out_scale[(size_t)b * p.Co + n];
+                if (p.residual) v += p.residual[opix * p.Co + n];
+                if (p.bias) v += p.bias[n];
+                if (p.act) v = (v > 0.f ? v : v * p.slope) * p.gain;
+                p.y[opix * p.Co + n] = v;
+            }
+        }
+    }
+}
+
+struct TileCfg {
+    int BM, BN, BK;
+};
+
+inline TileCfg pick_cfg(int cout, int cin) {
+    TileCfg c;
+    c.BN = cout <= 32 ? 32 : 128;
+    c.BK = cin < 32 ? 8 : 32;
+    c.BM = c.BN == 32 ? 256 : 128;
+    return c;
+}
+
+template <int BM, int BN, int BK, int WMv, int WNv>
+int launch_cfg(GatherParams& p, hipStream_t s) {
+    p.tiles_m = gif::cdiv(p.M, BM);
+    p.tiles_n = p.RP / BN;
+    size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
+    auto kern = conv_gather_mfma<BM, BN, BK, WMv, WNv>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+    return 0;
+}
+
+int launch(GatherParams& p, hipStream_t s) {
+    if (p.M <= 0 || p.ntaps <= 0) return 0;
+    TileCfg c = pick_cfg(p.Co, p.Ci);
+    if (c.BN == 128 && c.BK == 32) return launch_cfg<128, 128, 32, 2, 2>(p, s);
+    if (c.BN == 128 && c.BK == 8) return launch_cfg<128, 128, 8, 2, 2>(p, s);
+    if (c.BN == 32 && c.BK == 32) return launch_cfg<256, 32, 32, 4, 1>(p, s);
+    return launch_cfg<256, 32, 8, 4, 1>(p, s);
+}
+
+int check_geom(const gif_conv_geom* g, const char* who) {
+    GIF_REQUIRE(g, "%s: null geometry", who);
+    GIF_REQUIRE(g->B >= 0 && g->Hb > 0 && g->Wb > 0 && g->Hs > 0 && g->Ws > 0, "%s: bad spatial dims", who);
+    GIF_REQUIRE(g->Cb > 0 && g->Cs > 0 && g->Cb % 4 == 0 && g->Cs % 4 == 0,
+                "%s: channel counts must be positive multiples of 4 (Cb=%d Cs=%d)", who, g->Cb, g->Cs);
+    GIF_REQUIRE(g->KH >= 1 && g->KH <= 3 && g->KW >= 1 && g->KW <= 3, "%s: kernel %dx%d unsupported", who, g->KH, g->KW);
+    GIF_REQUIRE(g->stride == 1 || g->stride == 2, "%s: stride %d unsupported", who, g->stride);
+    GIF_REQUIRE(g->pad >= 0, "%s: negative pad", who);
+    GIF_REQUIRE((g->Hs - 1) * g->stride + g->KH - g->pad <= g->Hb + g->pad &&
+                    (g->Ws - 1) * g->stride + g->KW - g->pad <= g->Wb + g->pad,
+                "%s: small grid %dx%d does not fit big grid %dx%d (k=%d s=%d p=%d)", who, g->Hs, g->Ws, g->Hb,
+                g->Wb, g->KH, g->stride, g->pad);
+    return 0;
+}
+
+void fill_epilogue(GatherParams& p, const gif_conv_epilogue* e) {
+    p.in_scale = e ? e->in_scale : nullptr;
+    p.out_scale = e ? e->out_scale : nullptr;
+    p.bias = e ? e->bias : nullptr;
+    p.residual = e ? e->residual : nullptr;
+    p.act = e ? e->act : 0;
+    p.slope = e ? e->slope : 0.f;
+    p.gain = e ? e->gain : 1.f;
+}
+
+inline int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+
+}  // namespace
+
+extern "C" {
+
+int gif_conv2d_pack_dims(int cout, int cin, int* RP, int* CP) {
+    GIF_REQUIRE(cout > 0 && cin > 0 && RP && CP, "pack_dims: bad arguments");
+    TileCfg c = pick_cfg(cout, cin);
+    *RP = (cout + c.BN - 1) / c.BN * c.BN;
+    *CP = (cin + c.BK - 1) / c.BK * c.BK;
+    return 0;
+}
+
+int gif_conv2d_fwd_f32(const float* big, const float* wp, float* small, const gif_conv_geom* g,
+                       const gif_conv_epilogue* e, gif_stream_t stream) {
+    if (int rc = check_geom(g, "conv2d_fwd")) return rc;
+    if (g->B == 0) return 0;
+    GIF_REQUIRE(big && wp && small, "conv2d_fwd: null pointer");
+    GatherParams p{};
+    p.x = big; p.wp = wp; p.y = small;
+    fill_epilogue(p, e);
+    p.B = g->B; p.Hi = g->Hb; p.Wi = g->Wb; p.Ci = g->Cb;
+    p.Ho = g->Hs; p.Wo = g->Ws; p.Co = g->Cs;
+    p.Hp = g->Hs; p.Wp = g->Ws; p.os = 1; p.ooy = 0; p.oox = 0; p.is = g->stride;
+    p.ntaps = g->KH * g->KW;
+    for (int ky = 0; ky < g->KH; ++ky)
+        for (int kx = 0; kx < g->KW; ++kx) {
+            int t = ky * g->KW + kx;
+            p.dy[t] = ky - g->pad; p.dx[t] = kx - g->pad; p.widx[t] = t;
+        }
+    gif_conv2d_pack_dims(p.Co, p.Ci, &p.RP, &p.CP);
+    p.M = p.B * p.Hp * p.Wp;
+    double flops = 2.0 * p.M * (double)p.Co * p.Ci * p.ntaps;
+    gif::ProfScope prof(0, flops, gif::as_stream(stream));
+    launch(p, gif::as_stream(stream));
+    return gif::check_launch("conv2d_fwd");
+}
+
+int gif_conv2d_bwd_data_f32(const float* small, const float* wp, float* big, const gif_conv_geom* g,
+                            const gif_conv_epilogue* e, gif_stream_t stream) {
+    if (int rc = check_geom(g, "conv2d_bwd_data")) return rc;
+    if (g->B == 0) return 0;
+    GIF_REQUIRE(small && wp && big, "conv2d_bwd_data: null pointer");
+    hipStream_t s = gif::as_stream(stream);
+    GatherParams base{};
+    base.x = small; base.wp = wp; base.y = big;
+    fill_epilogue(base, e);
+    base.B = g->B; base.Hi = g->Hs; base.Wi = g->Ws; base.Ci = g->Cs;
+    base.Ho = g->Hb; base.Wo = g->Wb; base.Co = g->Cb;
+    gif_conv2d_pack_dims(base.Co, base.Ci, &base.RP, &base.CP);
+    const int st = g->stride;
+    auto pmod = [st](int a) { return ((a % st) + st) % st; };
+    // Build the (up to 4) output-parity phases; phases with no tap (e.g. 1x1 stride 2) are zero-filled.
+    GatherParams ph[4];
+    int nph = 0;
+    bool need_zero = false;
+    for (int py = 0; py < st; ++py)
+        for (int px = 0; px < st; ++px) {
+            GatherParams p = base;
+            p.Hp = (g->Hb - py + st - 1) / st;
+            p.Wp = (g->Wb - px + st - 1) / st;
+            if (p.Hp <= 0 || p.Wp <= 0) continue;
+            p.os = st; p.ooy = py; p.oox = px; p.is = 1;
+            p.ntaps = 0;
+            for (int ky = 0; ky < g->KH; ++ky)
+                for (int kx = 0; kx < g->KW; ++kx) {
+                    int ny = py + g->pad - ky, nx = px + g->pad - kx;
+                    if (pmod(ny) != 0 || pmod(nx) != 0) continue;
+                    int t = p.ntaps++;
+                    p.dy[t] = floordiv(ny, st); p.dx[t] = floordiv(nx, st); p.widx[t] = ky * g->KW + kx;
+                }
+            if (p.ntaps == 0) { need_zero = true; continue; }
+            p.M = p.B * p.Hp * p.Wp;
+            ph[nph++] = p;
+        }
+    if (need_zero) {
+        GIF_REQUIRE(!(e && (e->bias || e->residual || e->act)), "conv2d_bwd_data: epilogue unsupported with empty phases");
+        hipError_t me = hipMemsetAsync(big, 0, (size_t)g->B * g->Hb * g->Wb * g->Cb * sizeof(float), s);
+        if (me != hipSuccess) { gif::set_error("conv2d_bwd_data memset: %s", hipGetErrorString(me)); return (int)me; }
+    }
+    // algorithmic FLOPs of a transposed conv: every small-side pixel scatters through every tap
+    double flops = 2.0 * g->B * (double)g->Hs * g->Ws * g->KH * g->KW * (double)g->Cs * g->Cb;
+    {
+        gif::ProfScope prof(0, flops, s);
+        for (int i = 0; i < nph; ++i) launch(ph[i], s);
+    }
+    return gif::check_launch("conv2d_bwd_data");
+}
+}

@@ -1,0 +1,288 @@
+// fp32 MFMA weight-gradient kernel for gfx950 (NHWC) + weight pack / unpack.
+//
+// Replaces autograd's wgrad of the F.conv2d / F.conv_transpose2d calls in
+// stylegan2_common_layers.py:176, :330, :339, :345, :405-414.
+//   dW[t][o][i] = sum_{b,oy,ox} small[b,oy,ox,o]*ss[b,o] * big[b, oy*s+ky-pad, ox*s+kx-pad, i]*bs[b,i]
+// GEMM view per tap t: M = Cs (o), N = Cb (i), K = B*Hs*Ws pixels.  Both operands are channel-contiguous in
+// HBM, i.e. K is the SLOW axis: tiles are staged as [pixel][channel] and read back with lanes along the channel
+// axis (ds_read_b32, 128 contiguous bytes per half wave => conflict free), which is exactly the A[i][k] / B[k][j]
+// operand shape of v_mfma_f32_32x32x2_f32 with k = pixel.
+// The pixel axis is split over gridDim.z; every split writes its own partial tile (deterministic: no atomics),
+// and gif_unpack_wgrad_f32 reduces the splits while scattering into the canonical [O,I,KH,KW]-style tensor.
+// The per-sample scales implement the wgrad of the modulated convolution (x*s and dy*d) on the fly.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int BKP = 32;  // pixels per stage
+
+struct WgradParams {
+    const float* sm;  // small side [B,Hs,Ws,Cs]
+    const float* bg;  // big side   [B,Hb,Wb,Cb]
+    float* ws;        // [nsplit][T][RP][CP]
+    const float* ss;  // [B,Cs] or null
+    const float* bs;  // [B,Cb] or null
+    int B, Hs, Ws, Cs, Hb, Wb, Cb;
+    int KW, stride, pad, T;
+    int RP, CP;
+    long Ntot;   // B*Hs*Ws
+    long chunk;  // pixels per split (multiple of BKP)
+    int tiles_q;
+};
+
+template <int BP, int BQ, int WAVES_P, int WAVES_Q>
+__global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const WgradParams p) {
+    constexpr int THREADS = 64 * WAVES_P * WAVES_Q;
+    constexpr int WPt = BP / WAVES_P, WQt = BQ / WAVES_Q;
+    constexpr int MT = WPt / 32, NT = WQt / 32;
+    constexpr int P_F4 = BKP * BP / 4, Q_F4 = BKP * BQ / 4;
+    constexpr int P_IT = P_F4 / THREADS, Q_IT = Q_F4 / THREADS;
+    static_assert(P_F4 % THREADS == 0 && Q_F4 % THREADS == 0, "tile/thread mapping");
+
+    __shared__ __attribute__((aligned(16))) float Ps[2][BKP][BP];
+    __shared__ __attribute__((aligned(16))) float Qs[2][BKP][BQ];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wp0 = (wave / WAVES_Q) * WPt, wq0 = (wave % WAVES_Q) * WQt;
+    const int tq = blockIdx.x % p.tiles_q, tp = blockIdx.x / p.tiles_q;
+    const int r0 = tp * BP, c0 = tq * BQ;
+    const int t = blockIdx.y;
+    const int ky = t / p.KW, kx = t - ky * p.KW;
+    const int split = blockIdx.z;
+    const long n_begin = (long)split * p.chunk;
+    long n_end = n_begin + p.chunk;
+    if (n_end > p.Ntot) n_end = p.Ntot;
+    const int HWs = p.Hs * p.Ws;
+
+    float4 p_reg[P_IT], q_reg[Q_IT];
+
+    auto load_global = [&](long n0) {
+#pragma unroll
+        for (int it = 0; it < P_IT; ++it) {
+            int q = tid + it * THREADS;
+            int pr = q / (BP / 4), c4 = q % (BP / 4);
+            long n = n0 + pr;
+            int ch = r0 + c4 * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n < n_end && ch < p.Cs) {
+                v = *reinterpret_cast<const float4*>(p.sm + n * p.Cs + ch);
+                if (p.ss) {
+                    int b = (int)(n / HWs);
+                    float4 s = *reinterpret_cast<const float4*>(p.ss + (size_t)b * p.Cs + ch);
+                    v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
+                }
+            }
+            p_reg[it] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < Q_IT; ++it) {
+            int q = tid + it * THREADS;
+            int pr = q / (BQ / 4), c4 = q % (BQ / 4);
+            long n = n0 + pr;
+            int ch = c0 + c4 * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n < n_end && ch < p.Cb) {
+                int b = (int)(n / HWs);
+                int r = (int)(n - (long)b * HWs);
+                int oy = r / p.Ws, ox = r - oy * p.Ws;
+                int iy = oy * p.stride + ky - p.pad, ix = ox * p.stride + kx - p.pad;
+                if ((unsigned)iy < (unsigned)p.Hb && (unsigned)ix < (unsigned)p.Wb) {
+                    v = *reinterpret_cast<const float4*>(p.bg + (((size_t)b * p.Hb + iy) * p.Wb + ix) * p.Cb + ch);
+                    if (p.bs) {
+                        float4 s = *reinterpret_cast<const float4*>(p.bs + (size_t)b * p.Cb + ch);
+                        v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
+                    }
+                }
+            }
+            q_reg[it] = v;
+        }
+    };
+    auto store_lds = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < P_IT; ++it) {
+            int q = tid + it * THREADS;
+            int pr = q / (BP / 4), c4 = q % (BP / 4);
+            *reinterpret_cast<float4*>(&Ps[buf][pr][c4 * 4]) = p_reg[it];
+        }
+#pragma unroll
+        for (int it = 0; it < Q_IT; ++it) {
+            int q = tid + it * THREADS;
+            int pr = q / (BQ / 4), c4 = q % (BQ / 4);
+            *reinterpret_cast<float4*>(&Qs[buf][pr][c4 * 4]) = q_reg[it];
+        }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (n_begin < n_end) {
+        load_global(n_begin);
+        store_lds(0);
+        __syncthreads();
+        int cur = 0;
+        for (long n0 = n_begin; n0 < n_end; n0 += BKP) {
+            const bool more = n0 + BKP < n_end;
+            if (more) load_global(n0 + BKP);
+#pragma unroll
+            for (int ks = 0; ks < BKP / 2; ++ks) {
+                float av[MT], bv[NT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) av[i] = Ps[cur][2 * ks + lh][wp0 + i * 32 + li];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bv[j] = Qs[cur][2 * ks + lh][wq0 + j * 32 + li];
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+            }
+            if (more) store_lds(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+
+    float* out = p.ws + ((size_t)split * p.T + t) * p.RP * p.CP;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int row = r0 + wp0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                int col = c0 + wq0 + j * 32 + li;
+                out[(size_t)row * p.CP + col] = acc[i][j][r];
+            }
+        }
+}
+
+// wgrad tiles follow the SAME row/col padding as the forward packing (gif_conv2d_pack_dims(Cs, Cb)):
+// rows RP multiple of 32 or 128, cols CP multiple of 8 or 32 — so pad further to the tile here.
+inline int tile_of(int c) { return c <= 32 ? 32 : 128; }
+
+__global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int R, int C, int KH,
+                                   int KW, int RP, int CP, long sr, long sc, long sky, long skx, float scale) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)KH * KW * RP * CP;
+    if (idx >= total) return;
+    int c = (int)(idx % CP);
+    long rest = idx / CP;
+    int r = (int)(rest % RP);
+    int t = (int)(rest / RP);
+    int ky = t / KW, kx = t - ky * KW;
+    float v = 0.f;
+    if (r < R && c < C) v = scale * w[r * sr + c * sc + ky * sky + kx * skx];
+    wp[idx] = v;
+}
+
+__global__ void unpack_wgrad_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit, int R, int C,
+                                    int KH, int KW, int RP, int CP, long sr, long sc, long sky, long skx,
+                                    float scale) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)KH * KW * R * C;
+    if (idx >= total) return;
+    int c = (int)(idx % C);
+    long rest = idx / C;
+    int r = (int)(rest % R);
+    int t = (int)(rest / R);
+    int ky = t / KW, kx = t - ky * KW;
+    size_t stride = (size_t)KH * KW * RP * CP;
+    const float* src = ws + ((size_t)t * RP + r) * CP + c;
+    float acc = 0.f;
+    for (int s = 0; s < nsplit; ++s) acc += src[s * stride];
+    dw[r * sr + c * sc + ky * sky + kx * skx] = scale * acc;
+}
+
+// wgrad workspace dims: rows/cols padded to the wgrad tile (32 or 128)
+inline void wgrad_dims(int Cs, int Cb, int* RP, int* CP) {
+    int bp = tile_of(Cs), bq = tile_of(Cb);
+    *RP = (Cs + bp - 1) / bp * bp;
+    *CP = (Cb + bq - 1) / bq * bq;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gif_pack_weight_f32(const float* w, float* wp, int R, int C, int KH, int KW, int RP, int CP, int64_t sr,
+                        int64_t sc, int64_t sky, int64_t skx, float scale, gif_stream_t stream) {
+    GIF_REQUIRE(w && wp && R > 0 && C > 0 && RP >= R && CP >= C && KH > 0 && KW > 0, "pack_weight: bad arguments");
+    long total = (long)KH * KW * RP * CP;
+    pack_weight_kernel<<<gif::cdiv(total, 256), 256, 0, gif::as_stream(stream)>>>(w, wp, R, C, KH, KW, RP, CP, sr, sc,
+                                                                                    sky, skx, scale);
+    return gif::check_launch("pack_weight");
+}
+
+int gif_conv2d_wgrad_dims(int Cs, int Cb, int* RP, int* CP) {
+    GIF_REQUIRE(Cs > 0 && Cb > 0 && RP && CP, "wgrad_dims: bad arguments");
+    wgrad_dims(Cs, Cb, RP, CP);
+    return 0;
+}
+
+int gif_conv2d_wgrad_splits(const gif_conv_geom* g) {
+    if (!g || g->B <= 0) return 1;
+    int RP, CP;
+    wgrad_dims(g->Cs, g->Cb, &RP, &CP);
+    long tiles = (long)(RP / tile_of(g->Cs)) * (CP / tile_of(g->Cb)) * g->KH * g->KW;
+    long Ntot = (long)g->B * g->Hs * g->Ws;
+    long want = (1024 + tiles - 1) / tiles;
+    long max_by_work = (Ntot + 4 * BKP - 1) / (4 * BKP);  // >= 4 stages per split
+    long bytes_per_split = (long)g->KH * g->KW * RP * CP * 4;
+    long max_by_mem = (128L << 20) / bytes_per_split;
+    long n = want;
+    if (n > max_by_work) n = max_by_work;
+    if (n > max_by_mem) n = max_by_mem;
+    if (n < 1) n = 1;
+    return (int)n;
+}
+
+int gif_conv2d_wgrad_f32(const float* small, const float* big, float* ws, const float* small_scale,
+                         const float* big_scale, const gif_conv_geom* g, int nsplit, gif_stream_t stream) {
+    GIF_REQUIRE(g && small && big && ws && nsplit >= 1, "conv2d_wgrad: bad arguments");
+    GIF_REQUIRE(g->Cb % 4 == 0 && g->Cs % 4 == 0, "conv2d_wgrad: channels must be multiples of 4");
+    GIF_REQUIRE(g->KH >= 1 && g->KH <= 3 && g->KW >= 1 && g->KW <= 3 && (g->stride == 1 || g->stride == 2),
+                "conv2d_wgrad: unsupported kernel/stride");
+    WgradParams p{};
+    p.sm = small; p.bg = big; p.ws = ws; p.ss = small_scale; p.bs = big_scale;
+    p.B = g->B; p.Hs = g->Hs; p.Ws = g->Ws; p.Cs = g->Cs; p.Hb = g->Hb; p.Wb = g->Wb; p.Cb = g->Cb;
+    p.KW = g->KW; p.stride = g->stride; p.pad = g->pad; p.T = g->KH * g->KW;
+    wgrad_dims(g->Cs, g->Cb, &p.RP, &p.CP);
+    p.Ntot = (long)g->B * g->Hs * g->Ws;
+    long chunk = (p.Ntot + nsplit - 1) / nsplit;
+    p.chunk = (chunk + BKP - 1) / BKP * BKP;
+    if (p.chunk < BKP) p.chunk = BKP;
+    const int bp = tile_of(g->Cs), bq = tile_of(g->Cb);
+    p.tiles_q = p.CP / bq;
+    dim3 grid((unsigned)((p.RP / bp) * p.tiles_q), (unsigned)p.T, (unsigned)nsplit);
+    hipStream_t s = gif::as_stream(stream);
+    double flops = 2.0 * p.Ntot * (double)g->Cs * g->Cb * p.T;
+    {
+        gif::ProfScope prof(1, flops, s);
+        if (bp == 128 && bq == 128)
+            hipLaunchKernelGGL((conv_wgrad_mfma<128, 128, 2, 2>), grid, dim3(256), 0, s, p);
+        else if (bp == 128 && bq == 32)
+            hipLaunchKernelGGL((conv_wgrad_mfma<128, 32, 4, 1>), grid, dim3(256), 0, s, p);
+        else if (bp == 32 && bq == 128)
+            hipLaunchKernelGGL((conv_wgrad_mfma<32, 128, 1, 4>), grid, dim3(256), 0, s, p);
+        else
+            hipLaunchKernelGGL((conv_wgrad_mfma<32, 32, 1, 1>), grid, dim3(64), 0, s, p);
+    }
+    return gif::check_launch("conv2d_wgrad");
+}
+
+int gif_unpack_wgrad_f32(const float* ws, float* dw, int nsplit, int R, int C, int KH, int KW, int RP, int CP,
+                         int64_t sr, int64_t sc, int64_t sky, int64_t skx, float scale, gif_stream_t stream) {
+    GIF_REQUIRE(ws && dw && nsplit >= 1 && R > 0 && C > 0 && RP >= R && CP >= C, "unpack_wgrad: bad arguments");
+    long total = (long)KH * KW * R * C;
+    unpack_wgrad_kernel<<<gif::cdiv(total, 256), 256, 0, gif::as_stream(stream)>>>(ws, dw, nsplit, R, C, KH, KW, RP,
+                                                                                     CP, sr, sc, sky, skx, scale);
+    return gif::check_launch("unpack_wgrad");
+}
+}

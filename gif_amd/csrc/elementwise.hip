@@ -1,0 +1,382 @@
+// HBM-bound NHWC kernels of the G/D step for gfx950: upfirdn2d FIR resampling, fused bias + leaky-ReLU
+// (forward / backward), channel and per-sample reductions, minibatch standard deviation, squared-norm.
+// All of them move float4 (16 B) per lane along the contiguous channel axis; reductions finish inside a
+// wavefront with shuffles (64 lanes) and cross waves through a few LDS words.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4fma(float s, float4 a, float4 c) {
+    return make_float4(fmaf(s, a.x, c.x), fmaf(s, a.y, c.y), fmaf(s, a.z, c.z), fmaf(s, a.w, c.w));
+}
+__device__ __forceinline__ float lrelu(float v, float slope, float gain) { return (v > 0.f ? v : v * slope) * gain; }
+
+// ---------------------------------------------------------------------------------------------------------
+// upfirdn2d (stylegan2_common_layers.py:42-72).  One lane = one output pixel x 4 channels.
+//   y[oy,ox] = sum_{a,b} kf[a,b] * xp[oy*down + a, ox*down + b],   xp[u,v] = x[(u-pady0)/up, (v-padx0)/up]
+//   when divisible and in range, else 0;  kf = k flipped when flip (the reference flips, :64).
+// ---------------------------------------------------------------------------------------------------------
+struct UpfirdnParams {
+    const float* x;
+    const float* k;
+    float* y;
+    const float* bias;
+    const float* residual;
+    int B, Hi, Wi, C, Ho, Wo, up, down, padx0, pady0, KH, KW, flip, act;
+    float slope, gain;
+};
+
+__global__ void __launch_bounds__(256) upfirdn2d_kernel(const UpfirdnParams p) {
+    __shared__ float kf[16];
+    if (threadIdx.x < p.KH * p.KW) {
+        int a = threadIdx.x / p.KW, b = threadIdx.x % p.KW;
+        int sa = p.flip ? p.KH - 1 - a : a, sb = p.flip ? p.KW - 1 - b : b;
+        kf[threadIdx.x] = p.k[sa * p.KW + sb];
+    }
+    __syncthreads();
+    const int C4 = p.C >> 2;
+    const long total = (long)p.B * p.Ho * p.Wo * C4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        int c4 = (int)(idx % C4);
+        long pix = idx / C4;
+        int ox = (int)(pix % p.Wo);
+        long t = pix / p.Wo;
+        int oy = (int)(t % p.Ho);
+        int b = (int)(t / p.Ho);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* xb = p.x + (size_t)b * p.Hi * p.Wi * p.C + c4 * 4;
+        for (int a = 0; a < p.KH; ++a) {
+            int u = oy * p.down + a - p.pady0;
+            if (u < 0) continue;
+            int iy = u / p.up;
+            if (iy * p.up != u || iy >= p.Hi) continue;
+            for (int bb = 0; bb < p.KW; ++bb) {
+                int v = ox * p.down + bb - p.padx0;
+                if (v < 0) continue;
+                int ix = v / p.up;
+                if (ix * p.up != v || ix >= p.Wi) continue;
+                float4 xv = *reinterpret_cast<const float4*>(xb + ((size_t)iy * p.Wi + ix) * p.C);
+                acc = f4fma(kf[a * p.KW + bb], xv, acc);
+            }
+        }
+        size_t o = (size_t)pix * p.C + c4 * 4;
+        if (p.residual) acc = f4add(acc, *reinterpret_cast<const float4*>(p.residual + o));
+        if (p.bias) acc = f4add(acc, *reinterpret_cast<const float4*>(p.bias + c4 * 4));
+        if (p.act) {
+            acc.x = lrelu(acc.x, p.slope, p.gain); acc.y = lrelu(acc.y, p.slope, p.gain);
+            acc.z = lrelu(acc.z, p.slope, p.gain); acc.w = lrelu(acc.w, p.slope, p.gain);
+        }
+        *reinterpret_cast<float4*>(p.y + o) = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// bias + leaky ReLU (FusedLeakyReLU.forward, stylegan2_common_layers.py:32-39)
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) bias_act_kernel(const float* __restrict__ x, const float* __restrict__ bias,
+                                                       const float* __restrict__ res, float* __restrict__ y,
+                                                       long n4, int C4, float slope, float gain) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 v = reinterpret_cast<const float4*>(x)[i];
+        if (res) v = f4add(v, reinterpret_cast<const float4*>(res)[i]);
+        if (bias) v = f4add(v, reinterpret_cast<const float4*>(bias)[i % C4]);
+        v.x = lrelu(v.x, slope, gain); v.y = lrelu(v.y, slope, gain);
+        v.z = lrelu(v.z, slope, gain); v.w = lrelu(v.w, slope, gain);
+        reinterpret_cast<float4*>(y)[i] = v;
+    }
+}
+
+// Column-sum building block: block (bx) owns rows [bx*rows_per_block, ...), thread owns one float4 column
+// and one of R row lanes; cross-lane reduction over the R row lanes goes through LDS.
+// MODE 0: v = x ; MODE 1 (bias_act backward): v = gy * gain * (y > 0 ? 1 : slope), also stored to gx.
+// MODE 2 (mul): v = a*b, optional scaled output s[b,c]*a.
+template <int MODE>
+__global__ void __launch_bounds__(256)
+colsum_stage1(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out_ew,
+              const float* __restrict__ scale, float* __restrict__ partial, long nrows, int C4, long rows_per_block,
+              float slope, float gain, int want_sum) {
+    __shared__ float4 red[256];
+    const int R = 256 / C4;  // row lanes (C4 <= 256)
+    const int col = threadIdx.x % C4, rl = threadIdx.x / C4;
+    const bool active = rl < R;
+    // blockIdx.y = sample (MODE 2) — rows are relative to the sample
+    const long base = (long)blockIdx.y * nrows;
+    long r0 = (long)blockIdx.x * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    if (r1 > nrows) r1 = nrows;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (MODE == 2 && scale && active) sc = reinterpret_cast<const float4*>(scale)[(long)blockIdx.y * C4 + col];
+    if (active) {
+        for (long r = r0 + rl; r < r1; r += R) {
+            long i = (base + r) * C4 + col;
+            float4 v = reinterpret_cast<const float4*>(a)[i];
+            if (MODE == 1) {
+                float4 yv = reinterpret_cast<const float4*>(b)[i];
+                v.x *= gain * (yv.x > 0.f ? 1.f : slope); v.y *= gain * (yv.y > 0.f ? 1.f : slope);
+                v.z *= gain * (yv.z > 0.f ? 1.f : slope); v.w *= gain * (yv.w > 0.f ? 1.f : slope);
+                reinterpret_cast<float4*>(out_ew)[i] = v;
+            } else if (MODE == 2) {
+                float4 bv = reinterpret_cast<const float4*>(b)[i];
+                if (out_ew) reinterpret_cast<float4*>(out_ew)[i] = make_float4(sc.x * v.x, sc.y * v.y, sc.z * v.z, sc.w * v.w);
+                v.x *= bv.x; v.y *= bv.y; v.z *= bv.z; v.w *= bv.w;
+            }
+            acc = f4add(acc, v);
+        }
+    }
+    if (!want_sum) return;
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (rl == 0) {
+        for (int k = 1; k < R; ++k) acc = f4add(acc, red[k * C4 + col]);
+        reinterpret_cast<float4*>(partial)[((long)blockIdx.y * gridDim.x + blockIdx.x) * C4 + col] = acc;
+    }
+}
+
+// out[y][c] = sum_k partial[y][k][c]
+__global__ void colsum_stage2(const float* __restrict__ partial, float* __restrict__ out, int nblk, int C) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float* pp = partial + (size_t)blockIdx.y * nblk * C + c;
+    float acc = 0.f;
+    for (int k = 0; k < nblk; ++k) acc += pp[(size_t)k * C];
+    out[(size_t)blockIdx.y * C + c] = acc;
+}
+
+inline int colsum_blocks(long nrows, int C4) {
+    int R = 256 / C4;
+    long want = (nrows + (long)R * 16 - 1) / ((long)R * 16);  // >= 16 rows per row-lane
+    if (want > 512) want = 512;
+    if (want < 1) want = 1;
+    return (int)want;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// minibatch stddev (stg2_discriminator.py:59-65)
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) mbstd_stat_kernel(const float* __restrict__ x, float* __restrict__ stat, int M,
+                                                         int G, long n /*H*W*C*/) {
+    __shared__ float red[4];
+    const int m = blockIdx.x;
+    float acc = 0.f;
+    for (long e = threadIdx.x; e < n; e += blockDim.x) {
+        float mean = 0.f;
+        for (int g = 0; g < G; ++g) mean += x[((long)g * M + m) * n + e];
+        mean /= (float)G;
+        float var = 0.f;
+        for (int g = 0; g < G; ++g) {
+            float d = x[((long)g * M + m) * n + e] - mean;
+            var += d * d;
+        }
+        acc += sqrtf(var / (float)G + 1e-8f);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) stat[m] = (red[0] + red[1] + red[2] + red[3]) / (float)n;
+}
+
+__global__ void __launch_bounds__(256) mbstd_write_kernel(const float* __restrict__ x, const float* __restrict__ stat,
+                                                          float* __restrict__ y, int B, int HW, int C, int Cy, int M) {
+    const int Cy4 = Cy >> 2;
+    long total = (long)B * HW * Cy4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        int c4 = (int)(idx % Cy4);
+        long pix = idx / Cy4;
+        int b = (int)(pix / HW);
+        int c = c4 * 4;
+        float4 v;
+        if (c + 3 < C) {
+            v = *reinterpret_cast<const float4*>(x + pix * C + c);
+        } else {
+            float s = stat[b % M];
+            float e[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e[j] = (c + j < C) ? x[pix * C + c + j] : (c + j == C ? s : 0.f);
+            v = make_float4(e[0], e[1], e[2], e[3]);
+        }
+        *reinterpret_cast<float4*>(y + pix * Cy + c) = v;
+    }
+}
+
+// gx[b,e] = gy[b,e(:C)] + gstat[m]/n * (x[b,e]-mean)/(G*sd),  gstat[m] = sum over group members & pixels of gy[..., C]
+__global__ void __launch_bounds__(256) mbstd_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                        float* __restrict__ gx, int M, int G, int HW, int C, int Cy) {
+    __shared__ float red[4];
+    __shared__ float gs;
+    const int m = blockIdx.x;
+    const long n = (long)HW * C;
+    float acc = 0.f;
+    for (int e = threadIdx.x; e < G * HW; e += blockDim.x) {
+        int g = e / HW, hw = e - g * HW;
+        acc += gy[(((long)g * M + m) * HW + hw) * Cy + C];
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) gs = (red[0] + red[1] + red[2] + red[3]) / (float)n;
+    __syncthreads();
+    const float gstat = gs;
+    for (long e = threadIdx.x; e < n; e += blockDim.x) {
+        int hw = (int)(e / C), c = (int)(e - (long)hw * C);
+        float xv[8];
+        float mean = 0.f;
+        for (int g = 0; g < G; ++g) {
+            xv[g] = x[((long)g * M + m) * n + e];
+            mean += xv[g];
+        }
+        mean /= (float)G;
+        float var = 0.f;
+        for (int g = 0; g < G; ++g) var += (xv[g] - mean) * (xv[g] - mean);
+        float sd = sqrtf(var / (float)G + 1e-8f);
+        float k = gstat / ((float)G * sd);
+        for (int g = 0; g < G; ++g) {
+            long b = (long)g * M + m;
+            gx[b * n + e] = gy[(b * HW + hw) * Cy + c] + k * (xv[g] - mean);
+        }
+    }
+}
+
+// out[b] = sum g[b,:]^2  (grad_penalty_loss, losses.py:87-99)
+__global__ void __launch_bounds__(1024) sqnorm_kernel(const float* __restrict__ g, float* __restrict__ out, long n) {
+    __shared__ float red[16];
+    const float* gb = g + (size_t)blockIdx.x * n;
+    float acc = 0.f;
+    long n4 = n >> 2;
+    for (long i = threadIdx.x; i < n4; i += blockDim.x) {
+        float4 v = reinterpret_cast<const float4*>(gb)[i];
+        acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    for (long i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) acc += gb[i] * gb[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int k = 0; k < 16; ++k) s += red[k];
+        out[blockIdx.x] = s;
+    }
+}
+
+inline int ew_grid(long n) {
+    long b = (n + 255) / 256;
+    if (b > 256 * 16) b = 256 * 16;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gif_upfirdn2d_f32(const float* x, const float* k, float* y, int B, int Hi, int Wi, int C, int Ho, int Wo, int up,
+                      int down, int padx0, int pady0, int KH, int KW, int flip, const gif_conv_epilogue* e,
+                      gif_stream_t stream) {
+    GIF_REQUIRE(x && k && y, "upfirdn2d: null pointer");
+    GIF_REQUIRE(B >= 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 4 == 0, "upfirdn2d: bad dims (C=%d)", C);
+    GIF_REQUIRE(up >= 1 && down >= 1 && KH >= 1 && KW >= 1 && KH * KW <= 16, "upfirdn2d: bad up/down/kernel");
+    if (B == 0) return 0;
+    UpfirdnParams p{};
+    p.x = x; p.k = k; p.y = y;
+    p.bias = e ? e->bias : nullptr;
+    p.residual = e ? e->residual : nullptr;
+    p.act = e ? e->act : 0;
+    p.slope = e ? e->slope : 0.f;
+    p.gain = e ? e->gain : 1.f;
+    p.B = B; p.Hi = Hi; p.Wi = Wi; p.C = C; p.Ho = Ho; p.Wo = Wo; p.up = up; p.down = down;
+    p.padx0 = padx0; p.pady0 = pady0; p.KH = KH; p.KW = KW; p.flip = flip;
+    long total = (long)B * Ho * Wo * (C / 4);
+    upfirdn2d_kernel<<<ew_grid(total), 256, 0, gif::as_stream(stream)>>>(p);
+    return gif::check_launch("upfirdn2d");
+}
+
+int gif_bias_act_f32(const float* x, const float* bias, const float* residual, float* y, int64_t npix, int C,
+                     float slope, float gain, gif_stream_t stream) {
+    GIF_REQUIRE(x && y && npix >= 0 && C > 0 && C % 4 == 0, "bias_act: bad arguments (C=%d)", C);
+    if (npix == 0) return 0;
+    long n4 = npix * (C / 4);
+    bias_act_kernel<<<ew_grid(n4), 256, 0, gif::as_stream(stream)>>>(x, bias, residual, y, n4, C / 4, slope, gain);
+    return gif::check_launch("bias_act");
+}
+
+int64_t gif_colsum_partial_floats(int64_t npix, int C) {
+    if (C <= 0 || C % 4 || C > 1024) return 0;
+    return (int64_t)colsum_blocks(npix, C / 4) * C;
+}
+
+int gif_bias_act_bwd_f32(const float* gy, const float* y, float* gx, float* gbias, float* partial, int64_t npix, int C,
+                         float slope, float gain, gif_stream_t stream) {
+    GIF_REQUIRE(gy && y && gx && npix >= 0 && C > 0 && C % 4 == 0 && C <= 1024, "bias_act_bwd: bad arguments (C=%d)", C);
+    GIF_REQUIRE(!gbias || partial, "bias_act_bwd: gbias needs a partial buffer");
+    if (npix == 0) return 0;
+    hipStream_t s = gif::as_stream(stream);
+    int C4 = C / 4;
+    int nblk = colsum_blocks(npix, C4);
+    long rpb = (npix + nblk - 1) / nblk;
+    colsum_stage1<1><<<dim3(nblk, 1), 256, 0, s>>>(gy, y, gx, nullptr, partial, npix, C4, rpb, slope, gain, gbias != nullptr);
+    if (gbias) colsum_stage2<<<dim3(gif::cdiv(C, 256), 1), 256, 0, s>>>(partial, gbias, nblk, C);
+    return gif::check_launch("bias_act_bwd");
+}
+
+int gif_colsum_f32(const float* x, float* out, float* partial, int64_t npix, int C, gif_stream_t stream) {
+    GIF_REQUIRE(x && out && partial && npix >= 0 && C > 0 && C % 4 == 0 && C <= 1024, "colsum: bad arguments (C=%d)", C);
+    hipStream_t s = gif::as_stream(stream);
+    int C4 = C / 4;
+    int nblk = colsum_blocks(npix, C4);
+    long rpb = (npix + nblk - 1) / nblk;
+    colsum_stage1<0><<<dim3(nblk, 1), 256, 0, s>>>(x, nullptr, nullptr, nullptr, partial, npix, C4, rpb, 0.f, 1.f, 1);
+    colsum_stage2<<<dim3(gif::cdiv(C, 256), 1), 256, 0, s>>>(partial, out, nblk, C);
+    return gif::check_launch("colsum");
+}
+
+int gif_mul_reduce_chunks(int64_t HW) { return colsum_blocks(HW, 32) > 64 ? 64 : colsum_blocks(HW, 32); }
+
+int gif_mul_reduce_f32(const float* a, const float* b, const float* scale, float* scaled, float* out, float* partial,
+                       int B, int64_t HW, int C, gif_stream_t stream) {
+    GIF_REQUIRE(a && b && out && partial && B >= 0 && HW > 0 && C > 0 && C % 4 == 0 && C <= 1024,
+                "mul_reduce: bad arguments (C=%d)", C);
+    GIF_REQUIRE(!scaled || scale, "mul_reduce: scaled output needs scale");
+    if (B == 0) return 0;
+    hipStream_t s = gif::as_stream(stream);
+    int nchunk = gif_mul_reduce_chunks(HW);
+    long rpb = (HW + nchunk - 1) / nchunk;
+    colsum_stage1<2><<<dim3(nchunk, B), 256, 0, s>>>(a, b, scaled, scale, partial, HW, C / 4, rpb, 0.f, 1.f, 1);
+    colsum_stage2<<<dim3(gif::cdiv(C, 256), B), 256, 0, s>>>(partial, out, nchunk, C);
+    return gif::check_launch("mul_reduce");
+}
+
+int gif_mbstd_fwd_f32(const float* x, float* y, float* stat, int B, int H, int W, int C, int Cy, int G,
+                      gif_stream_t stream) {
+    GIF_REQUIRE(x && y && stat && B > 0 && G >= 1 && G <= 8 && B % G == 0, "mbstd: batch %d not divisible by group %d", B, G);
+    GIF_REQUIRE(C > 0 && Cy >= C + 1 && Cy % 4 == 0, "mbstd: bad channel counts C=%d Cy=%d", C, Cy);
+    hipStream_t s = gif::as_stream(stream);
+    int M = B / G;
+    mbstd_stat_kernel<<<M, 256, 0, s>>>(x, stat, M, G, (long)H * W * C);
+    long total = (long)B * H * W * (Cy / 4);
+    mbstd_write_kernel<<<ew_grid(total), 256, 0, s>>>(x, stat, y, B, H * W, C, Cy, M);
+    return gif::check_launch("mbstd_fwd");
+}
+
+int gif_mbstd_bwd_f32(const float* x, const float* gy, float* gx, int B, int H, int W, int C, int Cy, int G,
+                      gif_stream_t stream) {
+    GIF_REQUIRE(x && gy && gx && B > 0 && G >= 1 && G <= 8 && B % G == 0, "mbstd_bwd: bad batch/group");
+    GIF_REQUIRE(C > 0 && Cy >= C + 1, "mbstd_bwd: bad channel counts");
+    int M = B / G;
+    mbstd_bwd_kernel<<<M, 256, 0, gif::as_stream(stream)>>>(x, gy, gx, M, G, H * W, C, Cy);
+    return gif::check_launch("mbstd_bwd");
+}
+
+int gif_sqnorm_per_sample_f32(const float* g, float* out, int B, int64_t n, gif_stream_t stream) {
+    GIF_REQUIRE(g && out && B >= 0 && n > 0, "sqnorm: bad arguments");
+    if (B == 0) return 0;
+    sqnorm_kernel<<<B, 1024, 0, gif::as_stream(stream)>>>(g, out, n);
+    return gif::check_launch("sqnorm");
+}
+}

@@ -1,0 +1,92 @@
+// Error reporting + event-based kernel timing for bench.py's roofline line.
+#include <stdarg.h>
+
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+
+namespace gif {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+struct ProfRec {
+    hipEvent_t e0, e1;
+    double flops;
+};
+static bool g_prof_on = false;
+static std::mutex g_prof_mu;
+static std::vector<ProfRec> g_prof[2];
+static std::vector<hipEvent_t> g_pool;
+
+static hipEvent_t get_event() {
+    if (!g_pool.empty()) {
+        hipEvent_t e = g_pool.back();
+        g_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+ProfScope::ProfScope(int fam, double flops, hipStream_t s) : family(fam), stream(s) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    e0 = get_event();
+    e1 = get_event();
+    if (!e0 || !e1) {
+        e0 = e1 = nullptr;
+        return;
+    }
+    g_prof[family].push_back({e0, e1, flops});
+    (void)hipEventRecord(e0, stream);
+}
+
+ProfScope::~ProfScope() {
+    if (e1) (void)hipEventRecord(e1, stream);
+}
+
+}  // namespace gif
+
+extern "C" {
+
+const char* gif_last_error(void) { return gif::g_err; }
+int gif_abi_version(void) { return 1; }
+
+int gif_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(gif::g_prof_mu);
+    gif::g_prof_on = on != 0;
+    return 0;
+}
+
+int gif_prof_read(int family, double* ms, double* flops, int64_t* launches) {
+    if (family < 0 || family > 1) return GIF_EINVAL;
+    std::lock_guard<std::mutex> lk(gif::g_prof_mu);
+    double tms = 0, tf = 0;
+    int64_t n = 0;
+    for (auto& r : gif::g_prof[family]) {
+        (void)hipEventSynchronize(r.e1);
+        float t = 0;
+        if (hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) {
+            tms += t;
+            tf += r.flops;
+            ++n;
+        }
+        gif::g_pool.push_back(r.e0);
+        gif::g_pool.push_back(r.e1);
+    }
+    gif::g_prof[family].clear();
+    if (ms) *ms = tms;
+    if (flops) *flops = tf;
+    if (launches) *launches = n;
+    return 0;
+}
+}

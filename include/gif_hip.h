@@ -1,0 +1,165 @@
+/*
+ * gif_hip.h — C ABI of libgif_hip.so: the MI355X (gfx950) kernels behind GIF's StyleGAN2
+ * generator/discriminator hot path and its FLAME mesh rasteriser.
+ *
+ * The reference (ParthaEth/GIF) has exactly one native boundary — the pybind module
+ * `standard_rasterize_cuda` (my_utils/standard_rasterize_cuda/standard_rasterize_cuda.cpp:79-82) —
+ * and otherwise composes its layers from ATen calls (F.conv2d / F.conv_transpose2d / F.pad ...) inside
+ * model/stylegan2_common_layers.py.  Every entry point below names the reference construct it
+ * replaces.  All pointers are DEVICE pointers (fp32 / int32), all tensors are dense; activations are
+ * NHWC ("channels last"), channel counts are multiples of 4 (callers zero-pad 3/6/9/513-channel
+ * tensors).  `stream` is a hipStream_t passed as void*.  Every function returns 0 on success,
+ * a positive hipError_t on a runtime failure, or a negative GIF_E* code on a bad argument;
+ * gif_last_error() returns a static description of the last failure on the calling thread.
+ * Nothing here synchronises the device or allocates memory: scratch is passed in by the caller.
+ */
+#ifndef GIF_HIP_H
+#define GIF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GIF_EINVAL (-1)  /* bad argument (shape / alignment / null pointer) */
+#define GIF_ENOSUP (-2)  /* configuration not supported by this build */
+
+typedef void* gif_stream_t;
+
+const char* gif_last_error(void);
+int gif_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Mesh rasteriser — replaces standard_rasterize_cuda.standard_rasterize / standard_rasterize_colors
+ * (standard_rasterize_cuda.cpp:26-40, :59-75; kernels standard_rasterize_cuda_kernel.cu:111-233).
+ * face_vertices [B,F,3,3] (x,y in pixel units, z>0), depth [B,H,W], tri [B,H,W] int32,
+ * bary / images [B,H,W,3]: caller-allocated, caller-initialised, updated IN PLACE exactly like the
+ * reference (depth=min, tri=face index of the min, bary/colour of that face).  Exact-depth ties are
+ * resolved deterministically to the lowest face index (the reference leaves them to a race).
+ * `workspace` holds B*H*W uint64 keys (gif_rasterize_workspace_bytes).
+ * ---------------------------------------------------------------------------------------------- */
+int64_t gif_rasterize_workspace_bytes(int B, int H, int W);
+int gif_rasterize_f32(const float* face_vertices, float* depth, int32_t* tri, float* bary, int B, int F,
+                      int H, int W, void* workspace, gif_stream_t stream);
+int gif_rasterize_colors_f32(const float* face_vertices, const float* face_colors, float* depth,
+                             int32_t* tri, float* images, int B, int F, int H, int W, void* workspace,
+                             gif_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Convolution family (fp32 MFMA implicit GEMM) — replaces the F.conv2d / F.conv_transpose2d calls of
+ *   ModulatedConv2d.forward   stylegan2_common_layers.py:307-349 (groups=batch trick -> in/out scales)
+ *   EqualConv2d.forward       stylegan2_common_layers.py:175-184
+ *   NoiseInjection.noise_conv stylegan2_common_layers.py:405-414
+ * and their autograd (dgrad / wgrad).
+ *
+ * Geometry is always described through the underlying FORWARD convolution
+ *   small[b,oy,ox,o] = sum_{ky,kx,i} W[o,i,ky,kx] * big[b, oy*stride+ky-pad, ox*stride+kx-pad, i]
+ * "big" = [B,Hb,Wb,Cb] is the conv-input side, "small" = [B,Hs,Ws,Cs] the conv-output side.
+ *   gif_conv2d_fwd_f32      : big  -> small   (conv2d)
+ *   gif_conv2d_bwd_data_f32 : small -> big    (conv_transpose2d == dgrad), stride-2 runs as 4 dense phases
+ *   gif_conv2d_wgrad_f32    : (small, big) -> per-split partial dW
+ * Packed weights `wp` are [KH*KW][RP][CP] fp32 with rows = the op's OUTPUT channels, cols = the op's
+ * INPUT channels, zero padded to the tile sizes reported by gif_conv2d_pack_dims(); tap index is always
+ * the forward conv's ky*KW+kx.  Optional per-sample scales implement weight (de)modulation without
+ * materialising per-sample weights:  y = act(out_scale[b,co] * conv(in_scale[b,ci] * x) + residual + bias).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t B;
+    int32_t Hb, Wb, Cb; /* conv-input side  */
+    int32_t Hs, Ws, Cs; /* conv-output side */
+    int32_t KH, KW;     /* <= 3 x 3 */
+    int32_t stride;     /* 1 or 2 */
+    int32_t pad;
+} gif_conv_geom;
+
+typedef struct {
+    const float* in_scale;  /* [B, Cin]  or NULL */
+    const float* out_scale; /* [B, Cout] or NULL */
+    const float* bias;      /* [Cout]    or NULL */
+    const float* residual;  /* same shape as output or NULL (added before the activation) */
+    int32_t act;            /* 0: identity, 1: gain * leaky_relu(., slope) */
+    float slope, gain;
+} gif_conv_epilogue;
+
+/* rows/cols padding (RP, CP) of the packed weight for an op with `cout` output and `cin` input channels */
+int gif_conv2d_pack_dims(int cout, int cin, int* RP, int* CP);
+/* wp[t][r][c] = scale * w[r*sr + c*sc + ky*sky + kx*skx]  (element strides; zero for r>=R or c>=C) */
+int gif_pack_weight_f32(const float* w, float* wp, int R, int C, int KH, int KW, int RP, int CP, int64_t sr,
+                        int64_t sc, int64_t sky, int64_t skx, float scale, gif_stream_t stream);
+int gif_conv2d_fwd_f32(const float* big, const float* wp, float* small, const gif_conv_geom* g,
+                       const gif_conv_epilogue* e, gif_stream_t stream);
+int gif_conv2d_bwd_data_f32(const float* small, const float* wp, float* big, const gif_conv_geom* g,
+                            const gif_conv_epilogue* e, gif_stream_t stream);
+/* Partial weight gradients: ws[nsplit][KH*KW][RP][CP] with rows = small-side channels (o), cols = big-side
+ * channels (i); (RP,CP) = gif_conv2d_wgrad_dims(Cs, Cb).  nsplit from gif_conv2d_wgrad_splits().
+ * small_scale [B,Cs] / big_scale [B,Cb] (or NULL) are applied to the operands on load. */
+int gif_conv2d_wgrad_dims(int Cs, int Cb, int* RP, int* CP);
+int gif_conv2d_wgrad_splits(const gif_conv_geom* g);
+int gif_conv2d_wgrad_f32(const float* small, const float* big, float* ws, const float* small_scale,
+                         const float* big_scale, const gif_conv_geom* g, int nsplit, gif_stream_t stream);
+/* dw[r*sr + c*sc + ky*sky + kx*skx] = scale * sum_s ws[s][t][r][c]   (inverse of gif_pack_weight_f32) */
+int gif_unpack_wgrad_f32(const float* ws, float* dw, int nsplit, int R, int C, int KH, int KW, int RP, int CP,
+                         int64_t sr, int64_t sc, int64_t sky, int64_t skx, float scale, gif_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * upfirdn2d — replaces upfirdn2d() stylegan2_common_layers.py:42-72 (Blur :136-152, Upsample :94-112,
+ * Downsample :115-133): zero-insert by `up`, pad (negative = crop), correlate with the FIR `k` flipped
+ * when flip!=0 (the reference flips => true convolution), keep every `down`-th sample.
+ * x [B,Hi,Wi,C] -> y [B,Ho,Wo,C]; k is a DEVICE pointer to KH*KW taps.
+ * Optional fused epilogue y = act(fir + residual + bias) (same struct as the conv; scales ignored).
+ * ---------------------------------------------------------------------------------------------- */
+int gif_upfirdn2d_f32(const float* x, const float* k, float* y, int B, int Hi, int Wi, int C, int Ho, int Wo,
+                      int up, int down, int padx0, int pady0, int KH, int KW, int flip,
+                      const gif_conv_epilogue* e, gif_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused bias + leaky-ReLU — replaces FusedLeakyReLU.forward stylegan2_common_layers.py:32-39
+ * (y = gain * lrelu(x + residual + bias[c], slope)); x,y [npix, C].
+ * Backward: gx = gy * gain * (y > 0 ? 1 : slope); gbias[c] = sum_pix gx  (gbias may be NULL).
+ * `partial` is scratch of gif_colsum_partial_floats(npix, C) floats (only needed when gbias != NULL).
+ * ---------------------------------------------------------------------------------------------- */
+int gif_bias_act_f32(const float* x, const float* bias, const float* residual, float* y, int64_t npix, int C,
+                     float slope, float gain, gif_stream_t stream);
+int64_t gif_colsum_partial_floats(int64_t npix, int C);
+int gif_bias_act_bwd_f32(const float* gy, const float* y, float* gx, float* gbias, float* partial,
+                         int64_t npix, int C, float slope, float gain, gif_stream_t stream);
+/* out[c] = sum_n x[n,c] */
+int gif_colsum_f32(const float* x, float* out, float* partial, int64_t npix, int C, gif_stream_t stream);
+
+/* out[b,c] = sum_hw a[b,hw,c]*b[b,hw,c] ; if scaled != NULL also scaled[b,hw,c] = scale[b,c]*a[b,hw,c]
+ * (gradients of the modulation / demodulation scales of ModulatedConv2d).  partial: B*nchunk*C floats,
+ * nchunk = gif_mul_reduce_chunks(HW). */
+int gif_mul_reduce_chunks(int64_t HW);
+int gif_mul_reduce_f32(const float* a, const float* b, const float* scale, float* scaled, float* out,
+                       float* partial, int B, int64_t HW, int C, gif_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Minibatch standard deviation — replaces stg2_discriminator.py:59-65.
+ * x [B,H,W,C] -> y [B,H,W,Cy] (Cy >= C+1): y[..., :C] = x, y[..., C] = stat[b % M], rest 0, with
+ * M = B/G, stat[m] = mean_{c,h,w} sqrt(var_{g}(x[g*M+m]) + 1e-8) (biased variance over the G members).
+ * stat [M] is also returned for the backward.
+ * ---------------------------------------------------------------------------------------------- */
+int gif_mbstd_fwd_f32(const float* x, float* y, float* stat, int B, int H, int W, int C, int Cy, int G,
+                      gif_stream_t stream);
+int gif_mbstd_bwd_f32(const float* x, const float* gy, float* gx, int B, int H, int W, int C, int Cy, int G,
+                      gif_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * R1 / path-length reductions — replaces the norm in grad_penalty_loss loss_functions/losses.py:87-99
+ * and PathLengthRegularizor :102-124:  out[b] = sum_{chw} g[b,...]^2   (n = elements per sample).
+ * ---------------------------------------------------------------------------------------------- */
+int gif_sqnorm_per_sample_f32(const float* g, float* out, int B, int64_t n, gif_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Kernel timing for bench.py's roofline line: when enabled, every conv launch is bracketed by HIP
+ * events on its own stream; gif_prof_read() synchronises those events and returns accumulated
+ * milliseconds / algorithmic FLOPs / launch count per kernel family (0 fwd-gather, 1 wgrad).
+ * ---------------------------------------------------------------------------------------------- */
+int gif_prof_enable(int on);
+int gif_prof_read(int family, double* ms, double* flops, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GIF_HIP_H */
