@@ -1,0 +1,179 @@
+#!/usr/bin/env python
+"""bench.py — G+D train-step images/sec at 256x256, batch 32/GPU (BASELINE.json metric), one process per GPU.
+
+    python bench.py --gpus 1 --steps 16 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one full GIF training iteration (train.py:82-250): D step (D fwd real, G fwd, D fwd fake, backward,
+Adam) + G step (G fwd, D fwd, backward, Adam, EMA), R1 on every 16th iteration, run-29 model configuration
+(6-channel rendered condition, 9-channel D input, n_mlp=8, 69 158-entry embedding buffer), synthetic 256x256
+batches generated on device, random-init weights, fp32 (the reference's dtype) on the fp32 MFMA path.
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import contextlib
+import io
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE: 32)")
+    ap.add_argument("--res", type=int, default=256)
+    ap.add_argument("--vocab", type=int, default=69158)
+    ap.add_argument("--r1-every", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--no-prof", action="store_true", help="skip per-kernel HIP-event timing")
+    return ap.parse_args()
+
+
+def cpu_baseline(res, step_idx, batch):
+    """Oracle ("port") timed on the host cores: one full G+D training iteration (no R1) at the benchmark resolution
+    on a small batch (batch 32 needs ~80 GB of activations on the CPU)."""
+    from oracle import stylegan2_ref as R
+    from oracle.train_ref import RefTrainer
+    from gif_amd.discriminator import Discriminator
+    from gif_amd.generator import StyledGenerator
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    with contextlib.redirect_stdout(io.StringIO()):
+        g = StyledGenerator(embedding_vocab_size=64, rendered_flame_ascondition=True, normal_maps_as_cond=True)
+        d = Discriminator(size=res, num_color_chnls=9)
+    tr = RefTrainer(R.seeded_state_dict(g.state_dict(), 1), R.seeded_state_dict(d.state_dict(), 2), res_step=step_idx,
+                    size=res, r1_every=0)
+    gen = torch.Generator().manual_seed(0)
+    real = torch.rand(batch, 3, res, res, generator=gen) * 2 - 1
+    cond = torch.rand(batch, 6, res, res, generator=gen) * 2 - 1
+    idx = torch.randint(0, 64, (batch,), generator=gen)
+    t0 = time.time()
+    tr.step(0, real, cond, idx)
+    dt = time.time() - t0
+    return {"value": batch / dt, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"1 full G+D train step (no R1) at {res}x{res}, batch {batch}, oracle/train_ref.py (torch CPU fp32), "
+                      f"{dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+
+    from gif_amd import ops
+    from gif_amd.discriminator import Discriminator
+    from gif_amd.generator import StyledGenerator
+    from gif_amd.train_step import GifTrainer, flops_per_image
+
+    res_step = {64: 4, 128: 5, 256: 6, 512: 7, 1024: 8}[args.res]
+    torch.manual_seed(0)  # identical initial replicas on every rank (no broadcast needed)
+    with contextlib.redirect_stdout(io.StringIO()):
+        kw = dict(embedding_vocab_size=args.vocab, rendered_flame_ascondition=True, normal_maps_as_cond=True,
+                  core_tensor_res=4, n_mlp=8)
+        G = StyledGenerator(**kw)
+        G_ema = StyledGenerator(**kw)
+        D = Discriminator(size=args.res, num_color_chnls=9, channel_multiplier=2)
+    G_ema.load_state_dict(G.state_dict())
+    G, G_ema, D = G.to(dev), G_ema.to(dev), D.to(dev)
+    trainer = GifTrainer(G, D, G_ema, step=res_step, alpha=1.0, r1_every=args.r1_every)
+
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)  # every rank draws its own synthetic batch
+    B = args.batch
+
+    def batch():
+        real = torch.rand(B, 3, args.res, args.res, device=dev, generator=gen) * 2 - 1
+        cond = torch.rand(B, 6, args.res, args.res, device=dev, generator=gen) * 2 - 1
+        idx = torch.randint(0, args.vocab, (B,), device=dev, generator=gen)
+        return real, cond, idx
+
+    it = 0
+    for _ in range(args.warmup):
+        trainer.step(it, *batch())
+        it += 1
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    data = [batch() for _ in range(min(args.steps, 4))]  # synthetic batches resident in HBM before the timed region
+    if not args.no_prof:
+        ops.prof_read(0), ops.prof_read(1)
+        ops.prof_enable(True)
+    sync()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        trainer.step(it, *data[k % len(data)])
+        it += 1
+    sync()
+    dt = time.perf_counter() - t0
+    ops.prof_enable(False)
+
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = t.item()
+
+    if rank == 0:
+        imgs = world * B * args.steps
+        value = imgs / dt
+        fl_img = flops_per_image(args.res, args.r1_every)
+        step_tflops = value * fl_img / 1e12 / world
+        out = {
+            "metric": f"G+D train-step images/sec at {args.res}x{args.res}, batch {B}/GPU",
+            "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"GIF run-29 G+D training iteration, {args.res}x{args.res}, batch {B}/GPU, "
+                                   f"R1 every {args.r1_every}th step, fp32 MFMA (BASELINE configs[1]/[3] shape)",
+                       "global_batch": world * B, "resolution": args.res, "parallelism": f"dp{world}",
+                       "algorithmic_tflop_per_image": fl_img / 1e12},
+            "step_mfma_roofline": {"achieved": step_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": step_tflops / PEAK_F32_MFMA_TFLOPS,
+                                   "note": "whole step (incl. HBM-bound kernels, optimiser, host) vs fp32 MFMA peak, per GPU"},
+        }
+        if not args.no_prof:
+            ms0, fl0, n0 = ops.prof_read(0)
+            ms1, fl1, n1 = ops.prof_read(1)
+            ach = fl0 / (ms0 * 1e-3) / 1e12 if ms0 > 0 else 0.0
+            out["roofline"] = {"bound": "mfma", "kernel": "conv_gather_mfma (fwd / dgrad / transposed conv, fp32 MFMA)",
+                               "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                               "launches": n0, "avg_ms": ms0 / max(n0, 1), "gpu_ms_per_step": ms0 / args.steps}
+            ach1 = fl1 / (ms1 * 1e-3) / 1e12 if ms1 > 0 else 0.0
+            out["roofline_wgrad"] = {"bound": "mfma", "kernel": "conv_wgrad_mfma", "achieved": ach1,
+                                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach1 / PEAK_F32_MFMA_TFLOPS,
+                                     "launches": n1, "avg_ms": ms1 / max(n1, 1), "gpu_ms_per_step": ms1 / args.steps}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.res, res_step, args.cpu_batch)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,83 @@
+"""ctypes binding of libgif_hip.so (the C ABI declared in include/gif_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, this module raises.
+Build it with `python -c "import __graft_entry__ as g; g.build()"` or `make -C gif_amd/csrc`.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgif_hip.so")
+
+c_int, c_i64, c_float, c_void_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+P = c_void_p  # every device pointer travels as an integer address
+
+
+class ConvGeom(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("B", "Hb", "Wb", "Cb", "Hs", "Ws", "Cs", "KH", "KW", "stride", "pad")]
+
+
+class ConvEpilogue(ctypes.Structure):
+    _fields_ = [("in_scale", P), ("out_scale", P), ("bias", P), ("residual", P),
+                ("act", ctypes.c_int32), ("slope", c_float), ("gain", c_float)]
+
+
+GP, EP = ctypes.POINTER(ConvGeom), ctypes.POINTER(ConvEpilogue)
+
+# name -> (restype, argtypes); must list every symbol of include/gif_hip.h (tests/test_abi.py checks it)
+PROTOTYPES = {
+    "gif_last_error": (ctypes.c_char_p, []),
+    "gif_abi_version": (c_int, []),
+    "gif_rasterize_workspace_bytes": (c_i64, [c_int, c_int, c_int]),
+    "gif_rasterize_f32": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P]),
+    "gif_rasterize_colors_f32": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P, P]),
+    "gif_conv2d_pack_dims": (c_int, [c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "gif_pack_weight_f32": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_float, P]),
+    "gif_conv2d_fwd_f32": (c_int, [P, P, P, GP, EP, P]),
+    "gif_conv2d_bwd_data_f32": (c_int, [P, P, P, GP, EP, P]),
+    "gif_conv2d_wgrad_dims": (c_int, [c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "gif_conv2d_wgrad_splits": (c_int, [GP]),
+    "gif_conv2d_wgrad_f32": (c_int, [P, P, P, P, P, GP, c_int, P]),
+    "gif_unpack_wgrad_f32": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_float, P]),
+    "gif_upfirdn2d_f32": (c_int, [P, P, P] + [c_int] * 13 + [EP, P]),
+    "gif_bias_act_f32": (c_int, [P, P, P, P, c_i64, c_int, c_float, c_float, P]),
+    "gif_colsum_partial_floats": (c_i64, [c_i64, c_int]),
+    "gif_bias_act_bwd_f32": (c_int, [P, P, P, P, P, c_i64, c_int, c_float, c_float, P]),
+    "gif_colsum_f32": (c_int, [P, P, P, c_i64, c_int, P]),
+    "gif_mul_reduce_chunks": (c_int, [c_i64]),
+    "gif_mul_reduce_f32": (c_int, [P, P, P, P, P, P, c_int, c_i64, c_int, P]),
+    "gif_mbstd_fwd_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "gif_mbstd_bwd_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "gif_sqnorm_per_sample_f32": (c_int, [P, P, c_int, c_i64, P]),
+    "gif_prof_enable": (c_int, [c_int]),
+    "gif_prof_read": (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64)]),
+}
+
+_lib = None
+
+
+class GifHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libgif_hip.so once; raise loudly when it is not built (no CPU / eager fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GifHipError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `make -C gif_amd/csrc` "
+            "(or __graft_entry__.build()). gif_amd has no fallback path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so is stale
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().gif_last_error().decode(errors="replace")
+        raise GifHipError(f"{what} failed (rc={rc}): {msg}")

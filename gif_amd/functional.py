@@ -1,0 +1,264 @@
+"""torch.autograd bindings of the gfx950 kernels.
+
+Two families:
+  * Conv2dFn / WgradFn / BiasActFn / Upfirdn2dFn / MbstdFn — every backward is itself expressed with these
+    Functions, so they are differentiable to any order.  The discriminator uses them because R1
+    (grad_penalty_loss, loss_functions/losses.py:87-99, create_graph=True) back-propagates through D's backward.
+  * ModConvFn — the generator's modulated convolution (ModulatedConv2d.forward,
+    stylegan2_common_layers.py:307-349) as ONE fused op: y = d[b,co] * conv(s[b,ci] * x, W); once differentiable.
+All tensors are logical NCHW with NHWC memory (ops.nhwc).
+"""
+import torch
+from torch.autograd import Function
+
+from . import ops
+from .ops import ConvSpec
+
+
+# --------------------------------------------------------------------------------------------------------
+# plain convolution family (twice differentiable)
+# --------------------------------------------------------------------------------------------------------
+class Conv2dFn(Function):
+    """transposed=False: y = conv2d(x, w*wscale); True: y = conv_transpose2d(x, w*wscale) to size out_hw.
+    w is the canonical FORWARD-conv weight [O,I,KH,KW] in both cases."""
+
+    @staticmethod
+    def forward(ctx, x, w, spec, transposed, out_hw, wscale):
+        x = ops.nhwc(x)
+        ctx.spec, ctx.transposed, ctx.wscale = spec, transposed, wscale
+        ctx.save_for_backward(x, w)
+        if not transposed:
+            return ops.conv_fwd(x, w, spec, wscale)
+        return ops.conv_bwd_data(x, w, spec, tuple(out_hw), wscale)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        spec, tr, ws = ctx.spec, ctx.transposed, ctx.wscale
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = Conv2dFn.apply(gy, w, spec, not tr, tuple(x.shape[2:]), ws)
+            assert gx.shape == x.shape, (gx.shape, x.shape)
+        if ctx.needs_input_grad[1]:
+            O, I = w.shape[:2]
+            gw = WgradFn.apply(gy, x, spec, O, I, ws) if not tr else WgradFn.apply(x, gy, spec, O, I, ws)
+        return gx, gw, None, None, None, None
+
+
+class WgradFn(Function):
+    """dW[O,I,KH,KW] = wscale * sum_{b,pix} small (x) big   (small = conv-output side, big = conv-input side)."""
+
+    @staticmethod
+    def forward(ctx, small, big, spec, O, I, wscale):
+        small, big = ops.nhwc(small), ops.nhwc(big)
+        ctx.spec, ctx.wscale = spec, wscale
+        ctx.save_for_backward(small, big)
+        return ops.conv_wgrad(small, big, spec, O, I, wscale)
+
+    @staticmethod
+    def backward(ctx, ggw):
+        small, big = ctx.saved_tensors
+        gs = gb = None
+        if ctx.needs_input_grad[0]:
+            gs = Conv2dFn.apply(big, ggw, ctx.spec, False, None, ctx.wscale)
+        if ctx.needs_input_grad[1]:
+            gb = Conv2dFn.apply(small, ggw, ctx.spec, True, tuple(big.shape[2:]), ctx.wscale)
+        return gs, gb, None, None, None, None
+
+
+def conv2d(x, w, stride=1, pad=0, wscale=1.0):
+    """x [B,C,H,W] with C == pad4(w.shape[1]); returns [B, pad4(O), Ho, Wo]."""
+    return Conv2dFn.apply(x, w, ConvSpec(w.shape[2], w.shape[3], stride, pad), False, None, wscale)
+
+
+def conv_transpose2d(x, w, stride, pad, out_hw, wscale=1.0):
+    """Adjoint of conv2d(., w): x [B, pad4(O), Hs, Ws] -> [B, pad4(I), *out_hw]."""
+    return Conv2dFn.apply(x, w, ConvSpec(w.shape[2], w.shape[3], stride, pad), True, tuple(out_hw), wscale)
+
+
+# --------------------------------------------------------------------------------------------------------
+# fused bias + leaky ReLU (FusedLeakyReLU, stylegan2_common_layers.py:22-39)
+# --------------------------------------------------------------------------------------------------------
+class BiasActFn(Function):
+    @staticmethod
+    def forward(ctx, x, bias, residual, slope, gain):
+        y = ops.bias_act(x, bias, residual, slope, gain)
+        ctx.slope, ctx.gain = slope, gain
+        ctx.has_bias, ctx.has_res = bias is not None, residual is not None
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        want_b = ctx.has_bias and ctx.needs_input_grad[1]
+        gx, gb = BiasActBwdFn.apply(gy, y, want_b, ctx.slope, ctx.gain)
+        return (gx if ctx.needs_input_grad[0] else None, gb if want_b else None,
+                gx if (ctx.has_res and ctx.needs_input_grad[2]) else None, None, None)
+
+
+class BiasActBwdFn(Function):
+    """gx = gy * gain * (y>0 ? 1 : slope); gbias = sum_pix gx.  Linear in gy; the mask is locally constant in y."""
+
+    @staticmethod
+    def forward(ctx, gy, y, want_gbias, slope, gain):
+        gx, gb = ops.bias_act_bwd(gy, y, want_gbias, slope, gain)
+        ctx.slope, ctx.gain = slope, gain
+        ctx.save_for_backward(y)
+        if gb is None:
+            gb = gx.new_zeros(())
+            ctx.mark_non_differentiable(gb)
+        return gx, gb
+
+    @staticmethod
+    def backward(ctx, ggx, ggb):
+        (y,) = ctx.saved_tensors
+        t = ggx
+        if ggb is not None and ggb.dim() == 1:
+            t = ggb.view(1, -1, 1, 1).expand_as(y) if t is None else t + ggb.view(1, -1, 1, 1)
+        if t is None:
+            return None, None, None, None, None
+        ggy, _ = BiasActBwdFn.apply(t, y, False, ctx.slope, ctx.gain)
+        return ggy, None, None, None, None
+
+
+def bias_act(x, bias=None, residual=None, slope=0.2, gain=2 ** 0.5):
+    """gain * leaky_relu(x + residual + bias[c], slope); bias is a flat [C] tensor matching x's channel count."""
+    return BiasActFn.apply(x, bias, residual, slope, gain)
+
+
+# --------------------------------------------------------------------------------------------------------
+# upfirdn2d (stylegan2_common_layers.py:42-72)
+# --------------------------------------------------------------------------------------------------------
+class Upfirdn2dFn(Function):
+    @staticmethod
+    def forward(ctx, x, k, up, down, pad0, out_hw, flip):
+        x = ops.nhwc(x)
+        ctx.cfg = (up, down, pad0, flip, tuple(x.shape[2:]))
+        ctx.save_for_backward(k)
+        return ops.upfirdn2d(x, k, up, down, pad0, tuple(out_hw), flip)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (k,) = ctx.saved_tensors
+        up, down, pad0, flip, in_hw = ctx.cfg
+        # adjoint of a FIR resampler is a FIR resampler: swap up/down, reverse the taps, pad0' = K-1-pad0
+        gx = Upfirdn2dFn.apply(gy, k, down, up, k.shape[0] - 1 - pad0, in_hw, not flip)
+        return gx, None, None, None, None, None, None
+
+
+def upfirdn2d(x, kernel, up=1, down=1, pad=(0, 0)):
+    """Same call signature as the reference function; square kernels, symmetric-axis pads."""
+    kh, kw = kernel.shape
+    assert kh == kw, "square FIR kernels only"
+    H, W = x.shape[2:]
+    Ho = (H * up + pad[0] + pad[1] - kh) // down + 1
+    Wo = (W * up + pad[0] + pad[1] - kw) // down + 1
+    return Upfirdn2dFn.apply(x, kernel, up, down, pad[0], (Ho, Wo), True)
+
+
+# --------------------------------------------------------------------------------------------------------
+# minibatch standard deviation (stg2_discriminator.py:59-65)
+# --------------------------------------------------------------------------------------------------------
+def _mbstd_torch(x, G):
+    """Differentiable torch restatement on the tiny [B,C,4,4] tensor; used ONLY for the second-order term of R1."""
+    B, C, H, W = x.shape
+    s = x.reshape(G, B // G, C, H, W)
+    s = torch.sqrt(s.var(0, unbiased=False) + 1e-8).mean(dim=(1, 2, 3))  # [M]
+    return s
+
+
+class MbstdFn(Function):
+    @staticmethod
+    def forward(ctx, x, G, Cy):
+        x = ops.nhwc(x)
+        ctx.G = G
+        ctx.save_for_backward(x)
+        y, _ = ops.mbstd_fwd(x, G, Cy)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        return MbstdBwdFn.apply(x, gy, ctx.G), None, None
+
+
+class MbstdBwdFn(Function):
+    @staticmethod
+    def forward(ctx, x, gy, G):
+        ctx.G = G
+        ctx.save_for_backward(x, gy)
+        return ops.mbstd_bwd(x, gy, G)
+
+    @staticmethod
+    def backward(ctx, ggx):
+        x, gy = ctx.saved_tensors
+        G, C = ctx.G, x.shape[1]
+        B, M = x.shape[0], x.shape[0] // ctx.G
+        with torch.enable_grad():
+            xd = x.detach().requires_grad_(True)
+            gstat = gy[:, C].reshape(G, M, -1).sum(dim=(0, 2)).detach().requires_grad_(True)  # [M]
+            stat = _mbstd_torch(xd, G)
+            (gx_stat,) = torch.autograd.grad(stat, xd, gstat, create_graph=True)
+            # gx = gy[:, :C] + gx_stat(x, gstat);  contract with ggx
+            scalar = (gx_stat * ggx).sum()
+            gxd, ggstat = torch.autograd.grad(scalar, (xd, gstat))
+        ggy = torch.zeros_like(gy)
+        ggy[:, :C] = ggx
+        ggy[:, C] = ggstat.repeat(G)[:, None, None].expand(B, *gy.shape[2:])
+        return gxd.contiguous(memory_format=ops.CL), ggy, None
+
+
+def minibatch_stddev(x, group, Cy):
+    return MbstdFn.apply(x, group, Cy)
+
+
+# --------------------------------------------------------------------------------------------------------
+# generator: fused modulated convolution (once differentiable)
+# --------------------------------------------------------------------------------------------------------
+class ModConvFn(Function):
+    """y = d * conv(s * x, w * wscale) with per-sample s [B,Cin] (modulation) and d [B,Cout] (demodulation, or None).
+    transposed=True runs the stride-2 up-sampling branch (conv_transpose2d, stylegan2_common_layers.py:322-330)."""
+
+    @staticmethod
+    def forward(ctx, x, w, s, d, spec, transposed, out_hw, wscale):
+        x = ops.nhwc(x)
+        s = s.contiguous()
+        d = None if d is None else d.contiguous()
+        if not transposed:
+            y = ops.conv_fwd(x, w, spec, wscale, in_scale=s, out_scale=d)
+        else:
+            y = ops.conv_bwd_data(x, w, spec, tuple(out_hw), wscale, in_scale=s, out_scale=d)
+        ctx.spec, ctx.transposed, ctx.wscale = spec, transposed, wscale
+        ctx.save_for_backward(x, w, s, d if d is not None else x.new_zeros(()), y if d is not None else x.new_zeros(()))
+        ctx.has_d = d is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, s, d, y = ctx.saved_tensors
+        d = d if ctx.has_d else None
+        spec, tr, ws = ctx.spec, ctx.transposed, ctx.wscale
+        gy = ops.nhwc(gy)
+        O, I = w.shape[:2]
+        gx = gs = gd = gw = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
+            # gradient w.r.t. (s*x): adjoint conv applied to d*gy (d enters as the input scale of the adjoint)
+            if not tr:
+                dxs = ops.conv_bwd_data(gy, w, spec, tuple(x.shape[2:]), ws, in_scale=d)
+            else:
+                dxs = ops.conv_fwd(gy, w, spec, ws, in_scale=d)
+            gs, gx = ops.mul_reduce(dxs, x, scale=s, want_scaled=True)
+        if ctx.needs_input_grad[1]:
+            if not tr:
+                gw = ops.conv_wgrad(gy, x, spec, O, I, ws, small_scale=d, big_scale=s)
+            else:
+                gw = ops.conv_wgrad(x, gy, spec, O, I, ws, small_scale=s, big_scale=d)
+        if ctx.has_d and ctx.needs_input_grad[3]:
+            num, _ = ops.mul_reduce(gy, y)
+            gd = num / d
+        return gx, gw, gs, gd, None, None, None, None
+
+
+def modulated_conv2d(x, w, s, d, stride=1, pad=0, transposed=False, out_hw=None, wscale=1.0):
+    return ModConvFn.apply(x, w, s, d, ConvSpec(w.shape[2], w.shape[3], stride, pad), transposed, out_hw, wscale)

@@ -1,0 +1,352 @@
+"""MI355X-native layer library behind the reference's layer API.
+
+Host-side mirror of /root/reference/model/stylegan2_common_layers.py: same class names, constructor
+arguments, parameter / buffer names and shapes (so reference state_dicts load with strict=True) and the
+same forward() semantics — but every tensor op heavier than a 512x512 linear runs in the hand-written
+gfx950 kernels of libgif_hip.so (gif_amd/csrc) through gif_amd.functional.  Internally activations are
+NHWC fp32 with channel counts padded to a multiple of 4; module inputs/outputs keep the reference's logical
+[B,C,H,W] shapes.  There is no eager/CPU fallback: CPU tensors raise.
+"""
+import math
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from . import functional as GF
+from .ops import pad4
+
+
+def _pad_vec(v, n):
+    """flat per-channel vector padded with zeros to n entries (for 3->4 channel RGB tensors)."""
+    v = v.reshape(-1)
+    return v if v.numel() == n else F.pad(v, (0, n - v.numel()))
+
+
+class FusedLeakyReLU(nn.Module):
+    """sqrt(2) * leaky_relu(x + bias, 0.2) — reference :22-39 — one kernel (gif_bias_act_f32)."""
+
+    def __init__(self, channel, negative_slope=0.2, scale=2 ** 0.5):
+        super().__init__()
+        self.bias = nn.Parameter(torch.zeros(1, channel, 1, 1))
+        self.negative_slope = negative_slope
+        self.scale = scale
+
+    def forward(self, input, residual=None):
+        return GF.bias_act(input, _pad_vec(self.bias, input.shape[1]), residual, self.negative_slope, self.scale)
+
+
+def upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0)):
+    """FIR resampling — reference :42-72 — gif_upfirdn2d_f32."""
+    return GF.upfirdn2d(input, kernel, up=up, down=down, pad=pad)
+
+
+class PixelNorm(nn.Module):
+    def forward(self, input):  # [B,512] vectors: plain torch (reference :75-80)
+        return input * torch.rsqrt(torch.mean(input ** 2, dim=1, keepdim=True) + 1e-8)
+
+
+def make_kernel(k):
+    k = torch.tensor(k, dtype=torch.float32)
+    if k.ndim == 1:
+        k = k[None, :] * k[:, None]
+    k /= k.sum()
+    return k
+
+
+class Upsample(nn.Module):
+    def __init__(self, kernel, factor=2):
+        super().__init__()
+        self.factor = factor
+        self.register_buffer('kernel', make_kernel(kernel) * (factor ** 2))
+        p = self.kernel.shape[0] - factor
+        self.pad = ((p + 1) // 2 + factor - 1, p // 2)
+
+    def forward(self, input):
+        return upfirdn2d(input, self.kernel, up=self.factor, down=1, pad=self.pad)
+
+
+class Downsample(nn.Module):
+    def __init__(self, kernel, factor=2):
+        super().__init__()
+        self.factor = factor
+        self.register_buffer('kernel', make_kernel(kernel))
+        p = self.kernel.shape[0] - factor
+        self.pad = ((p + 1) // 2, p // 2)
+
+    def forward(self, input):
+        return upfirdn2d(input, self.kernel, up=1, down=self.factor, pad=self.pad)
+
+
+class Blur(nn.Module):
+    def __init__(self, kernel, pad, upsample_factor=1):
+        super().__init__()
+        kernel = make_kernel(kernel)
+        if upsample_factor > 1:
+            kernel = kernel * (upsample_factor ** 2)
+        self.register_buffer('kernel', kernel)
+        self.pad = pad
+
+    def forward(self, input):
+        return upfirdn2d(input, self.kernel, pad=self.pad)
+
+
+class EqualConv2d(nn.Module):
+    """conv2d(x, W / sqrt(fan_in)) — reference :155-190 — fp32 MFMA implicit GEMM (gif_conv2d_fwd_f32)."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, stride=1, padding=0, bias=True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(out_channel, in_channel, kernel_size, kernel_size))
+        self.scale = 1 / math.sqrt(in_channel * kernel_size ** 2)
+        self.stride = stride
+        self.padding = padding
+        self.bias = nn.Parameter(torch.zeros(out_channel)) if bias else None
+
+    def forward(self, input):
+        out = GF.conv2d(input, self.weight, self.stride, self.padding, wscale=self.scale)
+        if self.bias is not None:
+            out = GF.bias_act(out, _pad_vec(self.bias, out.shape[1]), None, 1.0, 1.0)
+        return out
+
+    def __repr__(self):
+        return (f'{self.__class__.__name__}({self.weight.shape[1]}, {self.weight.shape[0]},'
+                f' {self.weight.shape[2]}, stride={self.stride}, padding={self.padding})')
+
+
+class EqualLinear(nn.Module):
+    """Reference :193-235.  512x512 / 8192x512 GEMMs on [B,.] vectors: library GEMM through torch."""
+
+    def __init__(self, in_dim, out_dim, bias=True, bias_init=0, lr_mul=1, activation=None, scale_weight=1.0,
+                 apply_sqrt2_fac_in_eq_lin=False):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(out_dim, in_dim).div_(lr_mul / scale_weight))
+        self.bias = nn.Parameter(torch.zeros(out_dim).fill_(bias_init)) if bias else None
+        self.activation = activation
+        self.scale = (1 / math.sqrt(in_dim)) * lr_mul
+        self.lr_mul = lr_mul
+        self.apply_sqrt2_fac_in_eq_lin = apply_sqrt2_fac_in_eq_lin
+
+    def forward(self, input):
+        if self.activation:
+            out = F.linear(input, self.weight * self.scale)
+            out = F.leaky_relu(out + self.bias * self.lr_mul, negative_slope=0.2)
+            if self.apply_sqrt2_fac_in_eq_lin:
+                out = out * 1.41421356237
+        else:
+            out = F.linear(input, self.weight * self.scale, bias=self.bias * self.lr_mul)
+        return out
+
+    def __repr__(self):
+        return f'{self.__class__.__name__}({self.weight.shape[1]}, {self.weight.shape[0]})'
+
+
+class ScaledLeakyReLU(nn.Module):
+    def __init__(self, negative_slope=0.2):
+        super().__init__()
+        self.negative_slope = negative_slope
+
+    def forward(self, input):
+        return GF.bias_act(input, None, None, self.negative_slope, math.sqrt(2))
+
+
+class ModulatedConv2d(nn.Module):
+    """Reference :250-349.  The per-sample weight tensor of the reference (groups=batch) is never built:
+    y = d[b,co] * conv(s[b,ci] * x, scale*W), d = rsqrt(scale^2 * sum_ci s^2 * sum_k W^2 + eps) — identical algebra,
+    run as one fused MFMA kernel (GF.modulated_conv2d)."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, style_dim, demodulate=True, upsample=False,
+                 downsample=False, blur_kernel=[1, 3, 3, 1], apply_sqrt2_fac_in_eq_lin=False):
+        super().__init__()
+        self.eps = 1e-8
+        self.kernel_size = kernel_size
+        self.in_channel = in_channel
+        self.out_channel = out_channel
+        self.upsample = upsample
+        self.downsample = downsample
+        if upsample:
+            factor = 2
+            p = (len(blur_kernel) - factor) - (kernel_size - 1)
+            self.blur = Blur(blur_kernel, pad=((p + 1) // 2 + factor - 1, p // 2 + 1), upsample_factor=factor)
+        if downsample:
+            factor = 2
+            p = (len(blur_kernel) - factor) + (kernel_size - 1)
+            self.blur = Blur(blur_kernel, pad=((p + 1) // 2, p // 2))
+        self.scale = 1 / math.sqrt(in_channel * kernel_size ** 2)
+        self.padding = kernel_size // 2
+        self.weight = nn.Parameter(torch.randn(1, out_channel, in_channel, kernel_size, kernel_size))
+        self.modulation = EqualLinear(style_dim, in_channel, bias_init=1,
+                                      apply_sqrt2_fac_in_eq_lin=apply_sqrt2_fac_in_eq_lin)
+        self.demodulate = demodulate
+
+    def __repr__(self):
+        return (f'{self.__class__.__name__}({self.in_channel}, {self.out_channel}, {self.kernel_size}, '
+                f'upsample={self.upsample}, downsample={self.downsample})')
+
+    def scales(self, style):
+        """(s [B,Cin_act], d [B,Cout_act] or None) in fp32; tiny [B,512]-sized torch math, differentiable."""
+        s = self.modulation(style)
+        d = None
+        if self.demodulate:
+            wsq = self.weight[0].pow(2).sum(dim=(2, 3))  # [Cout, Cin]
+            d = torch.rsqrt((self.scale ** 2) * (s.pow(2) @ wsq.t()) + self.eps)
+        return s, d
+
+    def forward(self, input, style):
+        batch, in_act, height, width = input.shape
+        s, d = self.scales(style)
+        if in_act != self.in_channel:  # channel-padded activation: padded lanes are zero, scale is irrelevant
+            s = F.pad(s, (0, in_act - self.in_channel), value=1.0)
+        if d is not None and pad4(self.out_channel) != self.out_channel:
+            d = F.pad(d, (0, pad4(self.out_channel) - self.out_channel), value=1.0)
+        w = self.weight[0]  # [Cout, Cin, k, k]
+        if self.upsample:
+            # conv_transpose2d(x, W^T, stride 2): underlying forward conv maps Cout -> Cin, so canonical = W^T view
+            out = GF.modulated_conv2d(input, w.transpose(0, 1), s, d, stride=2, pad=0, transposed=True,
+                                      out_hw=(2 * height + self.kernel_size - 2, 2 * width + self.kernel_size - 2),
+                                      wscale=self.scale)
+            out = self.blur(out)
+        elif self.downsample:
+            out = GF.modulated_conv2d(self.blur(input), w, s, d, stride=2, pad=0, wscale=self.scale)
+        else:
+            out = GF.modulated_conv2d(input, w, s, d, stride=1, pad=self.padding, wscale=self.scale)
+        return out
+
+
+class NoiseInjection(nn.Module):
+    """GIF's condition-driven 'noise': 3x(conv3x3+bias), ReLU between — reference :388-431."""
+
+    @staticmethod
+    def small_init_weights(m):
+        if hasattr(m, 'weight'):
+            m.weight.data = torch.randn_like(m.weight) / 100
+        if hasattr(m, 'bias'):
+            m.bias.data.fill_(0.0001)
+
+    def __init__(self, noise_in_chalnnels, noise_out_channels):
+        super().__init__()
+        self.noise_in_chalnnels = noise_in_chalnnels
+        c = noise_in_chalnnels
+        # nn.Conv2d / nn.ReLU are parameter containers only (state_dict keys noise_conv.{0,2,4}.*); the math is HIP
+        self.noise_conv = nn.Sequential(
+            nn.Conv2d(c, 2 * c, 3, padding=1), nn.ReLU(),
+            nn.Conv2d(2 * c, 4 * c, 3, padding=1), nn.ReLU(),
+            nn.Conv2d(4 * c, noise_out_channels, 3, padding=1))
+        self.noise_conv.apply(NoiseInjection.small_init_weights)
+
+    def convolve(self, noise):
+        h = noise
+        for idx in (0, 2, 4):
+            conv = self.noise_conv[idx]
+            h = GF.conv2d(h, conv.weight, 1, 1)
+            last = idx == 4
+            # bias (+ReLU): leaky_relu with slope 0 / gain 1; the last conv has no activation (slope 1)
+            h = GF.bias_act(h, _pad_vec(conv.bias, h.shape[1]), None, 1.0 if last else 0.0, 1.0)
+        return h
+
+    def forward(self, image, noise):
+        batch, _, height, width = image.shape
+        if noise is None:
+            noise = image.new_empty(batch, pad4(self.noise_in_chalnnels), height, width).normal_()
+            noise[:, self.noise_in_chalnnels:] = 0
+        return GF.bias_act(image, None, self.convolve(noise), 1.0, 1.0)
+
+
+class ConstantInput(nn.Module):
+    def __init__(self, channel, size=4):
+        super().__init__()
+        self.input = nn.Parameter(torch.randn(1, channel, size, size))
+
+    def forward(self, input):
+        return self.input.repeat(input.shape[0], 1, 1, 1)
+
+
+class StyledConv(nn.Module):
+    """act(modconv(x, w) + noise_conv(cond) + bias) — reference :447-486; the add/bias/lrelu are one kernel."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, noise_in_dims, style_dim=512, upsample=False,
+                 blur_kernel=[1, 3, 3, 1], demodulate=True, apply_sqrt2_fac_in_eq_lin=False):
+        super().__init__()
+        self.conv = ModulatedConv2d(in_channel, out_channel, kernel_size, style_dim, upsample=upsample,
+                                    blur_kernel=blur_kernel, demodulate=demodulate,
+                                    apply_sqrt2_fac_in_eq_lin=apply_sqrt2_fac_in_eq_lin)
+        self.noise = NoiseInjection(noise_in_dims, out_channel)
+        self.activate = FusedLeakyReLU(out_channel)
+
+    def forward(self, input, style, noise=None):
+        out = self.conv(input, style)
+        if noise is None:
+            out = self.noise(out, noise=None)
+            return self.activate(out)
+        return self.activate(out, residual=self.noise.convolve(noise))
+
+
+class ToRGB(nn.Module):
+    """1x1 modulated conv without demodulation + bias + upsampled skip — reference :489-511.
+    Internally RGB tensors carry 4 channels (the 4th is zero)."""
+
+    def __init__(self, in_channel, style_dim, upsample=True, blur_kernel=[1, 3, 3, 1],
+                 apply_sqrt2_fac_in_eq_lin=False):
+        super().__init__()
+        if upsample:
+            self.upsample = Upsample(blur_kernel)
+        self.conv = ModulatedConv2d(in_channel, 3, 1, style_dim, demodulate=False,
+                                    apply_sqrt2_fac_in_eq_lin=apply_sqrt2_fac_in_eq_lin)
+        self.bias = nn.Parameter(torch.zeros(1, 3, 1, 1))
+
+    def forward(self, input, style, skip=None):
+        out = self.conv(input, style)
+        if skip is not None:
+            skip = self.upsample(skip)
+        return GF.bias_act(out, _pad_vec(self.bias, out.shape[1]), skip, 1.0, 1.0)
+
+
+def get_w_frm_z(n_mlp, style_dim, lr_mlp=1, scale_weight=1.0):
+    if n_mlp > 0:
+        layers = [PixelNorm()]
+        for i in range(n_mlp):
+            layers.append(EqualLinear(style_dim, style_dim, lr_mul=lr_mlp, activation='fused_lrelu',
+                                      scale_weight=scale_weight))
+        return nn.Sequential(*layers)
+
+    class Net(nn.Module):
+        def forward(self, *args):
+            return args[0]
+
+    return Net()
+
+
+class ConvLayer(nn.Sequential):
+    """[Blur] -> EqualConv2d -> FusedLeakyReLU — reference :752-799."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, downsample=False, blur_kernel=[1, 3, 3, 1], bias=True,
+                 activate=True):
+        layers = []
+        if downsample:
+            factor = 2
+            p = (len(blur_kernel) - factor) + (kernel_size - 1)
+            layers.append(Blur(blur_kernel, pad=((p + 1) // 2, p // 2)))
+            stride = 2
+            self.padding = 0
+        else:
+            stride = 1
+            self.padding = kernel_size // 2
+        layers.append(EqualConv2d(in_channel, out_channel, kernel_size, padding=self.padding, stride=stride,
+                                  bias=bias and not activate))
+        if activate:
+            layers.append(FusedLeakyReLU(out_channel) if bias else ScaledLeakyReLU(0.2))
+        super().__init__(*layers)
+
+
+class ResBlock(nn.Module):
+    """Reference :802-820; (out + skip)/sqrt(2) is one fused kernel."""
+
+    def __init__(self, in_channel, out_channel, blur_kernel=[1, 3, 3, 1]):
+        super().__init__()
+        self.conv1 = ConvLayer(in_channel, in_channel, 3)
+        self.conv2 = ConvLayer(in_channel, out_channel, 3, downsample=True)
+        self.skip = ConvLayer(in_channel, out_channel, 1, downsample=True, activate=False, bias=False)
+
+    def forward(self, input):
+        out = self.conv2(self.conv1(input))
+        skip = self.skip(input)
+        return GF.bias_act(out, None, skip, 1.0, 1 / math.sqrt(2))

@@ -1,0 +1,265 @@
+"""Raw (non-autograd) launches of the gfx950 kernels on torch device tensors.
+
+Conventions: activations are torch tensors of LOGICAL shape [B,C,H,W] whose memory is NHWC
+(torch.channels_last) fp32 with C % 4 == 0; everything runs on torch's current HIP stream.
+torch is used for device memory and streams only — all arithmetic is in libgif_hip.so.
+"""
+import ctypes
+from typing import NamedTuple, Optional
+
+import torch
+
+from . import _lib
+
+CL = torch.channels_last
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def pad4(c: int) -> int:
+    return (c + 3) // 4 * 4
+
+
+def nhwc(x: torch.Tensor) -> torch.Tensor:
+    """fp32, device-resident, NHWC memory.  Fails loudly on CPU tensors: there is no CPU path."""
+    if not x.is_cuda:
+        raise _lib.GifHipError("gif_amd kernels need device tensors (no CPU fallback); got a CPU tensor")
+    if x.dtype != torch.float32:
+        raise _lib.GifHipError(f"gif_amd kernels are fp32; got {x.dtype}")
+    if x.dim() != 4:
+        raise _lib.GifHipError(f"expected a 4-D activation, got shape {tuple(x.shape)}")
+    return x.contiguous(memory_format=CL)
+
+
+def empty_nhwc(B, C, H, W, device):
+    return torch.empty((B, C, H, W), device=device, dtype=torch.float32, memory_format=CL)
+
+
+class ConvSpec(NamedTuple):
+    """The underlying FORWARD convolution (see include/gif_hip.h)."""
+    KH: int
+    KW: int
+    stride: int
+    pad: int
+
+    def small_hw(self, Hb, Wb):
+        return ((Hb + 2 * self.pad - self.KH) // self.stride + 1, (Wb + 2 * self.pad - self.KW) // self.stride + 1)
+
+    def big_hw(self, Hs, Ws):
+        return ((Hs - 1) * self.stride + self.KH - 2 * self.pad, (Ws - 1) * self.stride + self.KW - 2 * self.pad)
+
+
+def _geom(B, Hb, Wb, Cb, Hs, Ws, Cs, spec: ConvSpec):
+    return _lib.ConvGeom(B, Hb, Wb, Cb, Hs, Ws, Cs, spec.KH, spec.KW, spec.stride, spec.pad)
+
+
+def _epilogue(in_scale=None, out_scale=None, bias=None, residual=None, act=False, slope=0.2, gain=2 ** 0.5):
+    return _lib.ConvEpilogue(_p(in_scale), _p(out_scale), _p(bias), _p(residual), 1 if act else 0, slope, gain)
+
+
+def pack_weight(w: torch.Tensor, rows_are_out: bool, cout_act: int, cin_act: int, scale: float = 1.0):
+    """Pack a canonical forward-conv weight view w[O,I,KH,KW] (any strides) into [T][RP][CP].
+
+    rows_are_out=True : rows = O, cols = I (operand of gif_conv2d_fwd_f32)
+    rows_are_out=False: rows = I, cols = O (operand of gif_conv2d_bwd_data_f32)
+    cout_act / cin_act are the channel counts of the op's output / input ACTIVATIONS (>= canonical counts).
+    """
+    lib = _lib.load()
+    O, I, KH, KW = w.shape
+    so, si, sky, skx = w.stride()
+    R, C, sr, sc = (O, I, so, si) if rows_are_out else (I, O, si, so)
+    assert R <= cout_act and C <= cin_act, (R, cout_act, C, cin_act)
+    RP, CP = ctypes.c_int(), ctypes.c_int()
+    _lib.check(lib.gif_conv2d_pack_dims(cout_act, cin_act, ctypes.byref(RP), ctypes.byref(CP)), "pack_dims")
+    wp = torch.empty((KH * KW, RP.value, CP.value), device=w.device, dtype=torch.float32)
+    _lib.check(lib.gif_pack_weight_f32(w.data_ptr(), wp.data_ptr(), R, C, KH, KW, RP.value, CP.value, sr, sc, sky, skx,
+                                       float(scale), _stream()), "pack_weight")
+    return wp
+
+
+def conv_fwd(big, w, spec: ConvSpec, wscale=1.0, **epi):
+    """small = conv2d(big, w[O,I,KH,KW]) ; returns [B, pad4(O), Hs, Ws]."""
+    lib = _lib.load()
+    big = nhwc(big)
+    B, Cb, Hb, Wb = big.shape
+    O = w.shape[0]
+    Cs = pad4(O)
+    Hs, Ws = spec.small_hw(Hb, Wb)
+    wp = pack_weight(w, True, Cs, Cb, wscale)
+    out = empty_nhwc(B, Cs, Hs, Ws, big.device)
+    g = _geom(B, Hb, Wb, Cb, Hs, Ws, Cs, spec)
+    e = _epilogue(**epi)
+    _lib.check(lib.gif_conv2d_fwd_f32(big.data_ptr(), wp.data_ptr(), out.data_ptr(), ctypes.byref(g), ctypes.byref(e),
+                                      _stream()), "conv2d_fwd")
+    return out
+
+
+def conv_bwd_data(small, w, spec: ConvSpec, big_hw, wscale=1.0, **epi):
+    """big = conv_transpose2d(small, w[O,I,KH,KW]) ; returns [B, pad4(I), Hb, Wb]."""
+    lib = _lib.load()
+    small = nhwc(small)
+    B, Cs, Hs, Ws = small.shape
+    I = w.shape[1]
+    Cb = pad4(I)
+    Hb, Wb = big_hw
+    wp = pack_weight(w, False, Cb, Cs, wscale)
+    out = empty_nhwc(B, Cb, Hb, Wb, small.device)
+    g = _geom(B, Hb, Wb, Cb, Hs, Ws, Cs, spec)
+    e = _epilogue(**epi)
+    _lib.check(lib.gif_conv2d_bwd_data_f32(small.data_ptr(), wp.data_ptr(), out.data_ptr(), ctypes.byref(g),
+                                           ctypes.byref(e), _stream()), "conv2d_bwd_data")
+    return out
+
+
+def conv_wgrad(small, big, spec: ConvSpec, O, I, wscale=1.0, small_scale=None, big_scale=None):
+    """dW[O,I,KH,KW] = wscale * sum small (x) big  (contiguous canonical layout)."""
+    lib = _lib.load()
+    small, big = nhwc(small), nhwc(big)
+    B, Cs, Hs, Ws = small.shape
+    _, Cb, Hb, Wb = big.shape
+    assert O <= Cs and I <= Cb
+    g = _geom(B, Hb, Wb, Cb, Hs, Ws, Cs, spec)
+    RP, CP = ctypes.c_int(), ctypes.c_int()
+    _lib.check(lib.gif_conv2d_wgrad_dims(Cs, Cb, ctypes.byref(RP), ctypes.byref(CP)), "wgrad_dims")
+    nsplit = lib.gif_conv2d_wgrad_splits(ctypes.byref(g))
+    T = spec.KH * spec.KW
+    ws = torch.empty((nsplit, T, RP.value, CP.value), device=small.device, dtype=torch.float32)
+    _lib.check(lib.gif_conv2d_wgrad_f32(small.data_ptr(), big.data_ptr(), ws.data_ptr(), _p(small_scale), _p(big_scale),
+                                        ctypes.byref(g), nsplit, _stream()), "conv2d_wgrad")
+    dw = torch.empty((O, I, spec.KH, spec.KW), device=small.device, dtype=torch.float32)
+    so, si, sky, skx = dw.stride()
+    _lib.check(lib.gif_unpack_wgrad_f32(ws.data_ptr(), dw.data_ptr(), nsplit, O, I, spec.KH, spec.KW, RP.value, CP.value,
+                                        so, si, sky, skx, float(wscale), _stream()), "unpack_wgrad")
+    return dw
+
+
+def upfirdn2d(x, k, up, down, pad0, out_hw, flip=True, bias=None, residual=None, act=False, slope=0.2, gain=2 ** 0.5):
+    lib = _lib.load()
+    x = nhwc(x)
+    B, C, Hi, Wi = x.shape
+    Ho, Wo = out_hw
+    KH, KW = k.shape
+    k = k.contiguous()
+    y = empty_nhwc(B, C, Ho, Wo, x.device)
+    e = _epilogue(bias=bias, residual=residual, act=act, slope=slope, gain=gain)
+    _lib.check(lib.gif_upfirdn2d_f32(x.data_ptr(), k.data_ptr(), y.data_ptr(), B, Hi, Wi, C, Ho, Wo, up, down, pad0, pad0,
+                                     KH, KW, 1 if flip else 0, ctypes.byref(e), _stream()), "upfirdn2d")
+    return y
+
+
+def bias_act(x, bias=None, residual=None, slope=0.2, gain=2 ** 0.5):
+    lib = _lib.load()
+    x = nhwc(x)
+    B, C, H, W = x.shape
+    if residual is not None:
+        residual = nhwc(residual)
+        assert residual.shape == x.shape
+    y = empty_nhwc(B, C, H, W, x.device)
+    _lib.check(lib.gif_bias_act_f32(x.data_ptr(), _p(bias), _p(residual), y.data_ptr(), B * H * W, C, slope, gain,
+                                    _stream()), "bias_act")
+    return y
+
+
+def bias_act_bwd(gy, y, want_gbias, slope=0.2, gain=2 ** 0.5):
+    lib = _lib.load()
+    gy, y = nhwc(gy), nhwc(y)
+    B, C, H, W = y.shape
+    npix = B * H * W
+    gx = empty_nhwc(B, C, H, W, y.device)
+    gbias = partial = None
+    if want_gbias:
+        gbias = torch.empty((C,), device=y.device, dtype=torch.float32)
+        partial = torch.empty((lib.gif_colsum_partial_floats(npix, C),), device=y.device, dtype=torch.float32)
+    _lib.check(lib.gif_bias_act_bwd_f32(gy.data_ptr(), y.data_ptr(), gx.data_ptr(), _p(gbias), _p(partial), npix, C, slope,
+                                        gain, _stream()), "bias_act_bwd")
+    return gx, gbias
+
+
+def colsum(x):
+    """[B,C,H,W] (NHWC) -> [C] sum over B,H,W."""
+    lib = _lib.load()
+    x = nhwc(x)
+    B, C, H, W = x.shape
+    npix = B * H * W
+    out = torch.empty((C,), device=x.device, dtype=torch.float32)
+    partial = torch.empty((lib.gif_colsum_partial_floats(npix, C),), device=x.device, dtype=torch.float32)
+    _lib.check(lib.gif_colsum_f32(x.data_ptr(), out.data_ptr(), partial.data_ptr(), npix, C, _stream()), "colsum")
+    return out
+
+
+def mul_reduce(a, b, scale=None, want_scaled=False):
+    """out[b,c] = sum_hw a*b ; optionally scaled = scale[b,c]*a."""
+    lib = _lib.load()
+    a, b = nhwc(a), nhwc(b)
+    B, C, H, W = a.shape
+    assert b.shape == a.shape
+    nchunk = lib.gif_mul_reduce_chunks(H * W)
+    out = torch.empty((B, C), device=a.device, dtype=torch.float32)
+    partial = torch.empty((B * nchunk * C,), device=a.device, dtype=torch.float32)
+    scaled = empty_nhwc(B, C, H, W, a.device) if want_scaled else None
+    if scale is not None:
+        scale = scale.contiguous()
+        assert scale.shape == (B, C)
+    _lib.check(lib.gif_mul_reduce_f32(a.data_ptr(), b.data_ptr(), _p(scale), _p(scaled), out.data_ptr(), partial.data_ptr(),
+                                      B, H * W, C, _stream()), "mul_reduce")
+    return out, scaled
+
+
+def mbstd_fwd(x, G, Cy):
+    lib = _lib.load()
+    x = nhwc(x)
+    B, C, H, W = x.shape
+    y = empty_nhwc(B, Cy, H, W, x.device)
+    stat = torch.empty((B // G,), device=x.device, dtype=torch.float32)
+    _lib.check(lib.gif_mbstd_fwd_f32(x.data_ptr(), y.data_ptr(), stat.data_ptr(), B, H, W, C, Cy, G, _stream()), "mbstd_fwd")
+    return y, stat
+
+
+def mbstd_bwd(x, gy, G):
+    lib = _lib.load()
+    x, gy = nhwc(x), nhwc(gy)
+    B, C, H, W = x.shape
+    Cy = gy.shape[1]
+    gx = empty_nhwc(B, C, H, W, x.device)
+    _lib.check(lib.gif_mbstd_bwd_f32(x.data_ptr(), gy.data_ptr(), gx.data_ptr(), B, H, W, C, Cy, G, _stream()), "mbstd_bwd")
+    return gx
+
+
+def sqnorm_per_sample(g):
+    lib = _lib.load()
+    if not g.is_cuda or g.dtype != torch.float32:
+        raise _lib.GifHipError("sqnorm_per_sample needs an fp32 device tensor")
+    g = g if g.is_contiguous() or g.is_contiguous(memory_format=CL) else g.contiguous()
+    B = g.shape[0]
+    out = torch.empty((B,), device=g.device, dtype=torch.float32)
+    _lib.check(lib.gif_sqnorm_per_sample_f32(g.data_ptr(), out.data_ptr(), B, g.numel() // max(B, 1), _stream()), "sqnorm")
+    return out
+
+
+def rasterize(face_vertices, depth, tri, out3, h, w, face_colors=None):
+    lib = _lib.load()
+    B, F = face_vertices.shape[:2]
+    ws = torch.empty((max(B * h * w, 1),), device=face_vertices.device, dtype=torch.int64)
+    if face_colors is None:
+        rc = lib.gif_rasterize_f32(face_vertices.data_ptr(), depth.data_ptr(), tri.data_ptr(), out3.data_ptr(), B, F, h, w,
+                                   ws.data_ptr(), _stream())
+    else:
+        rc = lib.gif_rasterize_colors_f32(face_vertices.data_ptr(), face_colors.data_ptr(), depth.data_ptr(), tri.data_ptr(),
+                                          out3.data_ptr(), B, F, h, w, ws.data_ptr(), _stream())
+    _lib.check(rc, "rasterize")
+
+
+def prof_enable(on: bool):
+    _lib.load().gif_prof_enable(1 if on else 0)
+
+
+def prof_read(family: int):
+    ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+    _lib.load().gif_prof_read(family, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
+    return ms.value, fl.value, n.value

@@ -1,0 +1,77 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol include/gif_hip.h
+declares, the ctypes prototypes cover all of them, argument validation works without a GPU, and the product
+path refuses CPU tensors instead of silently falling back."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from gif_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "gif_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(gif_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported_and_bound():
+    lib = _lib.load()
+    names = declared_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in gif_hip.h but not exported by libgif_hip.so"
+        assert n in _lib.PROTOTYPES, f"{n} has no ctypes prototype"
+    assert sorted(_lib.PROTOTYPES) == names
+    assert lib.gif_abi_version() == 1
+
+
+def test_argument_validation_without_gpu():
+    lib = _lib.load()
+    assert lib.gif_rasterize_workspace_bytes(2, 16, 8) == 2 * 16 * 8 * 8
+    rp, cp = ctypes.c_int(), ctypes.c_int()
+    assert lib.gif_conv2d_pack_dims(512, 512, ctypes.byref(rp), ctypes.byref(cp)) == 0
+    assert (rp.value, cp.value) == (512, 512)
+    assert lib.gif_conv2d_pack_dims(3, 24, ctypes.byref(rp), ctypes.byref(cp)) == 0
+    assert rp.value % 32 == 0 and cp.value % 8 == 0 and rp.value >= 3 and cp.value >= 24
+    # bad geometry is rejected before any launch
+    g = _lib.ConvGeom(1, 8, 8, 6, 8, 8, 8, 3, 3, 1, 1)  # Cb = 6 is not a multiple of 4
+    e = _lib.ConvEpilogue()
+    rc = lib.gif_conv2d_fwd_f32(None, None, None, ctypes.byref(g), ctypes.byref(e), None)
+    assert rc == -1 and b"multiples of 4" in lib.gif_last_error()
+    assert lib.gif_upfirdn2d_f32(None, None, None, *([1] * 13), ctypes.byref(e), None) == -1
+    # empty work is a no-op, not an error (F = 0 faces)
+    assert lib.gif_rasterize_f32(None, None, None, None, 2, 0, 4, 4, None, None) == 0
+
+
+def test_no_cpu_fallback():
+    from gif_amd import functional as GF, ops
+    with pytest.raises(_lib.GifHipError):
+        ops.nhwc(torch.zeros(1, 4, 4, 4))
+    with pytest.raises(_lib.GifHipError):
+        GF.bias_act(torch.zeros(1, 4, 4, 4), None)
+    from gif_amd import standard_rasterize as sr
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        sr.standard_rasterize(torch.zeros(1, 1, 3, 3), torch.zeros(1, 4, 4), torch.zeros(1, 4, 4, dtype=torch.int32),
+                              torch.zeros(1, 4, 4, 3), 4, 4)
+
+
+def test_state_dict_keys_match_reference_template():
+    """Reference state_dicts must load strict=True: key names and shapes are pinned by the golden template."""
+    import contextlib, io
+    from gif_amd.generator import StyledGenerator
+    from gif_amd.discriminator import Discriminator
+    gold = torch.load(os.path.join(ROOT, "tests", "golden", "stylegan2_golden.pt"), weights_only=True)
+    with contextlib.redirect_stdout(io.StringIO()):
+        g = StyledGenerator(embedding_vocab_size=50, rendered_flame_ascondition=True, normal_maps_as_cond=True)
+        d = Discriminator(size=32, num_color_chnls=9)
+    assert {k: tuple(v.shape) for k, v in g.state_dict().items()} == gold["g_template"]
+    assert {k: tuple(v.shape) for k, v in d.state_dict().items()} == gold["d_template"]
+    for k, v in gold["g_kernels"].items():
+        assert torch.equal(g.state_dict()[k], v), k
+    for k, v in gold["d_kernels"].items():
+        assert torch.equal(d.state_dict()[k], v), k

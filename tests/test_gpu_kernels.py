@@ -1,0 +1,303 @@
+"""-m gpu: every HIP kernel (through the C ABI, via gif_amd.ops / gif_amd.functional) against the CPU oracle on
+the same seeded inputs.  Integer/index results bit-exact; fp32 results within the stated tolerance (summation
+order differs: MFMA k-ordered fmaf chains vs MKL-DNN)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_util import assert_close, dev, host, pad4, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5  # fp32 accumulation-order tolerance, relative to the tensor's max magnitude
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert torch.cuda.is_available(), "-m gpu tests need an MI355X"
+    from gif_amd import _lib
+    _lib.load()
+
+
+# ------------------------------------------------------------------------------------------------ rasteriser
+def _body():
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "body_mesh.npz"))
+    return g, (g["vertices"] * np.float32(0.8))[None], g["faces"][None]
+
+
+def test_rasterize_golden_visibility():
+    from gif_amd import standard_rasterize as sr
+    g, v, f = _body()
+    vt, ft = torch.from_numpy(v).cuda(), torch.from_numpy(f).cuda()
+    vis = sr.get_visibility(vt, ft, 512, 512)
+    assert np.array_equal(vis[0].cpu().numpy().astype(np.uint8), g["vis"])
+    visz = sr.get_visibility_z(vt, ft, 512, 512)
+    assert np.array_equal(visz[0].cpu().numpy().astype(np.uint8), g["vis_z"])
+
+
+@pytest.mark.parametrize("hw", [(512, 512), (256, 256), (64, 96)])
+def test_rasterize_bit_exact_vs_oracle(hw):
+    from gif_amd import standard_rasterize as sr
+    from oracle import rasterize_oracle as ro
+    h, w = hw
+    g, v, f = _body()
+    # batch of 3: rotated / scaled copies so that depth order and coverage differ per image
+    rng = np.random.RandomState(0)
+    vs = []
+    for i in range(3):
+        a = rng.uniform(-0.6, 0.6)
+        Rm = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], np.float32)
+        vs.append((v[0] @ Rm.T * np.float32(1.0 + 0.2 * i)).astype(np.float32))
+    v3 = np.stack(vs)
+    f3 = np.repeat(f, 3, 0)
+    vi = ro.to_image_space(v3, h, w)
+    fv = ro.face_vertices(vi, f3)
+    d0, t0, b0 = ro.new_buffers(3, h, w)
+    ro.standard_rasterize(fv, d0, t0, b0, h, w)
+    fvt = torch.from_numpy(fv).cuda()
+    d1, t1, b1 = sr.new_buffers(3, h, w, "cuda")
+    out = sr.standard_rasterize(fvt, d1, t1, b1, h, w)
+    assert out[0] is d1 and out[1] is t1 and out[2] is b1  # in place + returned, like the reference
+    assert np.array_equal(t1.cpu().numpy(), t0), "face index buffer"
+    assert np.array_equal(d1.cpu().numpy().view(np.uint32), d0.view(np.uint32)), "depth bits"
+    assert np.array_equal(b1.cpu().numpy().view(np.uint32), b0.view(np.uint32)), "barycentric bits"
+    # colours variant: vertex normals-like attribute
+    col = np.ascontiguousarray(rng.standard_normal(fv.shape).astype(np.float32))
+    d2, t2, i2 = ro.new_buffers(3, h, w)
+    ro.standard_rasterize_colors(fv, col, d2, t2, i2, h, w)
+    d3, t3, i3 = sr.new_buffers(3, h, w, "cuda")
+    sr.standard_rasterize_colors(fvt, torch.from_numpy(col).cuda(), d3, t3, i3, h, w)
+    assert np.array_equal(t3.cpu().numpy(), t2)
+    assert np.array_equal(i3.cpu().numpy().view(np.uint32), i2.view(np.uint32)), "interpolated attribute bits"
+    # a second call on the already-filled buffers is idempotent (the reference launches its kernel twice)
+    sr.standard_rasterize(fvt, d1, t1, b1, h, w)
+    assert np.array_equal(t1.cpu().numpy(), t0) and np.array_equal(d1.cpu().numpy(), d0)
+
+
+def test_rasterize_edge_cases():
+    from gif_amd import standard_rasterize as sr
+    d, t, b = sr.new_buffers(2, 8, 8, "cuda")
+    sr.standard_rasterize(torch.zeros(2, 0, 3, 3, device="cuda"), d, t, b, 8, 8)  # no faces
+    assert (t == -1).all() and (d == 1e6).all()
+    # exact depth tie between two identical faces -> lowest face index, deterministically
+    tri = torch.tensor([[[1, 1, 2], [1, 6, 2], [6, 1, 2]]], dtype=torch.float32)
+    fv = torch.stack([tri, tri], 1).reshape(1, 2, 3, 3).cuda().contiguous()
+    for _ in range(5):
+        d, t, b = sr.new_buffers(1, 8, 8, "cuda")
+        sr.standard_rasterize(fv, d, t, b, 8, 8)
+        assert set(t.unique().tolist()) == {-1, 0}
+    with pytest.raises(RuntimeError, match="contiguous"):
+        sr.standard_rasterize(fv.transpose(2, 3), d, t, b, 8, 8)
+
+
+# ------------------------------------------------------------------------------------------------ convolutions
+CONV_CASES = [
+    # (B, Cin, Cout, K, stride, pad, H)            which layer of the model it stands for
+    (2, 128, 128, 3, 1, 1, 32),   # G/D 3x3 same
+    (3, 512, 512, 3, 1, 1, 8),    # 512-ch layers, batch not a tile multiple
+    (2, 6, 12, 3, 1, 1, 16),      # noise conv 1 (6 -> 8 padded in, 12 out)
+    (2, 12, 24, 3, 1, 1, 16),     # noise conv 2
+    (2, 24, 256, 3, 1, 1, 16),    # noise conv 3
+    (2, 9, 128, 1, 1, 0, 32),     # D first layer (9 -> 12 padded)
+    (2, 128, 3, 1, 1, 0, 32),     # ToRGB-shaped 1x1
+    (2, 128, 256, 3, 2, 0, 33),   # D conv2: stride 2 on the blurred (H+1) map
+    (2, 128, 256, 1, 2, 0, 31),   # D skip: 1x1 stride 2 on the (H-1) map
+    (1, 513, 512, 3, 1, 1, 4),    # final_conv (513 -> 516 padded)
+    (5, 64, 160, 3, 1, 1, 7),     # ragged everything
+]
+
+
+def _conv_case(case, seed=0):
+    B, Ci, Co, K, s, p, H = case
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Ci, H, H, generator=g)
+    w = torch.randn(Co, Ci, K, K, generator=g) / (Ci * K * K) ** 0.5
+    return x, w
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd(case):
+    from gif_amd import ops
+    B, Ci, Co, K, s, p, H = case
+    x, w = _conv_case(case)
+    ref = F.conv2d(x, w, stride=s, padding=p)
+    got = ops.conv_fwd(dev(x), w.cuda(), ops.ConvSpec(K, K, s, p))
+    assert got.shape[1] == pad4(Co)
+    assert_close(host(got, Co), ref, TOL, f"conv_fwd {case}")
+    if pad4(Co) != Co:
+        assert (host(got)[:, Co:] == 0).all(), "padded output channels must be zero"
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_bwd_data(case):
+    from gif_amd import ops
+    B, Ci, Co, K, s, p, H = case
+    x, w = _conv_case(case)
+    Hs = (H + 2 * p - K) // s + 1
+    gy = torch.randn(B, Co, Hs, Hs, generator=torch.Generator().manual_seed(1))
+    ref = F.conv_transpose2d(gy, w, stride=s, padding=p, output_padding=H - ((Hs - 1) * s + K - 2 * p))
+    got = ops.conv_bwd_data(dev(gy), w.cuda(), ops.ConvSpec(K, K, s, p), (H, H))
+    assert_close(host(got, Ci), ref, TOL, f"conv_bwd_data {case}")
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_wgrad(case):
+    from gif_amd import ops
+    B, Ci, Co, K, s, p, H = case
+    x, w = _conv_case(case)
+    w = w.requires_grad_(True)
+    y = F.conv2d(x, w, stride=s, padding=p)
+    gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(2))
+    (ref,) = torch.autograd.grad(y, w, gy)
+    got = ops.conv_wgrad(dev(gy), dev(x), ops.ConvSpec(K, K, s, p), Co, Ci)
+    assert_close(got, ref, 5e-5, f"conv_wgrad {case}")
+
+
+def test_conv_scales_and_epilogue():
+    """modulation (in_scale), demodulation (out_scale), residual, bias, leaky-ReLU fused in the conv kernel."""
+    from gif_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B, Ci, Co, H = 3, 128, 256, 16
+    x, w = torch.randn(B, Ci, H, H, generator=g), torch.randn(Co, Ci, 3, 3, generator=g) / 34
+    s, d = torch.rand(B, Ci, generator=g) + 0.5, torch.rand(B, Co, generator=g) + 0.5
+    res, bias = torch.randn(B, Co, H, H, generator=g), torch.randn(Co, generator=g)
+    ref = F.conv2d(x * s[:, :, None, None], w, padding=1) * d[:, :, None, None]
+    got = ops.conv_fwd(dev(x), w.cuda(), ops.ConvSpec(3, 3, 1, 1), in_scale=s.cuda(), out_scale=d.cuda())
+    assert_close(host(got), ref, TOL, "scaled conv")
+    ref2 = 2 ** 0.5 * F.leaky_relu(ref + res + bias[None, :, None, None], 0.2)
+    got2 = ops.conv_fwd(dev(x), w.cuda(), ops.ConvSpec(3, 3, 1, 1), in_scale=s.cuda(), out_scale=d.cuda(),
+                        bias=bias.cuda(), residual=dev(res), act=True)
+    assert_close(host(got2), ref2, TOL, "fused epilogue")
+    # transposed stride-2 with scales: the generator's up-sampling branch
+    wt = torch.randn(Ci, Co, 3, 3, generator=g) / 34  # canonical [O=Ci(small side), I=Co]
+    ref3 = F.conv_transpose2d(x * s[:, :, None, None], wt, stride=2) * d[:, :, None, None]
+    got3 = ops.conv_bwd_data(dev(x), wt.cuda(), ops.ConvSpec(3, 3, 2, 0), (2 * H + 1, 2 * H + 1), in_scale=s.cuda(),
+                             out_scale=d.cuda())
+    assert_close(host(got3), ref3, TOL, "scaled transposed conv")
+
+
+def test_conv_wgrad_with_scales():
+    from gif_amd import ops
+    g = torch.Generator().manual_seed(4)
+    B, Ci, Co, H = 4, 128, 128, 16
+    x, gy = torch.randn(B, Ci, H, H, generator=g), torch.randn(B, Co, H, H, generator=g)
+    s, d = torch.rand(B, Ci, generator=g) + 0.5, torch.rand(B, Co, generator=g) + 0.5
+    w = torch.zeros(Co, Ci, 3, 3, requires_grad=True)
+    y = F.conv2d(x * s[:, :, None, None], w, padding=1) * d[:, :, None, None]
+    (ref,) = torch.autograd.grad(y, w, gy)
+    got = ops.conv_wgrad(dev(gy), dev(x), ops.ConvSpec(3, 3, 1, 1), Co, Ci, 0.5, small_scale=d.cuda(), big_scale=s.cuda())
+    assert_close(got, 0.5 * ref, 5e-5, "scaled wgrad")
+
+
+# ------------------------------------------------------------------------------------------------ FIR / pointwise
+@pytest.mark.parametrize("cfg", [(1, 1, (2, 2), 16), (1, 1, (1, 1), 17), (2, 1, (2, 1), 8), (1, 2, (1, 1), 16),
+                                 (1, 1, (-1, 2), 9), (2, 2, (3, 0), 8), (1, 1, (1, 1), 33)])
+def test_upfirdn2d_fwd_bwd(cfg):
+    from gif_amd import functional as GF
+    from oracle import stylegan2_ref as R
+    up, down, pad, H = cfg
+    g = torch.Generator().manual_seed(5)
+    k = R.make_kernel([1, 3, 3, 1]) * up ** 2
+    x = torch.randn(2, 12, H, H + 3, generator=g).requires_grad_(True)
+    ref = R.upfirdn2d(x, k, up, down, pad)
+    xd = dev(x, True)
+    got = GF.upfirdn2d(xd, k.cuda(), up, down, pad)
+    assert_close(host(got), ref, 1e-6, f"upfirdn2d {cfg}")
+    gy = torch.randn(ref.shape, generator=g)
+    (gref,) = torch.autograd.grad(ref, x, gy)
+    (ggot,) = torch.autograd.grad(got, xd, dev(gy))
+    assert_close(host(ggot), gref, 1e-6, f"upfirdn2d backward {cfg}")
+
+
+def test_bias_act_and_reductions():
+    from gif_amd import functional as GF, ops
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(3, 36, 9, 11, generator=g).requires_grad_(True)
+    b = torch.randn(36, generator=g).requires_grad_(True)
+    r = torch.randn(3, 36, 9, 11, generator=g).requires_grad_(True)
+    ref = 2 ** 0.5 * F.leaky_relu(x + r + b[None, :, None, None], 0.2)
+    xd, bd, rd = dev(x, True), b.detach().cuda().requires_grad_(True), dev(r, True)
+    got = GF.bias_act(xd, bd, rd)
+    assert_close(host(got), ref, 1e-6, "bias_act")
+    gy = torch.randn(ref.shape, generator=g)
+    gref = torch.autograd.grad(ref, (x, b, r), gy)
+    ggot = torch.autograd.grad(got, (xd, bd, rd), dev(gy))
+    for a, e, n in zip(ggot, gref, "x b r".split()):
+        assert_close(a.detach().cpu(), e, 2e-6, f"bias_act grad {n}")
+    assert_close(ops.colsum(dev(x)).cpu(), x.detach().sum(dim=(0, 2, 3)), 2e-6, "colsum")
+    out, scaled = ops.mul_reduce(dev(x), dev(r), scale=torch.ones(3, 36).cuda() * 2, want_scaled=True)
+    assert_close(out.cpu(), (x * r).detach().sum(dim=(2, 3)), 5e-6, "mul_reduce")
+    assert_close(host(scaled), 2 * x.detach(), 1e-7, "mul_reduce scaled")
+    big = torch.randn(2, 128, 64, 64, generator=g)
+    assert_close(ops.colsum(dev(big)).cpu(), big.sum(dim=(0, 2, 3)), 1e-5, "colsum big")
+    assert_close(ops.sqnorm_per_sample(dev(big)).cpu(), big.pow(2).sum(dim=(1, 2, 3)), 1e-5, "sqnorm")
+
+
+@pytest.mark.parametrize("B", [4, 8, 2, 32])
+def test_minibatch_stddev(B):
+    from gif_amd import functional as GF
+    from oracle import stylegan2_ref as R
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B, 512, 4, 4, generator=g).requires_grad_(True)
+    ref = R.minibatch_stddev(x)
+    xd = dev(x, True)
+    got = GF.minibatch_stddev(xd, min(B, 4), 516)
+    assert_close(host(got, 513), ref, 1e-6, "mbstd fwd")
+    assert (host(got)[:, 513:] == 0).all()
+    gy = torch.randn(B, 513, 4, 4, generator=g)
+    (gref,) = torch.autograd.grad(ref, x, gy, create_graph=True)
+    (ggot,) = torch.autograd.grad(got, xd, dev(gy), create_graph=True)
+    assert_close(host(ggot), gref, 1e-5, "mbstd bwd")
+    # second order (R1 path): d/dx of <grad, v>
+    v = torch.randn(B, 512, 4, 4, generator=g)
+    (g2ref,) = torch.autograd.grad((gref * v).sum(), x)
+    (g2got,) = torch.autograd.grad((ggot * dev(v)).sum(), xd)
+    assert_close(host(g2got), g2ref, 1e-4, "mbstd double backward")
+
+
+# ------------------------------------------------------------------------------------------------ autograd wiring
+def test_conv_autograd_first_and_second_order():
+    """GF.conv2d vs torch autograd: grads w.r.t. x and w, and the R1-style double backward."""
+    from gif_amd import functional as GF
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(2, 16, 12, 12, generator=g).requires_grad_(True)
+    w = (torch.randn(32, 16, 3, 3, generator=g) / 12).requires_grad_(True)
+    xd, wd = dev(x, True), w.detach().cuda().requires_grad_(True)
+    for stride, pad in ((1, 1), (2, 0)):
+        ref = F.conv2d(x, w * 0.7, stride=stride, padding=pad)
+        got = GF.conv2d(xd, wd, stride, pad, wscale=0.7)
+        assert_close(host(got), ref, TOL, "conv2d")
+        # R1-style: penalty = |d sum(y^2)/dx|^2, then gradient of the penalty w.r.t. w and x
+        (gx_ref,) = torch.autograd.grad((ref ** 2).sum(), x, create_graph=True)
+        (gx_got,) = torch.autograd.grad((got ** 2).sum(), xd, create_graph=True)
+        assert_close(host(gx_got), gx_ref, 5e-5, "first-order grad")
+        pr, pg = gx_ref.pow(2).sum(), gx_got.pow(2).sum()
+        r2 = torch.autograd.grad(pr, (x, w))
+        g2 = torch.autograd.grad(pg, (xd, wd))
+        assert_close(host(g2[0]), r2[0], 2e-4, "second-order grad x")
+        assert_close(g2[1].cpu(), r2[1], 2e-4, "second-order grad w")
+
+
+def test_modulated_conv_autograd():
+    from gif_amd import layers as L
+    from oracle import stylegan2_ref as R
+    torch.manual_seed(9)
+    for upsample in (False, True):
+        m = L.ModulatedConv2d(64, 128, 3, 512, upsample=upsample).cuda()
+        sd = {k: v.detach().cpu().clone().requires_grad_(not k.endswith("kernel")) for k, v in m.state_dict().items()}
+        x = torch.randn(3, 64, 8, 8).requires_grad_(True)
+        st = torch.randn(3, 512).requires_grad_(True)
+        ref = R.modulated_conv2d(x, sd["weight"], sd["modulation.weight"], sd["modulation.bias"], st, True, upsample,
+                                 sd.get("blur.kernel"))
+        xd, std = dev(x, True), st.detach().cuda().requires_grad_(True)
+        got = m(xd, std)
+        assert_close(host(got), ref, 3e-5, f"modconv up={upsample}")
+        gy = torch.randn(ref.shape)
+        gref = torch.autograd.grad(ref, (x, st, sd["weight"], sd["modulation.weight"], sd["modulation.bias"]), gy)
+        ggot = torch.autograd.grad(got, (xd, std, m.weight, m.modulation.weight, m.modulation.bias), dev(gy))
+        for a, e, n in zip(ggot, gref, ["x", "style", "weight", "mod.w", "mod.b"]):
+            a = host(a) if a.dim() == 4 else a.detach().cpu()
+            assert_close(a, e, 1e-4, f"modconv up={upsample} grad {n}")

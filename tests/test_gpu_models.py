@@ -1,0 +1,112 @@
+"""-m gpu: whole-model parity of the HIP generator / discriminator against (a) golden vectors produced by the real
+reference and (b) the CPU oracle at the benchmark resolution.  Tolerances: north-star L_inf < 1e-3 on the generator
+image (we hold 1e-4 relative), gradients 2e-4 relative to their max magnitude."""
+import contextlib
+import io
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_util import assert_close, rel_err
+from test_oracle_stylegan2 import _gold, d_state, g_state
+
+pytestmark = pytest.mark.gpu
+
+
+def _build_g(vocab=50):
+    from gif_amd.generator import StyledGenerator
+    with contextlib.redirect_stdout(io.StringIO()):
+        return StyledGenerator(embedding_vocab_size=vocab, rendered_flame_ascondition=True, normal_maps_as_cond=True)
+
+
+def _build_d(size):
+    from gif_amd.discriminator import Discriminator
+    return Discriminator(size=size, num_color_chnls=9)
+
+
+def test_generator_golden_forward_backward():
+    gold = _gold()
+    c = gold["g32"]
+    g = _build_g()
+    g.load_state_dict(g_state(gold, c["seed"]), strict=True)  # reference-shaped state_dict, strict
+    g = g.cuda()
+    out = g(c["cond"].cuda(), None, step=3, alpha=1, input_indices=c["idx"].cuda())
+    assert isinstance(out, list) and len(out) == 1 and out[0].shape == (2, 3, 32, 32)
+    out = out[0]
+    assert (out.detach().cpu() - c["out"]).abs().max().item() < 1e-3  # north-star bound
+    assert_close(out, c["out"], 1e-4, "G(32x32) vs reference golden")
+    loss = (out * torch.linspace(-1, 1, out.numel(), device="cuda").view_as(out)).sum()
+    loss.backward()
+    gen = g.generator
+    checks = [(gen.const_input.input.grad, c["grad_const"]),
+              (gen.progression[0].st_cv1.conv.weight.grad[0, :2], c["grad_w_4x4"]),
+              (gen.progression[2].st_cv1.conv.modulation.bias.grad, c["grad_mod_b_16"]),
+              (gen.progression[3].st_cv2.noise.noise_conv[4].weight.grad[:8], c["grad_noise_w_32"]),
+              (gen.to_rgb[3].conv.weight.grad, c["grad_rgb_w_32"]),
+              (g.z_to_w[8].bias.grad, c["grad_z_to_w_8_b"])]
+    for i, (got, ref) in enumerate(checks):
+        assert_close(got, ref, 2e-4, f"G grad #{i}")
+
+
+def test_generator_config1_golden():
+    """BASELINE config 1: step=4 (64x64), batch 4, zero condition, z fed as float32 input_indices."""
+    gold = _gold()
+    c = gold["g64"]
+    g = _build_g()
+    g.load_state_dict(g_state(gold, c["seed"]), strict=True)
+    g = g.cuda().eval()
+    with torch.no_grad():
+        out = g(torch.zeros(4, 6, 64, 64, device="cuda"), None, step=4, alpha=1, input_indices=c["z"].cuda())[0]
+    assert (out.cpu() - c["out"]).abs().max().item() < 1e-3
+    assert_close(out, c["out"], 1e-4, "G config 1")
+
+
+def test_discriminator_golden_scores_r1_grads():
+    from gif_amd import losses
+    gold = _gold()
+    c = gold["d32"]
+    d = _build_d(32)
+    d.load_state_dict(d_state(gold, c["seed"]), strict=True)
+    d = d.cuda()
+    img = c["img"].cuda().requires_grad_(True)
+    scores, none = d([img], condition=c["cond"].cuda())
+    assert none is None and scores.shape == (4, 1)
+    assert_close(scores, c["scores"], 1e-4, "D scores")
+    pen = losses.grad_penalty_loss([img], scores, step=None)
+    assert_close(pen, c["r1"], 2e-4, "R1 penalty")
+    (F.softplus(-scores).mean() + pen.mean()).backward()
+    assert_close(d.convs[0][0].weight.grad, c["grad_first_w"], 3e-4, "D grad first conv (through R1 double backward)")
+    assert_close(d.convs[1].conv2[1].weight.grad[:4], c["grad_res1_conv2_w"], 3e-4, "D grad res1.conv2")
+    assert_close(d.final_conv[0].weight.grad[:2], c["grad_final_conv_w"], 3e-4, "D grad final_conv")
+    assert_close(d.final_linear[1].weight.grad, c["grad_lin1_w"], 3e-4, "D grad last linear")
+    assert_close(img.grad, c["grad_img"], 3e-4, "grad wrt image")
+    with torch.no_grad():
+        s8 = d([gold["d32_b8"]["img"].cuda()], condition=gold["d32_b8"]["cond"].cuda())[0]
+    assert_close(s8, gold["d32_b8"]["scores"], 1e-4, "D scores, two stddev groups")
+    with pytest.raises(Exception):  # batch 6: group 4 does not divide 6 -> the reference's view() raises too
+        d([torch.zeros(6, 3, 32, 32, device="cuda")], condition=torch.zeros(6, 6, 32, 32, device="cuda"))
+
+
+def test_generator_and_discriminator_256_vs_oracle():
+    """Benchmark resolution (step 6, 256x256), batch 2: HIP path vs the CPU oracle on identical seeded weights."""
+    from oracle import stylegan2_ref as R
+    torch.manual_seed(0)
+    g = _build_g(vocab=16)
+    sd = R.seeded_state_dict(g.state_dict(), 21)
+    g.load_state_dict(sd, strict=True)
+    cond = torch.rand(2, 6, 256, 256) * 2 - 1
+    idx = torch.tensor([2, 9])
+    with torch.no_grad():
+        ref = R.generator_forward(sd, cond, 6, idx)
+        got = g.cuda()(cond.cuda(), None, step=6, alpha=1, input_indices=idx.cuda())[0]
+    assert (got.cpu() - ref).abs().max().item() < 1e-3, "north-star: generator output L_inf < 1e-3"
+    assert_close(got, ref, 1e-4, "G(256)")
+    d = _build_d(256)
+    sdd = R.seeded_state_dict(d.state_dict(), 22)
+    d.load_state_dict(sdd, strict=True)
+    with torch.no_grad():
+        sref = R.discriminator_forward(sdd, ref, cond, 256)
+        sgot = d.cuda()(got, condition=cond.cuda())[0]
+    assert_close(sgot, sref, 2e-4, "D(256) scores")
