@@ -39,20 +39,21 @@ def parse():
     ap.add_argument("--vocab", type=int, default=69158)
     ap.add_argument("--r1-every", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--cpu-batch", type=int, default=1)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(host cores, 16)")
+    ap.add_argument("--cpu-baseline-worker", type=str, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--no-prof", action="store_true", help="skip per-kernel HIP-event timing")
     return ap.parse_args()
 
 
-def cpu_baseline(res, step_idx, batch):
-    """Oracle ("port") timed on the host cores: one full G+D training iteration (no R1) at the benchmark resolution
-    on a small batch (batch 32 needs ~80 GB of activations on the CPU)."""
+def cpu_baseline_worker(res, step_idx, batch, threads):
+    """Runs in a child process: oracle ("port") timed on `threads` host cores — one full G+D training iteration
+    (no R1) at the benchmark resolution on a small batch (batch 32 needs ~80 GB of activations on the CPU)."""
+    torch.set_num_threads(threads)
     from oracle import stylegan2_ref as R
     from oracle.train_ref import RefTrainer
     from gif_amd.discriminator import Discriminator
     from gif_amd.generator import StyledGenerator
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
     with contextlib.redirect_stdout(io.StringIO()):
         g = StyledGenerator(embedding_vocab_size=64, rendered_flame_ascondition=True, normal_maps_as_cond=True)
         d = Discriminator(size=res, num_color_chnls=9)
@@ -65,13 +66,32 @@ def cpu_baseline(res, step_idx, batch):
     t0 = time.time()
     tr.step(0, real, cond, idx)
     dt = time.time() - t0
-    return {"value": batch / dt, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"1 full G+D train step (no R1) at {res}x{res}, batch {batch}, oracle/train_ref.py (torch CPU fp32), "
-                      f"{dt:.1f} s"}
+    print(json.dumps({"value": batch / dt, "unit": "images/s", "cores": threads, "kind": "port",
+                      "sample": f"1 full G+D train step (no R1) at {res}x{res}, batch {batch}, oracle/train_ref.py "
+                                f"(torch CPU fp32, {threads} threads of {os.cpu_count()} host cores), {dt:.1f} s"}))
+
+
+def cpu_baseline(res, step_idx, batch, threads, timeout_s=240):
+    """Bounded: a child process with a fixed thread count and a hard timeout, so bench.py always finishes in minutes."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", f"{res},{step_idx},{batch},{threads}"]
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+        return json.loads(line)
+    except Exception as e:  # timeout or failure: report it, never block the GPU numbers
+        return {"value": None, "unit": "images/s", "cores": threads, "kind": "port",
+                "sample": f"cpu baseline did not finish within {timeout_s}s ({type(e).__name__})"}
 
 
 def main():
     args = parse()
+    if args.cpu_baseline_worker:
+        r, st, b, th = (int(v) for v in args.cpu_baseline_worker.split(","))
+        return cpu_baseline_worker(r, st, b, th)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -169,7 +189,8 @@ def main():
                                      "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach1 / PEAK_F32_MFMA_TFLOPS,
                                      "launches": n1, "avg_ms": ms1 / max(n1, 1), "gpu_ms_per_step": ms1 / args.steps}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.res, res_step, args.cpu_batch)
+            threads = args.cpu_threads or min(os.cpu_count() or 1, 16)
+            out["cpu_baseline"] = cpu_baseline(args.res, res_step, args.cpu_batch, threads)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -1,0 +1,37 @@
+"""Summarise a rocprofv3 (ROCm 7.2, rocpd sqlite output) kernel trace into a per-kernel stats table
+(the `--stats` CSV equivalent): calls, total / average / min / max duration, share of GPU time.
+Usage: python tools/rocpd_stats.py gpurun_out/prof/x_results.db [> profiles/name.md]"""
+import re
+import sqlite3
+import sys
+
+
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"^void ", "", name)
+    m = re.match(r"([\w:<>, ]+?)\(", name)
+    s = m.group(1) if m else name
+    return s if len(s) <= 110 else s[:107] + "..."
+
+
+def main(path):
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+    namecol = "name" if "name" in cols else "kernel_name"
+    rows = cur.execute(f"select {namecol}, start, end from kernels").fetchall()
+    agg = {}
+    for n, s, e in rows:
+        a = agg.setdefault(short(n), [0, 0.0, 1e30, 0.0])
+        d = (e - s) / 1e3  # ns -> us
+        a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
+    total = sum(a[1] for a in agg.values())
+    print(f"| kernel | calls | total ms | avg us | min us | max us | % |")
+    print("|---|---:|---:|---:|---:|---:|---:|")
+    for n, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print(f"| `{n}` | {a[0]} | {a[1] / 1e3:.2f} | {a[1] / a[0]:.1f} | {a[2]:.1f} | {a[3]:.1f} | {100 * a[1] / total:.1f} |")
+    print(f"\ntotal kernel time {total / 1e3:.1f} ms over {len(rows)} dispatches")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
