@@ -39,13 +39,15 @@ class FlatGradBucket:
     def __init__(self, params, process_group=None):
         self.params = [p for p in params]
         self.group = process_group
-        n = sum(p.numel() for p in self.params)
+        align = 64  # floats: every view starts on a 256-byte boundary (vectorised optimiser / RCCL paths)
+        offs, n = [], 0
+        for p in self.params:
+            offs.append(n)
+            n += (p.numel() + align - 1) // align * align
         dev = self.params[0].device
         self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
-        off = 0
-        for p in self.params:
+        for p, off in zip(self.params, offs):
             p.grad = self.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
 
     def zero(self):
         self.flat.zero_()
