@@ -56,21 +56,32 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + idx;
 }
 
+// Staging state of one thread: registers only (every index below is a compile-time constant after unrolling).
+template <int A_IT, int B_IT>
+struct Stage {
+    float4 a[A_IT];
+    float4 s[A_IT];
+    float4 b[B_IT];
+    unsigned mask;
+};
+
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
 __global__ void __launch_bounds__(256) conv_gather_mfma(const GatherParams p) {
     constexpr int THREADS = 256;
     constexpr int LD = BK + 4;  // padded LDS row (floats)
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int MT = WM / 32, NT = WN / 32;
-    constexpr int F4_ROW = BK / 4;  // float4 per tile row
-    constexpr int A_F4 = BM * F4_ROW, B_F4 = BN * F4_ROW;
-    constexpr int A_IT = (A_F4 + THREADS - 1) / THREADS, B_IT = (B_F4 + THREADS - 1) / THREADS;
+    constexpr int F4_ROW = BK / 4;                 // float4 per tile row
+    constexpr int ROWS_PER_IT = THREADS / F4_ROW;  // tile rows covered by one pass of the 256 threads
+    constexpr int A_IT = BM / ROWS_PER_IT;
+    constexpr int B_IT = (BN + ROWS_PER_IT - 1) / ROWS_PER_IT;
+    constexpr bool B_FULL = (BN % ROWS_PER_IT) == 0;
     static_assert(WAVES_M * WAVES_N == 4, "4 waves");
-    static_assert(A_F4 % THREADS == 0 || A_F4 < THREADS, "A tile / thread mapping");
+    static_assert(BM % ROWS_PER_IT == 0, "A tile / thread mapping");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                 // [2][BM][LD]
-    float* Bs = smem + 2 * BM * LD;   // [2][BN][LD]
+    float* As = smem;                // [2][BM][LD]
+    float* Bs = smem + 2 * BM * LD;  // [2][BN][LD]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -82,77 +93,76 @@ __global__ void __launch_bounds__(256) conv_gather_mfma(const GatherParams p) {
     const int m0 = tm * BM, n0 = tn * BN;
     const int HWp = p.Hp * p.Wp;
 
-    // ---- per-thread A rows (fixed over the K loop)
-    int a_iy0[A_IT], a_ix0[A_IT], a_b[A_IT];
-    bool a_ok[A_IT];
-    int a_row[A_IT], a_c4[A_IT];
+    const int t_row = tid / F4_ROW, t_c4 = (tid % F4_ROW) * 4;
+    const bool b_row_ok = B_FULL || (t_row + (B_IT - 1) * ROWS_PER_IT) < BN;
+
+    // ---- per-thread A rows (fixed over the K loop).  32-bit element offsets (host checks numel < 2^31):
+    // a_base = offset of (b, iy0, ix0, t_c4); a tap / K-chunk only adds the wave-uniform (dy*Wi+dx)*Ci + kc.
+    int a_iy0[A_IT], a_ix0[A_IT], a_base[A_IT], a_soff[A_IT];
+    unsigned row_ok = 0;
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
-        int q = tid + it * THREADS;
-        int row = q / F4_ROW, c4 = q % F4_ROW;
-        a_row[it] = row;
-        a_c4[it] = c4;
-        int m = m0 + row;
-        bool ok = (q < A_F4) && (m < p.M);
+        int m = m0 + t_row + it * ROWS_PER_IT;
+        bool ok = m < p.M;
         int mm = ok ? m : 0;
         int b = mm / HWp;
         int r = mm - b * HWp;
         int oy = r / p.Wp, ox = r - oy * p.Wp;
-        a_b[it] = b;
         a_iy0[it] = oy * p.is;
         a_ix0[it] = ox * p.is;
-        a_ok[it] = ok;
+        a_base[it] = ((b * p.Hi + a_iy0[it]) * p.Wi + a_ix0[it]) * p.Ci + t_c4;
+        a_soff[it] = b * p.Ci + t_c4;
+        row_ok |= (ok ? 1u : 0u) << it;
     }
 
-    float4 a_reg[A_IT], b_reg[B_IT];
+    Stage<A_IT, B_IT> st;
     const int ksteps_c = p.CP / BK;
     const int nsteps = p.ntaps * ksteps_c;
+    const bool has_scale = p.in_scale != nullptr;
+    int ld_t = 0, ld_kc = 0;  // (tap, K-chunk) of the next load_global call
 
-    auto load_global = [&](int step) {
-        const int t = step / ksteps_c;
-        const int kc = (step - t * ksteps_c) * BK;
-        const int dy = p.dy[t], dx = p.dx[t];
-        const float* wt = p.wp + ((size_t)p.widx[t] * p.RP + n0) * p.CP + kc;
+    // Branch-free global loads: out-of-range lanes read a valid dummy address and are zeroed when staged to LDS;
+    // the modulation multiply is deferred to the LDS store so no load result is consumed before the MFMAs.
+    auto load_global = [&]() __attribute__((always_inline)) {
+        const int dy = p.dy[ld_t], dx = p.dx[ld_t];
+        const int kc = ld_kc;
+        const float* wt = p.wp + ((size_t)p.widx[ld_t] * p.RP + n0 + t_row) * p.CP + kc + t_c4;
+        const int tap_off = (dy * p.Wi + dx) * p.Ci + kc;
+        const bool ch_ok = kc + t_c4 < p.Ci;
+        unsigned mask = 0;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
-            int iy = a_iy0[it] + dy, ix = a_ix0[it] + dx;
-            int ch = kc + a_c4[it] * 4;
-            bool ok = a_ok[it] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi && ch < p.Ci;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) {
-                v = *reinterpret_cast<const float4*>(p.x + (((size_t)a_b[it] * p.Hi + iy) * p.Wi + ix) * p.Ci + ch);
-                if (p.in_scale) {
-                    float4 s = *reinterpret_cast<const float4*>(p.in_scale + (size_t)a_b[it] * p.Ci + ch);
-                    v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
-                }
-            }
-            a_reg[it] = v;
+            bool ok = ((row_ok >> it) & 1u) && ch_ok && (unsigned)(a_iy0[it] + dy) < (unsigned)p.Hi &&
+                      (unsigned)(a_ix0[it] + dx) < (unsigned)p.Wi;
+            int off = ok ? a_base[it] + tap_off : 0;
+            st.a[it] = *reinterpret_cast<const float4*>(p.x + off);
+            if (has_scale) st.s[it] = *reinterpret_cast<const float4*>(p.in_scale + (ok ? a_soff[it] + kc : 0));
+            mask |= (ok ? 1u : 0u) << it;
         }
+        st.mask = mask;
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
-            int q = tid + it * THREADS;
-            if (B_F4 % THREADS == 0 || q < B_F4) {
-                int row = q / F4_ROW, c4 = q % F4_ROW;
-                b_reg[it] = *reinterpret_cast<const float4*>(wt + (size_t)row * p.CP + c4 * 4);
-            }
+            bool ok = (it < B_IT - 1) || b_row_ok;
+            st.b[it] = *reinterpret_cast<const float4*>(ok ? wt + (size_t)it * ROWS_PER_IT * p.CP : p.wp);
         }
+        ld_kc += BK;
+        if (ld_kc >= p.CP) { ld_kc = 0; ++ld_t; }
     };
-    auto store_lds = [&](int buf) {
-        float* Ab = As + buf * BM * LD;
-        float* Bb = Bs + buf * BN * LD;
+    auto store_lds = [&](int buf) __attribute__((always_inline)) {
+        float* Ab = As + buf * BM * LD + t_row * LD + t_c4;
+        float* Bb = Bs + buf * BN * LD + t_row * LD + t_c4;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
-            int q = tid + it * THREADS;
-            if (A_F4 % THREADS == 0 || q < A_F4)
-                *reinterpret_cast<float4*>(Ab + a_row[it] * LD + a_c4[it] * 4) = a_reg[it];
+            float4 v = st.a[it];
+            if (has_scale) {
+                v.x *= st.s[it].x; v.y *= st.s[it].y; v.z *= st.s[it].z; v.w *= st.s[it].w;
+            }
+            if (!((st.mask >> it) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(Ab + it * ROWS_PER_IT * LD) = v;
         }
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
-            int q = tid + it * THREADS;
-            if (B_F4 % THREADS == 0 || q < B_F4) {
-                int row = q / F4_ROW, c4 = q % F4_ROW;
-                *reinterpret_cast<float4*>(Bb + row * LD + c4 * 4) = b_reg[it];
-            }
+            if ((it < B_IT - 1) || b_row_ok) *reinterpret_cast<float4*>(Bb + it * ROWS_PER_IT * LD) = st.b[it];
         }
     };
 
@@ -164,17 +174,9 @@ __global__ void __launch_bounds__(256) conv_gather_mfma(const GatherParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    load_global(0);
-    store_lds(0);
-    __syncthreads();
-
-    int cur = 0;
-    for (int step = 0; step < nsteps; ++step) {
-        const bool more = step + 1 < nsteps;
-        if (more) load_global(step + 1);
-
-        const float* Ab = As + cur * BM * LD + (wm0 + li) * LD + lh * 4;
-        const float* Bb = Bs + cur * BN * LD + (wn0 + li) * LD + lh * 4;
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+        const float* Ab = As + buf * BM * LD + (wm0 + li) * LD + lh * 4;
+        const float* Bb = Bs + buf * BN * LD + (wn0 + li) * LD + lh * 4;
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
             float4 av[MT], bv[NT];
@@ -195,21 +197,47 @@ __global__ void __launch_bounds__(256) conv_gather_mfma(const GatherParams p) {
                 }
             }
         }
-        if (more) store_lds(cur ^ 1);
+    };
+
+    load_global();
+    store_lds(0);
+    __syncthreads();
+    int cur = 0;
+    for (int step = 0; step + 1 < nsteps; ++step) {
+        load_global();  // step+1: in flight during the MFMAs below
+        __builtin_amdgcn_sched_barrier(0);  // keep every global load ahead of the MFMA block (hipcc sinks them otherwise)
+        compute(cur);
+        __builtin_amdgcn_sched_barrier(0);
+        store_lds(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
+    compute(cur);
 
     // ---- epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
+        // rows of this lane inside the 32-row tile: base + {0,1,2,3} + 8*g ; one division for the base row,
+        // then carry-propagating increments (falls back to division for very narrow sub-grids)
+        const int mb = m0 + wm0 + i * 32 + 4 * lh;
+        int b0 = mb / HWp;
+        int r0 = mb - b0 * HWp;
+        int oy0 = r0 / p.Wp, ox0 = r0 - oy0 * p.Wp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int d = (r & 3) + 8 * (r >> 2);
+            const int m = mb + d;
+            int b = b0, oy = oy0, ox = ox0 + d;
+            if (p.Wp >= 32) {
+                if (ox >= p.Wp) { ox -= p.Wp; oy += 1; }
+                if (oy >= p.Hp) { oy -= p.Hp; b += 1; }
+            } else {
+                b = m / HWp;
+                int rr = m - b * HWp;
+                oy = rr / p.Wp;
+                ox = rr - oy * p.Wp;
+            }
             if (m >= p.M) continue;
-            int b = m / HWp;
-            int rr = m - b * HWp;
-            int oy = rr / p.Wp, ox = rr - oy * p.Wp;
             size_t opix = ((size_t)b * p.Ho + (oy * p.os + p.ooy)) * p.Wo + (ox * p.os + p.oox);
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
@@ -256,6 +284,10 @@ int launch_cfg(GatherParams& p, hipStream_t s) {
 
 int launch(GatherParams& p, hipStream_t s) {
     if (p.M <= 0 || p.ntaps <= 0) return 0;
+    if ((long)p.B * p.Hi * p.Wi * p.Ci >= (1L << 31) || (long)p.B * p.Ho * p.Wo * p.Co >= (1L << 31)) {
+        gif::set_error("conv: tensors of >= 2^31 elements are not supported (32-bit offsets)");
+        return GIF_ENOSUP;
+    }
     TileCfg c = pick_cfg(p.Co, p.Ci);
     if (c.BN == 128 && c.BK == 32) return launch_cfg<128, 128, 32, 2, 2>(p, s);
     if (c.BN == 128 && c.BK == 8) return launch_cfg<128, 128, 8, 2, 2>(p, s);
@@ -323,7 +355,7 @@ int gif_conv2d_fwd_f32(const float* big, const float* wp, float* small, const gi
     p.M = p.B * p.Hp * p.Wp;
     double flops = 2.0 * p.M * (double)p.Co * p.Ci * p.ntaps;
     gif::ProfScope prof(0, flops, gif::as_stream(stream));
-    launch(p, gif::as_stream(stream));
+    if (int rc = launch(p, gif::as_stream(stream))) return rc;
     return gif::check_launch("conv2d_fwd");
 }
 
@@ -373,7 +405,8 @@ int gif_conv2d_bwd_data_f32(const float* small, const float* wp, float* big, con
     double flops = 2.0 * g->B * (double)g->Hs * g->Ws * g->KH * g->KW * (double)g->Cs * g->Cb;
     {
         gif::ProfScope prof(0, flops, s);
-        for (int i = 0; i < nph; ++i) launch(ph[i], s);
+        for (int i = 0; i < nph; ++i)
+            if (int rc = launch(ph[i], s)) return rc;
     }
     return gif::check_launch("conv2d_bwd_data");
 }

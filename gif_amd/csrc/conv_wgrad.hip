@@ -36,9 +36,9 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const 
     constexpr int THREADS = 64 * WAVES_P * WAVES_Q;
     constexpr int WPt = BP / WAVES_P, WQt = BQ / WAVES_Q;
     constexpr int MT = WPt / 32, NT = WQt / 32;
-    constexpr int P_F4 = BKP * BP / 4, Q_F4 = BKP * BQ / 4;
-    constexpr int P_IT = P_F4 / THREADS, Q_IT = Q_F4 / THREADS;
-    static_assert(P_F4 % THREADS == 0 && Q_F4 % THREADS == 0, "tile/thread mapping");
+    constexpr int P_ROWS = THREADS / (BP / 4), Q_ROWS = THREADS / (BQ / 4);  // pixel rows per pass
+    constexpr int P_IT = BKP / P_ROWS, Q_IT = BKP / Q_ROWS;
+    static_assert(BKP % P_ROWS == 0 && BKP % Q_ROWS == 0 && P_IT >= 1 && Q_IT >= 1, "tile/thread mapping");
 
     __shared__ __attribute__((aligned(16))) float Ps[2][BKP][BP];
     __shared__ __attribute__((aligned(16))) float Qs[2][BKP][BQ];
@@ -51,66 +51,84 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const 
     const int t = blockIdx.y;
     const int ky = t / p.KW, kx = t - ky * p.KW;
     const int split = blockIdx.z;
-    const long n_begin = (long)split * p.chunk;
-    long n_end = n_begin + p.chunk;
-    if (n_end > p.Ntot) n_end = p.Ntot;
-    const int HWs = p.Hs * p.Ws;
+    const int n_begin = (int)((long)split * p.chunk);
+    int n_end = n_begin + (int)p.chunk;
+    if (n_end > (int)p.Ntot) n_end = (int)p.Ntot;
+    const unsigned HWs = (unsigned)(p.Hs * p.Ws);
 
-    float4 p_reg[P_IT], q_reg[Q_IT];
+    const int p_row = tid / (BP / 4), p_ch = r0 + (tid % (BP / 4)) * 4;
+    const int q_row = tid / (BQ / 4), q_ch = c0 + (tid % (BQ / 4)) * 4;
+    const bool p_ch_ok = p_ch < p.Cs, q_ch_ok = q_ch < p.Cb;
+    const bool has_ss = p.ss != nullptr, has_bs = p.bs != nullptr;
 
-    auto load_global = [&](long n0) {
+    float4 p_reg[P_IT], ps_reg[P_IT], q_reg[Q_IT], qs_reg[Q_IT];
+    unsigned p_mask = 0, q_mask = 0;
+
+    // Per-thread pixel cursors, advanced by BKP pixels per stage with carry propagation (no divisions in the loop).
+    // P side: linear pixel n (address n*Cs) and its sample index (for the per-sample scale).
+    // Q side: (b, oy, ox) of the small-grid pixel; the big-grid pixel is (oy*stride+ky-pad, ox*stride+kx-pad).
+    int p_n[P_IT], p_b[P_IT], p_rem[P_IT];
+    int q_n[Q_IT], q_b[Q_IT], q_oy[Q_IT], q_ox[Q_IT];
+#pragma unroll
+    for (int it = 0; it < P_IT; ++it) {
+        int n = n_begin + p_row + it * P_ROWS;
+        p_n[it] = n;
+        p_b[it] = (int)((unsigned)n / HWs);
+        p_rem[it] = n - p_b[it] * (int)HWs;
+    }
+#pragma unroll
+    for (int it = 0; it < Q_IT; ++it) {
+        int n = n_begin + q_row + it * Q_ROWS;
+        q_n[it] = n;
+        unsigned b = (unsigned)n / HWs;
+        unsigned r = (unsigned)n - b * HWs;
+        unsigned oy = r / (unsigned)p.Ws;
+        q_b[it] = (int)b; q_oy[it] = (int)oy; q_ox[it] = (int)(r - oy * (unsigned)p.Ws);
+    }
+
+    // Branch-free loads (invalid lanes read a dummy address and are zeroed at the LDS store); per-sample scales are
+    // multiplied in at the LDS store, after the MFMAs of the current stage.
+    auto load_global = [&]() __attribute__((always_inline)) {
+        p_mask = 0;
+        q_mask = 0;
 #pragma unroll
         for (int it = 0; it < P_IT; ++it) {
-            int q = tid + it * THREADS;
-            int pr = q / (BP / 4), c4 = q % (BP / 4);
-            long n = n0 + pr;
-            int ch = r0 + c4 * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (n < n_end && ch < p.Cs) {
-                v = *reinterpret_cast<const float4*>(p.sm + n * p.Cs + ch);
-                if (p.ss) {
-                    int b = (int)(n / HWs);
-                    float4 s = *reinterpret_cast<const float4*>(p.ss + (size_t)b * p.Cs + ch);
-                    v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
-                }
-            }
-            p_reg[it] = v;
+            bool ok = p_ch_ok && p_n[it] < n_end;
+            p_reg[it] = *reinterpret_cast<const float4*>(p.sm + (ok ? p_n[it] * p.Cs + p_ch : 0));
+            if (has_ss) ps_reg[it] = *reinterpret_cast<const float4*>(p.ss + (ok ? p_b[it] * p.Cs + p_ch : 0));
+            p_mask |= (ok ? 1u : 0u) << it;
+            p_n[it] += BKP;
+            p_rem[it] += BKP;
+            while (p_rem[it] >= (int)HWs) { p_rem[it] -= (int)HWs; ++p_b[it]; }
         }
 #pragma unroll
         for (int it = 0; it < Q_IT; ++it) {
-            int q = tid + it * THREADS;
-            int pr = q / (BQ / 4), c4 = q % (BQ / 4);
-            long n = n0 + pr;
-            int ch = c0 + c4 * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (n < n_end && ch < p.Cb) {
-                int b = (int)(n / HWs);
-                int r = (int)(n - (long)b * HWs);
-                int oy = r / p.Ws, ox = r - oy * p.Ws;
-                int iy = oy * p.stride + ky - p.pad, ix = ox * p.stride + kx - p.pad;
-                if ((unsigned)iy < (unsigned)p.Hb && (unsigned)ix < (unsigned)p.Wb) {
-                    v = *reinterpret_cast<const float4*>(p.bg + (((size_t)b * p.Hb + iy) * p.Wb + ix) * p.Cb + ch);
-                    if (p.bs) {
-                        float4 s = *reinterpret_cast<const float4*>(p.bs + (size_t)b * p.Cb + ch);
-                        v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
-                    }
-                }
-            }
-            q_reg[it] = v;
+            int iy = q_oy[it] * p.stride + ky - p.pad, ix = q_ox[it] * p.stride + kx - p.pad;
+            bool ok = q_ch_ok && q_n[it] < n_end && (unsigned)iy < (unsigned)p.Hb && (unsigned)ix < (unsigned)p.Wb;
+            q_reg[it] = *reinterpret_cast<const float4*>(
+                p.bg + (ok ? ((q_b[it] * p.Hb + iy) * p.Wb + ix) * p.Cb + q_ch : 0));
+            if (has_bs) qs_reg[it] = *reinterpret_cast<const float4*>(p.bs + (ok ? q_b[it] * p.Cb + q_ch : 0));
+            q_mask |= (ok ? 1u : 0u) << it;
+            q_n[it] += BKP;
+            q_ox[it] += BKP;
+            while (q_ox[it] >= p.Ws) { q_ox[it] -= p.Ws; ++q_oy[it]; }
+            while (q_oy[it] >= p.Hs) { q_oy[it] -= p.Hs; ++q_b[it]; }
         }
     };
-    auto store_lds = [&](int buf) {
+    auto store_lds = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int it = 0; it < P_IT; ++it) {
-            int q = tid + it * THREADS;
-            int pr = q / (BP / 4), c4 = q % (BP / 4);
-            *reinterpret_cast<float4*>(&Ps[buf][pr][c4 * 4]) = p_reg[it];
+            float4 v = p_reg[it];
+            if (has_ss) { v.x *= ps_reg[it].x; v.y *= ps_reg[it].y; v.z *= ps_reg[it].z; v.w *= ps_reg[it].w; }
+            if (!((p_mask >> it) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(&Ps[buf][p_row + it * P_ROWS][(tid % (BP / 4)) * 4]) = v;
         }
 #pragma unroll
         for (int it = 0; it < Q_IT; ++it) {
-            int q = tid + it * THREADS;
-            int pr = q / (BQ / 4), c4 = q % (BQ / 4);
-            *reinterpret_cast<float4*>(&Qs[buf][pr][c4 * 4]) = q_reg[it];
+            float4 v = q_reg[it];
+            if (has_bs) { v.x *= qs_reg[it].x; v.y *= qs_reg[it].y; v.z *= qs_reg[it].z; v.w *= qs_reg[it].w; }
+            if (!((q_mask >> it) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(&Qs[buf][q_row + it * Q_ROWS][(tid % (BQ / 4)) * 4]) = v;
         }
     };
 
@@ -122,31 +140,48 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+        // operand fragments of k-step ks+1 are fetched from LDS before the MFMAs of k-step ks (register double buffer)
+        float av[2][MT], bv[2][NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) av[0][i] = Ps[buf][lh][wp0 + i * 32 + li];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bv[0][j] = Qs[buf][lh][wq0 + j * 32 + li];
+#pragma unroll
+        for (int ks = 0; ks < BKP / 2; ++ks) {
+            const int c = ks & 1, n = c ^ 1;
+            if (ks + 1 < BKP / 2) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) av[n][i] = Ps[buf][2 * ks + 2 + lh][wp0 + i * 32 + li];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bv[n][j] = Qs[buf][2 * ks + 2 + lh][wq0 + j * 32 + li];
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c][i], bv[c][j], acc[i][j], 0, 0, 0);
+            // pin the schedule: the LDS reads of k-step ks+1 are issued BEFORE the MFMAs of k-step ks
+            __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);  // DS reads
+            __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);  // MFMA
+        }
+    };
+
     if (n_begin < n_end) {
-        load_global(n_begin);
+        load_global();
         store_lds(0);
         __syncthreads();
         int cur = 0;
-        for (long n0 = n_begin; n0 < n_end; n0 += BKP) {
-            const bool more = n0 + BKP < n_end;
-            if (more) load_global(n0 + BKP);
-#pragma unroll
-            for (int ks = 0; ks < BKP / 2; ++ks) {
-                float av[MT], bv[NT];
-#pragma unroll
-                for (int i = 0; i < MT; ++i) av[i] = Ps[cur][2 * ks + lh][wp0 + i * 32 + li];
-#pragma unroll
-                for (int j = 0; j < NT; ++j) bv[j] = Qs[cur][2 * ks + lh][wq0 + j * 32 + li];
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-            }
-            if (more) store_lds(cur ^ 1);
+        for (int n0 = n_begin; n0 + BKP < n_end; n0 += BKP) {
+            load_global();  // stage n0 + BKP
+            __builtin_amdgcn_sched_barrier(0);
+            compute(cur);
+            __builtin_amdgcn_sched_barrier(0);
+            store_lds(cur ^ 1);
             __syncthreads();
             cur ^= 1;
         }
+        compute(cur);
     }
 
     float* out = p.ws + ((size_t)split * p.T + t) * p.RP * p.CP;
@@ -232,7 +267,9 @@ int gif_conv2d_wgrad_splits(const gif_conv_geom* g) {
     wgrad_dims(g->Cs, g->Cb, &RP, &CP);
     long tiles = (long)(RP / tile_of(g->Cs)) * (CP / tile_of(g->Cb)) * g->KH * g->KW;
     long Ntot = (long)g->B * g->Hs * g->Ws;
-    long want = (1024 + tiles - 1) / tiles;
+    // 2 workgroups fit per CU (64 KB LDS each) => 512 concurrent slots on 256 CUs: fill k full rounds of 512
+    // and never spill a few blocks into an extra, almost empty round (floor, not ceil)
+    long want = tiles >= 1024 ? 1 : 1024 / tiles;
     long max_by_work = (Ntot + 4 * BKP - 1) / (4 * BKP);  // >= 4 stages per split
     long bytes_per_split = (long)g->KH * g->KW * RP * CP * 4;
     long max_by_mem = (128L << 20) / bytes_per_split;
@@ -249,6 +286,8 @@ int gif_conv2d_wgrad_f32(const float* small, const float* big, float* ws, const 
     GIF_REQUIRE(g->Cb % 4 == 0 && g->Cs % 4 == 0, "conv2d_wgrad: channels must be multiples of 4");
     GIF_REQUIRE(g->KH >= 1 && g->KH <= 3 && g->KW >= 1 && g->KW <= 3 && (g->stride == 1 || g->stride == 2),
                 "conv2d_wgrad: unsupported kernel/stride");
+    GIF_REQUIRE((long)g->B * g->Hs * g->Ws * g->Cs < (1L << 31) && (long)g->B * g->Hb * g->Wb * g->Cb < (1L << 31),
+                "conv2d_wgrad: tensors of >= 2^31 elements are not supported (32-bit offsets)");
     WgradParams p{};
     p.sm = small; p.bg = big; p.ws = ws; p.ss = small_scale; p.bs = big_scale;
     p.B = g->B; p.Hs = g->Hs; p.Ws = g->Ws; p.Cs = g->Cs; p.Hb = g->Hb; p.Wb = g->Wb; p.Cb = g->Cb;

@@ -77,6 +77,82 @@ __global__ void __launch_bounds__(256) upfirdn2d_kernel(const UpfirdnParams p) {
     }
 }
 
+// Fast path for the blur (up = down = 1, 4x4 FIR): one lane produces a TY x TX patch of output pixels for 4
+// channels, so every input float4 is loaded once per patch ((TY+3)*(TX+3) loads for TY*TX outputs: 4.4 loads
+// per output instead of 16).  Lanes are consecutive along the channel axis => fully coalesced 16-B accesses.
+template <int TY, int TX>
+__global__ void __launch_bounds__(256) blur4x4_tiled_kernel(const UpfirdnParams p) {
+    __shared__ float kfs[16];
+    if (threadIdx.x < 16) {
+        int a = threadIdx.x >> 2, b = threadIdx.x & 3;
+        kfs[threadIdx.x] = p.k[p.flip ? (3 - a) * 4 + (3 - b) : a * 4 + b];
+    }
+    __syncthreads();
+    float kf[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) kf[i] = kfs[i];
+    const int C4 = p.C >> 2;
+    const int nyb = (p.Ho + TY - 1) / TY, nxb = (p.Wo + TX - 1) / TX;
+    const long total = (long)p.B * nyb * nxb * C4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        int c4 = (int)(idx % C4);
+        long t = idx / C4;
+        int xb = (int)(t % nxb);
+        t /= nxb;
+        int yb = (int)(t % nyb);
+        int b = (int)(t / nyb);
+        const int oy0 = yb * TY, ox0 = xb * TX;
+        const float* xb_ = p.x + (size_t)b * p.Hi * p.Wi * p.C + c4 * 4;
+        float4 acc[TY][TX];
+#pragma unroll
+        for (int i = 0; i < TY; ++i)
+#pragma unroll
+            for (int j = 0; j < TX; ++j) acc[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < TY + 3; ++r) {
+            const int iy = oy0 + r - p.pady0;
+            const bool rok = (unsigned)iy < (unsigned)p.Hi;
+#pragma unroll
+            for (int c = 0; c < TX + 3; ++c) {
+                const int ix = ox0 + c - p.padx0;
+                const bool ok = rok && (unsigned)ix < (unsigned)p.Wi;
+                float4 v = *reinterpret_cast<const float4*>(xb_ + (ok ? ((size_t)iy * p.Wi + ix) * p.C : 0));
+                if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int ty = 0; ty < TY; ++ty) {
+                    const int a = r - ty;
+                    if (a < 0 || a > 3) continue;
+#pragma unroll
+                    for (int tx = 0; tx < TX; ++tx) {
+                        const int bb = c - tx;
+                        if (bb < 0 || bb > 3) continue;
+                        acc[ty][tx] = f4fma(kf[a * 4 + bb], v, acc[ty][tx]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int ty = 0; ty < TY; ++ty) {
+            const int oy = oy0 + ty;
+            if (oy >= p.Ho) continue;
+#pragma unroll
+            for (int tx = 0; tx < TX; ++tx) {
+                const int ox = ox0 + tx;
+                if (ox >= p.Wo) continue;
+                size_t o = (((size_t)b * p.Ho + oy) * p.Wo + ox) * p.C + c4 * 4;
+                float4 v = acc[ty][tx];
+                if (p.residual) v = f4add(v, *reinterpret_cast<const float4*>(p.residual + o));
+                if (p.bias) v = f4add(v, *reinterpret_cast<const float4*>(p.bias + c4 * 4));
+                if (p.act) {
+                    v.x = lrelu(v.x, p.slope, p.gain); v.y = lrelu(v.y, p.slope, p.gain);
+                    v.z = lrelu(v.z, p.slope, p.gain); v.w = lrelu(v.w, p.slope, p.gain);
+                }
+                *reinterpret_cast<float4*>(p.y + o) = v;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // bias + leaky ReLU (FusedLeakyReLU.forward, stylegan2_common_layers.py:32-39)
 // ---------------------------------------------------------------------------------------------------------
@@ -140,14 +216,20 @@ colsum_stage1(const float* __restrict__ a, const float* __restrict__ b, float* _
     }
 }
 
-// out[y][c] = sum_k partial[y][k][c]
-__global__ void colsum_stage2(const float* __restrict__ partial, float* __restrict__ out, int nblk, int C) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const float* pp = partial + (size_t)blockIdx.y * nblk * C + c;
+// out[y][c] = sum_k partial[y][k][c] ; block = 64 channels x 4 partial-row lanes (short dependent chains)
+__global__ void __launch_bounds__(256) colsum_stage2(const float* __restrict__ partial, float* __restrict__ out, int nblk,
+                                                     int C) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     float acc = 0.f;
-    for (int k = 0; k < nblk; ++k) acc += pp[(size_t)k * C];
-    out[(size_t)blockIdx.y * C + c] = acc;
+    if (c < C) {
+        const float* pp = partial + (size_t)blockIdx.y * nblk * C + c;
+        for (int k = rl; k < nblk; k += 4) acc += pp[(size_t)k * C];
+    }
+    red[rl][cl] = acc;
+    __syncthreads();
+    if (rl == 0 && c < C) out[(size_t)blockIdx.y * C + c] = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
 }
 
 inline int colsum_blocks(long nrows, int C4) {
@@ -292,6 +374,12 @@ int gif_upfirdn2d_f32(const float* x, const float* k, float* y, int B, int Hi, i
     p.gain = e ? e->gain : 1.f;
     p.B = B; p.Hi = Hi; p.Wi = Wi; p.C = C; p.Ho = Ho; p.Wo = Wo; p.up = up; p.down = down;
     p.padx0 = padx0; p.pady0 = pady0; p.KH = KH; p.KW = KW; p.flip = flip;
+    if (up == 1 && down == 1 && KH == 4 && KW == 4) {
+        constexpr int TY = 2, TX = 4;
+        long total = (long)B * ((Ho + TY - 1) / TY) * ((Wo + TX - 1) / TX) * (C / 4);
+        blur4x4_tiled_kernel<TY, TX><<<ew_grid(total), 256, 0, gif::as_stream(stream)>>>(p);
+        return gif::check_launch("upfirdn2d(blur)");
+    }
     long total = (long)B * Ho * Wo * (C / 4);
     upfirdn2d_kernel<<<ew_grid(total), 256, 0, gif::as_stream(stream)>>>(p);
     return gif::check_launch("upfirdn2d");
@@ -321,7 +409,7 @@ int gif_bias_act_bwd_f32(const float* gy, const float* y, float* gx, float* gbia
     int nblk = colsum_blocks(npix, C4);
     long rpb = (npix + nblk - 1) / nblk;
     colsum_stage1<1><<<dim3(nblk, 1), 256, 0, s>>>(gy, y, gx, nullptr, partial, npix, C4, rpb, slope, gain, gbias != nullptr);
-    if (gbias) colsum_stage2<<<dim3(gif::cdiv(C, 256), 1), 256, 0, s>>>(partial, gbias, nblk, C);
+    if (gbias) colsum_stage2<<<dim3(gif::cdiv(C, 64), 1), 256, 0, s>>>(partial, gbias, nblk, C);
     return gif::check_launch("bias_act_bwd");
 }
 
@@ -332,7 +420,7 @@ int gif_colsum_f32(const float* x, float* out, float* partial, int64_t npix, int
     int nblk = colsum_blocks(npix, C4);
     long rpb = (npix + nblk - 1) / nblk;
     colsum_stage1<0><<<dim3(nblk, 1), 256, 0, s>>>(x, nullptr, nullptr, nullptr, partial, npix, C4, rpb, 0.f, 1.f, 1);
-    colsum_stage2<<<dim3(gif::cdiv(C, 256), 1), 256, 0, s>>>(partial, out, nblk, C);
+    colsum_stage2<<<dim3(gif::cdiv(C, 64), 1), 256, 0, s>>>(partial, out, nblk, C);
     return gif::check_launch("colsum");
 }
 
@@ -348,7 +436,7 @@ int gif_mul_reduce_f32(const float* a, const float* b, const float* scale, float
     int nchunk = gif_mul_reduce_chunks(HW);
     long rpb = (HW + nchunk - 1) / nchunk;
     colsum_stage1<2><<<dim3(nchunk, B), 256, 0, s>>>(a, b, scaled, scale, partial, HW, C / 4, rpb, 0.f, 1.f, 1);
-    colsum_stage2<<<dim3(gif::cdiv(C, 256), B), 256, 0, s>>>(partial, out, nchunk, C);
+    colsum_stage2<<<dim3(gif::cdiv(C, 64), B), 256, 0, s>>>(partial, out, nchunk, C);
     return gif::check_launch("mul_reduce");
 }
 
