@@ -173,11 +173,13 @@ __global__ void __launch_bounds__(256) bias_act_kernel(const float* __restrict__
 // and one of R row lanes; cross-lane reduction over the R row lanes goes through LDS.
 // MODE 0: v = x ; MODE 1 (bias_act backward): v = gy * gain * (y > 0 ? 1 : slope), also stored to gx.
 // MODE 2 (mul): v = a*b, optional scaled output s[b,c]*a.
+// MODE 3: v = a * (inv_act(b) - res - bias[c]) with inv_act the inverse of gain*lrelu(., slope) (fused-epilogue modconv).
 template <int MODE>
 __global__ void __launch_bounds__(256)
 colsum_stage1(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out_ew,
               const float* __restrict__ scale, float* __restrict__ partial, long nrows, int C4, long rows_per_block,
-              float slope, float gain, int want_sum) {
+              float slope, float gain, int want_sum, const float* __restrict__ res = nullptr,
+              const float* __restrict__ bias = nullptr) {
     __shared__ float4 red[256];
     const int R = 256 / C4;  // row lanes (C4 <= 256)
     const int col = threadIdx.x % C4, rl = threadIdx.x / C4;
@@ -190,6 +192,9 @@ colsum_stage1(const float* __restrict__ a, const float* __restrict__ b, float* _
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
     if (MODE == 2 && scale && active) sc = reinterpret_cast<const float4*>(scale)[(long)blockIdx.y * C4 + col];
+    float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (MODE == 3 && bias && active) bs = reinterpret_cast<const float4*>(bias)[col];
+    const float ig = 1.f / gain, igs = 1.f / (gain * slope);
     if (active) {
         for (long r = r0 + rl; r < r1; r += R) {
             long i = (base + r) * C4 + col;
@@ -203,6 +208,11 @@ colsum_stage1(const float* __restrict__ a, const float* __restrict__ b, float* _
                 float4 bv = reinterpret_cast<const float4*>(b)[i];
                 if (out_ew) reinterpret_cast<float4*>(out_ew)[i] = make_float4(sc.x * v.x, sc.y * v.y, sc.z * v.z, sc.w * v.w);
                 v.x *= bv.x; v.y *= bv.y; v.z *= bv.z; v.w *= bv.w;
+            } else if (MODE == 3) {
+                float4 yv = reinterpret_cast<const float4*>(b)[i];
+                float4 rv = res ? reinterpret_cast<const float4*>(res)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                v.x *= yv.x * (yv.x > 0.f ? ig : igs) - rv.x - bs.x; v.y *= yv.y * (yv.y > 0.f ? ig : igs) - rv.y - bs.y;
+                v.z *= yv.z * (yv.z > 0.f ? ig : igs) - rv.z - bs.z; v.w *= yv.w * (yv.w > 0.f ? ig : igs) - rv.w - bs.w;
             }
             acc = f4add(acc, v);
         }
@@ -438,6 +448,21 @@ int gif_mul_reduce_f32(const float* a, const float* b, const float* scale, float
     colsum_stage1<2><<<dim3(nchunk, B), 256, 0, s>>>(a, b, scaled, scale, partial, HW, C / 4, rpb, 0.f, 1.f, 1);
     colsum_stage2<<<dim3(gif::cdiv(C, 64), B), 256, 0, s>>>(partial, out, nchunk, C);
     return gif::check_launch("mul_reduce");
+}
+
+int gif_act_inv_mul_reduce_f32(const float* g, const float* y, const float* residual, const float* bias, float* out,
+                               float* partial, int B, int64_t HW, int C, float slope, float gain, gif_stream_t stream) {
+    GIF_REQUIRE(g && y && out && partial && B >= 0 && HW > 0 && C > 0 && C % 4 == 0 && C <= 1024,
+                "act_inv_mul_reduce: bad arguments (C=%d)", C);
+    GIF_REQUIRE(slope > 0.f && gain > 0.f, "act_inv_mul_reduce: activation must be invertible (slope, gain > 0)");
+    if (B == 0) return 0;
+    hipStream_t s = gif::as_stream(stream);
+    int nchunk = gif_mul_reduce_chunks(HW);
+    long rpb = (HW + nchunk - 1) / nchunk;
+    colsum_stage1<3><<<dim3(nchunk, B), 256, 0, s>>>(g, y, nullptr, nullptr, partial, HW, C / 4, rpb, slope, gain, 1, residual,
+                                                      bias);
+    colsum_stage2<<<dim3(gif::cdiv(C, 64), B), 256, 0, s>>>(partial, out, nchunk, C);
+    return gif::check_launch("act_inv_mul_reduce");
 }
 
 int gif_mbstd_fwd_f32(const float* x, float* y, float* stat, int B, int H, int W, int C, int Cy, int G,

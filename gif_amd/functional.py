@@ -66,6 +66,37 @@ class WgradFn(Function):
         return gs, gb, None, None, None, None
 
 
+class ConvBiasActFn(Function):
+    """y = gain*lrelu(conv2d(x, w*wscale) + bias): bias and activation run in the conv kernel's epilogue (ConvLayer =
+    EqualConv2d + FusedLeakyReLU, stylegan2_common_layers.py:752-799).  The backward is composed of BiasActBwdFn,
+    Conv2dFn and WgradFn, hence differentiable to any order (R1)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, spec, wscale, slope, gain):
+        x = ops.nhwc(x)
+        y = ops.conv_fwd(x, w, spec, wscale, bias=bias, act=True, slope=slope, gain=gain)
+        ctx.cfg = (spec, wscale, slope, gain, bias is not None)
+        ctx.save_for_backward(x, w, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        spec, ws, slope, gain, has_bias = ctx.cfg
+        want_b = has_bias and ctx.needs_input_grad[2]
+        gpre, gb = BiasActBwdFn.apply(gy, y, want_b, slope, gain)
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = Conv2dFn.apply(gpre, w, spec, True, tuple(x.shape[2:]), ws)
+        if ctx.needs_input_grad[1]:
+            gw = WgradFn.apply(gpre, x, spec, w.shape[0], w.shape[1], ws)
+        return gx, gw, (gb if want_b else None), None, None, None, None
+
+
+def conv2d_bias_act(x, w, bias, stride=1, pad=0, wscale=1.0, slope=0.2, gain=2 ** 0.5):
+    return ConvBiasActFn.apply(x, w, bias, ConvSpec(w.shape[2], w.shape[3], stride, pad), wscale, slope, gain)
+
+
 def conv2d(x, w, stride=1, pad=0, wscale=1.0):
     """x [B,C,H,W] with C == pad4(w.shape[1]); returns [B, pad4(O), Ho, Wo]."""
     return Conv2dFn.apply(x, w, ConvSpec(w.shape[2], w.shape[3], stride, pad), False, None, wscale)
@@ -145,6 +176,39 @@ class Upfirdn2dFn(Function):
         # adjoint of a FIR resampler is a FIR resampler: swap up/down, reverse the taps, pad0' = K-1-pad0
         gx = Upfirdn2dFn.apply(gy, k, down, up, k.shape[0] - 1 - pad0, in_hw, not flip)
         return gx, None, None, None, None, None, None
+
+
+class BlurBiasActFn(Function):
+    """y = gain*lrelu(upfirdn2d(x) + residual + bias): the FIR kernel's epilogue adds the condition-noise, the bias and
+    applies the leaky ReLU (StyledConv with upsample: Blur -> NoiseInjection -> FusedLeakyReLU, :322-333, :479-486)."""
+
+    @staticmethod
+    def forward(ctx, x, k, pad0, out_hw, residual, bias, slope, gain):
+        x = ops.nhwc(x)
+        y = ops.upfirdn2d(x, k, 1, 1, pad0, tuple(out_hw), True, bias=bias, residual=residual, act=True, slope=slope,
+                          gain=gain)
+        ctx.cfg = (pad0, tuple(x.shape[2:]), slope, gain, residual is not None, bias is not None)
+        ctx.save_for_backward(k, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        k, y = ctx.saved_tensors
+        pad0, in_hw, slope, gain, has_res, has_bias = ctx.cfg
+        want_b = has_bias and ctx.needs_input_grad[5]
+        gpre, gb = BiasActBwdFn.apply(gy, y, want_b, slope, gain)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = Upfirdn2dFn.apply(gpre, k, 1, 1, k.shape[0] - 1 - pad0, in_hw, False)
+        return (gx, None, None, None, gpre if (has_res and ctx.needs_input_grad[4]) else None,
+                gb if want_b else None, None, None)
+
+
+def blur_bias_act(x, kernel, pad, residual, bias, slope=0.2, gain=2 ** 0.5):
+    kh = kernel.shape[0]
+    H, W = x.shape[2:]
+    out_hw = (H + pad[0] + pad[1] - kh + 1, W + pad[0] + pad[1] - kh + 1)
+    return BlurBiasActFn.apply(x, kernel, pad[0], out_hw, residual, bias, slope, gain)
 
 
 def upfirdn2d(x, kernel, up=1, down=1, pad=(0, 0)):
@@ -258,6 +322,51 @@ class ModConvFn(Function):
             num, _ = ops.mul_reduce(gy, y)
             gd = num / d
         return gx, gw, gs, gd, None, None, None, None
+
+
+class ModConvActFn(Function):
+    """y = gain*lrelu(d * conv(s * x, w*wscale) + residual + bias): the whole StyledConv (same-resolution branch,
+    stylegan2_common_layers.py:479-486) as ONE MFMA kernel launch — modulation on the A-tile load, demodulation,
+    condition-noise add, bias and leaky ReLU in the epilogue.  Once differentiable (generator)."""
+
+    @staticmethod
+    def forward(ctx, x, w, s, d, residual, bias, spec, wscale, slope, gain):
+        x = ops.nhwc(x)
+        s, d = s.contiguous(), d.contiguous()
+        residual = None if residual is None else ops.nhwc(residual)
+        y = ops.conv_fwd(x, w, spec, wscale, in_scale=s, out_scale=d, residual=residual, bias=bias, act=True, slope=slope,
+                         gain=gain)
+        ctx.cfg = (spec, wscale, slope, gain)
+        ctx.has = (residual is not None, bias is not None)
+        z = x.new_zeros(())
+        ctx.save_for_backward(x, w, s, d, y, residual if residual is not None else z, bias if bias is not None else z)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, s, d, y, residual, bias = ctx.saved_tensors
+        spec, ws, slope, gain = ctx.cfg
+        has_res, has_bias = ctx.has
+        residual = residual if has_res else None
+        bias = bias if has_bias else None
+        O, I = w.shape[:2]
+        want_b = has_bias and ctx.needs_input_grad[5]
+        gpre, gb = ops.bias_act_bwd(gy, y, want_b, slope, gain)
+        gx = gs = gd = gw = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
+            dxs = ops.conv_bwd_data(gpre, w, spec, tuple(x.shape[2:]), ws, in_scale=d)
+            gs, gx = ops.mul_reduce(dxs, x, scale=s, want_scaled=True)
+        if ctx.needs_input_grad[1]:
+            gw = ops.conv_wgrad(gpre, x, spec, O, I, ws, small_scale=d, big_scale=s)
+        if ctx.needs_input_grad[3]:
+            # d * z = act^-1(y) - residual - bias  =>  gd = sum_hw gpre * z
+            gd = ops.act_inv_mul_reduce(gpre, y, residual, bias, slope, gain) / d
+        return (gx, gw, gs, gd, gpre if (has_res and ctx.needs_input_grad[4]) else None, gb if want_b else None,
+                None, None, None, None)
+
+
+def modulated_conv2d_act(x, w, s, d, residual, bias, pad, wscale=1.0, slope=0.2, gain=2 ** 0.5):
+    return ModConvActFn.apply(x, w, s, d, residual, bias, ConvSpec(w.shape[2], w.shape[3], 1, pad), wscale, slope, gain)
 
 
 def modulated_conv2d(x, w, s, d, stride=1, pad=0, transposed=False, out_hw=None, wscale=1.0):

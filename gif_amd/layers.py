@@ -191,13 +191,32 @@ class ModulatedConv2d(nn.Module):
             d = torch.rsqrt((self.scale ** 2) * (s.pow(2) @ wsq.t()) + self.eps)
         return s, d
 
-    def forward(self, input, style):
-        batch, in_act, height, width = input.shape
+    def _padded_scales(self, style, in_act):
         s, d = self.scales(style)
         if in_act != self.in_channel:  # channel-padded activation: padded lanes are zero, scale is irrelevant
             s = F.pad(s, (0, in_act - self.in_channel), value=1.0)
         if d is not None and pad4(self.out_channel) != self.out_channel:
             d = F.pad(d, (0, pad4(self.out_channel) - self.out_channel), value=1.0)
+        return s, d
+
+    def forward_fused_act(self, input, style, residual, bias, slope=0.2, gain=2 ** 0.5):
+        """act(modconv(input, style) + residual + bias) with everything after the contraction fused into the kernel
+        epilogues: same-resolution branch = one MFMA launch; up-sampling branch = conv_transpose + one FIR launch."""
+        batch, in_act, height, width = input.shape
+        s, d = self._padded_scales(style, in_act)
+        w = self.weight[0]
+        if self.upsample:
+            out = GF.modulated_conv2d(input, w.transpose(0, 1), s, d, stride=2, pad=0, transposed=True,
+                                      out_hw=(2 * height + self.kernel_size - 2, 2 * width + self.kernel_size - 2),
+                                      wscale=self.scale)
+            return GF.blur_bias_act(out, self.blur.kernel, self.blur.pad, residual, bias, slope, gain)
+        if self.downsample or d is None:
+            return GF.bias_act(self.forward(input, style), bias, residual, slope, gain)
+        return GF.modulated_conv2d_act(input, w, s, d, residual, bias, self.padding, self.scale, slope, gain)
+
+    def forward(self, input, style):
+        batch, in_act, height, width = input.shape
+        s, d = self._padded_scales(style, in_act)
         w = self.weight[0]  # [Cout, Cin, k, k]
         if self.upsample:
             # conv_transpose2d(x, W^T, stride 2): underlying forward conv maps Cout -> Cin, so canonical = W^T view
@@ -273,11 +292,11 @@ class StyledConv(nn.Module):
         self.activate = FusedLeakyReLU(out_channel)
 
     def forward(self, input, style, noise=None):
-        out = self.conv(input, style)
-        if noise is None:
-            out = self.noise(out, noise=None)
-            return self.activate(out)
-        return self.activate(out, residual=self.noise.convolve(noise))
+        if noise is None:  # random-noise fallback of the reference (:424-425): unfused
+            return self.activate(self.noise(self.conv(input, style), noise=None))
+        act = self.activate
+        return self.conv.forward_fused_act(input, style, self.noise.convolve(noise),
+                                           _pad_vec(act.bias, pad4(self.conv.out_channel)), act.negative_slope, act.scale)
 
 
 class ToRGB(nn.Module):
@@ -335,6 +354,20 @@ class ConvLayer(nn.Sequential):
         if activate:
             layers.append(FusedLeakyReLU(out_channel) if bias else ScaledLeakyReLU(0.2))
         super().__init__(*layers)
+
+    def forward(self, input):
+        mods = list(self)
+        if isinstance(mods[0], Blur):
+            input = mods[0](input)
+            mods = mods[1:]
+        conv = mods[0]
+        if len(mods) == 2 and isinstance(mods[1], FusedLeakyReLU) and conv.bias is None:
+            act = mods[1]  # EqualConv2d + FusedLeakyReLU => bias and lrelu run in the conv kernel's epilogue
+            return GF.conv2d_bias_act(input, conv.weight, _pad_vec(act.bias, pad4(conv.weight.shape[0])), conv.stride,
+                                      conv.padding, conv.scale, act.negative_slope, act.scale)
+        for m in mods:
+            input = m(input)
+        return input
 
 
 class ResBlock(nn.Module):

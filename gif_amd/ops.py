@@ -211,6 +211,19 @@ def mul_reduce(a, b, scale=None, want_scaled=False):
     return out, scaled
 
 
+def act_inv_mul_reduce(g, y, residual, bias, slope, gain):
+    """out[b,c] = sum_hw g * (act^-1(y) - residual - bias[c])  (see gif_hip.h)."""
+    lib = _lib.load()
+    g, y = nhwc(g), nhwc(y)
+    B, C, H, W = y.shape
+    nchunk = lib.gif_mul_reduce_chunks(H * W)
+    out = torch.empty((B, C), device=y.device, dtype=torch.float32)
+    partial = torch.empty((B * nchunk * C,), device=y.device, dtype=torch.float32)
+    _lib.check(lib.gif_act_inv_mul_reduce_f32(g.data_ptr(), y.data_ptr(), _p(residual), _p(bias), out.data_ptr(),
+                                              partial.data_ptr(), B, H * W, C, slope, gain, _stream()), "act_inv_mul_reduce")
+    return out
+
+
 def mbstd_fwd(x, G, Cy):
     lib = _lib.load()
     x = nhwc(x)

@@ -134,6 +134,12 @@ int gif_mul_reduce_chunks(int64_t HW);
 int gif_mul_reduce_f32(const float* a, const float* b, const float* scale, float* scaled, float* out,
                        float* partial, int B, int64_t HW, int C, gif_stream_t stream);
 
+/* out[b,c] = sum_hw g * (act^-1(y) - residual - bias[c]) with act = gain*leaky_relu(., slope): the gradient of the
+ * demodulation scale d[b,c] (times d) when bias/noise/activation are fused into the modulated conv's epilogue, i.e.
+ * y = act(d*z + residual + bias) => d*z = act^-1(y) - residual - bias.  residual / bias may be NULL. */
+int gif_act_inv_mul_reduce_f32(const float* g, const float* y, const float* residual, const float* bias, float* out,
+                               float* partial, int B, int64_t HW, int C, float slope, float gain, gif_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Minibatch standard deviation — replaces stg2_discriminator.py:59-65.
  * x [B,H,W,C] -> y [B,H,W,Cy] (Cy >= C+1): y[..., :C] = x, y[..., C] = stat[b % M], rest 0, with

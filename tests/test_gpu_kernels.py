@@ -301,3 +301,59 @@ def test_modulated_conv_autograd():
         for a, e, n in zip(ggot, gref, ["x", "style", "weight", "mod.w", "mod.b"]):
             a = host(a) if a.dim() == 4 else a.detach().cpu()
             assert_close(a, e, 1e-4, f"modconv up={upsample} grad {n}")
+
+
+# ------------------------------------------------------------------------------------------------ fused epilogues
+def test_conv_bias_act_fused_any_order():
+    """ConvLayer = conv + bias + lrelu in ONE kernel; gradients up to second order (R1 path) vs torch autograd."""
+    from gif_amd import functional as GF
+    g = torch.Generator().manual_seed(10)
+    x = torch.randn(2, 16, 12, 12, generator=g).requires_grad_(True)
+    w = (torch.randn(32, 16, 3, 3, generator=g) / 12).requires_grad_(True)
+    b = (0.3 * torch.randn(32, generator=g)).requires_grad_(True)
+    xd, wd, bd = dev(x, True), w.detach().cuda().requires_grad_(True), b.detach().cuda().requires_grad_(True)
+    for stride, pad in ((1, 1), (2, 0)):
+        ref = 2 ** 0.5 * F.leaky_relu(F.conv2d(x, w * 0.7, stride=stride, padding=pad) + b[None, :, None, None], 0.2)
+        got = GF.conv2d_bias_act(xd, wd, bd, stride, pad, wscale=0.7)
+        assert_close(host(got), ref, TOL, "fused conv+bias+act")
+        gref = torch.autograd.grad((ref ** 2).sum(), (x, w, b), create_graph=True)
+        ggot = torch.autograd.grad((got ** 2).sum(), (xd, wd, bd), create_graph=True)
+        for a, e, n in zip(ggot, gref, "x w b".split()):
+            assert_close(host(a) if a.dim() == 4 and n == "x" else a.detach().cpu(), e, 1e-4, f"fused conv grad {n}")
+        r2 = torch.autograd.grad(gref[0].pow(2).sum(), (x, w, b))
+        g2 = torch.autograd.grad(ggot[0].pow(2).sum(), (xd, wd, bd))
+        assert_close(host(g2[0]), r2[0], 3e-4, "fused conv second-order x")
+        assert_close(g2[1].cpu(), r2[1], 3e-4, "fused conv second-order w")
+        assert_close(g2[2].cpu(), r2[2], 3e-4, "fused conv second-order b")
+
+
+@pytest.mark.parametrize("upsample", [False, True])
+def test_styled_conv_fused_vs_oracle(upsample):
+    """StyledConv (modconv + condition-noise + bias + lrelu, fused epilogues) forward and all gradients vs the oracle."""
+    from gif_amd import layers as L
+    from oracle import stylegan2_ref as R
+    torch.manual_seed(11)
+    m = L.StyledConv(64, 128, 3, noise_in_dims=6, upsample=upsample).cuda()
+    with torch.no_grad():
+        m.activate.bias.normal_(0, 0.2)
+        for i in (0, 2, 4):
+            m.noise.noise_conv[i].weight.mul_(20)
+    keys = list(m.state_dict().keys())
+    sd = {k: v.detach().cpu().clone().requires_grad_(not k.endswith("kernel")) for k, v in m.state_dict().items()}
+    H = 8
+    Ho = 2 * H if upsample else H
+    x = torch.randn(3, 64, H, H).requires_grad_(True)
+    st = torch.randn(3, 512).requires_grad_(True)
+    cond = torch.rand(3, 6, Ho, Ho) * 2 - 1
+    ref = R.styled_conv(sd, "", x, st, cond, upsample)
+    xd, std = dev(x, True), st.detach().cuda().requires_grad_(True)
+    got = m(xd, std, dev(cond))
+    assert_close(host(got), ref, 3e-5, f"StyledConv up={upsample}")
+    gy = torch.randn(ref.shape)
+    names = [k for k in keys if not k.endswith("kernel")]
+    gref = torch.autograd.grad(ref, [x, st] + [sd[k] for k in names], gy)
+    params = dict(m.named_parameters())
+    ggot = torch.autograd.grad(got, [xd, std] + [params[k] for k in names], dev(gy))
+    for a, e, n in zip(ggot, gref, ["x", "style"] + names):
+        a = host(a) if (a.dim() == 4 and n == "x") else a.detach().cpu()
+        assert_close(a, e, 2e-4, f"StyledConv up={upsample} grad {n}")
