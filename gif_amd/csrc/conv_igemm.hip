@@ -214,42 +214,55 @@ __global__ void __launch_bounds__(256) conv_gather_mfma(const GatherParams p) {
     }
     compute(cur);
 
-    // ---- epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // ---- epilogue.  The accumulator tile is transposed through LDS (the staging buffers are free now) so that global
+    // I/O is row-wise float4: residual / out_scale / bias loads and the output store are 16 B per lane and fully
+    // coalesced along the channel axis, instead of 64 scalar accesses per lane.
+    // C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    constexpr int LDC = BN + 4;
+    float* Cs = smem;  // [BM][LDC]
+    __syncthreads();   // every wave is done reading the A/B stages
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        // rows of this lane inside the 32-row tile: base + {0,1,2,3} + 8*g ; one division for the base row,
-        // then carry-propagating increments (falls back to division for very narrow sub-grids)
-        const int mb = m0 + wm0 + i * 32 + 4 * lh;
-        int b0 = mb / HWp;
-        int r0 = mb - b0 * HWp;
-        int oy0 = r0 / p.Wp, ox0 = r0 - oy0 * p.Wp;
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int d = (r & 3) + 8 * (r >> 2);
-            const int m = mb + d;
-            int b = b0, oy = oy0, ox = ox0 + d;
-            if (p.Wp >= 32) {
-                if (ox >= p.Wp) { ox -= p.Wp; oy += 1; }
-                if (oy >= p.Hp) { oy -= p.Hp; b += 1; }
-            } else {
-                b = m / HWp;
-                int rr = m - b * HWp;
-                oy = rr / p.Wp;
-                ox = rr - oy * p.Wp;
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                Cs[row * LDC + wn0 + j * 32 + li] = acc[i][j][r];
             }
-            if (m >= p.M) continue;
-            size_t opix = ((size_t)b * p.Ho + (oy * p.os + p.ooy)) * p.Wo + (ox * p.os + p.oox);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                int n = n0 + wn0 + j * 32 + li;
-                if (n >= p.Co) continue;
-                float v = acc[i][j][r];
-                if (p.out_scale) v *= p.out_scale[(size_t)b * p.Co + n];
-                if (p.residual) v += p.residual[opix * p.Co + n];
-                if (p.bias) v += p.bias[n];
-                if (p.act) v = (v > 0.f ? v : v * p.slope) * p.gain;
-                p.y[opix * p.Co + n] = v;
+    __syncthreads();
+    constexpr int C4_ROW = BN / 4;               // float4 per tile row
+    constexpr int EROWS = THREADS / C4_ROW;      // tile rows per pass
+    constexpr int E_IT = BM / EROWS;
+    const int e_row0 = tid / C4_ROW, e_c = (tid % C4_ROW) * 4;
+    const int n = n0 + e_c;
+    if (n < p.Co) {
+        float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias) bias4 = *reinterpret_cast<const float4*>(p.bias + n);
+#pragma unroll 4
+        for (int it = 0; it < E_IT; ++it) {
+            const int row = e_row0 + it * EROWS;
+            const int m = m0 + row;
+            if (m >= p.M) break;
+            int b = m / HWp;
+            int rr = m - b * HWp;
+            int oy = rr / p.Wp, ox = rr - oy * p.Wp;
+            size_t o = (((size_t)b * p.Ho + (oy * p.os + p.ooy)) * p.Wo + (ox * p.os + p.oox)) * p.Co + n;
+            float4 v = *reinterpret_cast<const float4*>(Cs + row * LDC + e_c);
+            if (p.out_scale) {
+                float4 d = *reinterpret_cast<const float4*>(p.out_scale + (size_t)b * p.Co + n);
+                v.x *= d.x; v.y *= d.y; v.z *= d.z; v.w *= d.w;
             }
+            if (p.residual) {
+                float4 rv = *reinterpret_cast<const float4*>(p.residual + o);
+                v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+            }
+            v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+            if (p.act) {
+                v.x = (v.x > 0.f ? v.x : v.x * p.slope) * p.gain; v.y = (v.y > 0.f ? v.y : v.y * p.slope) * p.gain;
+                v.z = (v.z > 0.f ? v.z : v.z * p.slope) * p.gain; v.w = (v.w > 0.f ? v.w : v.w * p.slope) * p.gain;
+            }
+            *reinterpret_cast<float4*>(p.y + o) = v;
         }
     }
 }
@@ -270,7 +283,9 @@ template <int BM, int BN, int BK, int WMv, int WNv>
 int launch_cfg(GatherParams& p, hipStream_t s) {
     p.tiles_m = gif::cdiv(p.M, BM);
     p.tiles_n = p.RP / BN;
-    size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
+    size_t lds_stage = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
+    size_t lds_epi = (size_t)BM * (BN + 4) * sizeof(float);
+    size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;
     auto kern = conv_gather_mfma<BM, BN, BK, WMv, WNv>;
     static bool attr_set = false;
     if (!attr_set) {

@@ -28,8 +28,17 @@ struct WgradParams {
     int RP, CP;
     long Ntot;   // B*Hs*Ws
     long chunk;  // pixels per split (multiple of BKP)
-    int tiles_q;
+    int tiles_q, tiles_pq;
 };
+
+// XCD-aware, bijective block remap: XCD k (= blockIdx % 8 by dispatch order) gets a contiguous range of logical ids.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int nx = 8;
+    int xcd = bid % nx, idx = bid / nx;
+    int q = nwg / nx, r = nwg % nx;
+    int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
 
 template <int BP, int BQ, int WAVES_P, int WAVES_Q>
 __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const WgradParams p) {
@@ -46,11 +55,15 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int wp0 = (wave / WAVES_Q) * WPt, wq0 = (wave % WAVES_Q) * WQt;
-    const int tq = blockIdx.x % p.tiles_q, tp = blockIdx.x / p.tiles_q;
+    // logical id = ((split * T) + tap) * tiles + tile: the 9 taps (and channel tiles) of one pixel chunk read the SAME
+    // activations, so they are made consecutive and therefore co-resident on one XCD's L2.
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = lid % p.tiles_pq;
+    const int t = (lid / p.tiles_pq) % p.T;
+    const int split = lid / (p.tiles_pq * p.T);
+    const int tq = tile % p.tiles_q, tp = tile / p.tiles_q;
     const int r0 = tp * BP, c0 = tq * BQ;
-    const int t = blockIdx.y;
     const int ky = t / p.KW, kx = t - ky * p.KW;
-    const int split = blockIdx.z;
     const int n_begin = (int)((long)split * p.chunk);
     int n_end = n_begin + (int)p.chunk;
     if (n_end > (int)p.Ntot) n_end = (int)p.Ntot;
@@ -299,7 +312,8 @@ int gif_conv2d_wgrad_f32(const float* small, const float* big, float* ws, const 
     if (p.chunk < BKP) p.chunk = BKP;
     const int bp = tile_of(g->Cs), bq = tile_of(g->Cb);
     p.tiles_q = p.CP / bq;
-    dim3 grid((unsigned)((p.RP / bp) * p.tiles_q), (unsigned)p.T, (unsigned)nsplit);
+    p.tiles_pq = (p.RP / bp) * p.tiles_q;
+    dim3 grid((unsigned)(p.tiles_pq * p.T * nsplit));
     hipStream_t s = gif::as_stream(stream);
     double flops = 2.0 * p.Ntot * (double)g->Cs * g->Cb * p.T;
     {
