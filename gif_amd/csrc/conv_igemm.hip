@@ -17,13 +17,15 @@
 // double buffered, global loads for step s+1 are issued before the MFMAs of step s.
 // Lane (i = lane&31, h = lane>>5) feeds A[i][k] / B[k][i] with k = 8*kk + 4*h + t for MFMA t of group kk: the
 // same K permutation on both operands, so one ds_read_b128 per 32-row tile yields the operands of 4 MFMAs.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: plain vector loads/stores, never memcpy
 
-constexpr int kMaxTaps = 9;
 
 struct GatherParams {
     const float* x;
@@ -38,13 +40,15 @@ struct GatherParams {
     int Hp, Wp;         // output sub-grid of this launch
     int os, ooy, oox;   // output pixel = (oy'*os + ooy, ox'*os + oox)
     int is;             // input  pixel = (oy'*is + dy[t], ox'*is + dx[t])
-    int ntaps;
-    int dy[kMaxTaps], dx[kMaxTaps], widx[kMaxTaps];
+    // taps of this launch form a (nky x nkx) grid, generated arithmetically (no per-step table loads):
+    //   tap (a,b): dy = dy0 + a*ddy, dx = dx0 + b*ddx, weight slice = (ky0 + a*kstep)*KW + (kx0 + b*kstep)
+    int ntaps, nky, nkx, dy0, ddy, dx0, ddx, ky0, kx0, kstep, KW;
     int RP, CP;  // packed weight rows (>= Co, multiple of BN) / cols (>= Ci, multiple of BK)
     int act;
     float slope, gain;
     int M;  // B*Hp*Wp
     int tiles_m, tiles_n;
+    int stab_nb, stab_stride;  // LDS table of per-sample input scales (LDS-DMA kernel): samples per tile, row stride
 };
 
 // XCD-aware, bijective block remap (cdna guide T1): consecutive logical tiles share an XCD's L2.
@@ -56,12 +60,81 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + idx;
 }
 
+// Epilogue shared by both kernels.  The accumulator tile is transposed through LDS (the staging buffers are free by
+// then) so that global I/O is row-wise float4: residual / out_scale / bias loads and the output store are 16 B per lane
+// and fully coalesced along the channel axis.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5).
+template <int BM, int BN, int LD, int MT, int NT>
+__device__ __forceinline__ void conv_epilogue(const GatherParams& p, f32x16 (&acc)[MT][NT], float* smem, int m0, int n0,
+                                              int wm0, int wn0, int tid, int li, int lh, int HWp) {
+    constexpr int THREADS = 256;
+    constexpr int LDC = BN + 4;
+    // the tile goes through LDS in EPI_CHUNKS row chunks so that it fits into the staging buffers' footprint
+    constexpr int STAGE_FLOATS = 2 * (BM + BN) * LD;
+    constexpr int EPI_CHUNKS = (BM * LDC <= STAGE_FLOATS) ? 1 : (BM / 2 * LDC <= STAGE_FLOATS) ? 2
+                               : (BM / 4 * LDC <= STAGE_FLOATS) ? 4 : 8;
+    constexpr int CR = BM / EPI_CHUNKS;  // rows per chunk
+    static_assert(CR % 32 == 0 && CR * LDC <= STAGE_FLOATS, "epilogue chunk must fit the staging LDS");
+    float* Cs = smem;  // [CR][LDC]
+    constexpr int C4_ROW = BN / 4;           // float4 per tile row
+    constexpr int EROWS = THREADS / C4_ROW;  // tile rows per pass
+    constexpr int E_IT = CR / EROWS;
+    static_assert(CR % EROWS == 0, "epilogue row mapping");
+    const int e_row0 = tid / C4_ROW, e_c = (tid % C4_ROW) * 4;
+    const int n = n0 + e_c;
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias && n < p.Co) bias4 = *reinterpret_cast<const float4*>(p.bias + n);
+#pragma unroll
+    for (int c = 0; c < EPI_CHUNKS; ++c) {
+        __syncthreads();  // staging buffers (c == 0) / previous chunk fully consumed
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int rbase = wm0 + i * 32;           // wave-uniform
+            if (rbase / CR != c) continue;
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int row = rbase - c * CR + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    Cs[row * LDC + wn0 + j * 32 + li] = acc[i][j][r];
+                }
+        }
+        __syncthreads();
+        if (n < p.Co) {
+#pragma unroll 4
+            for (int it = 0; it < E_IT; ++it) {
+                const int row = e_row0 + it * EROWS;
+                const int m = m0 + c * CR + row;
+                if (m >= p.M) break;
+                int b = m / HWp;
+                int rr = m - b * HWp;
+                int oy = rr / p.Wp, ox = rr - oy * p.Wp;
+                size_t o = (((size_t)b * p.Ho + (oy * p.os + p.ooy)) * p.Wo + (ox * p.os + p.oox)) * p.Co + n;
+                float4 v = *reinterpret_cast<const float4*>(Cs + row * LDC + e_c);
+                if (p.out_scale) {
+                    float4 d = *reinterpret_cast<const float4*>(p.out_scale + (size_t)b * p.Co + n);
+                    v.x *= d.x; v.y *= d.y; v.z *= d.z; v.w *= d.w;
+                }
+                if (p.residual) {
+                    float4 rv = *reinterpret_cast<const float4*>(p.residual + o);
+                    v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                }
+                v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+                if (p.act) {
+                    v.x = (v.x > 0.f ? v.x : v.x * p.slope) * p.gain; v.y = (v.y > 0.f ? v.y : v.y * p.slope) * p.gain;
+                    v.z = (v.z > 0.f ? v.z : v.z * p.slope) * p.gain; v.w = (v.w > 0.f ? v.w : v.w * p.slope) * p.gain;
+                }
+                *reinterpret_cast<float4*>(p.y + o) = v;
+            }
+        }
+    }
+}
+
 // Staging state of one thread: registers only (every index below is a compile-time constant after unrolling).
 template <int A_IT, int B_IT>
 struct Stage {
-    float4 a[A_IT];
-    float4 s[A_IT];
-    float4 b[B_IT];
+    f32x4 a[A_IT];
+    f32x4 s[A_IT];
+    f32x4 b[B_IT];
     unsigned mask;
 };
 
@@ -119,14 +192,15 @@ __global__ void __launch_bounds__(256) conv_gather_mfma(const GatherParams p) {
     const int ksteps_c = p.CP / BK;
     const int nsteps = p.ntaps * ksteps_c;
     const bool has_scale = p.in_scale != nullptr;
-    int ld_t = 0, ld_kc = 0;  // (tap, K-chunk) of the next load_global call
+    int ld_a = 0, ld_b = 0, ld_kc = 0;  // (tap row, tap col, K-chunk) of the next load_global call
 
     // Branch-free global loads: out-of-range lanes read a valid dummy address and are zeroed when staged to LDS;
     // the modulation multiply is deferred to the LDS store so no load result is consumed before the MFMAs.
     auto load_global = [&]() __attribute__((always_inline)) {
-        const int dy = p.dy[ld_t], dx = p.dx[ld_t];
+        const int dy = p.dy0 + ld_a * p.ddy, dx = p.dx0 + ld_b * p.ddx;
+        const int widx = (p.ky0 + ld_a * p.kstep) * p.KW + p.kx0 + ld_b * p.kstep;
         const int kc = ld_kc;
-        const float* wt = p.wp + ((size_t)p.widx[ld_t] * p.RP + n0 + t_row) * p.CP + kc + t_c4;
+        const float* wt = p.wp + ((size_t)widx * p.RP + n0 + t_row) * p.CP + kc + t_c4;
         const int tap_off = (dy * p.Wi + dx) * p.Ci + kc;
         const bool ch_ok = kc + t_c4 < p.Ci;
         unsigned mask = 0;
@@ -135,34 +209,35 @@ __global__ void __launch_bounds__(256) conv_gather_mfma(const GatherParams p) {
             bool ok = ((row_ok >> it) & 1u) && ch_ok && (unsigned)(a_iy0[it] + dy) < (unsigned)p.Hi &&
                       (unsigned)(a_ix0[it] + dx) < (unsigned)p.Wi;
             int off = ok ? a_base[it] + tap_off : 0;
-            st.a[it] = *reinterpret_cast<const float4*>(p.x + off);
-            if (has_scale) st.s[it] = *reinterpret_cast<const float4*>(p.in_scale + (ok ? a_soff[it] + kc : 0));
+            st.a[it] = *reinterpret_cast<const f32x4*>(p.x + off);
+            if (has_scale) st.s[it] = *reinterpret_cast<const f32x4*>(p.in_scale + (ok ? a_soff[it] + kc : 0));
             mask |= (ok ? 1u : 0u) << it;
         }
         st.mask = mask;
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
             bool ok = (it < B_IT - 1) || b_row_ok;
-            st.b[it] = *reinterpret_cast<const float4*>(ok ? wt + (size_t)it * ROWS_PER_IT * p.CP : p.wp);
+            st.b[it] = *reinterpret_cast<const f32x4*>(ok ? wt + (size_t)it * ROWS_PER_IT * p.CP : p.wp);
         }
         ld_kc += BK;
-        if (ld_kc >= p.CP) { ld_kc = 0; ++ld_t; }
+        if (ld_kc >= p.CP) {
+            ld_kc = 0;
+            if (++ld_b == p.nkx) { ld_b = 0; ++ld_a; }
+        }
     };
     auto store_lds = [&](int buf) __attribute__((always_inline)) {
         float* Ab = As + buf * BM * LD + t_row * LD + t_c4;
         float* Bb = Bs + buf * BN * LD + t_row * LD + t_c4;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
-            float4 v = st.a[it];
-            if (has_scale) {
-                v.x *= st.s[it].x; v.y *= st.s[it].y; v.z *= st.s[it].z; v.w *= st.s[it].w;
-            }
-            if (!((st.mask >> it) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4*>(Ab + it * ROWS_PER_IT * LD) = v;
+            f32x4 v = st.a[it];
+            if (has_scale) v *= st.s[it];
+            if (!((st.mask >> it) & 1u)) v = (f32x4)(0.f);
+            *reinterpret_cast<f32x4*>(Ab + it * ROWS_PER_IT * LD) = v;
         }
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
-            if ((it < B_IT - 1) || b_row_ok) *reinterpret_cast<float4*>(Bb + it * ROWS_PER_IT * LD) = st.b[it];
+            if ((it < B_IT - 1) || b_row_ok) *reinterpret_cast<f32x4*>(Bb + it * ROWS_PER_IT * LD) = st.b[it];
         }
     };
 
@@ -214,57 +289,163 @@ __global__ void __launch_bounds__(256) conv_gather_mfma(const GatherParams p) {
     }
     compute(cur);
 
-    // ---- epilogue.  The accumulator tile is transposed through LDS (the staging buffers are free now) so that global
-    // I/O is row-wise float4: residual / out_scale / bias loads and the output store are 16 B per lane and fully
-    // coalesced along the channel axis, instead of 64 scalar accesses per lane.
-    // C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-    constexpr int LDC = BN + 4;
-    float* Cs = smem;  // [BM][LDC]
-    __syncthreads();   // every wave is done reading the A/B stages
+    conv_epilogue<BM, BN, LD, MT, NT>(p, acc, smem, m0, n0, wm0, wn0, tid, li, lh, HWp);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// LDS-DMA variant for BK = 32 without input modulation (all discriminator convs / dgrads, the generator's
+// condition-noise convs).  Ablation on MI355X (profiles/r1_conv_ablation.md): MFMA loop alone 151 TF, + global loads
+// 145 TF, + VGPR->LDS store pass 122 TF — the ds_write burst (and the staging VGPRs) is what costs, not the loads.
+// Here every tile row segment goes global -> LDS directly (global_load_lds_dwordx4): no staging registers, no
+// ds_write, no zero-fill selects.  The DMA destination is lane-linear (wave-uniform base + lane*16 B), so LDS rows are
+// the unpadded 128-B K-chunks; bank conflicts of the ds_read_b128 operand reads are removed by an XOR swizzle of the
+// 16-B chunk index with (row>>1)&7, applied on the SOURCE address of the DMA and on the read address (guide rule 21).
+// Out-of-image / out-of-range lanes read a 16-byte zero page instead of being masked.
+// SCALE: input modulation (ModulatedConv2d's s[b,ci], or d[b,co] in its dgrad) through an LDS table, see below.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) float g_zero_page[4];
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool SCALE>
+__global__ void __launch_bounds__(256) conv_gather_mfma_glds(const GatherParams p) {
+    constexpr int BK = 32, LD = BK, KG = BK / 8;  // LD: unpadded LDS row (floats)
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int MT = WM / 32, NT = WN / 32;
+    constexpr int A_IT = BM / 32, B_IT = BN / 32;  // 256 lanes x 16 B = 32 rows of 128 B per pass
+    static_assert(WAVES_M * WAVES_N == 4 && BM % 32 == 0 && BN % 32 == 0, "tile config");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                // [2][BM][32]
+    float* Bs = smem + 2 * BM * LD;  // [2][BN][32]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int HWp = p.Hp * p.Wp;
+    // this lane fills LDS row (tid>>3)+32*it, physical 16-B chunk tid&7, with the LOGICAL chunk (tid&7)^f(row)
+    const int t_row = tid >> 3;
+    const int src_c4 = ((tid & 7) ^ ((t_row >> 1) & 7)) * 4;
+
+    int a_iy0[A_IT], a_ix0[A_IT], a_base[A_IT];
+    unsigned row_ok = 0;
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+        int m = m0 + t_row + it * 32;
+        bool ok = m < p.M;
+        int mm = ok ? m : 0;
+        int b = mm / HWp;
+        int r = mm - b * HWp;
+        int oy = r / p.Wp, ox = r - oy * p.Wp;
+        a_iy0[it] = oy * p.is;
+        a_ix0[it] = ox * p.is;
+        a_base[it] = ((b * p.Hi + a_iy0[it]) * p.Wi + a_ix0[it]) * p.Ci + src_c4;
+        row_ok |= (ok ? 1u : 0u) << it;
+    }
+    // Modulated convs: the DMA cannot scale data in flight, so the per-sample input scales s[b, 0:Ci) of the (few)
+    // samples this tile touches are parked in an LDS table and multiplied into the A fragments after the operand read
+    // ("weight modulation" applied on the activation side; algebraically identical).  Filled BEFORE the first DMA so no
+    // ordinary global load is outstanding while DMAs are in flight (hipcc would drain them with vmcnt(0)).
+    float* Stab = smem + 2 * (BM + BN) * LD;  // [stab_nb][stab_stride], tail of each row zeroed
+    int s_row[MT];
+    if (SCALE) {
+        const int b_first = m0 / HWp;
+        for (int e = tid; e < p.stab_nb * p.stab_stride; e += 256) {
+            int bl = e / p.stab_stride, c = e - bl * p.stab_stride;
+            int b = b_first + bl;
+            Stab[e] = (c < p.Ci && b < p.B) ? p.in_scale[(size_t)b * p.Ci + c] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            int m = m0 + wm0 + i * 32 + li;
+            if (m >= p.M) m = p.M - 1;
+            s_row[i] = (m / HWp - b_first) * p.stab_stride + lh * 4;
+        }
+        __syncthreads();
+    }
+    const int nsteps = p.ntaps * (p.CP / BK);
+    int ld_a = 0, ld_b = 0, ld_kc = 0;
+    int cmp_kc = 0;  // K-chunk of the step being computed (for the scale lookup)
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+
+    auto issue = [&](int buf) __attribute__((always_inline)) {
+        const int dy = p.dy0 + ld_a * p.ddy, dx = p.dx0 + ld_b * p.ddx;
+        const int widx = (p.ky0 + ld_a * p.kstep) * p.KW + p.kx0 + ld_b * p.kstep;
+        const int kc = ld_kc;
+        const int tap_off = (dy * p.Wi + dx) * p.Ci + kc;
+        const bool ch_ok = kc + src_c4 < p.Ci;
+        float* Ad = As + buf * BM * LD + wave * 8 * LD;  // wave-uniform; lane l lands at +l*4 floats
+        float* Bd = Bs + buf * BN * LD + wave * 8 * LD;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            bool ok = ((row_ok >> it) & 1u) && ch_ok && (unsigned)(a_iy0[it] + dy) < (unsigned)p.Hi &&
+                      (unsigned)(a_ix0[it] + dx) < (unsigned)p.Wi;
+            const float* g = ok ? p.x + (a_base[it] + tap_off) : g_zero_page;
+            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Ad + it * 32 * LD), 16, 0, 0);
+        }
+        const float* wt = p.wp + ((size_t)widx * p.RP + n0 + t_row) * p.CP + kc + src_c4;
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it)
+            __builtin_amdgcn_global_load_lds((gptr_t)(wt + (size_t)it * 32 * p.CP), (lptr_t)(Bd + it * 32 * LD), 16, 0, 0);
+        ld_kc += BK;
+        if (ld_kc >= p.CP) {
+            ld_kc = 0;
+            if (++ld_b == p.nkx) { ld_b = 0; ++ld_a; }
+        }
+    };
+
+    f32x16 acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                Cs[row * LDC + wn0 + j * 32 + li] = acc[i][j][r];
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int fsw = (li >> 1) & 7;  // (row>>1)&7 of every row this lane reads (tile bases are multiples of 32)
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+        const float* Ab = As + buf * BM * LD + (wm0 + li) * LD;
+        const float* Bb = Bs + buf * BN * LD + (wn0 + li) * LD;
+#pragma unroll
+        for (int kk = 0; kk < KG; ++kk) {
+            const int c = ((kk * 2 + lh) ^ fsw) * 4;
+            f32x4 av[MT], bv[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) av[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LD + c);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bv[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LD + c);
+            if (SCALE) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+                    av[i] *= *reinterpret_cast<const f32x4*>(Stab + s_row[i] + cmp_kc + kk * 8);
             }
-    __syncthreads();
-    constexpr int C4_ROW = BN / 4;               // float4 per tile row
-    constexpr int EROWS = THREADS / C4_ROW;      // tile rows per pass
-    constexpr int E_IT = BM / EROWS;
-    const int e_row0 = tid / C4_ROW, e_c = (tid % C4_ROW) * 4;
-    const int n = n0 + e_c;
-    if (n < p.Co) {
-        float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.bias) bias4 = *reinterpret_cast<const float4*>(p.bias + n);
-#pragma unroll 4
-        for (int it = 0; it < E_IT; ++it) {
-            const int row = e_row0 + it * EROWS;
-            const int m = m0 + row;
-            if (m >= p.M) break;
-            int b = m / HWp;
-            int rr = m - b * HWp;
-            int oy = rr / p.Wp, ox = rr - oy * p.Wp;
-            size_t o = (((size_t)b * p.Ho + (oy * p.os + p.ooy)) * p.Wo + (ox * p.os + p.oox)) * p.Co + n;
-            float4 v = *reinterpret_cast<const float4*>(Cs + row * LDC + e_c);
-            if (p.out_scale) {
-                float4 d = *reinterpret_cast<const float4*>(p.out_scale + (size_t)b * p.Co + n);
-                v.x *= d.x; v.y *= d.y; v.z *= d.z; v.w *= d.w;
-            }
-            if (p.residual) {
-                float4 rv = *reinterpret_cast<const float4*>(p.residual + o);
-                v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-            }
-            v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
-            if (p.act) {
-                v.x = (v.x > 0.f ? v.x : v.x * p.slope) * p.gain; v.y = (v.y > 0.f ? v.y : v.y * p.slope) * p.gain;
-                v.z = (v.z > 0.f ? v.z : v.z * p.slope) * p.gain; v.w = (v.w > 0.f ? v.w : v.w * p.slope) * p.gain;
-            }
-            *reinterpret_cast<float4*>(p.y + o) = v;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][t], bv[j][t], acc[i][j], 0, 0, 0);
         }
+        cmp_kc += BK;
+        if (cmp_kc >= p.CP) cmp_kc = 0;
+    };
+
+    issue(0);
+    __syncthreads();  // the workgroup release waits for the outstanding LDS-DMA (vmcnt(0)) of every wave
+    int cur = 0;
+    for (int step = 0; step + 1 < nsteps; ++step) {
+        issue(cur ^ 1);  // DMA of step+1 runs under the MFMAs of step
+        compute(cur);
+        __syncthreads();
+        cur ^= 1;
     }
+    compute(cur);
+    conv_epilogue<BM, BN, LD, MT, NT>(p, acc, smem, m0, n0, wm0, wn0, tid, li, lh, HWp);
 }
 
 struct TileCfg {
@@ -279,15 +460,11 @@ inline TileCfg pick_cfg(int cout, int cin) {
     return c;
 }
 
-template <int BM, int BN, int BK, int WMv, int WNv>
-int launch_cfg(GatherParams& p, hipStream_t s) {
+template <typename K>
+int launch_kernel(K kern, GatherParams& p, int BM, int BN, int BK, hipStream_t s, bool& attr_set) {
     p.tiles_m = gif::cdiv(p.M, BM);
     p.tiles_n = p.RP / BN;
-    size_t lds_stage = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
-    size_t lds_epi = (size_t)BM * (BN + 4) * sizeof(float);
-    size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;
-    auto kern = conv_gather_mfma<BM, BN, BK, WMv, WNv>;
-    static bool attr_set = false;
+    size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
@@ -297,6 +474,53 @@ int launch_cfg(GatherParams& p, hipStream_t s) {
     return 0;
 }
 
+template <int BM, int BN, int BK, int WMv, int WNv>
+int launch_simple(GatherParams& p, hipStream_t s) {
+    static bool attr = false;
+    return launch_kernel(conv_gather_mfma<BM, BN, BK, WMv, WNv>, p, BM, BN, BK, s, attr);
+}
+
+template <int BM, int BN, int WMv, int WNv, bool SCALE>
+int launch_glds_impl(GatherParams& p, hipStream_t s) {
+    static size_t attr_bytes = 0;
+    p.tiles_m = gif::cdiv(p.M, BM);
+    p.tiles_n = p.RP / BN;
+    size_t lds = (size_t)2 * (BM + BN) * 32 * sizeof(float);
+    p.stab_nb = 0;
+    p.stab_stride = 0;
+    if (SCALE) {
+        const int HWp = p.Hp * p.Wp;
+        int nb = (BM - 1) / HWp + 2;  // samples a BM-row tile can touch
+        if (nb > p.B) nb = p.B;
+        p.stab_nb = nb;
+        p.stab_stride = p.CP + 4;  // +4: consecutive samples start 4 banks apart
+        lds += (size_t)nb * p.stab_stride * sizeof(float);
+    }
+    if (lds > 160 * 1024) return -100;  // caller falls back to the register-staged kernel
+    auto kern = conv_gather_mfma_glds<BM, BN, WMv, WNv, SCALE>;
+    if (lds > attr_bytes) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_bytes = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(256), lds, s, p);
+    return 0;
+}
+
+template <int BM, int BN, int WMv, int WNv>
+int launch_glds(GatherParams& p, hipStream_t s) {
+    return p.in_scale ? launch_glds_impl<BM, BN, WMv, WNv, true>(p, s) : launch_glds_impl<BM, BN, WMv, WNv, false>(p, s);
+}
+
+// GIF_CONV_VARIANT=1 forces the register-staged kernel everywhere (A/B benchmarking only)
+int conv_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("GIF_CONV_VARIANT");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
+
 int launch(GatherParams& p, hipStream_t s) {
     if (p.M <= 0 || p.ntaps <= 0) return 0;
     if ((long)p.B * p.Hi * p.Wi * p.Ci >= (1L << 31) || (long)p.B * p.Ho * p.Wo * p.Co >= (1L << 31)) {
@@ -304,10 +528,18 @@ int launch(GatherParams& p, hipStream_t s) {
         return GIF_ENOSUP;
     }
     TileCfg c = pick_cfg(p.Co, p.Ci);
-    if (c.BN == 128 && c.BK == 32) return launch_cfg<128, 128, 32, 2, 2>(p, s);
-    if (c.BN == 128 && c.BK == 8) return launch_cfg<128, 128, 8, 2, 2>(p, s);
-    if (c.BN == 32 && c.BK == 32) return launch_cfg<256, 32, 32, 4, 1>(p, s);
-    return launch_cfg<256, 32, 8, 4, 1>(p, s);
+    // LDS-DMA path: every BK = 32 layer (rows are 16-byte aligned in HBM because Ci % 4 == 0)
+    const bool glds = c.BK == 32 && conv_variant() != 1;
+    if (c.BN == 128 && c.BK == 32) {
+        if (glds && launch_glds<128, 128, 2, 2>(p, s) == 0) return 0;
+        return launch_simple<128, 128, 32, 2, 2>(p, s);
+    }
+    if (c.BN == 128 && c.BK == 8) return launch_simple<128, 128, 8, 2, 2>(p, s);
+    if (c.BN == 32 && c.BK == 32) {
+        if (glds && launch_glds<256, 32, 4, 1>(p, s) == 0) return 0;
+        return launch_simple<256, 32, 32, 4, 1>(p, s);
+    }
+    return launch_simple<256, 32, 8, 4, 1>(p, s);
 }
 
 int check_geom(const gif_conv_geom* g, const char* who) {
@@ -335,7 +567,6 @@ void fill_epilogue(GatherParams& p, const gif_conv_epilogue* e) {
     p.gain = e ? e->gain : 1.f;
 }
 
-inline int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 
 }  // namespace
 
@@ -360,12 +591,9 @@ int gif_conv2d_fwd_f32(const float* big, const float* wp, float* small, const gi
     p.B = g->B; p.Hi = g->Hb; p.Wi = g->Wb; p.Ci = g->Cb;
     p.Ho = g->Hs; p.Wo = g->Ws; p.Co = g->Cs;
     p.Hp = g->Hs; p.Wp = g->Ws; p.os = 1; p.ooy = 0; p.oox = 0; p.is = g->stride;
-    p.ntaps = g->KH * g->KW;
-    for (int ky = 0; ky < g->KH; ++ky)
-        for (int kx = 0; kx < g->KW; ++kx) {
-            int t = ky * g->KW + kx;
-            p.dy[t] = ky - g->pad; p.dx[t] = kx - g->pad; p.widx[t] = t;
-        }
+    p.nky = g->KH; p.nkx = g->KW; p.ntaps = g->KH * g->KW;
+    p.dy0 = -g->pad; p.ddy = 1; p.dx0 = -g->pad; p.ddx = 1;
+    p.ky0 = 0; p.kx0 = 0; p.kstep = 1; p.KW = g->KW;
     gif_conv2d_pack_dims(p.Co, p.Ci, &p.RP, &p.CP);
     p.M = p.B * p.Hp * p.Wp;
     double flops = 2.0 * p.M * (double)p.Co * p.Ci * p.ntaps;
@@ -399,14 +627,13 @@ int gif_conv2d_bwd_data_f32(const float* small, const float* wp, float* big, con
             p.Wp = (g->Wb - px + st - 1) / st;
             if (p.Hp <= 0 || p.Wp <= 0) continue;
             p.os = st; p.ooy = py; p.oox = px; p.is = 1;
-            p.ntaps = 0;
-            for (int ky = 0; ky < g->KH; ++ky)
-                for (int kx = 0; kx < g->KW; ++kx) {
-                    int ny = py + g->pad - ky, nx = px + g->pad - kx;
-                    if (pmod(ny) != 0 || pmod(nx) != 0) continue;
-                    int t = p.ntaps++;
-                    p.dy[t] = floordiv(ny, st); p.dx[t] = floordiv(nx, st); p.widx[t] = ky * g->KW + kx;
-                }
+            // taps with ky == (py+pad) mod st (and likewise kx): small pixel = big' + (py+pad-ky)/st
+            p.ky0 = pmod(py + g->pad); p.kx0 = pmod(px + g->pad); p.kstep = st; p.KW = g->KW;
+            p.nky = p.ky0 < g->KH ? (g->KH - p.ky0 + st - 1) / st : 0;
+            p.nkx = p.kx0 < g->KW ? (g->KW - p.kx0 + st - 1) / st : 0;
+            p.ntaps = p.nky * p.nkx;
+            p.dy0 = (py + g->pad - p.ky0) / st; p.ddy = -1;
+            p.dx0 = (px + g->pad - p.kx0) / st; p.ddx = -1;
             if (p.ntaps == 0) { need_zero = true; continue; }
             p.M = p.B * p.Hp * p.Wp;
             ph[nph++] = p;
