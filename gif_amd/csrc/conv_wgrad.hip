@@ -10,6 +10,8 @@
 // The pixel axis is split over gridDim.z; every split writes its own partial tile (deterministic: no atomics),
 // and gif_unpack_wgrad_f32 reduces the splits while scattering into the canonical [O,I,KH,KW]-style tensor.
 // The per-sample scales implement the wgrad of the modulated convolution (x*s and dy*d) on the fly.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -40,7 +42,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + idx;
 }
 
-template <int BP, int BQ, int WAVES_P, int WAVES_Q>
+__device__ __attribute__((aligned(16))) float g_wgrad_zero_page[4];
+
+// GLDS = true (no per-sample scales): both operand tiles go global -> LDS directly (global_load_lds_dwordx4, lane-linear
+// destination == the [pixel][channel] tile layout), no staging registers / ds_write; invalid lanes read a zero page.
+template <int BP, int BQ, int WAVES_P, int WAVES_Q, bool GLDS>
 __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const WgradParams p) {
     constexpr int THREADS = 64 * WAVES_P * WAVES_Q;
     constexpr int WPt = BP / WAVES_P, WQt = BQ / WAVES_Q;
@@ -101,12 +107,22 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const 
 
     // Branch-free loads (invalid lanes read a dummy address and are zeroed at the LDS store); per-sample scales are
     // multiplied in at the LDS store, after the MFMAs of the current stage.
-    auto load_global = [&]() __attribute__((always_inline)) {
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto load_global = [&](int buf) __attribute__((always_inline)) {
         p_mask = 0;
         q_mask = 0;
 #pragma unroll
         for (int it = 0; it < P_IT; ++it) {
             bool ok = p_ch_ok && p_n[it] < n_end;
+            if (GLDS) {
+                // thread tid lands at float offset 4*tid of pass `it` (== Ps[buf][p_row + it*P_ROWS][4*(tid % (BP/4))])
+                const float* g = ok ? p.sm + (p_n[it] * p.Cs + p_ch) : g_wgrad_zero_page;
+                __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(&Ps[buf][it * P_ROWS][0] + wave_u * 256), 16, 0, 0);
+                p_n[it] += BKP;
+                continue;
+            }
             p_reg[it] = *reinterpret_cast<const float4*>(p.sm + (ok ? p_n[it] * p.Cs + p_ch : 0));
             if (has_ss) ps_reg[it] = *reinterpret_cast<const float4*>(p.ss + (ok ? p_b[it] * p.Cs + p_ch : 0));
             p_mask |= (ok ? 1u : 0u) << it;
@@ -118,10 +134,15 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const 
         for (int it = 0; it < Q_IT; ++it) {
             int iy = q_oy[it] * p.stride + ky - p.pad, ix = q_ox[it] * p.stride + kx - p.pad;
             bool ok = q_ch_ok && q_n[it] < n_end && (unsigned)iy < (unsigned)p.Hb && (unsigned)ix < (unsigned)p.Wb;
-            q_reg[it] = *reinterpret_cast<const float4*>(
-                p.bg + (ok ? ((q_b[it] * p.Hb + iy) * p.Wb + ix) * p.Cb + q_ch : 0));
-            if (has_bs) qs_reg[it] = *reinterpret_cast<const float4*>(p.bs + (ok ? q_b[it] * p.Cb + q_ch : 0));
-            q_mask |= (ok ? 1u : 0u) << it;
+            if (GLDS) {
+                const float* g = ok ? p.bg + (((q_b[it] * p.Hb + iy) * p.Wb + ix) * p.Cb + q_ch) : g_wgrad_zero_page;
+                __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(&Qs[buf][it * Q_ROWS][0] + wave_u * 256), 16, 0, 0);
+            } else {
+                q_reg[it] = *reinterpret_cast<const float4*>(
+                    p.bg + (ok ? ((q_b[it] * p.Hb + iy) * p.Wb + ix) * p.Cb + q_ch : 0));
+                if (has_bs) qs_reg[it] = *reinterpret_cast<const float4*>(p.bs + (ok ? q_b[it] * p.Cb + q_ch : 0));
+                q_mask |= (ok ? 1u : 0u) << it;
+            }
             q_n[it] += BKP;
             q_ox[it] += BKP;
             while (q_ox[it] >= p.Ws) { q_ox[it] -= p.Ws; ++q_oy[it]; }
@@ -129,6 +150,7 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const 
         }
     };
     auto store_lds = [&](int buf) __attribute__((always_inline)) {
+        if (GLDS) return;  // the DMA already wrote the tiles
 #pragma unroll
         for (int it = 0; it < P_IT; ++it) {
             float4 v = p_reg[it];
@@ -181,12 +203,12 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const 
     };
 
     if (n_begin < n_end) {
-        load_global();
+        load_global(0);
         store_lds(0);
         __syncthreads();
         int cur = 0;
         for (int n0 = n_begin; n0 + BKP < n_end; n0 += BKP) {
-            load_global();  // stage n0 + BKP
+            load_global(cur ^ 1);  // stage n0 + BKP
             __builtin_amdgcn_sched_barrier(0);
             compute(cur);
             __builtin_amdgcn_sched_barrier(0);
@@ -318,14 +340,16 @@ int gif_conv2d_wgrad_f32(const float* small, const float* big, float* ws, const 
     double flops = 2.0 * p.Ntot * (double)g->Cs * g->Cb * p.T;
     {
         gif::ProfScope prof(1, flops, s);
-        if (bp == 128 && bq == 128)
-            hipLaunchKernelGGL((conv_wgrad_mfma<128, 128, 2, 2>), grid, dim3(256), 0, s, p);
-        else if (bp == 128 && bq == 32)
-            hipLaunchKernelGGL((conv_wgrad_mfma<128, 32, 4, 1>), grid, dim3(256), 0, s, p);
-        else if (bp == 32 && bq == 128)
-            hipLaunchKernelGGL((conv_wgrad_mfma<32, 128, 1, 4>), grid, dim3(256), 0, s, p);
-        else
-            hipLaunchKernelGGL((conv_wgrad_mfma<32, 32, 1, 1>), grid, dim3(64), 0, s, p);
+        const char* env = getenv("GIF_CONV_VARIANT");
+        const bool glds = !small_scale && !big_scale && !(env && atoi(env) == 1);
+#define GIF_WGRAD_LAUNCH(BP_, BQ_, WP_, WQ_, TH_)                                                              \
+    if (glds) hipLaunchKernelGGL((conv_wgrad_mfma<BP_, BQ_, WP_, WQ_, true>), grid, dim3(TH_), 0, s, p);       \
+    else hipLaunchKernelGGL((conv_wgrad_mfma<BP_, BQ_, WP_, WQ_, false>), grid, dim3(TH_), 0, s, p)
+        if (bp == 128 && bq == 128) { GIF_WGRAD_LAUNCH(128, 128, 2, 2, 256); }
+        else if (bp == 128 && bq == 32) { GIF_WGRAD_LAUNCH(128, 32, 4, 1, 256); }
+        else if (bp == 32 && bq == 128) { GIF_WGRAD_LAUNCH(32, 128, 1, 4, 256); }
+        else { GIF_WGRAD_LAUNCH(32, 32, 1, 1, 64); }
+#undef GIF_WGRAD_LAUNCH
     }
     return gif::check_launch("conv2d_wgrad");
 }
