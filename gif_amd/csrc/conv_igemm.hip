@@ -307,7 +307,7 @@ __device__ __attribute__((aligned(16))) float g_zero_page[4];
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool SCALE>
 __global__ void __launch_bounds__(256) conv_gather_mfma_glds(const GatherParams p) {
-    constexpr int BK = 32, LD = BK, KG = BK / 8;  // LD: unpadded LDS row (floats)
+    constexpr int BK = 32, LD = BK;  // LD: unpadded LDS row (floats); 4 k-groups of 8 per step
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int MT = WM / 32, NT = WN / 32;
     constexpr int A_IT = BM / 32, B_IT = BN / 32;  // 256 lanes x 16 B = 32 rows of 128 B per pass
@@ -407,44 +407,64 @@ __global__ void __launch_bounds__(256) conv_gather_mfma_glds(const GatherParams 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int fsw = (li >> 1) & 7;  // (row>>1)&7 of every row this lane reads (tile bases are multiples of 32)
-    auto compute = [&](int buf) __attribute__((always_inline)) {
+    // operand fragments of one k-group (8 k): register double buffer, read one group ahead of its MFMAs
+    f32x4 av[2][MT], bv[2][NT];
+    auto frag_read = [&](int buf, int kk, int slot, int kc) __attribute__((always_inline)) {
         const float* Ab = As + buf * BM * LD + (wm0 + li) * LD;
         const float* Bb = Bs + buf * BN * LD + (wn0 + li) * LD;
+        const int c = ((kk * 2 + lh) ^ fsw) * 4;
 #pragma unroll
-        for (int kk = 0; kk < KG; ++kk) {
-            const int c = ((kk * 2 + lh) ^ fsw) * 4;
-            f32x4 av[MT], bv[NT];
+        for (int i = 0; i < MT; ++i) av[slot][i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LD + c);
 #pragma unroll
-            for (int i = 0; i < MT; ++i) av[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LD + c);
+        for (int j = 0; j < NT; ++j) bv[slot][j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LD + c);
+        if (SCALE) {
 #pragma unroll
-            for (int j = 0; j < NT; ++j) bv[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LD + c);
-            if (SCALE) {
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-                    av[i] *= *reinterpret_cast<const f32x4*>(Stab + s_row[i] + cmp_kc + kk * 8);
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][t], bv[j][t], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < MT; ++i) av[slot][i] *= *reinterpret_cast<const f32x4*>(Stab + s_row[i] + kc + kk * 8);
         }
-        cmp_kc += BK;
-        if (cmp_kc >= p.CP) cmp_kc = 0;
     };
+    auto mfma_group = [&](int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[slot][i][t], bv[slot][j][t], acc[i][j], 0, 0, 0);
+        // pin: the LDS reads of the NEXT group (issued just before this call) go out ahead of these MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x100, MT + NT + (SCALE ? MT : 0), 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * MT * NT, 0);
+    };
+    auto next_kc = [&](int kc) { return (kc + BK >= p.CP) ? 0 : kc + BK; };
 
+    // Schedule of one step (4 k-groups g0..g3 of the current buffer):
+    //   DMA(step+1) | g0 | g1 | g2 | vmcnt(0)+barrier | read g0 of step+1 | g3
+    // g3's fragments are in registers before the barrier, so every wave is done with the current buffer when it
+    // arrives, and the first operand read of the next step runs under the 16 MFMAs of g3 instead of after the barrier.
     issue(0);
     __syncthreads();  // the workgroup release waits for the outstanding LDS-DMA (vmcnt(0)) of every wave
     int cur = 0;
+    frag_read(0, 0, 0, 0);
     for (int step = 0; step + 1 < nsteps; ++step) {
-        issue(cur ^ 1);  // DMA of step+1 runs under the MFMAs of step
-        compute(cur);
+        issue(cur ^ 1);  // DMA of step+1 runs under the MFMAs of this step
+        frag_read(cur, 1, 1, cmp_kc);
+        mfma_group(0);
+        frag_read(cur, 2, 0, cmp_kc);
+        mfma_group(1);
+        frag_read(cur, 3, 1, cmp_kc);
+        mfma_group(0);
         __syncthreads();
+        cmp_kc = next_kc(cmp_kc);
         cur ^= 1;
+        frag_read(cur, 0, 0, cmp_kc);
+        mfma_group(1);
     }
-    compute(cur);
+    frag_read(cur, 1, 1, cmp_kc);
+    mfma_group(0);
+    frag_read(cur, 2, 0, cmp_kc);
+    mfma_group(1);
+    frag_read(cur, 3, 1, cmp_kc);
+    mfma_group(0);
+    mfma_group(1);
     conv_epilogue<BM, BN, LD, MT, NT>(p, acc, smem, m0, n0, wm0, wn0, tid, li, lh, HWp);
 }
 
