@@ -305,13 +305,19 @@ __global__ void __launch_bounds__(256) conv_gather_mfma(const GatherParams p) {
 // ------------------------------------------------------------------------------------------------------------------
 __device__ __attribute__((aligned(16))) float g_zero_page[4];
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool SCALE>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool SCALE, int BK>
 __global__ void __launch_bounds__(256) conv_gather_mfma_glds(const GatherParams p) {
-    constexpr int BK = 32, LD = BK;  // LD: unpadded LDS row (floats); 4 k-groups of 8 per step
+    constexpr int LD = BK;             // unpadded LDS row (floats)
+    constexpr int CH = BK / 4;         // 16-byte chunks per row
+    constexpr int RB = 64 / BK;        // rows per 256-byte LDS bank row (2 for 128-byte rows)
+    constexpr int RPP = 256 / CH;      // rows filled by one pass of the 256 lanes
+    constexpr int RPW = 64 / CH;       // rows filled by one wave instruction (1 KiB)
+    constexpr int KG = BK / 8;         // k-groups (8 k each) per step
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int MT = WM / 32, NT = WN / 32;
-    constexpr int A_IT = BM / 32, B_IT = BN / 32;  // 256 lanes x 16 B = 32 rows of 128 B per pass
-    static_assert(WAVES_M * WAVES_N == 4 && BM % 32 == 0 && BN % 32 == 0, "tile config");
+    constexpr int A_IT = BM / RPP, B_IT = (BN + RPP - 1) / RPP;
+    static_assert(WAVES_M * WAVES_N == 4 && BM % RPP == 0 && (BN % RPP == 0 || BN < RPP), "tile config");
+    static_assert(BK == 32, "only 128-byte rows are validated (a 64-byte-row variant measured 8-10 % slower)");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                // [2][BM][32]
@@ -326,15 +332,17 @@ __global__ void __launch_bounds__(256) conv_gather_mfma_glds(const GatherParams 
     const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     const int HWp = p.Hp * p.Wp;
-    // this lane fills LDS row (tid>>3)+32*it, physical 16-B chunk tid&7, with the LOGICAL chunk (tid&7)^f(row)
-    const int t_row = tid >> 3;
-    const int src_c4 = ((tid & 7) ^ ((t_row >> 1) & 7)) * 4;
+    // this lane fills LDS row tid/CH + RPP*it, physical 16-B chunk tid%CH, with the LOGICAL chunk (tid%CH)^f(row),
+    // f(row) = (row / RB) % CH: the 16 rows of a ds_read_b128 lane group then hit 16 distinct 16-B slots
+    const int t_row = tid / CH;
+    const int src_c4 = ((tid % CH) ^ ((t_row / RB) % CH)) * 4;
+    const bool b_lane_ok = (BN % RPP == 0) || t_row < BN;
 
     int a_iy0[A_IT], a_ix0[A_IT], a_base[A_IT];
     unsigned row_ok = 0;
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
-        int m = m0 + t_row + it * 32;
+        int m = m0 + t_row + it * RPP;
         bool ok = m < p.M;
         int mm = ok ? m : 0;
         int b = mm / HWp;
@@ -378,19 +386,22 @@ __global__ void __launch_bounds__(256) conv_gather_mfma_glds(const GatherParams 
         const int kc = ld_kc;
         const int tap_off = (dy * p.Wi + dx) * p.Ci + kc;
         const bool ch_ok = kc + src_c4 < p.Ci;
-        float* Ad = As + buf * BM * LD + wave * 8 * LD;  // wave-uniform; lane l lands at +l*4 floats
-        float* Bd = Bs + buf * BN * LD + wave * 8 * LD;
+        float* Ad = As + buf * BM * LD + wave * RPW * LD;  // wave-uniform; lane l lands at +l*4 floats
+        float* Bd = Bs + buf * BN * LD + wave * RPW * LD;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             bool ok = ((row_ok >> it) & 1u) && ch_ok && (unsigned)(a_iy0[it] + dy) < (unsigned)p.Hi &&
                       (unsigned)(a_ix0[it] + dx) < (unsigned)p.Wi;
             const float* g = ok ? p.x + (a_base[it] + tap_off) : g_zero_page;
-            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Ad + it * 32 * LD), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Ad + it * RPP * LD), 16, 0, 0);
         }
         const float* wt = p.wp + ((size_t)widx * p.RP + n0 + t_row) * p.CP + kc + src_c4;
+        if (BN % RPP == 0 || wave * RPW < BN) {  // wave-uniform: waves beyond the B tile issue nothing
 #pragma unroll
-        for (int it = 0; it < B_IT; ++it)
-            __builtin_amdgcn_global_load_lds((gptr_t)(wt + (size_t)it * 32 * p.CP), (lptr_t)(Bd + it * 32 * LD), 16, 0, 0);
+            for (int it = 0; it < B_IT; ++it)
+                __builtin_amdgcn_global_load_lds((gptr_t)(b_lane_ok ? wt + (size_t)it * RPP * p.CP : g_zero_page),
+                                                 (lptr_t)(Bd + it * RPP * LD), 16, 0, 0);
+        }
         ld_kc += BK;
         if (ld_kc >= p.CP) {
             ld_kc = 0;
@@ -406,7 +417,7 @@ __global__ void __launch_bounds__(256) conv_gather_mfma_glds(const GatherParams 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int fsw = (li >> 1) & 7;  // (row>>1)&7 of every row this lane reads (tile bases are multiples of 32)
+    const int fsw = (li / RB) % CH;  // f(row) of every row this lane reads (tile bases are multiples of 32)
     // operand fragments of one k-group (8 k): register double buffer, read one group ahead of its MFMAs
     f32x4 av[2][MT], bv[2][NT];
     auto frag_read = [&](int buf, int kk, int slot, int kc) __attribute__((always_inline)) {
@@ -436,35 +447,38 @@ __global__ void __launch_bounds__(256) conv_gather_mfma_glds(const GatherParams 
     };
     auto next_kc = [&](int kc) { return (kc + BK >= p.CP) ? 0 : kc + BK; };
 
-    // Schedule of one step (4 k-groups g0..g3 of the current buffer):
-    //   DMA(step+1) | g0 | g1 | g2 | vmcnt(0)+barrier | read g0 of step+1 | g3
-    // g3's fragments are in registers before the barrier, so every wave is done with the current buffer when it
-    // arrives, and the first operand read of the next step runs under the 16 MFMAs of g3 instead of after the barrier.
+    // Schedule of one step (KG k-groups g0..g{KG-1} of the current buffer):
+    //   DMA(step+1) | g0 | ... | g{KG-2} | vmcnt(0)+barrier | read g0 of step+1 | g{KG-1}
+    // The last group's fragments are in registers before the barrier, so every wave is done with the current buffer
+    // when it arrives, and the first operand read of the next step runs under the MFMAs of the last group.
     issue(0);
     __syncthreads();  // the workgroup release waits for the outstanding LDS-DMA (vmcnt(0)) of every wave
     int cur = 0;
     frag_read(0, 0, 0, 0);
     for (int step = 0; step + 1 < nsteps; ++step) {
         issue(cur ^ 1);  // DMA of step+1 runs under the MFMAs of this step
-        frag_read(cur, 1, 1, cmp_kc);
-        mfma_group(0);
-        frag_read(cur, 2, 0, cmp_kc);
-        mfma_group(1);
-        frag_read(cur, 3, 1, cmp_kc);
-        mfma_group(0);
+#pragma unroll
+        for (int g = 0; g + 1 < KG; ++g) {
+            frag_read(cur, g + 1, (g + 1) & 1, cmp_kc);
+            mfma_group(g & 1);
+        }
         __syncthreads();
         cmp_kc = next_kc(cmp_kc);
         cur ^= 1;
-        frag_read(cur, 0, 0, cmp_kc);
-        mfma_group(1);
+        frag_read(cur, 0, KG & 1, cmp_kc);
+        mfma_group((KG - 1) & 1);
+        if (KG & 1) {  // odd group count: realign the register slots (KG is even for BK = 16 / 32, kept for safety)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) av[0][i] = av[1][i];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bv[0][j] = bv[1][j];
+        }
     }
-    frag_read(cur, 1, 1, cmp_kc);
-    mfma_group(0);
-    frag_read(cur, 2, 0, cmp_kc);
-    mfma_group(1);
-    frag_read(cur, 3, 1, cmp_kc);
-    mfma_group(0);
-    mfma_group(1);
+#pragma unroll
+    for (int g = 0; g < KG; ++g) {
+        if (g + 1 < KG) frag_read(cur, g + 1, (g + 1) & 1, cmp_kc);
+        mfma_group(g & 1);
+    }
     conv_epilogue<BM, BN, LD, MT, NT>(p, acc, smem, m0, n0, wm0, wn0, tid, li, lh, HWp);
 }
 
@@ -500,12 +514,12 @@ int launch_simple(GatherParams& p, hipStream_t s) {
     return launch_kernel(conv_gather_mfma<BM, BN, BK, WMv, WNv>, p, BM, BN, BK, s, attr);
 }
 
-template <int BM, int BN, int WMv, int WNv, bool SCALE>
+template <int BM, int BN, int WMv, int WNv, bool SCALE, int BK>
 int launch_glds_impl(GatherParams& p, hipStream_t s) {
     static size_t attr_bytes = 0;
     p.tiles_m = gif::cdiv(p.M, BM);
     p.tiles_n = p.RP / BN;
-    size_t lds = (size_t)2 * (BM + BN) * 32 * sizeof(float);
+    size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
     p.stab_nb = 0;
     p.stab_stride = 0;
     if (SCALE) {
@@ -517,7 +531,7 @@ int launch_glds_impl(GatherParams& p, hipStream_t s) {
         lds += (size_t)nb * p.stab_stride * sizeof(float);
     }
     if (lds > 160 * 1024) return -100;  // caller falls back to the register-staged kernel
-    auto kern = conv_gather_mfma_glds<BM, BN, WMv, WNv, SCALE>;
+    auto kern = conv_gather_mfma_glds<BM, BN, WMv, WNv, SCALE, BK>;
     if (lds > attr_bytes) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_bytes = lds;
@@ -526,9 +540,10 @@ int launch_glds_impl(GatherParams& p, hipStream_t s) {
     return 0;
 }
 
-template <int BM, int BN, int WMv, int WNv>
+template <int BM, int BN, int WMv, int WNv, int BK = 32>
 int launch_glds(GatherParams& p, hipStream_t s) {
-    return p.in_scale ? launch_glds_impl<BM, BN, WMv, WNv, true>(p, s) : launch_glds_impl<BM, BN, WMv, WNv, false>(p, s);
+    return p.in_scale ? launch_glds_impl<BM, BN, WMv, WNv, true, BK>(p, s)
+                      : launch_glds_impl<BM, BN, WMv, WNv, false, BK>(p, s);
 }
 
 // GIF_CONV_VARIANT=1 forces the register-staged kernel everywhere (A/B benchmarking only)

@@ -17,7 +17,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int BKP = 32;  // pixels per stage
+constexpr int BKP_MAX = 32;  // host-side rounding unit of the pixel chunks (any BKP below divides it)
 
 struct WgradParams {
     const float* sm;  // small side [B,Hs,Ws,Cs]
@@ -46,7 +46,7 @@ __device__ __attribute__((aligned(16))) float g_wgrad_zero_page[4];
 
 // GLDS = true (no per-sample scales): both operand tiles go global -> LDS directly (global_load_lds_dwordx4, lane-linear
 // destination == the [pixel][channel] tile layout), no staging registers / ds_write; invalid lanes read a zero page.
-template <int BP, int BQ, int WAVES_P, int WAVES_Q, bool GLDS>
+template <int BP, int BQ, int WAVES_P, int WAVES_Q, bool GLDS, int BKP>
 __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const WgradParams p) {
     constexpr int THREADS = 64 * WAVES_P * WAVES_Q;
     constexpr int WPt = BP / WAVES_P, WQt = BQ / WAVES_Q;
@@ -145,8 +145,17 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const 
             }
             q_n[it] += BKP;
             q_ox[it] += BKP;
-            while (q_ox[it] >= p.Ws) { q_ox[it] -= p.Ws; ++q_oy[it]; }
-            while (q_oy[it] >= p.Hs) { q_oy[it] -= p.Hs; ++q_b[it]; }
+            if (p.Ws >= BKP) {  // uniform: at most one row wrap per stage
+                const bool wx = q_ox[it] >= p.Ws;
+                q_ox[it] -= wx ? p.Ws : 0;
+                q_oy[it] += wx ? 1 : 0;
+                const bool wy = q_oy[it] >= p.Hs;
+                q_oy[it] -= wy ? p.Hs : 0;
+                q_b[it] += wy ? 1 : 0;
+            } else {
+                while (q_ox[it] >= p.Ws) { q_ox[it] -= p.Ws; ++q_oy[it]; }
+                while (q_oy[it] >= p.Hs) { q_oy[it] -= p.Hs; ++q_b[it]; }
+            }
         }
     };
     auto store_lds = [&](int buf) __attribute__((always_inline)) {
@@ -305,7 +314,7 @@ int gif_conv2d_wgrad_splits(const gif_conv_geom* g) {
     // 2 workgroups fit per CU (64 KB LDS each) => 512 concurrent slots on 256 CUs: fill k full rounds of 512
     // and never spill a few blocks into an extra, almost empty round (floor, not ceil)
     long want = tiles >= 1024 ? 1 : 1024 / tiles;
-    long max_by_work = (Ntot + 4 * BKP - 1) / (4 * BKP);  // >= 4 stages per split
+    long max_by_work = (Ntot + 4 * BKP_MAX - 1) / (4 * BKP_MAX);  // >= 4 stages per split
     long bytes_per_split = (long)g->KH * g->KW * RP * CP * 4;
     long max_by_mem = (128L << 20) / bytes_per_split;
     long n = want;
@@ -330,8 +339,8 @@ int gif_conv2d_wgrad_f32(const float* small, const float* big, float* ws, const 
     wgrad_dims(g->Cs, g->Cb, &p.RP, &p.CP);
     p.Ntot = (long)g->B * g->Hs * g->Ws;
     long chunk = (p.Ntot + nsplit - 1) / nsplit;
-    p.chunk = (chunk + BKP - 1) / BKP * BKP;
-    if (p.chunk < BKP) p.chunk = BKP;
+    p.chunk = (chunk + BKP_MAX - 1) / BKP_MAX * BKP_MAX;
+    if (p.chunk < BKP_MAX) p.chunk = BKP_MAX;
     const int bp = tile_of(g->Cs), bq = tile_of(g->Cb);
     p.tiles_q = p.CP / bq;
     p.tiles_pq = (p.RP / bp) * p.tiles_q;
@@ -341,11 +350,15 @@ int gif_conv2d_wgrad_f32(const float* small, const float* big, float* ws, const 
     {
         gif::ProfScope prof(1, flops, s);
         const char* env = getenv("GIF_CONV_VARIANT");
-        const bool glds = !small_scale && !big_scale && !(env && atoi(env) == 1);
-#define GIF_WGRAD_LAUNCH(BP_, BQ_, WP_, WQ_, TH_)                                                              \
-    if (glds) hipLaunchKernelGGL((conv_wgrad_mfma<BP_, BQ_, WP_, WQ_, true>), grid, dim3(TH_), 0, s, p);       \
-    else hipLaunchKernelGGL((conv_wgrad_mfma<BP_, BQ_, WP_, WQ_, false>), grid, dim3(TH_), 0, s, p)
-        if (bp == 128 && bq == 128) { GIF_WGRAD_LAUNCH(128, 128, 2, 2, 256); }
+        const int variant = env ? atoi(env) : 0;
+        const bool glds = !small_scale && !big_scale && variant != 1;
+#define GIF_WGRAD_LAUNCH(BP_, BQ_, WP_, WQ_, TH_)                                                                  \
+    if (glds) hipLaunchKernelGGL((conv_wgrad_mfma<BP_, BQ_, WP_, WQ_, true, 32>), grid, dim3(TH_), 0, s, p);       \
+    else hipLaunchKernelGGL((conv_wgrad_mfma<BP_, BQ_, WP_, WQ_, false, 32>), grid, dim3(TH_), 0, s, p)
+        if (bp == 128 && bq == 128 && glds) {
+            // 16-pixel stages: 32 KB of LDS per workgroup => 4 workgroups (16 waves) per CU; +6 % over 32-pixel stages
+            hipLaunchKernelGGL((conv_wgrad_mfma<128, 128, 2, 2, true, 16>), grid, dim3(256), 0, s, p);
+        } else if (bp == 128 && bq == 128) { GIF_WGRAD_LAUNCH(128, 128, 2, 2, 256); }
         else if (bp == 128 && bq == 32) { GIF_WGRAD_LAUNCH(128, 32, 4, 1, 256); }
         else if (bp == 32 && bq == 128) { GIF_WGRAD_LAUNCH(32, 128, 1, 4, 256); }
         else { GIF_WGRAD_LAUNCH(32, 32, 1, 1, 64); }
