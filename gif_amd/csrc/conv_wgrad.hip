@@ -55,8 +55,12 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const 
     constexpr int P_IT = BKP / P_ROWS, Q_IT = BKP / Q_ROWS;
     static_assert(BKP % P_ROWS == 0 && BKP % Q_ROWS == 0 && P_IT >= 1 && Q_IT >= 1, "tile/thread mapping");
 
-    __shared__ __attribute__((aligned(16))) float Ps[2][BKP][BP];
-    __shared__ __attribute__((aligned(16))) float Qs[2][BKP][BQ];
+    // ONE LDS object (two separate __shared__ arrays make hipcc drain the LDS-DMA with vmcnt(0) before every ds_read)
+    extern __shared__ __attribute__((aligned(16))) float wg_smem[];
+    typedef float PTile[BKP][BP];
+    typedef float QTile[BKP][BQ];
+    PTile* Ps = reinterpret_cast<PTile*>(wg_smem);                      // [2][BKP][BP]
+    QTile* Qs = reinterpret_cast<QTile*>(wg_smem + 2 * BKP * BP);       // [2][BKP][BQ]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -242,6 +246,18 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const 
         }
 }
 
+template <int BP, int BQ, int WP_, int WQ_, bool GLDS, int BKP>
+void wgrad_launch(dim3 grid, int threads, hipStream_t s, const WgradParams& p) {
+    static bool attr = false;
+    const size_t lds = (size_t)2 * BKP * (BP + BQ) * sizeof(float);
+    auto kern = conv_wgrad_mfma<BP, BQ, WP_, WQ_, GLDS, BKP>;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(threads), lds, s, p);
+}
+
 // wgrad tiles follow the SAME row/col padding as the forward packing (gif_conv2d_pack_dims(Cs, Cb)):
 // rows RP multiple of 32 or 128, cols CP multiple of 8 or 32 — so pad further to the tile here.
 inline int tile_of(int c) { return c <= 32 ? 32 : 128; }
@@ -353,11 +369,11 @@ int gif_conv2d_wgrad_f32(const float* small, const float* big, float* ws, const 
         const int variant = env ? atoi(env) : 0;
         const bool glds = !small_scale && !big_scale && variant != 1;
 #define GIF_WGRAD_LAUNCH(BP_, BQ_, WP_, WQ_, TH_)                                                                  \
-    if (glds) hipLaunchKernelGGL((conv_wgrad_mfma<BP_, BQ_, WP_, WQ_, true, 32>), grid, dim3(TH_), 0, s, p);       \
-    else hipLaunchKernelGGL((conv_wgrad_mfma<BP_, BQ_, WP_, WQ_, false, 32>), grid, dim3(TH_), 0, s, p)
-        if (bp == 128 && bq == 128 && glds) {
+    if (glds) wgrad_launch<BP_, BQ_, WP_, WQ_, true, 32>(grid, TH_, s, p);                                        \
+    else wgrad_launch<BP_, BQ_, WP_, WQ_, false, 32>(grid, TH_, s, p)
+        if (bp == 128 && bq == 128 && glds && variant != 7) {
             // 16-pixel stages: 32 KB of LDS per workgroup => 4 workgroups (16 waves) per CU; +6 % over 32-pixel stages
-            hipLaunchKernelGGL((conv_wgrad_mfma<128, 128, 2, 2, true, 16>), grid, dim3(256), 0, s, p);
+            wgrad_launch<128, 128, 2, 2, true, 16>(grid, 256, s, p);
         } else if (bp == 128 && bq == 128) { GIF_WGRAD_LAUNCH(128, 128, 2, 2, 256); }
         else if (bp == 128 && bq == 32) { GIF_WGRAD_LAUNCH(128, 32, 4, 1, 256); }
         else if (bp == 32 && bq == 128) { GIF_WGRAD_LAUNCH(32, 128, 1, 4, 256); }
