@@ -31,6 +31,7 @@ struct WgradParams {
     long Ntot;   // B*Hs*Ws
     long chunk;  // pixels per split (multiple of BKP)
     int tiles_q, tiles_pq;
+    int stab_nb;  // LDS scale table (scaled LDS-DMA path): samples a pixel chunk can touch
 };
 
 // XCD-aware, bijective block remap: XCD k (= blockIdx % 8 by dispatch order) gets a contiguous range of logical ids.
@@ -46,7 +47,10 @@ __device__ __attribute__((aligned(16))) float g_wgrad_zero_page[4];
 
 // GLDS = true (no per-sample scales): both operand tiles go global -> LDS directly (global_load_lds_dwordx4, lane-linear
 // destination == the [pixel][channel] tile layout), no staging registers / ds_write; invalid lanes read a zero page.
-template <int BP, int BQ, int WAVES_P, int WAVES_Q, bool GLDS, int BKP>
+// TAB = true (GLDS with per-sample scales, needs Hs*Ws % BKP == 0 so that a stage never straddles two samples): the
+// scale vectors ss[b, r0:r0+BP) / bs[b, c0:c0+BQ) of the samples this chunk touches sit in an LDS table and are
+// multiplied into the operand fragments (the DMA cannot scale data in flight).
+template <int BP, int BQ, int WAVES_P, int WAVES_Q, bool GLDS, int BKP, bool TAB = false>
 __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const WgradParams p) {
     constexpr int THREADS = 64 * WAVES_P * WAVES_Q;
     constexpr int WPt = BP / WAVES_P, WQt = BQ / WAVES_Q;
@@ -82,7 +86,24 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const 
     const int p_row = tid / (BP / 4), p_ch = r0 + (tid % (BP / 4)) * 4;
     const int q_row = tid / (BQ / 4), q_ch = c0 + (tid % (BQ / 4)) * 4;
     const bool p_ch_ok = p_ch < p.Cs, q_ch_ok = q_ch < p.Cb;
-    const bool has_ss = p.ss != nullptr, has_bs = p.bs != nullptr;
+    const bool has_ss = !TAB && p.ss != nullptr, has_bs = !TAB && p.bs != nullptr;
+    float* Stab = wg_smem + 2 * BKP * (BP + BQ);  // [stab_nb][BP + BQ]
+    int tab_row = 0, tab_rem = 0;                 // table row / pixel offset inside the sample of the stage being computed
+    if (TAB) {
+        const int b_first = n_begin / (int)HWs;
+        for (int e = tid; e < p.stab_nb * (BP + BQ); e += THREADS) {
+            int bl = e / (BP + BQ), c = e - bl * (BP + BQ);
+            int b = b_first + bl;
+            float v = 0.f;
+            if (b < p.B) {
+                if (c < BP) v = (r0 + c < p.Cs) ? (p.ss ? p.ss[(size_t)b * p.Cs + r0 + c] : 1.f) : 0.f;
+                else v = (c0 + c - BP < p.Cb) ? (p.bs ? p.bs[(size_t)b * p.Cb + c0 + c - BP] : 1.f) : 0.f;
+            }
+            Stab[e] = v;
+        }
+        tab_rem = n_begin - b_first * (int)HWs;
+        __syncthreads();
+    }
 
     float4 p_reg[P_IT], ps_reg[P_IT], q_reg[Q_IT], qs_reg[Q_IT];
     unsigned p_mask = 0, q_mask = 0;
@@ -191,6 +212,16 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const 
     auto compute = [&](int buf) __attribute__((always_inline)) {
         // operand fragments of k-step ks+1 are fetched from LDS before the MFMAs of k-step ks (register double buffer)
         float av[2][MT], bv[2][NT];
+        float psv[MT], qsv[NT];
+        if (TAB) {
+            const float* row = Stab + tab_row * (BP + BQ);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) psv[i] = row[wp0 + i * 32 + li];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) qsv[j] = row[BP + wq0 + j * 32 + li];
+            tab_rem += BKP;
+            if (tab_rem >= (int)HWs) { tab_rem -= (int)HWs; ++tab_row; }
+        }
 #pragma unroll
         for (int i = 0; i < MT; ++i) av[0][i] = Ps[buf][lh][wp0 + i * 32 + li];
 #pragma unroll
@@ -203,6 +234,12 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const 
                 for (int i = 0; i < MT; ++i) av[n][i] = Ps[buf][2 * ks + 2 + lh][wp0 + i * 32 + li];
 #pragma unroll
                 for (int j = 0; j < NT; ++j) bv[n][j] = Qs[buf][2 * ks + 2 + lh][wq0 + j * 32 + li];
+            }
+            if (TAB) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) av[c][i] *= psv[i];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bv[c][j] *= qsv[j];
             }
 #pragma unroll
             for (int i = 0; i < MT; ++i)
@@ -246,14 +283,14 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const 
         }
 }
 
-template <int BP, int BQ, int WP_, int WQ_, bool GLDS, int BKP>
+template <int BP, int BQ, int WP_, int WQ_, bool GLDS, int BKP, bool TAB = false>
 void wgrad_launch(dim3 grid, int threads, hipStream_t s, const WgradParams& p) {
-    static bool attr = false;
-    const size_t lds = (size_t)2 * BKP * (BP + BQ) * sizeof(float);
-    auto kern = conv_wgrad_mfma<BP, BQ, WP_, WQ_, GLDS, BKP>;
-    if (!attr) {
+    static size_t attr_bytes = 0;
+    const size_t lds = (size_t)(2 * BKP * (BP + BQ) + (TAB ? p.stab_nb * (BP + BQ) : 0)) * sizeof(float);
+    auto kern = conv_wgrad_mfma<BP, BQ, WP_, WQ_, GLDS, BKP, TAB>;
+    if (lds > attr_bytes) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
+        attr_bytes = lds;
     }
     hipLaunchKernelGGL(kern, grid, dim3(threads), lds, s, p);
 }
@@ -371,7 +408,15 @@ int gif_conv2d_wgrad_f32(const float* small, const float* big, float* ws, const 
 #define GIF_WGRAD_LAUNCH(BP_, BQ_, WP_, WQ_, TH_)                                                                  \
     if (glds) wgrad_launch<BP_, BQ_, WP_, WQ_, true, 32>(grid, TH_, s, p);                                        \
     else wgrad_launch<BP_, BQ_, WP_, WQ_, false, 32>(grid, TH_, s, p)
-        if (bp == 128 && bq == 128 && glds && variant != 7) {
+        const long HWs = (long)g->Hs * g->Ws;
+        p.stab_nb = (int)((p.chunk + HWs - 1) / HWs + 1);
+        if (p.stab_nb > g->B) p.stab_nb = g->B;
+        const bool tab = (small_scale || big_scale) && variant != 1 && HWs % 16 == 0 &&
+                         (size_t)p.stab_nb * 256 * sizeof(float) <= 64 * 1024;
+        if (bp == 128 && bq == 128 && tab) {
+            // modulated wgrad (x*s, dy*d): LDS-DMA operands + scale table
+            wgrad_launch<128, 128, 2, 2, true, 16, true>(grid, 256, s, p);
+        } else if (bp == 128 && bq == 128 && glds && variant != 7) {
             // 16-pixel stages: 32 KB of LDS per workgroup => 4 workgroups (16 waves) per CU; +6 % over 32-pixel stages
             wgrad_launch<128, 128, 2, 2, true, 16>(grid, 256, s, p);
         } else if (bp == 128 && bq == 128) { GIF_WGRAD_LAUNCH(128, 128, 2, 2, 256); }
