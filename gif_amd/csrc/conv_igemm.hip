@@ -566,6 +566,10 @@ int launch(GatherParams& p, hipStream_t s) {
     // LDS-DMA path: every BK = 32 layer (rows are 16-byte aligned in HBM because Ci % 4 == 0)
     const bool glds = c.BK == 32 && conv_variant() != 1;
     if (c.BN == 128 && c.BK == 32) {
+        // low-resolution layers (4x4 .. 16x16 at batch 32): a 128x128 grid would leave most CUs idle behind a
+        // 144-step K loop; 64x64 tiles give 4x the workgroups (and 32 KB of LDS: 4 per CU) at a quarter of the latency
+        const long tiles128 = (long)gif::cdiv(p.M, 128) * (p.RP / 128);
+        if (glds && tiles128 < 384 && launch_glds<64, 64, 2, 2>(p, s) == 0) return 0;
         if (glds && launch_glds<128, 128, 2, 2>(p, s) == 0) return 0;
         return launch_simple<128, 128, 32, 2, 2>(p, s);
     }
