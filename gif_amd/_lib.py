@@ -31,6 +31,7 @@ PROTOTYPES = {
     "gif_rasterize_workspace_bytes": (c_i64, [c_int, c_int, c_int]),
     "gif_rasterize_f32": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P]),
     "gif_rasterize_colors_f32": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P, P]),
+    "gif_vertex_normals_f32": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),
     "gif_conv2d_pack_dims": (c_int, [c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "gif_pack_weight_f32": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_float, P]),
     "gif_conv2d_fwd_f32": (c_int, [P, P, P, GP, EP, P]),

@@ -46,6 +46,13 @@ int gif_rasterize_colors_f32(const float* face_vertices, const float* face_color
                              int32_t* tri, float* images, int B, int F, int H, int W, void* workspace,
                              gif_stream_t stream);
 
+/* Per-vertex normals — replaces vertex_normals() model/mesh_and_3d_helpers.py:5-37 (condition-render pipeline,
+ * SURVEY §8(f) row 1).  verts [B,V,3]; faces [F,3] int32 (topology shared by the batch); csr_off [V+1] / csr_ent [3F]:
+ * vertex -> entries (face*4 + corner), ordered corner 1, corner 2, corner 0 with faces ascending (the order of the
+ * reference's three index_add_ passes); normals [B,V,3] = normalize(sum of face cross products, eps 1e-6). */
+int gif_vertex_normals_f32(const float* verts, const int32_t* faces, const int32_t* csr_off, const int32_t* csr_ent,
+                           float* normals, int B, int V, int F, gif_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Convolution family (fp32 MFMA implicit GEMM) — replaces the F.conv2d / F.conv_transpose2d calls of
  *   ModulatedConv2d.forward   stylegan2_common_layers.py:307-349 (groups=batch trick -> in/out scales)
