@@ -110,3 +110,43 @@ def test_generator_and_discriminator_256_vs_oracle():
         sref = R.discriminator_forward(sdd, ref, cond, 256)
         sgot = d.cuda()(got, condition=cond.cuda())[0]
     assert_close(sgot, sref, 2e-4, "D(256) scores")
+
+
+def test_config3_render_condition_into_train_step_with_r1_and_path_length():
+    """BASELINE config 3 (reduced size for test time): mesh -> HIP vertex normals + rasteriser -> 6-channel condition ->
+    one full G+D training iteration on an R1 step with the path-length regulariser enabled; checks the plumbing end to
+    end (finite losses, parameters move, EMA follows)."""
+    import numpy as np
+    from gif_amd import render
+    from gif_amd.train_step import GifTrainer
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "body_mesh.npz"))
+    B, R = 4, 64
+    rng = np.random.RandomState(0)
+    verts = []
+    for i in range(B):  # small random rotations about y, as a stand-in for FLAME pose variation
+        a = rng.uniform(-0.4, 0.4)
+        Rm = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], np.float32)
+        verts.append((g["vertices"] @ Rm.T).astype(np.float32))
+    v = torch.from_numpy(np.stack(verts)).cuda()
+    f = torch.from_numpy(g["faces"]).cuda()
+    cam = torch.tensor([[0.95, 0.0, 0.35]] * B, device="cuda")
+    v_ndc = render.batch_orth_proj(v, cam)
+    tex = (v - v.amin(dim=1, keepdim=True)) / (v.amax(dim=1, keepdim=True) - v.amin(dim=1, keepdim=True))
+    cond = render.render_condition(v_ndc, f, tex, R, R)
+    assert cond.shape == (B, 6, R, R) and (cond[:, 3:].abs().sum(dim=(1, 2, 3)) > 0).all()
+    torch.manual_seed(0)
+    G, G_ema, D = _build_g(16).cuda(), _build_g(16).cuda(), _build_d(R).cuda()
+    G_ema.load_state_dict(G.state_dict())
+    tr = GifTrainer(G, D, G_ema, step=4, gen_reg_type='PATH_LEN_REG')
+    w0 = G.generator.progression[4].st_cv2.conv.weight.detach().clone()
+    e0 = G_ema.generator.progression[4].st_cv2.conv.weight.detach().clone()
+    real = torch.rand(B, 3, R, R, device="cuda") * 2 - 1
+    idx = torch.randint(0, 16, (B,), device="cuda")
+    d_loss, g_loss = tr.step(15, real, cond, idx)  # i = 15 -> R1 iteration
+    torch.cuda.synchronize()
+    assert torch.isfinite(d_loss) and torch.isfinite(g_loss)
+    w1 = G.generator.progression[4].st_cv2.conv.weight
+    assert (w1 - w0).abs().max() > 0, "generator parameters must move"
+    e1 = G_ema.generator.progression[4].st_cv2.conv.weight
+    decay = 0.5 ** (32 / 10000)
+    assert torch.allclose(e1, decay * e0 + (1 - decay) * w1, atol=1e-6), "EMA update (generic_utils.accumulate)"

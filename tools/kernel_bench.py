@@ -49,6 +49,29 @@ def main():
         t_w = timeit(lambda: ops.conv_wgrad(gy, x, spec, co, ci))
         print(f"{name:32s} fwd {t_f:8.3f} ms {fl / t_f / 1e9:7.1f} TF | dgrad {t_d:8.3f} ms {fl / t_d / 1e9:7.1f} TF | "
               f"wgrad {t_w:8.3f} ms {fl / t_w / 1e9:7.1f} TF")
+    # rasteriser: FLAME-sized synthetic mesh (V=5023-ish, F=9976) at 256x256, batch B (atomic / latency bound)
+    import numpy as np
+    from gif_amd import standard_rasterize as sr
+    rng = np.random.RandomState(0)
+    nlat, nlon = 72, 70  # 5040 vertices, 9936 faces: a UV sphere of FLAME size
+    th, ph = np.meshgrid(np.linspace(0.05, np.pi - 0.05, nlat), np.linspace(0, 2 * np.pi, nlon, endpoint=False), indexing="ij")
+    vs = np.stack([np.sin(th) * np.cos(ph), np.cos(th), np.sin(th) * np.sin(ph)], -1).reshape(-1, 3).astype(np.float32) * 0.8
+    idx = np.arange(nlat * nlon).reshape(nlat, nlon)
+    a, b_, c, d = idx[:-1], np.roll(idx, -1, 1)[:-1], idx[1:], np.roll(idx, -1, 1)[1:]
+    fs = np.concatenate([np.stack([a, c, b_], -1).reshape(-1, 3), np.stack([b_, c, d], -1).reshape(-1, 3)]).astype(np.int32)
+    v_t = torch.from_numpy(np.repeat(vs[None], B, 0)).cuda()
+    f_t = torch.from_numpy(np.repeat(fs[None], B, 0)).cuda()
+    fv = sr.face_vertices(sr.to_image_space(v_t, 256, 256), f_t)
+
+    def rast():
+        d_, t_, b2 = sr.new_buffers(B, 256, 256, "cuda")
+        sr.standard_rasterize(fv, d_, t_, b2, 256, 256)
+        return t_
+
+    t_r = timeit(rast)
+    cov = int((rast() >= 0).sum())
+    print(f"rasterize V={vs.shape[0]} F={fs.shape[0]} @256x256 x{B}: {t_r:7.3f} ms  {B * fs.shape[0] / t_r / 1e6:8.1f} Gtri/s-e-3 "
+          f"({B * fs.shape[0] / t_r / 1e3:.0f} Mtri/s)  {B * 65536 / t_r / 1e3:.0f} Mpix/s  covered {cov / (B * 65536):.2f}")
     # HBM-bound kernels at the top resolution
     for c, h in ((128, 256), (256, 128), (512, 64)):
         x = torch.randn(B, c, h, h, device=dev).contiguous(memory_format=torch.channels_last)
