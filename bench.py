@@ -183,6 +183,9 @@ def main():
             out["roofline"] = {"bound": "mfma", "kernel": "conv_gather_mfma (fwd / dgrad / transposed conv, fp32 MFMA)",
                                "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                               "traffic_probe": {"note": "PMC pass on the largest layer shape (128->128 3x3 @256x256, batch 32), "
+                                                         "profiles/r1_pmc_dominant_kernels.md: 2*FETCH_SIZE + WRITE_SIZE per launch",
+                                                 "hbm_bytes": 3.68e9, "algorithmic_bytes": 2.15e9, "mfma_busy": 0.824},
                                "launches": n0, "avg_ms": ms0 / max(n0, 1), "gpu_ms_per_step": ms0 / args.steps}
             ach1 = fl1 / (ms1 * 1e-3) / 1e12 if ms1 > 0 else 0.0
             out["roofline_wgrad"] = {"bound": "mfma", "kernel": "conv_wgrad_mfma", "achieved": ach1,
