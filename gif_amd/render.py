@@ -15,8 +15,6 @@ import torch
 from . import _lib
 from . import standard_rasterize as sr
 
-_CSR_CACHE = {}
-
 
 def _topology_csr(faces_cpu: np.ndarray):
     """vertex -> (face, corner) entries ordered like the reference's index_add_ passes: corner 1, 2, 0; faces ascending."""
@@ -40,16 +38,22 @@ def vertex_normals(vertices, faces):
     if not vertices.is_cuda:
         raise _lib.GifHipError("vertex_normals needs device tensors (no CPU fallback)")
     B, V, _ = vertices.shape
-    key = (faces.data_ptr(), tuple(faces.shape), V, str(vertices.device))
-    if key not in _CSR_CACHE:
+    # the topology tables live ON the faces tensor (attribute), validated by its in-place version counter: no global
+    # cache keyed by an address that could be recycled
+    cached = getattr(faces, "_gif_csr", None)
+    if cached is None or cached[0] != (faces._version, V, str(vertices.device)):
         f_cpu = faces.detach().cpu().numpy().astype(np.int64)
+        if f_cpu.size and (f_cpu.min() < 0 or f_cpu.max() >= V):
+            raise _lib.GifHipError(f"vertex_normals: face index out of range [0,{V})")
         ent, counts = _topology_csr(f_cpu)
         off = np.zeros(V + 1, np.int32)
         off[1:len(counts) + 1] = np.cumsum(counts)[:V]
         off[len(counts) + 1:] = off[len(counts)]
         dev = vertices.device
-        _CSR_CACHE[key] = (faces.to(torch.int32).contiguous(), torch.from_numpy(off).to(dev), torch.from_numpy(ent).to(dev))
-    f32, off, ent = _CSR_CACHE[key]
+        cached = ((faces._version, V, str(dev)),
+                  (faces.to(torch.int32).contiguous(), torch.from_numpy(off).to(dev), torch.from_numpy(ent).to(dev)))
+        faces._gif_csr = cached
+    f32, off, ent = cached[1]
     verts = vertices.contiguous().float()
     out = torch.empty_like(verts)
     lib = _lib.load()

@@ -61,7 +61,7 @@ def pixel_norm(x):  # :75-80
     return x * torch.rsqrt(torch.mean(x ** 2, dim=1, keepdim=True) + 1e-8)
 
 
-def modulated_conv2d(x, weight, mod_w, mod_b, style, demodulate=True, upsample=False, blur_k=None):
+def modulated_conv2d(x, weight, mod_w, mod_b, style, demodulate=True, upsample=False, blur_k=None, downsample=False):
     """ModulatedConv2d.forward :307-349 (weight [1,Co,Ci,k,k]; modulation = EqualLinear(512->Ci, bias_init 1))."""
     B, Ci, H, W = x.shape
     _, Co, _, k, _ = weight.shape
@@ -75,6 +75,12 @@ def modulated_conv2d(x, weight, mod_w, mod_b, style, demodulate=True, upsample=F
         out = out.view(B, Co, out.shape[2], out.shape[3])
         p = (4 - 2) - (k - 1)
         return upfirdn2d(out, blur_k, pad=((p + 1) // 2 + 1, p // 2 + 1))  # Blur(pad0,pad1) of :272-278
+    if downsample:  # :335-341 (Blur with pad computed at :280-286, then stride-2 grouped conv)
+        p = (4 - 2) + (k - 1)
+        xb = upfirdn2d(x, blur_k, pad=((p + 1) // 2, p // 2))
+        out = F.conv2d(xb.reshape(1, B * Ci, xb.shape[2], xb.shape[3]), w.view(B * Co, Ci, k, k), padding=0, stride=2,
+                       groups=B)
+        return out.view(B, Co, out.shape[2], out.shape[3])
     out = F.conv2d(x.reshape(1, B * Ci, H, W), w.view(B * Co, Ci, k, k), padding=k // 2, groups=B)  # :343-347
     return out.view(B, Co, out.shape[2], out.shape[3])
 

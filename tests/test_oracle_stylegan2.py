@@ -117,3 +117,23 @@ def test_oracle_equals_imported_reference():
     x = torch.randn(2, 5, 9, 9)
     for up, down, pad in ((1, 1, (2, 2)), (2, 1, (2, 1)), (1, 2, (1, 1)), (1, 1, (-1, 2)), (2, 2, (3, 0))):
         assert torch.equal(R.upfirdn2d(x, k, up, down, pad), L.upfirdn2d(x, k, up, down, pad))
+
+
+@pytest.mark.reference
+def test_oracle_layer_variants_equal_imported_reference():
+    """Less-travelled layer options: down-sampling modulated conv, no-demod 1x1 (ToRGB), up-sampling modulated conv."""
+    from oracle import reference_import as ri
+    _, _, L = ri.reference_modules()
+    torch.manual_seed(3)
+    x, st = torch.randn(2, 16, 8, 8), torch.randn(2, 512)
+    for kw in (dict(downsample=True), dict(upsample=True), dict()):
+        m = L.ModulatedConv2d(16, 24, 3, 512, **kw)
+        sd = m.state_dict()
+        ref = m(x, st)
+        got = R.modulated_conv2d(x, sd["weight"], sd["modulation.weight"], sd["modulation.bias"], st, True,
+                                 kw.get("upsample", False), sd.get("blur.kernel"), kw.get("downsample", False))
+        assert ref.shape == got.shape and (ref - got).abs().max() < 1e-5, kw
+    m = L.ModulatedConv2d(16, 3, 1, 512, demodulate=False)
+    sd = m.state_dict()
+    assert (m(x, st) - R.modulated_conv2d(x, sd["weight"], sd["modulation.weight"], sd["modulation.bias"], st,
+                                          demodulate=False)).abs().max() < 1e-5
