@@ -357,6 +357,63 @@ __global__ void __launch_bounds__(1024) sqnorm_kernel(const float* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Condition pyramid level (stg2_generator.py:309-314): F.interpolate(cond, (S,S), 'bilinear', align_corners=False) for
+// an integer down-scale factor f = R/S.  For even f the two source taps per axis are f*d + f/2 - 1 and + f/2 with
+// weight 0.5 each; f == 1 is a copy.  Same operation order as ATen's kernel: 0.5*(0.5*a+0.5*b) + 0.5*(0.5*c+0.5*d).
+// Backward scatters 0.25*g to the 4 taps (each source pixel receives at most one contribution => plain stores).
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) bilinear_down_kernel(const float* __restrict__ x, float* __restrict__ y, int B,
+                                                            int R, int S, int C4) {
+    const int f = R / S, o0 = f / 2 - 1;
+    long total = (long)B * S * S * C4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        int c4 = (int)(idx % C4);
+        long pix = idx / C4;
+        int ox = (int)(pix % S);
+        long t = pix / S;
+        int oy = (int)(t % S), b = (int)(t / S);
+        const float4* xb = reinterpret_cast<const float4*>(x) + (size_t)b * R * R * C4 + c4;
+        float4 r;
+        if (f == 1) {
+            r = xb[((size_t)oy * R + ox) * C4];
+        } else {
+            int y0 = oy * f + o0, x0 = ox * f + o0;
+            float4 a = xb[((size_t)y0 * R + x0) * C4], bq = xb[((size_t)y0 * R + x0 + 1) * C4];
+            float4 c = xb[((size_t)(y0 + 1) * R + x0) * C4], d = xb[((size_t)(y0 + 1) * R + x0 + 1) * C4];
+            r.x = 0.5f * (0.5f * a.x + 0.5f * bq.x) + 0.5f * (0.5f * c.x + 0.5f * d.x);
+            r.y = 0.5f * (0.5f * a.y + 0.5f * bq.y) + 0.5f * (0.5f * c.y + 0.5f * d.y);
+            r.z = 0.5f * (0.5f * a.z + 0.5f * bq.z) + 0.5f * (0.5f * c.z + 0.5f * d.z);
+            r.w = 0.5f * (0.5f * a.w + 0.5f * bq.w) + 0.5f * (0.5f * c.w + 0.5f * d.w);
+        }
+        reinterpret_cast<float4*>(y)[idx] = r;
+    }
+}
+
+__global__ void __launch_bounds__(256) bilinear_down_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, int B,
+                                                                int R, int S, int C4) {
+    const int f = R / S, o0 = f / 2 - 1;
+    long total = (long)B * R * R * C4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        int c4 = (int)(idx % C4);
+        long pix = idx / C4;
+        int ix = (int)(pix % R);
+        long t = pix / R;
+        int iy = (int)(t % R), b = (int)(t / R);
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (f == 1) {
+            r = reinterpret_cast<const float4*>(gy)[idx];
+        } else {
+            int ry = iy % f - o0, rx = ix % f - o0;  // tap position inside the f x f cell: taps are 0 and 1
+            if ((ry == 0 || ry == 1) && (rx == 0 || rx == 1)) {
+                float4 g = reinterpret_cast<const float4*>(gy)[(((size_t)b * S + iy / f) * S + ix / f) * C4 + c4];
+                r = make_float4(0.25f * g.x, 0.25f * g.y, 0.25f * g.z, 0.25f * g.w);
+            }
+        }
+        reinterpret_cast<float4*>(gx)[idx] = r;
+    }
+}
+
 inline int ew_grid(long n) {
     long b = (n + 255) / 256;
     if (b > 256 * 16) b = 256 * 16;
@@ -463,6 +520,18 @@ int gif_act_inv_mul_reduce_f32(const float* g, const float* y, const float* resi
                                                       bias);
     colsum_stage2<<<dim3(gif::cdiv(C, 64), B), 256, 0, s>>>(partial, out, nchunk, C);
     return gif::check_launch("act_inv_mul_reduce");
+}
+
+int gif_bilinear_down_f32(const float* x, float* y, int B, int R, int S, int C, int backward, gif_stream_t stream) {
+    GIF_REQUIRE(x && y && B >= 0 && R > 0 && S > 0 && C > 0 && C % 4 == 0, "bilinear_down: bad arguments");
+    GIF_REQUIRE(R % S == 0 && (R == S || (R / S) % 2 == 0), "bilinear_down: R/S must be 1 or an even integer (got %d/%d)", R, S);
+    if (B == 0) return 0;
+    hipStream_t s = gif::as_stream(stream);
+    if (!backward)
+        bilinear_down_kernel<<<ew_grid((long)B * S * S * (C / 4)), 256, 0, s>>>(x, y, B, R, S, C / 4);
+    else  // x = grad of the level [B,S,S,C], y = grad of the full-resolution condition [B,R,R,C]
+        bilinear_down_bwd_kernel<<<ew_grid((long)B * R * R * (C / 4)), 256, 0, s>>>(x, y, B, R, S, C / 4);
+    return gif::check_launch("bilinear_down");
 }
 
 int gif_mbstd_fwd_f32(const float* x, float* y, float* stat, int B, int H, int W, int C, int Cy, int G,

@@ -222,6 +222,38 @@ def upfirdn2d(x, kernel, up=1, down=1, pad=(0, 0)):
 
 
 # --------------------------------------------------------------------------------------------------------
+# condition pyramid (stg2_generator.py:309-314)
+# --------------------------------------------------------------------------------------------------------
+class BilinearDownFn(Function):
+    @staticmethod
+    def forward(ctx, x, S):
+        ctx.cfg = (x.shape[2], S)
+        return ops.bilinear_down(x, S)
+
+    @staticmethod
+    def backward(ctx, gy):
+        R, S = ctx.cfg
+        return BilinearDownBwdFn.apply(gy, R, S), None
+
+
+class BilinearDownBwdFn(Function):  # linear map: its backward is the forward again
+    @staticmethod
+    def forward(ctx, gy, R, S):
+        ctx.cfg = (R, S)
+        return ops.bilinear_down(gy, S, backward_to=R)
+
+    @staticmethod
+    def backward(ctx, ggx):
+        R, S = ctx.cfg
+        return BilinearDownFn.apply(ggx, S), None, None
+
+
+def bilinear_down(x, S):
+    """F.interpolate(x, (S,S), 'bilinear', align_corners=False) for square inputs with R/S == 1 or even."""
+    return BilinearDownFn.apply(x, S)
+
+
+# --------------------------------------------------------------------------------------------------------
 # minibatch standard deviation (stg2_discriminator.py:59-65)
 # --------------------------------------------------------------------------------------------------------
 def _mbstd_torch(x, G):

@@ -3,8 +3,8 @@
 Same classes (StyledGenerator, Generator, StyledConvStyleGAN2, ImgEmbedding, ConstantInput), constructor and
 forward() signatures, attribute names and state_dict keys (241 keys incl. the double-registered embedding
 buffer `image_embedding.embd_weight` / `img_embdng.embd_weight`).  The synthesis network runs on the HIP
-kernels through gif_amd.layers; only [B,512]-sized vector math (mapping network, style scales) and the
-bilinear condition pyramid stay in torch.  FlameTextureSpace (reference :336-421) is out of scope (needs the
+kernels through gif_amd.layers (incl. the bilinear condition pyramid); only [B,512]-sized vector math (mapping
+network, style scales) stays in torch.  FlameTextureSpace (reference :336-421) is out of scope (needs the
 missing photometric_optimization submodule + licensed FLAME assets).
 """
 import random
@@ -14,6 +14,7 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
+from . import functional as GF
 from . import ops
 from .layers import StyledConv, ToRGB, get_w_frm_z
 
@@ -140,10 +141,14 @@ class StyledGenerator(nn.Module):
             cond = F.pad(cond, (0, 0, 0, 0, 0, ops.pad4(c) - c))
         cond = cond.contiguous(memory_format=torch.channels_last)
         levels = []
+        H, W = cond.shape[2:]
         for i in range(step + 1):
             size = 4 * 2 ** i
-            lvl = F.interpolate(cond, size=(size, size), mode='bilinear', align_corners=False)
-            levels.append(lvl.contiguous(memory_format=torch.channels_last))
+            if H == W and H % size == 0 and (H == size or (H // size) % 2 == 0):
+                levels.append(GF.bilinear_down(cond, size))  # HIP: integer ratio, taps are exact 0.5/0.5
+            else:  # arbitrary ratio (e.g. a 2x2 dummy condition): ATen's generic bilinear resampler
+                lvl = F.interpolate(cond, size=(size, size), mode='bilinear', align_corners=False)
+                levels.append(lvl.contiguous(memory_format=torch.channels_last))
         return levels
 
     def forward(self, input, pose=None, noise=None, step=9, alpha=1, mean_style=None, style_weight=0,

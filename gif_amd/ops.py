@@ -211,6 +211,22 @@ def mul_reduce(a, b, scale=None, want_scaled=False):
     return out, scaled
 
 
+def bilinear_down(x, S, backward_to=None):
+    """Forward: x [B,C,R,R] -> [B,C,S,S].  backward_to=R: x is the gradient of a level, returns the gradient [B,C,R,R]."""
+    lib = _lib.load()
+    x = nhwc(x)
+    B, C = x.shape[:2]
+    if backward_to is None:
+        R = x.shape[2]
+        y = empty_nhwc(B, C, S, S, x.device)
+        _lib.check(lib.gif_bilinear_down_f32(x.data_ptr(), y.data_ptr(), B, R, S, C, 0, _stream()), "bilinear_down")
+    else:
+        R = backward_to
+        y = empty_nhwc(B, C, R, R, x.device)
+        _lib.check(lib.gif_bilinear_down_f32(x.data_ptr(), y.data_ptr(), B, R, S, C, 1, _stream()), "bilinear_down_bwd")
+    return y
+
+
 def act_inv_mul_reduce(g, y, residual, bias, slope, gain):
     """out[b,c] = sum_hw g * (act^-1(y) - residual - bias[c])  (see gif_hip.h)."""
     lib = _lib.load()

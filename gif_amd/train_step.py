@@ -87,10 +87,13 @@ class GifTrainer:
         G, D = self.G, self.D
         requires_grad(D, True)
         self.d_bucket.zero()
-        real_image = real_image.detach().requires_grad_(True)
+        r1_step = bool(self.r1_every) and (i + 1) % self.r1_every == 0
+        # the reference marks the real image as requiring grad on every iteration (train.py:135-136) but only uses the
+        # gradient on R1 iterations; requesting it only then skips a dead dgrad of D's first layer otherwise
+        real_image = real_image.detach().requires_grad_(r1_step)
         real_scores, _ = D([real_image], condition=cond, step=self.res_step, alpha=self.alpha)
         real_loss = F.softplus(-real_scores).mean()
-        if self.r1_every and (i + 1) % self.r1_every == 0:
+        if r1_step:
             real_loss = real_loss + losses.grad_penalty_loss([real_image], real_scores, step=None).mean()
         with torch.no_grad():  # the reference detaches the fake image right after the forward (train.py:160)
             fake = G(cond, None, step=self.res_step, alpha=self.alpha, input_indices=input_indices)[0]

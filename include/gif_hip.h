@@ -141,6 +141,11 @@ int gif_mul_reduce_chunks(int64_t HW);
 int gif_mul_reduce_f32(const float* a, const float* b, const float* scale, float* scaled, float* out,
                        float* partial, int B, int64_t HW, int C, gif_stream_t stream);
 
+/* Condition pyramid level — replaces F.interpolate(cond, (S,S), 'bilinear', align_corners=False) of
+ * StyledGenerator.forward (stg2_generator.py:309-314) for the integer ratios the model uses (R/S == 1 or even).
+ * backward == 0: x [B,R,R,C] -> y [B,S,S,C];  backward != 0: x = grad [B,S,S,C] -> y = grad [B,R,R,C]. */
+int gif_bilinear_down_f32(const float* x, float* y, int B, int R, int S, int C, int backward, gif_stream_t stream);
+
 /* out[b,c] = sum_hw g * (act^-1(y) - residual - bias[c]) with act = gain*leaky_relu(., slope): the gradient of the
  * demodulation scale d[b,c] (times d) when bias/noise/activation are fused into the modulated conv's epilogue, i.e.
  * y = act(d*z + residual + bias) => d*z = act^-1(y) - residual - bias.  residual / bias may be NULL. */

@@ -390,3 +390,20 @@ def test_vertex_normals_orth_proj_and_condition_render():
     # 8-bit quantisation: identical up to the rare pixel whose value sits on a quantisation edge
     assert (np.abs(got_n - ref_n) > 1e-6).mean() < 1e-3
     assert np.abs(got_n - ref_n).max() <= 2 / 255 + 1e-6
+
+
+@pytest.mark.parametrize("R,S", [(256, 256), (256, 128), (256, 64), (256, 4), (64, 8), (32, 16)])
+def test_condition_pyramid_level(R, S):
+    """HIP pyramid level == F.interpolate(bilinear, align_corners=False) for the model's integer ratios, fwd + bwd."""
+    from gif_amd import functional as GF
+    g = torch.Generator().manual_seed(12)
+    B = 2 if R == 256 else 3
+    x = (torch.rand(B, 8, R, R, generator=g) * 2 - 1).requires_grad_(True)
+    ref = F.interpolate(x, size=(S, S), mode="bilinear", align_corners=False)
+    xd = dev(x, True)
+    got = GF.bilinear_down(xd, S)
+    assert_close(host(got), ref, 1e-6, f"pyramid {R}->{S}")
+    gy = torch.randn(ref.shape, generator=g)
+    (gref,) = torch.autograd.grad(ref, x, gy)
+    (ggot,) = torch.autograd.grad(got, xd, dev(gy))
+    assert_close(host(ggot), gref, 1e-6, f"pyramid backward {R}->{S}")

@@ -200,9 +200,10 @@ def test_less_travelled_api_paths():
         mixed = g(cond.cuda(), None, step=3, input_indices=idx.cuda(), mean_style=ms.cuda(), style_weight=0.5)[0]
         assert_close(mixed, _oracle_synthesis(R, sd2, cond, ms + 0.5 * (w - ms), 3), 1e-4, "mean_style mixing")
     # discriminator: bare tensor input, no condition, 3 colour channels
-    d = _build_d3(32).cuda()
+    d = _build_d3(32)
     sdd = R.seeded_state_dict(d.state_dict(), 7)
     d.load_state_dict(sdd, strict=True)
+    d = d.cuda()
     img = torch.rand(4, 3, 32, 32) * 2 - 1
     with torch.no_grad():
         assert_close(d(img.cuda())[0], R.discriminator_forward(sdd, img, None, 32), 2e-4, "D without condition")
