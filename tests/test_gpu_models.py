@@ -228,3 +228,25 @@ def _oracle_synthesis(R, sd, cond, w, step):
             out = R.styled_conv(sd, p + 'st_cv2.', out, w, c_i, upsample=False)
         rgb = R.to_rgb(sd, f'generator.to_rgb.{i}.', out, w, rgb)
     return rgb
+
+
+def test_reuse_generator_forward_is_bit_identical():
+    """GifTrainer(reuse_generator_forward=True) must give exactly the losses and parameters of the reference call order."""
+    from gif_amd.train_step import GifTrainer
+    res = {}
+    for reuse in (False, True):
+        torch.manual_seed(0)
+        G, G_ema, D = _build_g(16).cuda(), _build_g(16).cuda(), _build_d(32).cuda()
+        G_ema.load_state_dict(G.state_dict())
+        tr = GifTrainer(G, D, G_ema, step=3, reuse_generator_forward=reuse)
+        gen = torch.Generator(device="cuda").manual_seed(1)
+        out = []
+        for i in (14, 15):  # a plain and an R1 iteration
+            real = torch.rand(4, 3, 32, 32, device="cuda", generator=gen) * 2 - 1
+            cond = torch.rand(4, 6, 32, 32, device="cuda", generator=gen) * 2 - 1
+            idx = torch.randint(0, 16, (4,), device="cuda", generator=gen)
+            out.append([t.item() for t in tr.step(i, real, cond, idx)])
+        res[reuse] = (out, G.generator.progression[3].st_cv2.conv.weight.detach().clone(),
+                      D.convs[1].conv1[0].weight.detach().clone())
+    assert res[False][0] == res[True][0]
+    assert torch.equal(res[False][1], res[True][1]) and torch.equal(res[False][2], res[True][2])
