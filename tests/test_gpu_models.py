@@ -250,3 +250,28 @@ def test_reuse_generator_forward_is_bit_identical():
                       D.convs[1].conv1[0].weight.detach().clone())
     assert res[False][0] == res[True][0]
     assert torch.equal(res[False][1], res[True][1]) and torch.equal(res[False][2], res[True][2])
+
+
+def test_generator_discriminator_1024_vs_oracle():
+    """BASELINE config 5 resolution (step 8, 1024x1024) in fp32, batch 1: every layer shape of the full progression
+    (512..32 channels) through the HIP path vs the CPU oracle.  (The fp16-activation variant of config 5 is not built.)"""
+    from oracle import stylegan2_ref as R
+    torch.manual_seed(0)
+    g = _build_g(vocab=4)
+    sd = R.seeded_state_dict(g.state_dict(), 31)
+    g.load_state_dict(sd, strict=True)
+    cond = torch.rand(1, 6, 1024, 1024) * 2 - 1
+    idx = torch.tensor([3])
+    with torch.no_grad():
+        ref = R.generator_forward(sd, cond, 8, idx)
+        got = g.cuda()(cond.cuda(), None, step=8, alpha=1, input_indices=idx.cuda())[0]
+    assert got.shape == (1, 3, 1024, 1024)
+    assert (got.cpu() - ref).abs().max().item() < 1e-3
+    assert_close(got, ref, 2e-4, "G(1024)")
+    d = _build_d(1024)
+    sdd = R.seeded_state_dict(d.state_dict(), 32)
+    d.load_state_dict(sdd, strict=True)
+    with torch.no_grad():
+        sref = R.discriminator_forward(sdd, ref, cond, 1024)
+        sgot = d.cuda()(got, condition=cond.cuda())[0]
+    assert_close(sgot, sref, 3e-4, "D(1024) score")
