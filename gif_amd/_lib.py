@@ -32,6 +32,8 @@ PROTOTYPES = {
     "gif_rasterize_f32": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P]),
     "gif_rasterize_colors_f32": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P, P]),
     "gif_vertex_normals_f32": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),
+    "gif_texture_map_f32": (c_int, [P] * 9 + [c_int] * 6 + [P]),
+    "gif_texture_map_bwd_f32": (c_int, [P] * 8 + [c_int] * 6 + [P]),
     "gif_conv2d_pack_dims": (c_int, [c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "gif_pack_weight_f32": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_float, P]),
     "gif_conv2d_fwd_f32": (c_int, [P, P, P, GP, EP, P]),

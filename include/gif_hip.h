@@ -53,6 +53,19 @@ int gif_rasterize_colors_f32(const float* face_vertices, const float* face_color
 int gif_vertex_normals_f32(const float* verts, const int32_t* faces, const int32_t* csr_off, const int32_t* csr_ent,
                            float* normals, int B, int V, int F, gif_stream_t stream);
 
+/* Texture stealing — replaces FlameTextureSpace.compute_texture_map (model/stg2_generator.py:378-421):
+ * per (sample, UV texel) barycentric 3-D point -> orthographic projection (y flipped) -> bilinear fetch of the source image
+ * (grid_sample, zero padding, align_corners=False), and the normal-z visibility mask.  img [B,C,H,W] NCHW; verts/normals
+ * [B,V,3]; cam [B,3] = (scale, tx, ty); texel_map [T*T] = index into the valid-texel lists or -1 (those texels sample the
+ * image centre, like the reference's zero grid); texel_faces [N,3] int32; texel_bc [N,3]; tex [B,C,T,T]; mask [B,1,T,T] u8.
+ * The backward accumulates d tex / d img into gimg [B,C,H,W] (zeroed inside). */
+int gif_texture_map_f32(const float* img, const float* verts, const float* normals, const float* cam,
+                        const int32_t* texel_map, const int32_t* texel_faces, const float* texel_bc, float* tex,
+                        uint8_t* mask, int B, int C, int H, int W, int V, int T, gif_stream_t stream);
+int gif_texture_map_bwd_f32(const float* gtex, const float* verts, const float* normals, const float* cam,
+                            const int32_t* texel_map, const int32_t* texel_faces, const float* texel_bc, float* gimg,
+                            int B, int C, int H, int W, int V, int T, gif_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Convolution family (fp32 MFMA implicit GEMM) — replaces the F.conv2d / F.conv_transpose2d calls of
  *   ModulatedConv2d.forward   stylegan2_common_layers.py:307-349 (groups=batch trick -> in/out scales)

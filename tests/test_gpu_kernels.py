@@ -407,3 +407,21 @@ def test_condition_pyramid_level(R, S):
     (gref,) = torch.autograd.grad(ref, x, gy)
     (ggot,) = torch.autograd.grad(got, xd, dev(gy))
     assert_close(host(ggot), gref, 1e-6, f"pyramid backward {R}->{S}")
+
+
+def test_texture_map_vs_reference_golden():
+    """FlameTextureSpace.compute_texture_map (HIP) vs the real reference method's output on the synthetic UV fixture."""
+    from gif_amd.texture_space import FlameTextureSpace
+    from test_oracle_texture import load_fixture
+    g, td, verts, normals = load_fixture()
+    fts = FlameTextureSpace(td, None).cuda()
+    img = torch.from_numpy(g["img"]).cuda().requires_grad_(True)
+    tex, mask = fts.compute_texture_map(img, verts.cuda(), normals.cuda(), camera_params=torch.from_numpy(g["cam"]).cuda())
+    assert tex.shape == (2, 3, 256, 256) and mask.shape == (2, 1, 256, 256)
+    assert np.abs(tex.detach().cpu().numpy() - g["tex"]).max() < 2e-6, "texture image"
+    assert np.array_equal(mask.cpu().numpy().astype(bool), g["mask"]), "visibility mask"
+    (tex * torch.linspace(-1, 1, tex.numel(), device="cuda").view_as(tex)).sum().backward()
+    gi = img.grad.cpu().numpy()
+    assert np.abs(gi - g["grad_img"]).max() <= 2e-4 * np.abs(g["grad_img"]).max(), "gradient w.r.t. the source image"
+    with pytest.raises(Exception, match="FLAME"):
+        fts(img, torch.zeros(2, 159, device="cuda"))
