@@ -12,11 +12,15 @@
 // The reference's per-sample weights (groups=batch) are never materialised: modulation is the in_scale on A,
 // demodulation the out_scale in the epilogue (conv(x*s, W)*d, algebraically identical).
 //
-// Tiling: 256 threads = 4 waves; v_mfma_f32_32x32x2_f32 (exact fp32, 157 TF peak).  A and B tiles are staged
-// through LDS K-contiguous with a +4-float row pad (odd number of 16-B slots => conflict-free ds_read_b128),
-// double buffered, global loads for step s+1 are issued before the MFMAs of step s.
-// Lane (i = lane&31, h = lane>>5) feeds A[i][k] / B[k][i] with k = 8*kk + 4*h + t for MFMA t of group kk: the
-// same K permutation on both operands, so one ds_read_b128 per 32-row tile yields the operands of 4 MFMAs.
+// Tiling: 256 threads = 4 waves; v_mfma_f32_32x32x2_f32 (exact fp32, 157 TF peak).  Lane (i = lane&31, h = lane>>5)
+// feeds A[i][k] / B[k][i] with k = 8*kk + 4*h + t for MFMA t of group kk: the same K permutation on both operands, so
+// one ds_read_b128 per 32-row tile yields the operands of 4 MFMAs.  Two staging schemes:
+//   * conv_gather_mfma_glds (every layer with Cin >= 32): LDS-DMA (global_load_lds_dwordx4), unpadded 128-byte LDS rows
+//     with an XOR chunk swizzle on the DMA source address, per-sample input scales from an LDS table — see the comment
+//     block above that kernel; tiles 128x128, 256x32 (Cout <= 32) and 64x64 (low-resolution layers).
+//   * conv_gather_mfma (Cin < 32, BK = 8, and fallback): global -> VGPR -> LDS with a +4-float row pad (odd number of
+//     16-B slots => conflict-free ds_read_b128), double buffered, loads of step s+1 issued before the MFMAs of step s.
+// Both share conv_epilogue(): accumulators -> LDS -> coalesced float4 rows with out_scale / residual / bias / lrelu.
 #include <stdlib.h>
 
 #include "common.h"

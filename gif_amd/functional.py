@@ -4,8 +4,12 @@ Two families:
   * Conv2dFn / WgradFn / BiasActFn / Upfirdn2dFn / MbstdFn — every backward is itself expressed with these
     Functions, so they are differentiable to any order.  The discriminator uses them because R1
     (grad_penalty_loss, loss_functions/losses.py:87-99, create_graph=True) back-propagates through D's backward.
-  * ModConvFn — the generator's modulated convolution (ModulatedConv2d.forward,
-    stylegan2_common_layers.py:307-349) as ONE fused op: y = d[b,co] * conv(s[b,ci] * x, W); once differentiable.
+    ConvBiasActFn / BlurBiasActFn fuse bias (+ condition noise) + leaky ReLU into the producing kernel's epilogue
+    and keep that property (their backward is composed of the Functions above).
+  * ModConvFn / ModConvActFn — the generator's modulated convolution (ModulatedConv2d.forward,
+    stylegan2_common_layers.py:307-349) as ONE fused op: y = [act](d[b,co] * conv(s[b,ci] * x, W) [+ noise + bias]);
+    once differentiable (the generator never needs a double backward in the shipped configurations).
+  * BilinearDownFn — the condition pyramid; _TextureMapFn lives in gif_amd/texture_space.py.
 All tensors are logical NCHW with NHWC memory (ops.nhwc).
 """
 import torch
