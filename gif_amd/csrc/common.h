@@ -36,7 +36,7 @@ struct ProfScope {
     int family;
     hipStream_t stream;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    ProfScope(int family, double flops, hipStream_t s);
+    ProfScope(int family, double flops, hipStream_t s, int d0 = 0, int d1 = 0, int d2 = 0, int d3 = 0);
     ~ProfScope();
 };
 

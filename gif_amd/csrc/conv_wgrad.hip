@@ -401,7 +401,7 @@ int gif_conv2d_wgrad_f32(const float* small, const float* big, float* ws, const 
     hipStream_t s = gif::as_stream(stream);
     double flops = 2.0 * p.Ntot * (double)g->Cs * g->Cb * p.T;
     {
-        gif::ProfScope prof(1, flops, s);
+        gif::ProfScope prof(1, flops, s, (int)p.Ntot, g->Cs, g->Cb, p.T * 10 + g->stride + (small_scale || big_scale ? 100 : 0));
         const char* env = getenv("GIF_CONV_VARIANT");
         const int variant = env ? atoi(env) : 0;
         const bool glds = !small_scale && !big_scale && variant != 1;

@@ -1,5 +1,6 @@
 // Error reporting + event-based kernel timing for bench.py's roofline line.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include <mutex>
 #include <vector>
@@ -20,6 +21,7 @@ void set_error(const char* fmt, ...) {
 struct ProfRec {
     hipEvent_t e0, e1;
     double flops;
+    int d[4];  // launch shape tag (M, N, K, taps) for the optional per-launch dump (GIF_PROF_DUMP=<file>)
 };
 static bool g_prof_on = false;
 static std::mutex g_prof_mu;
@@ -37,7 +39,7 @@ static hipEvent_t get_event() {
     return e;
 }
 
-ProfScope::ProfScope(int fam, double flops, hipStream_t s) : family(fam), stream(s) {
+ProfScope::ProfScope(int fam, double flops, hipStream_t s, int d0, int d1, int d2, int d3) : family(fam), stream(s) {
     if (!g_prof_on) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     e0 = get_event();
@@ -46,7 +48,7 @@ ProfScope::ProfScope(int fam, double flops, hipStream_t s) : family(fam), stream
         e0 = e1 = nullptr;
         return;
     }
-    g_prof[family].push_back({e0, e1, flops});
+    g_prof[family].push_back({e0, e1, flops, {d0, d1, d2, d3}});
     (void)hipEventRecord(e0, stream);
 }
 
@@ -72,6 +74,8 @@ int gif_prof_read(int family, double* ms, double* flops, int64_t* launches) {
     std::lock_guard<std::mutex> lk(gif::g_prof_mu);
     double tms = 0, tf = 0;
     int64_t n = 0;
+    const char* dump = getenv("GIF_PROF_DUMP");
+    FILE* fh = dump ? fopen(dump, "a") : nullptr;
     for (auto& r : gif::g_prof[family]) {
         (void)hipEventSynchronize(r.e1);
         float t = 0;
@@ -79,10 +83,12 @@ int gif_prof_read(int family, double* ms, double* flops, int64_t* launches) {
             tms += t;
             tf += r.flops;
             ++n;
+            if (fh) fprintf(fh, "%d,%d,%d,%d,%d,%.6f,%.0f\n", family, r.d[0], r.d[1], r.d[2], r.d[3], t, r.flops);
         }
         gif::g_pool.push_back(r.e0);
         gif::g_pool.push_back(r.e1);
     }
+    if (fh) fclose(fh);
     gif::g_prof[family].clear();
     if (ms) *ms = tms;
     if (flops) *flops = tf;
