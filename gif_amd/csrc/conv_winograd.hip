@@ -1,0 +1,350 @@
+// Winograd F(2x2, 3x3) path for the stride-1 / pad-1 3x3 convolutions (fp32, NHWC, gfx950).
+//
+// The same layers as conv_igemm.hip serves (ModulatedConv2d :343-347, EqualConv2d :176 of
+// model/stylegan2_common_layers.py, and their stride-1 data gradients), computed with 16 instead of 36 multiplies per
+// 2x2 output tile:   Y = A^T [ sum_ci (G g G^T) .* (B^T d B) ] A.
+// Three kernels:
+//   1. wino_input_transform : x [B,H,W,C] (times the per-sample modulation s[b,c] — free here) -> V [16][tiles][C]
+//   2. wino_weight_transform: canonical weight view (any strides, optional 180-degree flip for the dgrad) -> U [16][RP][CP]
+//   3. wino_gemm_mfma       : for each of the 16 positions p a dense GEMM  M_p[tile,co] = sum_ci V_p[tile,ci] U_p[co,ci]
+//      on v_mfma_f32_32x32x2_f32 with LDS-DMA staging (same unpadded-row + XOR-swizzle scheme as conv_gather_mfma_glds;
+//      no gather, no bounds: V is a dense matrix), and the OUTPUT TRANSFORM FUSED: after the K loop of position p the
+//      accumulators are folded into the four 2x2-output accumulators with the +-1/0 coefficients of A^T (x) A^T, so the
+//      16x-larger M tensor never exists.  The epilogue (demodulation, noise residual, bias, leaky ReLU) is the shared
+//      LDS-transposed float4 epilogue, run once per output position (a,b) of the 2x2 tile.
+// HBM traffic: V is 4x the input (written once, read once); MFMA work is 4/9 of the direct convolution.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __attribute__((aligned(16))) float g_wino_zero_page[4];
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int nx = 8;
+    int xcd = bid % nx, idx = bid / nx;
+    int q = nwg / nx, r = nwg % nx;
+    int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+// ------------------------------------------------------------------------------------------------ input transform
+// one lane = one 4x4 input patch of one tile x 4 channels; B^T d B with B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+__global__ void __launch_bounds__(256) wino_input_transform(const float* __restrict__ x, const float* __restrict__ scale,
+                                                            float* __restrict__ V, int B, int H, int W, int C) {
+    const int C4 = C >> 2, TH = H >> 1, TW = W >> 1;
+    const long ntiles = (long)B * TH * TW;
+    const long total = ntiles * C4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % C4);
+        const long tile = idx / C4;
+        const int tx = (int)(tile % TW);
+        const long t2 = tile / TW;
+        const int ty = (int)(t2 % TH), b = (int)(t2 / TH);
+        const float* xb = x + ((size_t)b * H * W) * C + c4 * 4;
+        f32x4 d[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int iy = 2 * ty - 1 + r;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int ix = 2 * tx - 1 + c;
+                const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                d[r][c] = ok ? *reinterpret_cast<const f32x4*>(xb + ((size_t)iy * W + ix) * C) : (f32x4)(0.f);
+            }
+        }
+        f32x4 s = (f32x4)(1.f);
+        if (scale) s = *reinterpret_cast<const f32x4*>(scale + (size_t)b * C + c4 * 4);
+        f32x4 t[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            t[0][c] = d[0][c] - d[2][c];
+            t[1][c] = d[1][c] + d[2][c];
+            t[2][c] = d[2][c] - d[1][c];
+            t[3][c] = d[1][c] - d[3][c];
+        }
+        float* vout = V + (size_t)tile * C + c4 * 4;
+        const size_t plane = (size_t)ntiles * C;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            f32x4 v0 = (t[r][0] - t[r][2]) * s, v1 = (t[r][1] + t[r][2]) * s;
+            f32x4 v2 = (t[r][2] - t[r][1]) * s, v3 = (t[r][1] - t[r][3]) * s;
+            *reinterpret_cast<f32x4*>(vout + (r * 4 + 0) * plane) = v0;
+            *reinterpret_cast<f32x4*>(vout + (r * 4 + 1) * plane) = v1;
+            *reinterpret_cast<f32x4*>(vout + (r * 4 + 2) * plane) = v2;
+            *reinterpret_cast<f32x4*>(vout + (r * 4 + 3) * plane) = v3;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ weight transform
+// U = G g G^T, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]; rows = op output channels, cols = op input channels
+__global__ void wino_weight_transform(const float* __restrict__ w, float* __restrict__ U, int R, int C, int RP, int CP,
+                                      long sr, long sc, long sky, long skx, int flip, float scale) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)RP * CP) return;
+    int c = (int)(idx % CP), r = (int)(idx / CP);
+    float g[3][3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            int sy = flip ? 2 - ky : ky, sx = flip ? 2 - kx : kx;
+            g[ky][kx] = (r < R && c < C) ? scale * w[r * sr + c * sc + sy * sky + sx * skx] : 0.f;
+        }
+    float u[4][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        u[0][j] = g[0][j];
+        u[1][j] = 0.5f * (g[0][j] + g[1][j] + g[2][j]);
+        u[2][j] = 0.5f * (g[0][j] - g[1][j] + g[2][j]);
+        u[3][j] = g[2][j];
+    }
+    const size_t plane = (size_t)RP * CP;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        U[(i * 4 + 0) * plane + idx] = u[i][0];
+        U[(i * 4 + 1) * plane + idx] = 0.5f * (u[i][0] + u[i][1] + u[i][2]);
+        U[(i * 4 + 2) * plane + idx] = 0.5f * (u[i][0] - u[i][1] + u[i][2]);
+        U[(i * 4 + 3) * plane + idx] = u[i][2];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ GEMM + output transform
+struct WinoParams {
+    const float* V;  // [16][ntiles][C]
+    const float* U;  // [16][RP][CP]
+    float* y;        // [B,H,W,Co]
+    const float* out_scale;
+    const float* bias;
+    const float* residual;
+    int B, H, W, C, Co, RP, CP;
+    int ntiles, TH, TW;
+    int act;
+    float slope, gain;
+    int tiles_m, tiles_n;
+};
+
+// 256 threads = 4 waves as 2 (M) x 2 (N); wave tile 64 tiles x 32 couts; block tile 128 x 64; BK = 32.
+constexpr int WBM = 128, WBN = 64, WBK = 32;
+
+__global__ void __launch_bounds__(256, 2) wino_gemm_mfma(const WinoParams p) {
+    constexpr int LD = WBK, CH = WBK / 4, RB = 64 / WBK, RPW = 64 / CH;
+    constexpr int MT = 2, NT = 1;
+    constexpr int A_IT = WBM / 32, B_IT = WBN / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                 // [2][WBM][LD]
+    float* Bs = smem + 2 * WBM * LD;  // [2][WBN][LD]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 32;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
+    const int m0 = tm * WBM, n0 = tn * WBN;
+    const int t_row = tid / CH;
+    const int src_c4 = ((tid % CH) ^ ((t_row / RB) % CH)) * 4;
+    const int fsw = (li / RB) % CH;
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+
+    // row offsets of this lane's A rows inside one position plane (elements); -1 => beyond the tile count
+    int a_off[A_IT];
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+        int m = m0 + t_row + it * 32;
+        a_off[it] = m < p.ntiles ? m * p.C + src_c4 : -1;
+    }
+    const size_t planeV = (size_t)p.ntiles * p.C, planeU = (size_t)p.RP * p.CP;
+    const int kchunks = p.CP / WBK;
+    const int nsteps = 16 * kchunks;
+    int ld_p = 0, ld_kc = 0;
+
+    auto issue = [&](int buf) __attribute__((always_inline)) {
+        const float* Vp = p.V + (size_t)ld_p * planeV + ld_kc;
+        const float* Up = p.U + (size_t)ld_p * planeU + (size_t)(n0 + t_row) * p.CP + ld_kc + src_c4;
+        const bool ch_ok = ld_kc + src_c4 < p.C;
+        float* Ad = As + buf * WBM * LD + wave * RPW * LD;
+        float* Bd = Bs + buf * WBN * LD + wave * RPW * LD;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const float* g = (ch_ok && a_off[it] >= 0) ? Vp + a_off[it] : g_wino_zero_page;
+            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Ad + it * 32 * LD), 16, 0, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it)
+            __builtin_amdgcn_global_load_lds((gptr_t)(Up + (size_t)it * 32 * p.CP), (lptr_t)(Bd + it * 32 * LD), 16, 0, 0);
+        ld_kc += WBK;
+        if (ld_kc >= p.CP) { ld_kc = 0; ++ld_p; }
+    };
+
+    f32x16 acc[MT];      // M_p tile of the current position
+    f32x16 yo[4][MT];    // the four outputs (a,b) of the 2x2 tile, accumulated over positions
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc[i][r] = 0.f;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) yo[o][i][r] = 0.f;
+        }
+    }
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+        const float* Ab = As + buf * WBM * LD + (wm0 + li) * LD;
+        const float* Bb = Bs + buf * WBN * LD + (wn0 + li) * LD;
+#pragma unroll
+        for (int kk = 0; kk < WBK / 8; ++kk) {
+            const int c = ((kk * 2 + lh) ^ fsw) * 4;
+            f32x4 av[MT], bv;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) av[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LD + c);
+            bv = *reinterpret_cast<const f32x4*>(Bb + c);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][t], bv[t], acc[i], 0, 0, 0);
+        }
+    };
+    // A^T = [1 1 1 0; 0 1 -1 -1]: coefficient of M[xi][nu] in Y[a][b] is cA(a,xi) * cA(b,nu)
+    auto coefA = [](int a, int xi) -> float { return a == 0 ? (xi < 3 ? 1.f : 0.f) : (xi == 0 ? 0.f : (xi == 1 ? 1.f : -1.f)); };
+    auto fold = [&](int pos) __attribute__((always_inline)) {
+        const int xi = pos >> 2, nu = pos & 3;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const float cf = coefA(o >> 1, xi) * coefA(o & 1, nu);
+            if (cf != 0.f) {  // wave-uniform
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) yo[o][i][r] += cf * acc[i][r];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    };
+
+    issue(0);
+    __syncthreads();
+    int cur = 0, kc_in_pos = 0, pos = 0;
+    for (int step = 0; step + 1 < nsteps; ++step) {
+        issue(cur ^ 1);
+        compute(cur);
+        if (++kc_in_pos == kchunks) { fold(pos); kc_in_pos = 0; ++pos; }
+        __syncthreads();
+        cur ^= 1;
+    }
+    compute(cur);
+    fold(pos);
+
+    // ---- epilogue: for each output position (a,b): transpose through LDS, then coalesced float4 rows
+    constexpr int LDC = WBN + 4;
+    float* Cs = smem;  // [WBM][LDC]  (128*68*4 = 34.8 KB <= 48 KB of staging)
+    constexpr int C4_ROW = WBN / 4, EROWS = 256 / C4_ROW, E_IT = WBM / EROWS;
+    const int e_row0 = tid / C4_ROW, e_c = (tid % C4_ROW) * 4;
+    const int n = n0 + e_c;
+    f32x4 bias4 = (f32x4)(0.f);
+    if (p.bias && n < p.Co) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                Cs[row * LDC + wn0 + li] = yo[o][i][r];
+            }
+        __syncthreads();
+        if (n < p.Co) {
+            const int oa = o >> 1, ob = o & 1;
+#pragma unroll 4
+            for (int it = 0; it < E_IT; ++it) {
+                const int row = e_row0 + it * EROWS;
+                const int m = m0 + row;
+                if (m >= p.ntiles) break;
+                int tx = m % p.TW;
+                int t2 = m / p.TW;
+                int ty = t2 % p.TH, b = t2 / p.TH;
+                size_t off = (((size_t)b * p.H + 2 * ty + oa) * p.W + 2 * tx + ob) * p.Co + n;
+                f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * LDC + e_c);
+                if (p.out_scale) v *= *reinterpret_cast<const f32x4*>(p.out_scale + (size_t)b * p.Co + n);
+                if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + off);
+                v += bias4;
+                if (p.act) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (v[e] > 0.f ? v[e] : v[e] * p.slope) * p.gain;
+                }
+                *reinterpret_cast<f32x4*>(p.y + off) = v;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+// RP / CP of the transformed weight U [16][RP][CP] for `cout` / `cin` channels
+int gif_winograd_pack_dims(int cout, int cin, int* RP, int* CP) {
+    GIF_REQUIRE(cout > 0 && cin > 0 && RP && CP, "winograd_pack_dims: bad arguments");
+    *RP = (cout + WBN - 1) / WBN * WBN;
+    *CP = (cin + WBK - 1) / WBK * WBK;
+    return 0;
+}
+
+int gif_winograd_weight_f32(const float* w, float* U, int R, int C, int RP, int CP, int64_t sr, int64_t sc, int64_t sky,
+                            int64_t skx, int flip, float scale, gif_stream_t stream) {
+    GIF_REQUIRE(w && U && R > 0 && C > 0 && RP >= R && CP >= C, "winograd_weight: bad arguments");
+    long total = (long)RP * CP;
+    wino_weight_transform<<<gif::cdiv(total, 256), 256, 0, gif::as_stream(stream)>>>(w, U, R, C, RP, CP, sr, sc, sky, skx,
+                                                                                      flip, scale);
+    return gif::check_launch("winograd_weight");
+}
+
+// y [B,H,W,Co] = act(out_scale * conv3x3_s1_p1(in_scale * x [B,H,W,C], weights behind U) + residual + bias).
+// V is scratch of 16 * B*(H/2)*(W/2) * C floats.  H, W even; C, Co multiples of 4.
+int gif_conv3x3_winograd_f32(const float* x, const float* U, float* y, float* V, int B, int H, int W, int C, int Co,
+                             const gif_conv_epilogue* e, gif_stream_t stream) {
+    GIF_REQUIRE(x && U && y && V && B >= 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "winograd: bad dims (H, W must be even)");
+    GIF_REQUIRE(C > 0 && Co > 0 && C % 4 == 0 && Co % 4 == 0, "winograd: channels must be multiples of 4");
+    if (B == 0) return 0;
+    const long ntiles = (long)B * (H / 2) * (W / 2);
+    GIF_REQUIRE(ntiles * C < (1L << 31) && (long)B * H * W * Co < (1L << 31), "winograd: tensor too large for 32-bit offsets");
+    hipStream_t s = gif::as_stream(stream);
+    double flops = 2.0 * B * H * W * 9.0 * C * Co;  // ALGORITHMIC (direct-convolution) FLOPs
+    gif::ProfScope prof(0, flops, s, (int)((long)B * H * W), Co, C, 1091);
+    {
+        long total = ntiles * (C / 4);
+        long blocks = (total + 255) / 256;
+        if (blocks > 256 * 32) blocks = 256 * 32;
+        wino_input_transform<<<(unsigned)blocks, 256, 0, s>>>(x, e ? e->in_scale : nullptr, V, B, H, W, C);
+    }
+    WinoParams p{};
+    p.V = V; p.U = U; p.y = y;
+    p.out_scale = e ? e->out_scale : nullptr;
+    p.bias = e ? e->bias : nullptr;
+    p.residual = e ? e->residual : nullptr;
+    p.act = e ? e->act : 0;
+    p.slope = e ? e->slope : 0.f;
+    p.gain = e ? e->gain : 1.f;
+    p.B = B; p.H = H; p.W = W; p.C = C; p.Co = Co;
+    gif_winograd_pack_dims(Co, C, &p.RP, &p.CP);
+    p.ntiles = (int)ntiles; p.TH = H / 2; p.TW = W / 2;
+    p.tiles_m = gif::cdiv(ntiles, WBM);
+    p.tiles_n = p.RP / WBN;
+    const size_t lds = (size_t)2 * (WBM + WBN) * WBK * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_gemm_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL(wino_gemm_mfma, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(256), lds, s, p);
+    return gif::check_launch("conv3x3_winograd");
+}
+}

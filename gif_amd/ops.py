@@ -5,6 +5,7 @@ Conventions: activations are torch tensors of LOGICAL shape [B,C,H,W] whose memo
 torch is used for device memory and streams only — all arithmetic is in libgif_hip.so.
 """
 import ctypes
+import os
 from typing import NamedTuple, Optional
 
 import torch
@@ -83,6 +84,49 @@ def pack_weight(w: torch.Tensor, rows_are_out: bool, cout_act: int, cin_act: int
     return wp
 
 
+# Winograd F(2x2,3x3) dispatch for stride-1 / pad-1 3x3 convs (conv_winograd.hip).  GIF_WINOGRAD=0 forces the direct
+# implicit-GEMM kernels; below GIF_WINOGRAD_MIN_TILES 2x2 tiles the launch cannot fill the chip and the direct path wins.
+WINOGRAD = os.environ.get("GIF_WINOGRAD", "1") != "0"
+WINOGRAD_MIN_TILES = int(os.environ.get("GIF_WINOGRAD_MIN_TILES", "8192"))
+_winograd_calls = 0
+
+
+def prof_winograd_calls():
+    """Number of Winograd launches so far (tests use it to prove the path under test actually ran)."""
+    return _winograd_calls
+
+
+def winograd_eligible(spec: ConvSpec, B, H, W, cin_act):
+    return (WINOGRAD and tuple(spec) == (3, 3, 1, 1) and H % 2 == 0 and W % 2 == 0 and cin_act >= 32
+            and B * (H // 2) * (W // 2) >= WINOGRAD_MIN_TILES)
+
+
+def conv3x3_winograd(x, w, rows_are_out: bool, cout_act: int, wscale=1.0, **epi):
+    """act(out_scale * conv3x3_s1_p1(in_scale * x, w) + residual + bias) via Winograd F(2x2,3x3).
+
+    rows_are_out=True : forward conv with w[O,I,3,3];  False: its data gradient (taps rotated, channels swapped)."""
+    global _winograd_calls
+    _winograd_calls += 1
+    lib = _lib.load()
+    x = nhwc(x)
+    B, C, H, W = x.shape
+    O, I = w.shape[:2]
+    so, si, sky, skx = w.stride()
+    R, Cc, sr, sc = (O, I, so, si) if rows_are_out else (I, O, si, so)
+    assert R <= cout_act and Cc <= C, (R, cout_act, Cc, C)
+    RP, CP = ctypes.c_int(), ctypes.c_int()
+    _lib.check(lib.gif_winograd_pack_dims(cout_act, C, ctypes.byref(RP), ctypes.byref(CP)), "winograd_pack_dims")
+    U = torch.empty((16, RP.value, CP.value), device=x.device, dtype=torch.float32)
+    _lib.check(lib.gif_winograd_weight_f32(w.data_ptr(), U.data_ptr(), R, Cc, RP.value, CP.value, sr, sc, sky, skx,
+                                           0 if rows_are_out else 1, float(wscale), _stream()), "winograd_weight")
+    V = torch.empty((16 * B * (H // 2) * (W // 2) * C,), device=x.device, dtype=torch.float32)
+    out = empty_nhwc(B, cout_act, H, W, x.device)
+    e = _epilogue(**epi)
+    _lib.check(lib.gif_conv3x3_winograd_f32(x.data_ptr(), U.data_ptr(), out.data_ptr(), V.data_ptr(), B, H, W, C, cout_act,
+                                            ctypes.byref(e), _stream()), "conv3x3_winograd")
+    return out
+
+
 def conv_fwd(big, w, spec: ConvSpec, wscale=1.0, **epi):
     """small = conv2d(big, w[O,I,KH,KW]) ; returns [B, pad4(O), Hs, Ws]."""
     lib = _lib.load()
@@ -91,6 +135,8 @@ def conv_fwd(big, w, spec: ConvSpec, wscale=1.0, **epi):
     O = w.shape[0]
     Cs = pad4(O)
     Hs, Ws = spec.small_hw(Hb, Wb)
+    if winograd_eligible(spec, B, Hb, Wb, Cb):
+        return conv3x3_winograd(big, w, True, Cs, wscale, **epi)
     wp = pack_weight(w, True, Cs, Cb, wscale)
     out = empty_nhwc(B, Cs, Hs, Ws, big.device)
     g = _geom(B, Hb, Wb, Cb, Hs, Ws, Cs, spec)
@@ -108,6 +154,8 @@ def conv_bwd_data(small, w, spec: ConvSpec, big_hw, wscale=1.0, **epi):
     I = w.shape[1]
     Cb = pad4(I)
     Hb, Wb = big_hw
+    if (Hb, Wb) == (Hs, Ws) and winograd_eligible(spec, B, Hs, Ws, Cs):
+        return conv3x3_winograd(small, w, False, Cb, wscale, **epi)
     wp = pack_weight(w, False, Cb, Cs, wscale)
     out = empty_nhwc(B, Cb, Hb, Wb, small.device)
     g = _geom(B, Hb, Wb, Cb, Hs, Ws, Cs, spec)

@@ -123,6 +123,24 @@ int gif_unpack_wgrad_f32(const float* ws, float* dw, int nsplit, int R, int C, i
                          int64_t sr, int64_t sc, int64_t sky, int64_t skx, float scale, gif_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Winograd F(2x2,3x3) path for the SAME stride-1 / pad-1 3x3 convolutions (ModulatedConv2d
+ * stylegan2_common_layers.py:343-347 without up/down-sampling, EqualConv2d :176, and their data
+ * gradients): 16 instead of 36 multiplies per 2x2 output tile, output transform + epilogue fused.
+ *   gif_winograd_pack_dims : padded dims of the transformed weight U [16][RP][CP]
+ *   gif_winograd_weight_f32: U = G g G^T from a strided canonical weight view (rows = op output
+ *                            channels, cols = op input channels); flip!=0 rotates the taps by 180 degrees
+ *                            (data gradient); `scale` = the equalised-lr factor
+ *   gif_conv3x3_winograd_f32: y [B,H,W,Co] = act(out_scale*conv3x3(in_scale*x [B,H,W,C]) + residual + bias);
+ *                            V = scratch of 16*B*(H/2)*(W/2)*C floats; H, W even; C, Co multiples of 4.
+ *                            Epilogue fields as in gif_conv2d_fwd_f32.
+ * ---------------------------------------------------------------------------------------------- */
+int gif_winograd_pack_dims(int cout, int cin, int* RP, int* CP);
+int gif_winograd_weight_f32(const float* w, float* U, int R, int C, int RP, int CP, int64_t sr, int64_t sc,
+                            int64_t sky, int64_t skx, int flip, float scale, gif_stream_t stream);
+int gif_conv3x3_winograd_f32(const float* x, const float* U, float* y, float* V, int B, int H, int W, int C,
+                             int Co, const gif_conv_epilogue* e, gif_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * upfirdn2d — replaces upfirdn2d() stylegan2_common_layers.py:42-72 (Blur :136-152, Upsample :94-112,
  * Downsample :115-133): zero-insert by `up`, pad (negative = crop), correlate with the FIR `k` flipped
  * when flip!=0 (the reference flips => true convolution), keep every `down`-th sample.

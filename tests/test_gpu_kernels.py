@@ -179,6 +179,66 @@ def test_conv_scales_and_epilogue():
     assert_close(host(got3), ref3, TOL, "scaled transposed conv")
 
 
+WINO_CASES = [
+    # (B, Cin, Cout, H, W)
+    (2, 128, 128, 32, 32),   # full tiles
+    (3, 512, 512, 8, 8),     # 48 2x2 tiles: a partial 128-tile block
+    (1, 513, 512, 4, 4),     # final_conv: 516 padded input channels (K not a multiple of 32)
+    (5, 64, 36, 6, 10),      # non-square, Cout < one 64-wide block, ragged tile count
+    (2, 36, 160, 12, 4),     # Cin barely above one K block
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_winograd_conv_fwd_and_bwd_data(case):
+    """Winograd F(2x2,3x3) kernels vs the direct convolution (ATen on the host) — forward and data gradient."""
+    from gif_amd import ops
+    B, Ci, Co, H, W = case
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (3 * Ci ** 0.5)
+    ref = F.conv2d(x, w, padding=1)
+    got = ops.conv3x3_winograd(dev(x), w.cuda(), True, pad4(Co))
+    assert_close(host(got, Co), ref, 3e-5, f"winograd fwd {case}")
+    if pad4(Co) != Co:
+        assert (host(got)[:, Co:] == 0).all()
+    gy = torch.randn(B, Co, H, W, generator=g)
+    ref_b = F.conv_transpose2d(gy, w, padding=1)
+    got_b = ops.conv3x3_winograd(dev(gy), w.cuda(), False, pad4(Ci))
+    assert_close(host(got_b, Ci), ref_b, 3e-5, f"winograd bwd_data {case}")
+    # non-contiguous canonical view (the transposed-weight view the modulated conv hands over)
+    wt = w.transpose(0, 1).contiguous().transpose(0, 1)
+    got_s = ops.conv3x3_winograd(dev(x), wt.cuda(), True, pad4(Co))
+    assert torch.equal(got_s, got)
+
+
+def test_winograd_scales_and_epilogue(monkeypatch):
+    from gif_amd import ops
+    g = torch.Generator().manual_seed(12)
+    B, Ci, Co, H = 3, 128, 256, 16
+    x, w = torch.randn(B, Ci, H, H, generator=g), torch.randn(Co, Ci, 3, 3, generator=g) / 34
+    s, d = torch.rand(B, Ci, generator=g) + 0.5, torch.rand(B, Co, generator=g) + 0.5
+    res, bias = torch.randn(B, Co, H, H, generator=g), torch.randn(Co, generator=g)
+    ref = 2 ** 0.5 * F.leaky_relu(F.conv2d(x * s[:, :, None, None], w * 0.7, padding=1) * d[:, :, None, None] + res
+                                  + bias[None, :, None, None], 0.2)
+    got = ops.conv3x3_winograd(dev(x), w.cuda(), True, Co, 0.7, in_scale=s.cuda(), out_scale=d.cuda(), bias=bias.cuda(),
+                               residual=dev(res), act=True)
+    assert_close(host(got), ref, 3e-5, "winograd fused epilogue")
+    # dispatch: conv_fwd / conv_bwd_data route eligible shapes to Winograd once the tile threshold allows it
+    monkeypatch.setattr(ops, "WINOGRAD_MIN_TILES", 0)
+    assert ops.winograd_eligible(ops.ConvSpec(3, 3, 1, 1), B, H, H, Ci)
+    assert not ops.winograd_eligible(ops.ConvSpec(3, 3, 2, 0), B, H, H, Ci)
+    assert not ops.winograd_eligible(ops.ConvSpec(3, 3, 1, 1), B, 7, 7, Ci)
+    assert not ops.winograd_eligible(ops.ConvSpec(3, 3, 1, 1), B, H, H, 24)
+    got2 = ops.conv_fwd(dev(x), w.cuda(), ops.ConvSpec(3, 3, 1, 1), 0.7, in_scale=s.cuda(), out_scale=d.cuda(),
+                        bias=bias.cuda(), residual=dev(res), act=True)
+    assert torch.equal(got2, got)
+    gy = torch.randn(B, Co, H, H, generator=g)
+    ref3 = F.conv_transpose2d(gy * d[:, :, None, None], w, padding=1) * s[:, :, None, None]
+    got3 = ops.conv_bwd_data(dev(gy), w.cuda(), ops.ConvSpec(3, 3, 1, 1), (H, H), in_scale=d.cuda(), out_scale=s.cuda())
+    assert_close(host(got3), ref3, 3e-5, "winograd dgrad with scales")
+
+
 def test_conv_wgrad_with_scales():
     from gif_amd import ops
     g = torch.Generator().manual_seed(4)

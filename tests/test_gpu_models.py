@@ -275,3 +275,17 @@ def test_generator_discriminator_1024_vs_oracle():
         sref = R.discriminator_forward(sdd, ref, cond, 1024)
         sgot = d.cuda()(got, condition=cond.cuda())[0]
     assert_close(sgot, sref, 3e-4, "D(1024) score")
+
+
+def test_goldens_with_every_eligible_layer_on_winograd(monkeypatch):
+    """The reference goldens again with the Winograd tile threshold at 0, so that EVERY stride-1 3x3 layer with >= 32
+    input channels (forward, data gradient, and the R1 double backward built from them) runs the F(2x2,3x3) kernels
+    — at the default threshold the small golden resolutions would stay on the direct kernels."""
+    from gif_amd import ops
+    monkeypatch.setattr(ops, "WINOGRAD_MIN_TILES", 0)
+    before = ops.prof_winograd_calls() if hasattr(ops, "prof_winograd_calls") else None
+    test_generator_golden_forward_backward()
+    test_generator_config1_golden()
+    test_discriminator_golden_scores_r1_grads()
+    test_generator_and_discriminator_256_vs_oracle()
+    assert before is None or ops.prof_winograd_calls() > before
