@@ -280,12 +280,37 @@ def test_generator_discriminator_1024_vs_oracle():
 def test_goldens_with_every_eligible_layer_on_winograd(monkeypatch):
     """The reference goldens again with the Winograd tile threshold at 0, so that EVERY stride-1 3x3 layer with >= 32
     input channels (forward, data gradient, and the R1 double backward built from them) runs the F(2x2,3x3) kernels
-    — at the default threshold the small golden resolutions would stay on the direct kernels."""
-    from gif_amd import ops
+    — at the default threshold the small golden resolutions would stay on the direct kernels.
+
+    Tolerances are the direct path's, except the gradient w.r.t. the discriminator's input image: Winograd's fp32
+    rounding (3e-6 of the layer's max) flips the leaky-ReLU branch of a handful of near-zero pre-activations, which
+    moves the few image-gradient pixels downstream of them by ~1e-3 of the max (measured: 27 of 12288 elements;
+    with a direct forward and a Winograd backward the same gradient agrees to 2e-6).  So that tensor is held to a
+    relative L2 bound plus a cap on the number of outliers instead of an L_inf bound."""
+    from gif_amd import losses, ops
     monkeypatch.setattr(ops, "WINOGRAD_MIN_TILES", 0)
-    before = ops.prof_winograd_calls() if hasattr(ops, "prof_winograd_calls") else None
+    before = ops.prof_winograd_calls()
     test_generator_golden_forward_backward()
     test_generator_config1_golden()
-    test_discriminator_golden_scores_r1_grads()
     test_generator_and_discriminator_256_vs_oracle()
-    assert before is None or ops.prof_winograd_calls() > before
+    assert ops.prof_winograd_calls() > before
+    gold = _gold()
+    c = gold["d32"]
+    d = _build_d(32)
+    d.load_state_dict(d_state(gold, c["seed"]), strict=True)
+    d = d.cuda()
+    img = c["img"].cuda().requires_grad_(True)
+    scores, _ = d([img], condition=c["cond"].cuda())
+    assert_close(scores, c["scores"], 1e-4, "D scores (winograd)")
+    pen = losses.grad_penalty_loss([img], scores, step=None)
+    assert_close(pen, c["r1"], 2e-4, "R1 penalty (winograd)")
+    (F.softplus(-scores).mean() + pen.mean()).backward()
+    assert_close(d.convs[0][0].weight.grad, c["grad_first_w"], 3e-4, "D grad first conv (winograd)")
+    assert_close(d.convs[1].conv2[1].weight.grad[:4], c["grad_res1_conv2_w"], 3e-4, "D grad res1.conv2 (winograd)")
+    assert_close(d.final_conv[0].weight.grad[:2], c["grad_final_conv_w"], 3e-4, "D grad final_conv (winograd)")
+    assert_close(d.final_linear[1].weight.grad, c["grad_lin1_w"], 3e-4, "D grad last linear (winograd)")
+    diff = (img.grad.cpu() - c["grad_img"]).abs()
+    ref = c["grad_img"]
+    assert (diff.norm() / ref.norm()).item() < 1e-3, "grad wrt image, relative L2"
+    assert (diff > 3e-4 * ref.abs().max()).float().mean().item() < 0.01, "grad wrt image: too many outliers"
+    assert diff.max().item() < 1e-2 * ref.abs().max().item()
