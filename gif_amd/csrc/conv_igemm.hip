@@ -53,6 +53,7 @@ struct GatherParams {
     int M;  // B*Hp*Wp
     int tiles_m, tiles_n;
     int stab_nb, stab_stride;  // LDS table of per-sample input scales (LDS-DMA kernel): samples per tile, row stride
+    const float* zero;         // 16 zero bytes in HBM: source of the LDS-DMA lanes that fall outside the tensor
 };
 
 // XCD-aware, bijective block remap (cdna guide T1): consecutive logical tiles share an XCD's L2.
@@ -396,14 +397,14 @@ __global__ void __launch_bounds__(256) conv_gather_mfma_glds(const GatherParams 
         for (int it = 0; it < A_IT; ++it) {
             bool ok = ((row_ok >> it) & 1u) && ch_ok && (unsigned)(a_iy0[it] + dy) < (unsigned)p.Hi &&
                       (unsigned)(a_ix0[it] + dx) < (unsigned)p.Wi;
-            const float* g = ok ? p.x + (a_base[it] + tap_off) : g_zero_page;
+            const float* g = ok ? p.x + (a_base[it] + tap_off) : p.zero;
             __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Ad + it * RPP * LD), 16, 0, 0);
         }
         const float* wt = p.wp + ((size_t)widx * p.RP + n0 + t_row) * p.CP + kc + src_c4;
         if (BN % RPP == 0 || wave * RPW < BN) {  // wave-uniform: waves beyond the B tile issue nothing
 #pragma unroll
             for (int it = 0; it < B_IT; ++it)
-                __builtin_amdgcn_global_load_lds((gptr_t)(b_lane_ok ? wt + (size_t)it * RPP * p.CP : g_zero_page),
+                __builtin_amdgcn_global_load_lds((gptr_t)(b_lane_ok ? wt + (size_t)it * RPP * p.CP : p.zero),
                                                  (lptr_t)(Bd + it * RPP * LD), 16, 0, 0);
         }
         ld_kc += BK;
@@ -540,6 +541,13 @@ int launch_glds_impl(GatherParams& p, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_bytes = lds;
     }
+    static const float* zero_page = nullptr;  // passed as a kernel argument: a GOT load inside the K loop costs a scalar
+    if (!zero_page) {                          // memory round trip + s_waitcnt per stage
+        void* zp = nullptr;
+        if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero_page)) != hipSuccess) return -101;
+        zero_page = static_cast<const float*>(zp);
+    }
+    p.zero = zero_page;
     hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(256), lds, s, p);
     return 0;
 }

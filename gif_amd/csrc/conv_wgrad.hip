@@ -32,6 +32,7 @@ struct WgradParams {
     long chunk;  // pixels per split (multiple of BKP)
     int tiles_q, tiles_pq;
     int stab_nb;  // LDS scale table (scaled LDS-DMA path): samples a pixel chunk can touch
+    const float* zero;  // 16 zero bytes in HBM (source of out-of-range LDS-DMA lanes), passed as an argument
 };
 
 // XCD-aware, bijective block remap: XCD k (= blockIdx % 8 by dispatch order) gets a contiguous range of logical ids.
@@ -143,7 +144,7 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const 
             bool ok = p_ch_ok && p_n[it] < n_end;
             if (GLDS) {
                 // thread tid lands at float offset 4*tid of pass `it` (== Ps[buf][p_row + it*P_ROWS][4*(tid % (BP/4))])
-                const float* g = ok ? p.sm + (p_n[it] * p.Cs + p_ch) : g_wgrad_zero_page;
+                const float* g = ok ? p.sm + (p_n[it] * p.Cs + p_ch) : p.zero;
                 __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(&Ps[buf][it * P_ROWS][0] + wave_u * 256), 16, 0, 0);
                 p_n[it] += BKP;
                 continue;
@@ -160,7 +161,7 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const 
             int iy = q_oy[it] * p.stride + ky - p.pad, ix = q_ox[it] * p.stride + kx - p.pad;
             bool ok = q_ch_ok && q_n[it] < n_end && (unsigned)iy < (unsigned)p.Hb && (unsigned)ix < (unsigned)p.Wb;
             if (GLDS) {
-                const float* g = ok ? p.bg + (((q_b[it] * p.Hb + iy) * p.Wb + ix) * p.Cb + q_ch) : g_wgrad_zero_page;
+                const float* g = ok ? p.bg + (((q_b[it] * p.Hb + iy) * p.Wb + ix) * p.Cb + q_ch) : p.zero;
                 __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(&Qs[buf][it * Q_ROWS][0] + wave_u * 256), 16, 0, 0);
             } else {
                 q_reg[it] = *reinterpret_cast<const float4*>(
@@ -399,6 +400,13 @@ int gif_conv2d_wgrad_f32(const float* small, const float* big, float* ws, const 
     p.tiles_pq = (p.RP / bp) * p.tiles_q;
     dim3 grid((unsigned)(p.tiles_pq * p.T * nsplit));
     hipStream_t s = gif::as_stream(stream);
+    static const float* zero_page = nullptr;
+    if (!zero_page) {
+        void* zp = nullptr;
+        GIF_REQUIRE(hipGetSymbolAddress(&zp, HIP_SYMBOL(g_wgrad_zero_page)) == hipSuccess, "conv2d_wgrad: zero page lookup failed");
+        zero_page = static_cast<const float*>(zp);
+    }
+    p.zero = zero_page;
     double flops = 2.0 * p.Ntot * (double)g->Cs * g->Cb * p.T;
     {
         gif::ProfScope prof(1, flops, s, (int)p.Ntot, g->Cs, g->Cb, p.T * 10 + g->stride + (small_scale || big_scale ? 100 : 0));

@@ -20,8 +20,6 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __attribute__((aligned(16))) float g_wino_zero_page[4];
-
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int nx = 8;
     int xcd = bid % nx, idx = bid / nx;
@@ -30,16 +28,30 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + idx;
 }
 
+// GEMM tile: 256 threads = 4 waves as 2 (M) x 2 (N); wave tile 64 tiles x 32 couts; block tile 128 x 64; BK = 32.
+constexpr int WBM = 128, WBN = 64, WBK = 32, WNSTAGE = 3;
+
 // ------------------------------------------------------------------------------------------------ input transform
-// one lane = one 4x4 input patch of one tile x 4 channels; B^T d B with B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+// one lane = one 4x4 input patch of one tile x 4 channels; B^T d B with B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1].
+// V is [16][ntiles_pad][CP]: the channel padding (C..CP) is written as zeros, the row padding (ntiles..ntiles_pad) is
+// never written and never matters (GEMM row m only feeds output row m, and rows >= ntiles are not stored), so the GEMM
+// streams V without any bounds logic.
 __global__ void __launch_bounds__(256) wino_input_transform(const float* __restrict__ x, const float* __restrict__ scale,
-                                                            float* __restrict__ V, int B, int H, int W, int C) {
-    const int C4 = C >> 2, TH = H >> 1, TW = W >> 1;
+                                                            float* __restrict__ V, int B, int H, int W, int C, int CP,
+                                                            long ntiles_pad) {
+    const int C4 = CP >> 2, TH = H >> 1, TW = W >> 1;
     const long ntiles = (long)B * TH * TW;
     const long total = ntiles * C4;
+    const size_t plane = (size_t)ntiles_pad * CP;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int c4 = (int)(idx % C4);
         const long tile = idx / C4;
+        float* vout = V + (size_t)tile * CP + c4 * 4;
+        if (c4 * 4 >= C) {  // channel padding
+#pragma unroll
+            for (int q = 0; q < 16; ++q) *reinterpret_cast<f32x4*>(vout + q * plane) = (f32x4)(0.f);
+            continue;
+        }
         const int tx = (int)(tile % TW);
         const long t2 = tile / TW;
         const int ty = (int)(t2 % TH), b = (int)(t2 / TH);
@@ -65,8 +77,6 @@ __global__ void __launch_bounds__(256) wino_input_transform(const float* __restr
             t[2][c] = d[2][c] - d[1][c];
             t[3][c] = d[1][c] - d[3][c];
         }
-        float* vout = V + (size_t)tile * C + c4 * 4;
-        const size_t plane = (size_t)ntiles * C;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             f32x4 v0 = (t[r][0] - t[r][2]) * s, v1 = (t[r][1] + t[r][2]) * s;
@@ -114,29 +124,31 @@ __global__ void wino_weight_transform(const float* __restrict__ w, float* __rest
 
 // ------------------------------------------------------------------------------------------------ GEMM + output transform
 struct WinoParams {
-    const float* V;  // [16][ntiles][C]
+    const float* V;  // [16][ntiles_pad][CP]
     const float* U;  // [16][RP][CP]
     float* y;        // [B,H,W,Co]
     const float* out_scale;
     const float* bias;
     const float* residual;
-    int B, H, W, C, Co, RP, CP;
-    int ntiles, TH, TW;
+    int B, H, W, Co, RP, CP;
+    int ntiles, ntiles_pad, TH, TW;
     int act;
     float slope, gain;
     int tiles_m, tiles_n;
 };
 
-// 256 threads = 4 waves as 2 (M) x 2 (N); wave tile 64 tiles x 32 couts; block tile 128 x 64; BK = 32.
-constexpr int WBM = 128, WBN = 64, WBK = 32;
+// A^T = [1 1 1 0; 0 1 -1 -1]: coefficient of M[xi][nu] in Y[a][b] is cA(a,xi) * cA(b,nu)
+__device__ __forceinline__ float wino_coef(int a, int xi) {
+    return a == 0 ? (xi < 3 ? 1.f : 0.f) : (xi == 0 ? 0.f : (xi == 1 ? 1.f : -1.f));
+}
 
 __global__ void __launch_bounds__(256, 2) wino_gemm_mfma(const WinoParams p) {
     constexpr int LD = WBK, CH = WBK / 4, RB = 64 / WBK, RPW = 64 / CH;
-    constexpr int MT = 2, NT = 1;
+    constexpr int MT = 2;
     constexpr int A_IT = WBM / 32, B_IT = WBN / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                 // [2][WBM][LD]
-    float* Bs = smem + 2 * WBM * LD;  // [2][WBN][LD]
+    float* As = smem;                       // [NSTAGE][WBM][LD]
+    float* Bs = smem + WNSTAGE * WBM * LD;  // [NSTAGE][WBN][LD]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -151,48 +163,51 @@ __global__ void __launch_bounds__(256, 2) wino_gemm_mfma(const WinoParams p) {
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
 
-    // row offsets of this lane's A rows inside one position plane (elements); -1 => beyond the tile count
-    int a_off[A_IT];
-#pragma unroll
-    for (int it = 0; it < A_IT; ++it) {
-        int m = m0 + t_row + it * 32;
-        a_off[it] = m < p.ntiles ? m * p.C + src_c4 : -1;
-    }
-    const size_t planeV = (size_t)p.ntiles * p.C, planeU = (size_t)p.RP * p.CP;
+    // Both operands are dense, padded matrices: per-lane 32-bit element offsets + one wave-uniform pointer per stage.
+    const unsigned a_off = (unsigned)(m0 + t_row) * (unsigned)p.CP + (unsigned)src_c4;
+    const unsigned b_off = (unsigned)(n0 + t_row) * (unsigned)p.CP + (unsigned)src_c4;
+    const size_t pass_stride = (size_t)32 * p.CP;  // 32 rows per 256-lane pass
+    const size_t planeV = (size_t)p.ntiles_pad * p.CP, planeU = (size_t)p.RP * p.CP;
     const int kchunks = p.CP / WBK;
     const int nsteps = 16 * kchunks;
-    int ld_p = 0, ld_kc = 0;
+    const float* vptr = p.V;  // wave-uniform cursors of the stage being loaded
+    const float* uptr = p.U;
+    int ld_kc = 0;
 
     auto issue = [&](int buf) __attribute__((always_inline)) {
-        const float* Vp = p.V + (size_t)ld_p * planeV + ld_kc;
-        const float* Up = p.U + (size_t)ld_p * planeU + (size_t)(n0 + t_row) * p.CP + ld_kc + src_c4;
-        const bool ch_ok = ld_kc + src_c4 < p.C;
         float* Ad = As + buf * WBM * LD + wave * RPW * LD;
         float* Bd = Bs + buf * WBN * LD + wave * RPW * LD;
 #pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            const float* g = (ch_ok && a_off[it] >= 0) ? Vp + a_off[it] : g_wino_zero_page;
-            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Ad + it * 32 * LD), 16, 0, 0);
-        }
+        for (int it = 0; it < A_IT; ++it)
+            __builtin_amdgcn_global_load_lds((gptr_t)((vptr + it * pass_stride) + a_off), (lptr_t)(Ad + it * 32 * LD), 16, 0, 0);
 #pragma unroll
         for (int it = 0; it < B_IT; ++it)
-            __builtin_amdgcn_global_load_lds((gptr_t)(Up + (size_t)it * 32 * p.CP), (lptr_t)(Bd + it * 32 * LD), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)((uptr + it * pass_stride) + b_off), (lptr_t)(Bd + it * 32 * LD), 16, 0, 0);
+        vptr += WBK;
+        uptr += WBK;
         ld_kc += WBK;
-        if (ld_kc >= p.CP) { ld_kc = 0; ++ld_p; }
+        if (ld_kc >= p.CP) {  // next position: same rows of the next plane
+            ld_kc = 0;
+            vptr += planeV - p.CP;
+            uptr += planeU - p.CP;
+        }
     };
 
-    f32x16 acc[MT];      // M_p tile of the current position
-    f32x16 yo[4][MT];    // the four outputs (a,b) of the 2x2 tile, accumulated over positions
+    // Two accumulator sets: while the MFMAs of position q run into one, the finished M_{q-1} in the other is folded into
+    // the four 2x2-output accumulators (and re-zeroed) by VALU instructions issued in the MFMAs' shadow.
+    f32x16 accA[MT], accB[MT];
+    f32x16 yo[4][MT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            acc[i][r] = 0.f;
+            accA[i][r] = 0.f;
+            accB[i][r] = 0.f;
 #pragma unroll
             for (int o = 0; o < 4; ++o) yo[o][i][r] = 0.f;
         }
-    }
-    auto compute = [&](int buf) __attribute__((always_inline)) {
+
+    auto compute = [&](int buf, f32x16(&acc)[MT]) __attribute__((always_inline)) {
         const float* Ab = As + buf * WBM * LD + (wm0 + li) * LD;
         const float* Bb = Bs + buf * WBN * LD + (wn0 + li) * LD;
 #pragma unroll
@@ -209,42 +224,78 @@ __global__ void __launch_bounds__(256, 2) wino_gemm_mfma(const WinoParams p) {
                     acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][t], bv[t], acc[i], 0, 0, 0);
         }
     };
-    // A^T = [1 1 1 0; 0 1 -1 -1]: coefficient of M[xi][nu] in Y[a][b] is cA(a,xi) * cA(b,nu)
-    auto coefA = [](int a, int xi) -> float { return a == 0 ? (xi < 3 ? 1.f : 0.f) : (xi == 0 ? 0.f : (xi == 1 ? 1.f : -1.f)); };
-    auto fold = [&](int pos) __attribute__((always_inline)) {
+    // branch-free (coefficients 0 / +-1 as data) so that the scheduler can place it between the MFMAs of `compute`
+    auto fold = [&](int pos, f32x16(&acc)[MT]) __attribute__((always_inline)) {
         const int xi = pos >> 2, nu = pos & 3;
+        float cf[4];
 #pragma unroll
-        for (int o = 0; o < 4; ++o) {
-            const float cf = coefA(o >> 1, xi) * coefA(o & 1, nu);
-            if (cf != 0.f) {  // wave-uniform
+        for (int o = 0; o < 4; ++o) cf[o] = wino_coef(o >> 1, xi) * wino_coef(o & 1, nu);
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MT; ++i) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) yo[o][i][r] += cf * acc[i][r];
-            }
+            for (int o = 0; o < 4; ++o) yo[o][i] += cf[o] * acc[i];
+            acc[i] = (f32x16)(0.f);
         }
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     };
 
+    // scheduling hint for the stages that carry a fold: 32 x { 1 MFMA, 3 VALU } so the fold's v_pk_fma run in the MFMAs' shadow
+    auto interleave = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int g = 0; g < 32; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        }
+    };
+
+    // 3-stage ring: the DMA of stage s+2 is issued before the MFMAs of stage s.  `s_waitcnt vmcnt(NI)` (NI = DMA
+    // instructions per stage and wave) lets the newest stage stay in flight; the last two stages drain with vmcnt(0).
+    constexpr int NI = A_IT + B_IT;
+    static_assert(NI == 6, "the s_waitcnt immediate below encodes vmcnt(6)");
+    int cur = 0, step = 0;
+    auto advance = [&]() __attribute__((always_inline)) {
+        if (step + 2 < nsteps) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        cur = cur == 2 ? 0 : cur + 1;
+        ++step;
+    };
+    auto prefetch = [&]() __attribute__((always_inline)) {
+        if (step + 2 < nsteps) issue(cur >= 1 ? cur - 1 : 2);  // (cur + 2) % 3
+    };
     issue(0);
-    __syncthreads();
-    int cur = 0, kc_in_pos = 0, pos = 0;
-    for (int step = 0; step + 1 < nsteps; ++step) {
-        issue(cur ^ 1);
-        compute(cur);
-        if (++kc_in_pos == kchunks) { fold(pos); kc_in_pos = 0; ++pos; }
-        __syncthreads();
-        cur ^= 1;
+    issue(1);  // nsteps >= 16
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    for (int pp = 0; pp < 8; ++pp) {
+        // even position 2pp -> accA; its first stage also folds accB (= position 2pp-1)
+        prefetch();
+        compute(cur, accA);
+        fold(2 * pp - 1, accB);  // pp == 0: accB is still zero
+        interleave();
+        advance();
+        for (int kc = 1; kc < kchunks; ++kc) {
+            prefetch();
+            compute(cur, accA);
+            advance();
+        }
+        // odd position 2pp+1 -> accB; its first stage folds accA (= position 2pp)
+        prefetch();
+        compute(cur, accB);
+        fold(2 * pp, accA);
+        interleave();
+        if (step + 1 < nsteps) advance();
+        for (int kc = 1; kc < kchunks; ++kc) {
+            prefetch();
+            compute(cur, accB);
+            if (step + 1 < nsteps) advance();
+        }
     }
-    compute(cur);
-    fold(pos);
+    fold(15, accB);
 
     // ---- epilogue: for each output position (a,b): transpose through LDS, then coalesced float4 rows
     constexpr int LDC = WBN + 4;
-    float* Cs = smem;  // [WBM][LDC]  (128*68*4 = 34.8 KB <= 48 KB of staging)
+    float* Cs = smem;  // [WBM][LDC]  (128*68*4 = 34.8 KB of the 72 KB of staging)
     constexpr int C4_ROW = WBN / 4, EROWS = 256 / C4_ROW, E_IT = WBM / EROWS;
     const int e_row0 = tid / C4_ROW, e_c = (tid % C4_ROW) * 4;
     const int n = n0 + e_c;
@@ -298,6 +349,15 @@ int gif_winograd_pack_dims(int cout, int cin, int* RP, int* CP) {
     return 0;
 }
 
+// floats of the V scratch of gif_conv3x3_winograd_f32: 16 planes x (tiles padded to the GEMM's M block) x padded channels
+int64_t gif_winograd_workspace_floats(int B, int H, int W, int C) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
+    const int64_t ntiles = (int64_t)B * (H / 2) * (W / 2);
+    const int64_t ntiles_pad = (ntiles + WBM - 1) / WBM * WBM;
+    const int64_t CP = (C + WBK - 1) / WBK * WBK;
+    return 16 * ntiles_pad * CP;
+}
+
 int gif_winograd_weight_f32(const float* w, float* U, int R, int C, int RP, int CP, int64_t sr, int64_t sc, int64_t sky,
                             int64_t skx, int flip, float scale, gif_stream_t stream) {
     GIF_REQUIRE(w && U && R > 0 && C > 0 && RP >= R && CP >= C, "winograd_weight: bad arguments");
@@ -308,24 +368,27 @@ int gif_winograd_weight_f32(const float* w, float* U, int R, int C, int RP, int 
 }
 
 // y [B,H,W,Co] = act(out_scale * conv3x3_s1_p1(in_scale * x [B,H,W,C], weights behind U) + residual + bias).
-// V is scratch of 16 * B*(H/2)*(W/2) * C floats.  H, W even; C, Co multiples of 4.
+// V is scratch of gif_winograd_workspace_floats(B,H,W,C) floats.  H, W even; C, Co multiples of 4.
 int gif_conv3x3_winograd_f32(const float* x, const float* U, float* y, float* V, int B, int H, int W, int C, int Co,
                              const gif_conv_epilogue* e, gif_stream_t stream) {
     GIF_REQUIRE(x && U && y && V && B >= 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "winograd: bad dims (H, W must be even)");
     GIF_REQUIRE(C > 0 && Co > 0 && C % 4 == 0 && Co % 4 == 0, "winograd: channels must be multiples of 4");
     if (B == 0) return 0;
     const long ntiles = (long)B * (H / 2) * (W / 2);
-    GIF_REQUIRE(ntiles * C < (1L << 31) && (long)B * H * W * Co < (1L << 31), "winograd: tensor too large for 32-bit offsets");
+    WinoParams p{};
+    gif_winograd_pack_dims(Co, C, &p.RP, &p.CP);
+    const long ntiles_pad = (ntiles + WBM - 1) / WBM * WBM;
+    GIF_REQUIRE(ntiles_pad * p.CP < (1L << 31) && (long)B * H * W * Co < (1L << 31) && (long)B * H * W * C < (1L << 31),
+                "winograd: tensor too large for 32-bit offsets");
     hipStream_t s = gif::as_stream(stream);
     double flops = 2.0 * B * H * W * 9.0 * C * Co;  // ALGORITHMIC (direct-convolution) FLOPs
     gif::ProfScope prof(0, flops, s, (int)((long)B * H * W), Co, C, 1091);
     {
-        long total = ntiles * (C / 4);
+        long total = ntiles * (p.CP / 4);
         long blocks = (total + 255) / 256;
         if (blocks > 256 * 32) blocks = 256 * 32;
-        wino_input_transform<<<(unsigned)blocks, 256, 0, s>>>(x, e ? e->in_scale : nullptr, V, B, H, W, C);
+        wino_input_transform<<<(unsigned)blocks, 256, 0, s>>>(x, e ? e->in_scale : nullptr, V, B, H, W, C, p.CP, ntiles_pad);
     }
-    WinoParams p{};
     p.V = V; p.U = U; p.y = y;
     p.out_scale = e ? e->out_scale : nullptr;
     p.bias = e ? e->bias : nullptr;
@@ -333,12 +396,11 @@ int gif_conv3x3_winograd_f32(const float* x, const float* U, float* y, float* V,
     p.act = e ? e->act : 0;
     p.slope = e ? e->slope : 0.f;
     p.gain = e ? e->gain : 1.f;
-    p.B = B; p.H = H; p.W = W; p.C = C; p.Co = Co;
-    gif_winograd_pack_dims(Co, C, &p.RP, &p.CP);
-    p.ntiles = (int)ntiles; p.TH = H / 2; p.TW = W / 2;
-    p.tiles_m = gif::cdiv(ntiles, WBM);
+    p.B = B; p.H = H; p.W = W; p.Co = Co;
+    p.ntiles = (int)ntiles; p.ntiles_pad = (int)ntiles_pad; p.TH = H / 2; p.TW = W / 2;
+    p.tiles_m = (int)(ntiles_pad / WBM);
     p.tiles_n = p.RP / WBN;
-    const size_t lds = (size_t)2 * (WBM + WBN) * WBK * sizeof(float);
+    const size_t lds = (size_t)WNSTAGE * (WBM + WBN) * WBK * sizeof(float);
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_gemm_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

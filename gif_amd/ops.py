@@ -120,7 +120,7 @@ def conv3x3_winograd(x, w, rows_are_out: bool, cout_act: int, wscale=1.0, **epi)
     U = torch.empty((16, RP.value, CP.value), device=x.device, dtype=torch.float32)
     _lib.check(lib.gif_winograd_weight_f32(w.data_ptr(), U.data_ptr(), R, Cc, RP.value, CP.value, sr, sc, sky, skx,
                                            0 if rows_are_out else 1, float(wscale), _stream()), "winograd_weight")
-    V = torch.empty((16 * B * (H // 2) * (W // 2) * C,), device=x.device, dtype=torch.float32)
+    V = torch.empty((lib.gif_winograd_workspace_floats(B, H, W, C),), device=x.device, dtype=torch.float32)
     out = empty_nhwc(B, cout_act, H, W, x.device)
     e = _epilogue(**epi)
     _lib.check(lib.gif_conv3x3_winograd_f32(x.data_ptr(), U.data_ptr(), out.data_ptr(), V.data_ptr(), B, H, W, C, cout_act,

@@ -131,10 +131,13 @@ int gif_unpack_wgrad_f32(const float* ws, float* dw, int nsplit, int R, int C, i
  *                            channels, cols = op input channels); flip!=0 rotates the taps by 180 degrees
  *                            (data gradient); `scale` = the equalised-lr factor
  *   gif_conv3x3_winograd_f32: y [B,H,W,Co] = act(out_scale*conv3x3(in_scale*x [B,H,W,C]) + residual + bias);
- *                            V = scratch of 16*B*(H/2)*(W/2)*C floats; H, W even; C, Co multiples of 4.
+ *                            V = scratch of gif_winograd_workspace_floats(B,H,W,C) floats (16 planes of the
+ *                            transformed input, tile and channel dims padded to the GEMM blocks); H, W even;
+ *                            C, Co multiples of 4.
  *                            Epilogue fields as in gif_conv2d_fwd_f32.
  * ---------------------------------------------------------------------------------------------- */
 int gif_winograd_pack_dims(int cout, int cin, int* RP, int* CP);
+int64_t gif_winograd_workspace_floats(int B, int H, int W, int C);
 int gif_winograd_weight_f32(const float* w, float* U, int R, int C, int RP, int CP, int64_t sr, int64_t sc,
                             int64_t sky, int64_t skx, int flip, float scale, gif_stream_t stream);
 int gif_conv3x3_winograd_f32(const float* x, const float* U, float* y, float* V, int B, int H, int W, int C,
