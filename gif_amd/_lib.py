@@ -46,6 +46,9 @@ PROTOTYPES = {
     "gif_winograd_workspace_floats": (c_i64, [c_int, c_int, c_int, c_int]),
     "gif_winograd_weight_f32": (c_int, [P, P, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_int, c_float, P]),
     "gif_conv3x3_winograd_f32": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, EP, P]),
+    "gif_conv3x3_winograd_wgrad_splits": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "gif_conv3x3_winograd_wgrad_f32": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "gif_winograd_unpack_wgrad_f32": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_float, P]),
     "gif_upfirdn2d_f32": (c_int, [P, P, P] + [c_int] * 13 + [EP, P]),
     "gif_bias_act_f32": (c_int, [P, P, P, P, c_i64, c_int, c_float, c_float, P]),
     "gif_colsum_partial_floats": (c_i64, [c_i64, c_int]),

@@ -40,4 +40,12 @@ struct ProfScope {
     ~ProfScope();
 };
 
+// ---- Winograd transforms (conv_winograd.hip), shared with the Winograd wgrad in conv_wgrad.hip ----
+// padded dims of a transformed operand [16][ntiles_pad][CP]
+void winograd_padded_dims(long ntiles, int C, long* ntiles_pad, int* CP);
+// V = B^T d B per 4x4 input patch (x [B,H,W,C], optional per-sample channel scale [B,C])
+int winograd_input_transform(const float* x, const float* scale, float* V, int B, int H, int W, int C, hipStream_t s);
+// Mg = G g G^T per 2x2 tile of gy [B,H,W,C] (F(3x3,2x2) "filter" transform of the output gradient)
+int winograd_gy_transform(const float* gy, const float* scale, float* Mg, int B, int H, int W, int C, hipStream_t s);
+
 }  // namespace gif

@@ -33,6 +33,8 @@ struct WgradParams {
     int tiles_q, tiles_pq;
     int stab_nb;  // LDS scale table (scaled LDS-DMA path): samples a pixel chunk can touch
     const float* zero;  // 16 zero bytes in HBM (source of out-of-range LDS-DMA lanes), passed as an argument
+    // "planes" mode (Winograd wgrad): tap t has no spatial shift but its own operand planes sm + t*sm_plane, bg + t*bg_plane
+    long sm_plane, bg_plane;
 };
 
 // XCD-aware, bijective block remap: XCD k (= blockIdx % 8 by dispatch order) gets a contiguous range of logical ids.
@@ -78,7 +80,10 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const 
     const int split = lid / (p.tiles_pq * p.T);
     const int tq = tile % p.tiles_q, tp = tile / p.tiles_q;
     const int r0 = tp * BP, c0 = tq * BQ;
-    const int ky = t / p.KW, kx = t - ky * p.KW;
+    const bool planes = p.sm_plane != 0;
+    const int ky = planes ? 0 : t / p.KW, kx = planes ? 0 : t - ky * p.KW;
+    const float* const smb = p.sm + (size_t)t * p.sm_plane;
+    const float* const bgb = p.bg + (size_t)t * p.bg_plane;
     const int n_begin = (int)((long)split * p.chunk);
     int n_end = n_begin + (int)p.chunk;
     if (n_end > (int)p.Ntot) n_end = (int)p.Ntot;
@@ -144,12 +149,12 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const 
             bool ok = p_ch_ok && p_n[it] < n_end;
             if (GLDS) {
                 // thread tid lands at float offset 4*tid of pass `it` (== Ps[buf][p_row + it*P_ROWS][4*(tid % (BP/4))])
-                const float* g = ok ? p.sm + (p_n[it] * p.Cs + p_ch) : p.zero;
+                const float* g = ok ? smb + (p_n[it] * p.Cs + p_ch) : p.zero;
                 __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(&Ps[buf][it * P_ROWS][0] + wave_u * 256), 16, 0, 0);
                 p_n[it] += BKP;
                 continue;
             }
-            p_reg[it] = *reinterpret_cast<const float4*>(p.sm + (ok ? p_n[it] * p.Cs + p_ch : 0));
+            p_reg[it] = *reinterpret_cast<const float4*>(smb + (ok ? p_n[it] * p.Cs + p_ch : 0));
             if (has_ss) ps_reg[it] = *reinterpret_cast<const float4*>(p.ss + (ok ? p_b[it] * p.Cs + p_ch : 0));
             p_mask |= (ok ? 1u : 0u) << it;
             p_n[it] += BKP;
@@ -161,11 +166,11 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const 
             int iy = q_oy[it] * p.stride + ky - p.pad, ix = q_ox[it] * p.stride + kx - p.pad;
             bool ok = q_ch_ok && q_n[it] < n_end && (unsigned)iy < (unsigned)p.Hb && (unsigned)ix < (unsigned)p.Wb;
             if (GLDS) {
-                const float* g = ok ? p.bg + (((q_b[it] * p.Hb + iy) * p.Wb + ix) * p.Cb + q_ch) : p.zero;
+                const float* g = ok ? bgb + (((q_b[it] * p.Hb + iy) * p.Wb + ix) * p.Cb + q_ch) : p.zero;
                 __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(&Qs[buf][it * Q_ROWS][0] + wave_u * 256), 16, 0, 0);
             } else {
                 q_reg[it] = *reinterpret_cast<const float4*>(
-                    p.bg + (ok ? ((q_b[it] * p.Hb + iy) * p.Wb + ix) * p.Cb + q_ch : 0));
+                    bgb + (ok ? ((q_b[it] * p.Hb + iy) * p.Wb + ix) * p.Cb + q_ch : 0));
                 if (has_bs) qs_reg[it] = *reinterpret_cast<const float4*>(p.bs + (ok ? q_b[it] * p.Cb + q_ch : 0));
                 q_mask |= (ok ? 1u : 0u) << it;
             }
@@ -333,6 +338,39 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ ws, float* __restr
     dw[r * sr + c * sc + ky * sky + kx * skx] = scale * acc;
 }
 
+// Winograd F(3x3,2x2) output transform fused with the split reduction: dW = A'^T dU A' with
+// A'^T = [1 1 1 0; 0 1 -1 0; 0 1 1 -1] (the F(3,2) matrix with the sign of the input transform's last row folded in,
+// because V was produced by the F(2,3) input transform whose last row is the negative of F(3,2)'s).
+__global__ void wino_unpack_wgrad_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit, int R, int C,
+                                         int RP, int CP, long sr, long sc, long sky, long skx, float scale) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)R * C) return;
+    int c = (int)(idx % C), r = (int)(idx / C);
+    const size_t plane = (size_t)RP * CP, stride = 16 * plane;
+    const float* src = ws + (size_t)r * CP + c;
+    float u[4][4];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        float acc = 0.f;
+        for (int s = 0; s < nsplit; ++s) acc += src[s * stride + q * plane];
+        u[q >> 2][q & 3] = acc;
+    }
+    float t[3][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        t[0][j] = u[0][j] + u[1][j] + u[2][j];
+        t[1][j] = u[1][j] - u[2][j];
+        t[2][j] = u[1][j] + u[2][j] - u[3][j];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float* o = dw + r * sr + c * sc + i * sky;
+        o[0 * skx] = scale * (t[i][0] + t[i][1] + t[i][2]);
+        o[1 * skx] = scale * (t[i][1] - t[i][2]);
+        o[2 * skx] = scale * (t[i][1] + t[i][2] - t[i][3]);
+    }
+}
+
 // wgrad workspace dims: rows/cols padded to the wgrad tile (32 or 128)
 inline void wgrad_dims(int Cs, int Cb, int* RP, int* CP) {
     int bp = tile_of(Cs), bq = tile_of(Cb);
@@ -443,5 +481,80 @@ int gif_unpack_wgrad_f32(const float* ws, float* dw, int nsplit, int R, int C, i
     unpack_wgrad_kernel<<<gif::cdiv(total, 256), 256, 0, gif::as_stream(stream)>>>(ws, dw, nsplit, R, C, KH, KW, RP,
                                                                                      CP, sr, sc, sky, skx, scale);
     return gif::check_launch("unpack_wgrad");
+}
+
+/* ---- Winograd F(3x3,2x2) weight gradient of the stride-1 / pad-1 3x3 convolution -------------------------------------
+ * dU_q[o][i] = sum_tiles Mg_q[tile][o] * V_q[tile][i] for the 16 transform positions q (a 1x1 wgrad per plane, run by
+ * conv_wgrad_mfma in "planes" mode), then dW = A'^T dU A' in the unpack kernel: 16 instead of 36 multiplies per tile. */
+int gif_conv3x3_winograd_wgrad_splits(int B, int H, int W, int Cs, int Cb) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cs <= 0 || Cb <= 0) return 1;
+    int RP, CP;
+    wgrad_dims(Cs, Cb, &RP, &CP);
+    long tiles = (long)(RP / tile_of(Cs)) * (CP / tile_of(Cb)) * 16;
+    long Ntot = (long)B * (H / 2) * (W / 2);
+    long want = tiles >= 1024 ? 1 : 1024 / tiles;
+    long max_by_work = (Ntot + 4 * BKP_MAX - 1) / (4 * BKP_MAX);
+    long max_by_mem = (128L << 20) / (16L * RP * CP * 4);
+    long n = want;
+    if (n > max_by_work) n = max_by_work;
+    if (n > max_by_mem) n = max_by_mem;
+    if (n < 1) n = 1;
+    return (int)n;
+}
+
+int gif_conv3x3_winograd_wgrad_f32(const float* x, const float* gy, float* V, float* Mg, float* ws,
+                                   const float* small_scale, const float* big_scale, int B, int H, int W, int Cs, int Cb,
+                                   int nsplit, gif_stream_t stream) {
+    GIF_REQUIRE(x && gy && V && Mg && ws && nsplit >= 1, "winograd_wgrad: bad arguments");
+    GIF_REQUIRE(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "winograd_wgrad: bad dims (H, W must be even)");
+    GIF_REQUIRE(Cs > 0 && Cb > 0 && Cs % 4 == 0 && Cb % 4 == 0, "winograd_wgrad: channels must be multiples of 4");
+    hipStream_t s = gif::as_stream(stream);
+    const long ntiles = (long)B * (H / 2) * (W / 2);
+    int CsP = 0, CbP = 0;
+    long ntiles_pad = 0;
+    gif::winograd_padded_dims(ntiles, Cs, &ntiles_pad, &CsP);
+    gif::winograd_padded_dims(ntiles, Cb, &ntiles_pad, &CbP);
+    GIF_REQUIRE(ntiles_pad * CsP < (1L << 31) && ntiles_pad * CbP < (1L << 31), "winograd_wgrad: tensor too large for 32-bit offsets");
+    double flops = 2.0 * B * H * W * 9.0 * Cs * Cb;  // ALGORITHMIC (direct) FLOPs
+    gif::ProfScope prof(1, flops, s, (int)((long)B * H * W), Cs, Cb, 1091 + (small_scale || big_scale ? 100 : 0));
+    if (int rc = gif::winograd_input_transform(x, big_scale, V, B, H, W, Cb, s)) return rc;
+    if (int rc = gif::winograd_gy_transform(gy, small_scale, Mg, B, H, W, Cs, s)) return rc;
+    WgradParams p{};
+    p.sm = Mg; p.bg = V; p.ws = ws; p.ss = nullptr; p.bs = nullptr;
+    // one "image" of 1 x ntiles pixels per plane, 1x1 taps
+    p.B = 1; p.Hs = 1; p.Ws = (int)ntiles; p.Cs = CsP; p.Hb = 1; p.Wb = (int)ntiles; p.Cb = CbP;
+    p.KW = 1; p.stride = 1; p.pad = 0; p.T = 16;
+    p.sm_plane = ntiles_pad * CsP;
+    p.bg_plane = ntiles_pad * CbP;
+    wgrad_dims(CsP, CbP, &p.RP, &p.CP);
+    p.Ntot = ntiles;
+    long chunk = (p.Ntot + nsplit - 1) / nsplit;
+    p.chunk = (chunk + BKP_MAX - 1) / BKP_MAX * BKP_MAX;
+    if (p.chunk < BKP_MAX) p.chunk = BKP_MAX;
+    const int bp = tile_of(CsP), bq = tile_of(CbP);
+    p.tiles_q = p.CP / bq;
+    p.tiles_pq = (p.RP / bp) * p.tiles_q;
+    dim3 grid((unsigned)(p.tiles_pq * p.T * nsplit));
+    static const float* zero_page = nullptr;
+    if (!zero_page) {
+        void* zp = nullptr;
+        GIF_REQUIRE(hipGetSymbolAddress(&zp, HIP_SYMBOL(g_wgrad_zero_page)) == hipSuccess, "winograd_wgrad: zero page lookup failed");
+        zero_page = static_cast<const float*>(zp);
+    }
+    p.zero = zero_page;
+    if (bp == 128 && bq == 128) wgrad_launch<128, 128, 2, 2, true, 16>(grid, 256, s, p);
+    else if (bp == 128 && bq == 32) wgrad_launch<128, 32, 4, 1, true, 32>(grid, 256, s, p);
+    else if (bp == 32 && bq == 128) wgrad_launch<32, 128, 1, 4, true, 32>(grid, 256, s, p);
+    else wgrad_launch<32, 32, 1, 1, true, 32>(grid, 64, s, p);
+    return gif::check_launch("conv3x3_winograd_wgrad");
+}
+
+int gif_winograd_unpack_wgrad_f32(const float* ws, float* dw, int nsplit, int R, int C, int RP, int CP, int64_t sr,
+                                  int64_t sc, int64_t sky, int64_t skx, float scale, gif_stream_t stream) {
+    GIF_REQUIRE(ws && dw && nsplit >= 1 && R > 0 && C > 0 && RP >= R && CP >= C, "winograd_unpack_wgrad: bad arguments");
+    long total = (long)R * C;
+    wino_unpack_wgrad_kernel<<<gif::cdiv(total, 256), 256, 0, gif::as_stream(stream)>>>(ws, dw, nsplit, R, C, RP, CP, sr,
+                                                                                          sc, sky, skx, scale);
+    return gif::check_launch("winograd_unpack_wgrad");
 }
 }

@@ -89,6 +89,54 @@ __global__ void __launch_bounds__(256) wino_input_transform(const float* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------------ gy transform (wgrad)
+// F(3x3,2x2): the 2x2 tile of the output gradient is the "filter": Mg = G g G^T with G = [1 0; .5 .5; .5 -.5; 0 1].
+// Same [16][ntiles_pad][CP] layout as V (channel padding zeroed, row padding untouched: the wgrad GEMM bounds K itself).
+__global__ void __launch_bounds__(256) wino_gy_transform(const float* __restrict__ gy, const float* __restrict__ scale,
+                                                         float* __restrict__ Mg, int B, int H, int W, int C, int CP,
+                                                         long ntiles_pad) {
+    const int C4 = CP >> 2, TH = H >> 1, TW = W >> 1;
+    const long ntiles = (long)B * TH * TW;
+    const long total = ntiles * C4;
+    const size_t plane = (size_t)ntiles_pad * CP;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % C4);
+        const long tile = idx / C4;
+        float* out = Mg + (size_t)tile * CP + c4 * 4;
+        if (c4 * 4 >= C) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) *reinterpret_cast<f32x4*>(out + q * plane) = (f32x4)(0.f);
+            continue;
+        }
+        const int tx = (int)(tile % TW);
+        const long t2 = tile / TW;
+        const int ty = (int)(t2 % TH), b = (int)(t2 / TH);
+        const float* g0 = gy + (((size_t)b * H + 2 * ty) * W + 2 * tx) * C + c4 * 4;
+        f32x4 s = (f32x4)(1.f);
+        if (scale) s = *reinterpret_cast<const f32x4*>(scale + (size_t)b * C + c4 * 4);
+        f32x4 g[2][2];
+        g[0][0] = *reinterpret_cast<const f32x4*>(g0) * s;
+        g[0][1] = *reinterpret_cast<const f32x4*>(g0 + C) * s;
+        g[1][0] = *reinterpret_cast<const f32x4*>(g0 + (size_t)W * C) * s;
+        g[1][1] = *reinterpret_cast<const f32x4*>(g0 + (size_t)W * C + C) * s;
+        f32x4 m[4][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            m[0][j] = g[0][j];
+            m[1][j] = 0.5f * (g[0][j] + g[1][j]);
+            m[2][j] = 0.5f * (g[0][j] - g[1][j]);
+            m[3][j] = g[1][j];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x4*>(out + (i * 4 + 0) * plane) = m[i][0];
+            *reinterpret_cast<f32x4*>(out + (i * 4 + 1) * plane) = 0.5f * (m[i][0] + m[i][1]);
+            *reinterpret_cast<f32x4*>(out + (i * 4 + 2) * plane) = 0.5f * (m[i][0] - m[i][1]);
+            *reinterpret_cast<f32x4*>(out + (i * 4 + 3) * plane) = m[i][1];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ weight transform
 // U = G g G^T, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]; rows = op output channels, cols = op input channels
 __global__ void wino_weight_transform(const float* __restrict__ w, float* __restrict__ U, int R, int C, int RP, int CP,
@@ -339,6 +387,39 @@ __global__ void __launch_bounds__(256, 2) wino_gemm_mfma(const WinoParams p) {
 
 }  // namespace
 
+namespace gif {
+
+void winograd_padded_dims(long ntiles, int C, long* ntiles_pad, int* CP) {
+    *ntiles_pad = (ntiles + WBM - 1) / WBM * WBM;
+    *CP = (C + WBK - 1) / WBK * WBK;
+}
+
+static unsigned transform_blocks(long total) {
+    long blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    return (unsigned)blocks;
+}
+
+int winograd_input_transform(const float* x, const float* scale, float* V, int B, int H, int W, int C, hipStream_t s) {
+    const long ntiles = (long)B * (H / 2) * (W / 2);
+    long ntiles_pad;
+    int CP;
+    winograd_padded_dims(ntiles, C, &ntiles_pad, &CP);
+    wino_input_transform<<<transform_blocks(ntiles * (CP / 4)), 256, 0, s>>>(x, scale, V, B, H, W, C, CP, ntiles_pad);
+    return check_launch("winograd_input_transform");
+}
+
+int winograd_gy_transform(const float* gy, const float* scale, float* Mg, int B, int H, int W, int C, hipStream_t s) {
+    const long ntiles = (long)B * (H / 2) * (W / 2);
+    long ntiles_pad;
+    int CP;
+    winograd_padded_dims(ntiles, C, &ntiles_pad, &CP);
+    wino_gy_transform<<<transform_blocks(ntiles * (CP / 4)), 256, 0, s>>>(gy, scale, Mg, B, H, W, C, CP, ntiles_pad);
+    return check_launch("winograd_gy_transform");
+}
+
+}  // namespace gif
+
 extern "C" {
 
 // RP / CP of the transformed weight U [16][RP][CP] for `cout` / `cin` channels
@@ -383,12 +464,7 @@ int gif_conv3x3_winograd_f32(const float* x, const float* U, float* y, float* V,
     hipStream_t s = gif::as_stream(stream);
     double flops = 2.0 * B * H * W * 9.0 * C * Co;  // ALGORITHMIC (direct-convolution) FLOPs
     gif::ProfScope prof(0, flops, s, (int)((long)B * H * W), Co, C, 1091);
-    {
-        long total = ntiles * (p.CP / 4);
-        long blocks = (total + 255) / 256;
-        if (blocks > 256 * 32) blocks = 256 * 32;
-        wino_input_transform<<<(unsigned)blocks, 256, 0, s>>>(x, e ? e->in_scale : nullptr, V, B, H, W, C, p.CP, ntiles_pad);
-    }
+    if (int rc = gif::winograd_input_transform(x, e ? e->in_scale : nullptr, V, B, H, W, C, s)) return rc;
     p.V = V; p.U = U; p.y = y;
     p.out_scale = e ? e->out_scale : nullptr;
     p.bias = e ? e->bias : nullptr;

@@ -88,6 +88,8 @@ def pack_weight(w: torch.Tensor, rows_are_out: bool, cout_act: int, cin_act: int
 # implicit-GEMM kernels; below GIF_WINOGRAD_MIN_TILES 2x2 tiles the launch cannot fill the chip and the direct path wins.
 WINOGRAD = os.environ.get("GIF_WINOGRAD", "1") != "0"
 WINOGRAD_MIN_TILES = int(os.environ.get("GIF_WINOGRAD_MIN_TILES", "8192"))
+WINOGRAD_WGRAD = os.environ.get("GIF_WINOGRAD_WGRAD", "1") != "0"
+WINOGRAD_WGRAD_MIN_TILES = int(os.environ.get("GIF_WINOGRAD_WGRAD_MIN_TILES", "2048"))  # split-K fills the chip earlier
 _winograd_calls = 0
 
 
@@ -96,10 +98,11 @@ def prof_winograd_calls():
     return _winograd_calls
 
 
-def winograd_eligible(spec: ConvSpec, B, H, W, cin_act, cout_act=64):
+def winograd_eligible(spec: ConvSpec, B, H, W, cin_act, cout_act=64, min_tiles=None):
     # cout < 48 wastes over a quarter of the GEMM's 64-wide N tile; the direct 256x32 kernel is faster there (measured)
+    min_tiles = WINOGRAD_MIN_TILES if min_tiles is None else min_tiles
     return (WINOGRAD and tuple(spec) == (3, 3, 1, 1) and H % 2 == 0 and W % 2 == 0 and cin_act >= 32 and cout_act >= 48
-            and B * (H // 2) * (W // 2) >= WINOGRAD_MIN_TILES)
+            and B * (H // 2) * (W // 2) >= min_tiles)
 
 
 def conv3x3_winograd(x, w, rows_are_out: bool, cout_act: int, wscale=1.0, **epi):
@@ -166,6 +169,36 @@ def conv_bwd_data(small, w, spec: ConvSpec, big_hw, wscale=1.0, **epi):
     return out
 
 
+def pad32(c: int) -> int:
+    return (c + 31) // 32 * 32
+
+
+def conv3x3_winograd_wgrad(small, big, O, I, wscale=1.0, small_scale=None, big_scale=None):
+    """dW[O,I,3,3] of the stride-1 / pad-1 3x3 conv via Winograd F(3x3,2x2) (transforms + 16 plane GEMMs + unpack)."""
+    global _winograd_calls
+    _winograd_calls += 1
+    lib = _lib.load()
+    small, big = nhwc(small), nhwc(big)
+    B, Cs, H, W = small.shape
+    Cb = big.shape[1]
+    assert big.shape == (B, Cb, H, W) and O <= Cs and I <= Cb
+    RP, CP = ctypes.c_int(), ctypes.c_int()
+    _lib.check(lib.gif_conv2d_wgrad_dims(pad32(Cs), pad32(Cb), ctypes.byref(RP), ctypes.byref(CP)), "wgrad_dims")
+    nsplit = lib.gif_conv3x3_winograd_wgrad_splits(B, H, W, Cs, Cb)
+    dev = small.device
+    V = torch.empty((lib.gif_winograd_workspace_floats(B, H, W, Cb),), device=dev, dtype=torch.float32)
+    Mg = torch.empty((lib.gif_winograd_workspace_floats(B, H, W, Cs),), device=dev, dtype=torch.float32)
+    ws = torch.empty((nsplit, 16, RP.value, CP.value), device=dev, dtype=torch.float32)
+    _lib.check(lib.gif_conv3x3_winograd_wgrad_f32(big.data_ptr(), small.data_ptr(), V.data_ptr(), Mg.data_ptr(), ws.data_ptr(),
+                                                  _p(small_scale), _p(big_scale), B, H, W, Cs, Cb, nsplit, _stream()),
+               "conv3x3_winograd_wgrad")
+    dw = torch.empty((O, I, 3, 3), device=dev, dtype=torch.float32)
+    so, si, sky, skx = dw.stride()
+    _lib.check(lib.gif_winograd_unpack_wgrad_f32(ws.data_ptr(), dw.data_ptr(), nsplit, O, I, RP.value, CP.value, so, si, sky,
+                                                 skx, float(wscale), _stream()), "winograd_unpack_wgrad")
+    return dw
+
+
 def conv_wgrad(small, big, spec: ConvSpec, O, I, wscale=1.0, small_scale=None, big_scale=None):
     """dW[O,I,KH,KW] = wscale * sum small (x) big  (contiguous canonical layout)."""
     lib = _lib.load()
@@ -173,6 +206,9 @@ def conv_wgrad(small, big, spec: ConvSpec, O, I, wscale=1.0, small_scale=None, b
     B, Cs, Hs, Ws = small.shape
     _, Cb, Hb, Wb = big.shape
     assert O <= Cs and I <= Cb
+    if (WINOGRAD_WGRAD and (Hb, Wb) == (Hs, Ws) and Cs >= 64 and Cb >= 64
+            and winograd_eligible(spec, B, Hs, Ws, Cb, Cs, min(WINOGRAD_MIN_TILES, WINOGRAD_WGRAD_MIN_TILES))):
+        return conv3x3_winograd_wgrad(small, big, O, I, wscale, small_scale, big_scale)
     g = _geom(B, Hb, Wb, Cb, Hs, Ws, Cs, spec)
     RP, CP = ctypes.c_int(), ctypes.c_int()
     _lib.check(lib.gif_conv2d_wgrad_dims(Cs, Cb, ctypes.byref(RP), ctypes.byref(CP)), "wgrad_dims")

@@ -142,6 +142,18 @@ int gif_winograd_weight_f32(const float* w, float* U, int R, int C, int RP, int 
                             int64_t sky, int64_t skx, int flip, float scale, gif_stream_t stream);
 int gif_conv3x3_winograd_f32(const float* x, const float* U, float* y, float* V, int B, int H, int W, int C,
                              int Co, const gif_conv_epilogue* e, gif_stream_t stream);
+/* Weight gradient of the same convolution via Winograd F(3x3,2x2) (replaces autograd's wgrad of the F.conv2d calls
+ * above): x [B,H,W,Cb] = conv input, gy [B,H,W,Cs] = output gradient, optional per-sample scales as in
+ * gif_conv2d_wgrad_f32.  V / Mg = scratch of gif_winograd_workspace_floats(B,H,W,Cb / Cs) floats; ws = per-split partial
+ * sums [nsplit][16][RP][CP] with (RP, CP) = gif_conv2d_wgrad_dims(pad32(Cs), pad32(Cb)); nsplit from
+ * gif_conv3x3_winograd_wgrad_splits.  gif_winograd_unpack_wgrad_f32 reduces the splits, applies the output transform and
+ * scatters scale * dW into the strided canonical [R=Cs.., C=Cb.., 3, 3] view (deterministic: no atomics). */
+int gif_conv3x3_winograd_wgrad_splits(int B, int H, int W, int Cs, int Cb);
+int gif_conv3x3_winograd_wgrad_f32(const float* x, const float* gy, float* V, float* Mg, float* ws,
+                                   const float* small_scale, const float* big_scale, int B, int H, int W, int Cs,
+                                   int Cb, int nsplit, gif_stream_t stream);
+int gif_winograd_unpack_wgrad_f32(const float* ws, float* dw, int nsplit, int R, int C, int RP, int CP, int64_t sr,
+                                  int64_t sc, int64_t sky, int64_t skx, float scale, gif_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * upfirdn2d — replaces upfirdn2d() stylegan2_common_layers.py:42-72 (Blur :136-152, Upsample :94-112,

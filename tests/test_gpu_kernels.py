@@ -212,6 +212,28 @@ def test_winograd_conv_fwd_and_bwd_data(case):
     assert torch.equal(got_s, got)
 
 
+@pytest.mark.parametrize("case", WINO_CASES + [(4, 128, 256, 16, 16)])
+def test_winograd_wgrad(case):
+    """Winograd F(3x3,2x2) weight gradient vs autograd of the direct convolution, with and without modulation scales."""
+    from gif_amd import ops
+    B, Ci, Co, H, W = case
+    g = torch.Generator().manual_seed(13)
+    x, gy = torch.randn(B, Ci, H, W, generator=g), torch.randn(B, Co, H, W, generator=g)
+    w = torch.zeros(Co, Ci, 3, 3, requires_grad=True)
+    (ref,) = torch.autograd.grad(F.conv2d(x, w, padding=1), w, gy)
+    got = ops.conv3x3_winograd_wgrad(dev(gy), dev(x), Co, Ci)
+    assert got.shape == (Co, Ci, 3, 3)
+    assert_close(got, ref, 5e-5, f"winograd wgrad {case}")
+    s, d = torch.rand(B, Ci, generator=g) + 0.5, torch.rand(B, Co, generator=g) + 0.5
+    (ref2,) = torch.autograd.grad(F.conv2d(x * s[:, :, None, None], w, padding=1) * d[:, :, None, None], w, gy)
+    sp = F.pad(s, (0, pad4(Ci) - Ci)).cuda()
+    dp = F.pad(d, (0, pad4(Co) - Co)).cuda()
+    got2 = ops.conv3x3_winograd_wgrad(dev(gy), dev(x), Co, Ci, 0.25, small_scale=dp, big_scale=sp)
+    assert_close(got2, 0.25 * ref2, 5e-5, f"winograd modulated wgrad {case}")
+    again = ops.conv3x3_winograd_wgrad(dev(gy), dev(x), Co, Ci, 0.25, small_scale=dp, big_scale=sp)
+    assert torch.equal(again, got2), "split-K reduction must be deterministic"
+
+
 def test_winograd_scales_and_epilogue(monkeypatch):
     from gif_amd import ops
     g = torch.Generator().manual_seed(12)

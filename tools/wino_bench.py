@@ -32,6 +32,20 @@ def main():
         err = ((y1 - y0).abs().max() / y0.abs().max()).item()
         print(f"{ci:4d}->{co:4d} @{h:3d}^2 x{B}: direct {t_dir:7.3f} ms {fl / t_dir / 1e9:6.1f} TF | winograd {t_win:7.3f} ms "
               f"{fl / t_win / 1e9:6.1f} TF-equiv | x{t_dir / t_win:4.2f} | rel diff {err:.1e}", flush=True)
+        if h < 16:
+            continue
+        gy = torch.randn(B, co, h, h, device="cuda").contiguous(memory_format=torch.channels_last)
+        for mod in (False, True):
+            kw = dict(small_scale=d, big_scale=s) if mod else {}
+            ops.WINOGRAD_WGRAD = False
+            t_dir = timeit(lambda: ops.conv_wgrad(gy, x, spec, co, ci, **kw))
+            w0 = ops.conv_wgrad(gy, x, spec, co, ci, **kw)
+            ops.WINOGRAD_WGRAD = True
+            t_win = timeit(lambda: ops.conv_wgrad(gy, x, spec, co, ci, **kw))
+            w1 = ops.conv_wgrad(gy, x, spec, co, ci, **kw)
+            err = ((w1 - w0).abs().max() / w0.abs().max()).item()
+            print(f"      wgrad{' (modulated)' if mod else '':12s}: direct {t_dir:7.3f} ms {fl / t_dir / 1e9:6.1f} TF | winograd {t_win:7.3f} ms "
+                  f"{fl / t_win / 1e9:6.1f} TF-equiv | x{t_dir / t_win:4.2f} | rel diff {err:.1e}", flush=True)
 
 
 if __name__ == "__main__":
