@@ -87,6 +87,61 @@ def cpu_baseline(res, step_idx, batch, threads, timeout_s=240):
                 "sample": f"cpu baseline did not finish within {timeout_s}s ({type(e).__name__})"}
 
 
+# PMC passes (separate rocprofv3 --pmc runs, profiles/r1_pmc_winograd.md / r1_pmc_dominant_kernels.md) on the largest layer
+# shape (128->128 3x3 @256x256, batch 32): HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (KiB, gfx950 corrections)
+PMC_TRAFFIC = {
+    "wino_gemm_mfma": {"hbm_bytes": 5.63e9, "algorithmic_bytes": 5.37e9, "mfma_busy": 0.58,
+                       "note": "V planes read once (4.29 GB) + output written once (1.07 GB); top layer, 2.9 ms"},
+    "conv_gather_mfma_glds": {"hbm_bytes": 3.68e9, "algorithmic_bytes": 2.15e9, "mfma_busy": 0.824,
+                              "note": "direct 3x3 conv, same shape"},
+}
+WINOGRAD_EXECUTED = 16.0 / 36.0  # MFMA FLOPs a Winograd F(2x2,3x3)/F(3x3,2x2) GEMM executes per algorithmic FLOP
+
+
+def roofline_objects(ops, steps):
+    """Per-family HIP-event timings -> the `roofline` object of the dominant kernel + one object per other MFMA family.
+
+    `achieved` is what the MFMA pipe actually executed per second (<= peak); for the Winograd GEMMs the ALGORITHMIC
+    (direct-convolution) rate, which is 36/16 of that, is reported next to it as `algorithmic_achieved`."""
+    fams = {
+        0: ("conv_gather_mfma_glds (direct fwd / dgrad / transposed conv, fp32 MFMA)", 1.0, "conv_gather_mfma_glds"),
+        1: ("conv_wgrad_mfma (direct weight gradient)", 1.0, None),
+        2: ("wino_gemm_mfma (Winograd F(2x2,3x3) fwd / dgrad GEMM + fused output transform and epilogue)",
+            WINOGRAD_EXECUTED, "wino_gemm_mfma"),
+        3: ("conv_wgrad_mfma in planes mode (Winograd F(3x3,2x2) weight-gradient GEMM)", WINOGRAD_EXECUTED, None),
+    }
+    objs = {}
+    for fam, (name, exec_frac, pmc) in fams.items():
+        ms, fl, n = ops.prof_read(fam)
+        if n == 0 or ms <= 0:
+            continue
+        alg = fl / (ms * 1e-3) / 1e12
+        o = {"bound": "mfma", "kernel": name, "achieved": alg * exec_frac, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+             "frac": alg * exec_frac / PEAK_F32_MFMA_TFLOPS, "traffic": None, "launches": n, "avg_ms": ms / n,
+             "gpu_ms_per_step": ms / steps}
+        if exec_frac != 1.0:
+            o["algorithmic_achieved"] = alg
+            o["algorithmic_frac"] = alg / PEAK_F32_MFMA_TFLOPS
+            o["note"] = "achieved = executed MFMA FLOP/s (16/36 of the algorithmic direct-convolution FLOPs)"
+        if pmc:
+            o["traffic_probe"] = PMC_TRAFFIC[pmc]
+        objs[fam] = o
+    out = {}
+    if objs:
+        dom = max(objs, key=lambda f: objs[f]["gpu_ms_per_step"])
+        out["roofline"] = objs.pop(dom)
+        names = {0: "roofline_conv_direct", 1: "roofline_wgrad_direct", 2: "roofline_conv_winograd", 3: "roofline_wgrad_winograd"}
+        for fam, o in objs.items():
+            out[names[fam]] = o
+    ms, by, n = ops.prof_read(4)
+    if n:
+        out["roofline_winograd_transforms"] = {"bound": "hbm", "kernel": "wino_input_transform / wino_gy_transform",
+                                               "achieved": by / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                               "frac": by / (ms * 1e-3) / 1e9 / 8000.0, "traffic": None, "launches": n,
+                                               "avg_ms": ms / n, "gpu_ms_per_step": ms / steps}
+    return out
+
+
 def main():
     args = parse()
     if args.cpu_baseline_worker:
@@ -142,7 +197,8 @@ def main():
 
     data = [batch() for _ in range(min(args.steps, 4))]  # synthetic batches resident in HBM before the timed region
     if not args.no_prof:
-        ops.prof_read(0), ops.prof_read(1)
+        for fam in range(5):
+            ops.prof_read(fam)
         ops.prof_enable(True)
     sync()
     t0 = time.perf_counter()
@@ -177,20 +233,7 @@ def main():
                                    "note": "whole step (incl. HBM-bound kernels, optimiser, host) vs fp32 MFMA peak, per GPU"},
         }
         if not args.no_prof:
-            ms0, fl0, n0 = ops.prof_read(0)
-            ms1, fl1, n1 = ops.prof_read(1)
-            ach = fl0 / (ms0 * 1e-3) / 1e12 if ms0 > 0 else 0.0
-            out["roofline"] = {"bound": "mfma", "kernel": "conv_gather_mfma (fwd / dgrad / transposed conv, fp32 MFMA)",
-                               "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                               "traffic_probe": {"note": "PMC pass on the largest layer shape (128->128 3x3 @256x256, batch 32), "
-                                                         "profiles/r1_pmc_dominant_kernels.md: 2*FETCH_SIZE + WRITE_SIZE per launch",
-                                                 "hbm_bytes": 3.68e9, "algorithmic_bytes": 2.15e9, "mfma_busy": 0.824},
-                               "launches": n0, "avg_ms": ms0 / max(n0, 1), "gpu_ms_per_step": ms0 / args.steps}
-            ach1 = fl1 / (ms1 * 1e-3) / 1e12 if ms1 > 0 else 0.0
-            out["roofline_wgrad"] = {"bound": "mfma", "kernel": "conv_wgrad_mfma", "achieved": ach1,
-                                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach1 / PEAK_F32_MFMA_TFLOPS,
-                                     "launches": n1, "avg_ms": ms1 / max(n1, 1), "gpu_ms_per_step": ms1 / args.steps}
+            out.update(roofline_objects(ops, args.steps))
         if world == 1 and not args.no_cpu_baseline:
             threads = args.cpu_threads or min(os.cpu_count() or 1, 16)
             out["cpu_baseline"] = cpu_baseline(args.res, res_step, args.cpu_batch, threads)

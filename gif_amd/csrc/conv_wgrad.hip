@@ -516,9 +516,13 @@ int gif_conv3x3_winograd_wgrad_f32(const float* x, const float* gy, float* V, fl
     gif::winograd_padded_dims(ntiles, Cb, &ntiles_pad, &CbP);
     GIF_REQUIRE(ntiles_pad * CsP < (1L << 31) && ntiles_pad * CbP < (1L << 31), "winograd_wgrad: tensor too large for 32-bit offsets");
     double flops = 2.0 * B * H * W * 9.0 * Cs * Cb;  // ALGORITHMIC (direct) FLOPs
-    gif::ProfScope prof(1, flops, s, (int)((long)B * H * W), Cs, Cb, 1091 + (small_scale || big_scale ? 100 : 0));
-    if (int rc = gif::winograd_input_transform(x, big_scale, V, B, H, W, Cb, s)) return rc;
-    if (int rc = gif::winograd_gy_transform(gy, small_scale, Mg, B, H, W, Cs, s)) return rc;
+    {
+        gif::ProfScope prof_t(4, 4.0 * ((double)B * H * W * (Cb + Cs) + 16.0 * ntiles_pad * (CbP + CsP)), s,
+                              (int)((long)B * H * W), Cb, Cs, 2);
+        if (int rc = gif::winograd_input_transform(x, big_scale, V, B, H, W, Cb, s)) return rc;
+        if (int rc = gif::winograd_gy_transform(gy, small_scale, Mg, B, H, W, Cs, s)) return rc;
+    }
+    gif::ProfScope prof(3, flops, s, (int)((long)B * H * W), Cs, Cb, 1091 + (small_scale || big_scale ? 100 : 0));
     WgradParams p{};
     p.sm = Mg; p.bg = V; p.ws = ws; p.ss = nullptr; p.bs = nullptr;
     // one "image" of 1 x ntiles pixels per plane, 1x1 taps

@@ -463,8 +463,12 @@ int gif_conv3x3_winograd_f32(const float* x, const float* U, float* y, float* V,
                 "winograd: tensor too large for 32-bit offsets");
     hipStream_t s = gif::as_stream(stream);
     double flops = 2.0 * B * H * W * 9.0 * C * Co;  // ALGORITHMIC (direct-convolution) FLOPs
-    gif::ProfScope prof(0, flops, s, (int)((long)B * H * W), Co, C, 1091);
-    if (int rc = gif::winograd_input_transform(x, e ? e->in_scale : nullptr, V, B, H, W, C, s)) return rc;
+    {
+        // x read once + V written once (the 4 overlapping patch reads of a pixel hit in L2)
+        gif::ProfScope prof_t(4, 4.0 * ((double)B * H * W * C + 16.0 * ntiles_pad * p.CP), s, (int)((long)B * H * W), C, 0, 1);
+        if (int rc = gif::winograd_input_transform(x, e ? e->in_scale : nullptr, V, B, H, W, C, s)) return rc;
+    }
+    gif::ProfScope prof(2, flops, s, (int)((long)B * H * W), Co, C, 1091);
     p.V = V; p.U = U; p.y = y;
     p.out_scale = e ? e->out_scale : nullptr;
     p.bias = e ? e->bias : nullptr;

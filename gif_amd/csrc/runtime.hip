@@ -25,7 +25,7 @@ struct ProfRec {
 };
 static bool g_prof_on = false;
 static std::mutex g_prof_mu;
-static std::vector<ProfRec> g_prof[2];
+static std::vector<ProfRec> g_prof[GIF_PROF_FAMILIES];
 static std::vector<hipEvent_t> g_pool;
 
 static hipEvent_t get_event() {
@@ -70,7 +70,7 @@ int gif_prof_enable(int on) {
 }
 
 int gif_prof_read(int family, double* ms, double* flops, int64_t* launches) {
-    if (family < 0 || family > 1) return GIF_EINVAL;
+    if (family < 0 || family >= GIF_PROF_FAMILIES) return GIF_EINVAL;
     std::lock_guard<std::mutex> lk(gif::g_prof_mu);
     double tms = 0, tf = 0;
     int64_t n = 0;
