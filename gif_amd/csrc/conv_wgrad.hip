@@ -505,7 +505,7 @@ int gif_conv3x3_winograd_wgrad_splits(int B, int H, int W, int Cs, int Cb) {
 int gif_conv3x3_winograd_wgrad_f32(const float* x, const float* gy, float* V, float* Mg, float* ws,
                                    const float* small_scale, const float* big_scale, int B, int H, int W, int Cs, int Cb,
                                    int nsplit, gif_stream_t stream) {
-    GIF_REQUIRE(x && gy && V && Mg && ws && nsplit >= 1, "winograd_wgrad: bad arguments");
+    GIF_REQUIRE(gy && V && Mg && ws && nsplit >= 1, "winograd_wgrad: bad arguments");  // x == NULL: V is already filled
     GIF_REQUIRE(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "winograd_wgrad: bad dims (H, W must be even)");
     GIF_REQUIRE(Cs > 0 && Cb > 0 && Cs % 4 == 0 && Cb % 4 == 0, "winograd_wgrad: channels must be multiples of 4");
     hipStream_t s = gif::as_stream(stream);
@@ -517,9 +517,10 @@ int gif_conv3x3_winograd_wgrad_f32(const float* x, const float* gy, float* V, fl
     GIF_REQUIRE(ntiles_pad * CsP < (1L << 31) && ntiles_pad * CbP < (1L << 31), "winograd_wgrad: tensor too large for 32-bit offsets");
     double flops = 2.0 * B * H * W * 9.0 * Cs * Cb;  // ALGORITHMIC (direct) FLOPs
     {
-        gif::ProfScope prof_t(4, 4.0 * ((double)B * H * W * (Cb + Cs) + 16.0 * ntiles_pad * (CbP + CsP)), s,
+        gif::ProfScope prof_t(4, 4.0 * ((double)B * H * W * ((x ? Cb : 0) + Cs) + 16.0 * ntiles_pad * ((x ? CbP : 0) + CsP)), s,
                               (int)((long)B * H * W), Cb, Cs, 2);
-        if (int rc = gif::winograd_input_transform(x, big_scale, V, B, H, W, Cb, s)) return rc;
+        if (x)  // else: the caller kept the forward pass's V (same x, same modulation)
+            if (int rc = gif::winograd_input_transform(x, big_scale, V, B, H, W, Cb, s)) return rc;
         if (int rc = gif::winograd_gy_transform(gy, small_scale, Mg, B, H, W, Cs, s)) return rc;
     }
     gif::ProfScope prof(3, flops, s, (int)((long)B * H * W), Cs, Cb, 1091 + (small_scale || big_scale ? 100 : 0));

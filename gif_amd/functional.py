@@ -31,8 +31,12 @@ class Conv2dFn(Function):
         x = ops.nhwc(x)
         ctx.spec, ctx.transposed, ctx.wscale = spec, transposed, wscale
         ctx.save_for_backward(x, w)
+        ctx.v = None
         if not transposed:
-            return ops.conv_fwd(x, w, spec, wscale)
+            # keep the Winograd-transformed input for the weight gradient (same x): saves one HBM-bound transform pass
+            y, v = ops.conv_fwd(x, w, spec, wscale, keep_v=True)
+            ctx.v = v if ctx.needs_input_grad[1] else None
+            return y
         return ops.conv_bwd_data(x, w, spec, tuple(out_hw), wscale)
 
     @staticmethod
@@ -45,7 +49,7 @@ class Conv2dFn(Function):
             assert gx.shape == x.shape, (gx.shape, x.shape)
         if ctx.needs_input_grad[1]:
             O, I = w.shape[:2]
-            gw = WgradFn.apply(gy, x, spec, O, I, ws) if not tr else WgradFn.apply(x, gy, spec, O, I, ws)
+            gw = WgradFn.apply(gy, x, spec, O, I, ws, ctx.v) if not tr else WgradFn.apply(x, gy, spec, O, I, ws)
         return gx, gw, None, None, None, None
 
 
@@ -53,11 +57,11 @@ class WgradFn(Function):
     """dW[O,I,KH,KW] = wscale * sum_{b,pix} small (x) big   (small = conv-output side, big = conv-input side)."""
 
     @staticmethod
-    def forward(ctx, small, big, spec, O, I, wscale):
+    def forward(ctx, small, big, spec, O, I, wscale, big_v=None):
         small, big = ops.nhwc(small), ops.nhwc(big)
         ctx.spec, ctx.wscale = spec, wscale
         ctx.save_for_backward(small, big)
-        return ops.conv_wgrad(small, big, spec, O, I, wscale)
+        return ops.conv_wgrad(small, big, spec, O, I, wscale, big_v=big_v)
 
     @staticmethod
     def backward(ctx, ggw):
@@ -67,7 +71,7 @@ class WgradFn(Function):
             gs = Conv2dFn.apply(big, ggw, ctx.spec, False, None, ctx.wscale)
         if ctx.needs_input_grad[1]:
             gb = Conv2dFn.apply(small, ggw, ctx.spec, True, tuple(big.shape[2:]), ctx.wscale)
-        return gs, gb, None, None, None, None
+        return gs, gb, None, None, None, None, None
 
 
 class ConvBiasActFn(Function):
@@ -78,7 +82,8 @@ class ConvBiasActFn(Function):
     @staticmethod
     def forward(ctx, x, w, bias, spec, wscale, slope, gain):
         x = ops.nhwc(x)
-        y = ops.conv_fwd(x, w, spec, wscale, bias=bias, act=True, slope=slope, gain=gain)
+        y, v = ops.conv_fwd(x, w, spec, wscale, keep_v=True, bias=bias, act=True, slope=slope, gain=gain)
+        ctx.v = v if ctx.needs_input_grad[1] else None  # Winograd-transformed x, reused by the weight gradient
         ctx.cfg = (spec, wscale, slope, gain, bias is not None)
         ctx.save_for_backward(x, w, y)
         return y
@@ -93,7 +98,7 @@ class ConvBiasActFn(Function):
         if ctx.needs_input_grad[0]:
             gx = Conv2dFn.apply(gpre, w, spec, True, tuple(x.shape[2:]), ws)
         if ctx.needs_input_grad[1]:
-            gw = WgradFn.apply(gpre, x, spec, w.shape[0], w.shape[1], ws)
+            gw = WgradFn.apply(gpre, x, spec, w.shape[0], w.shape[1], ws, ctx.v)
         return gx, gw, (gb if want_b else None), None, None, None, None
 
 
@@ -325,8 +330,10 @@ class ModConvFn(Function):
         x = ops.nhwc(x)
         s = s.contiguous()
         d = None if d is None else d.contiguous()
+        ctx.v = None
         if not transposed:
-            y = ops.conv_fwd(x, w, spec, wscale, in_scale=s, out_scale=d)
+            y, v = ops.conv_fwd(x, w, spec, wscale, keep_v=True, in_scale=s, out_scale=d)
+            ctx.v = v if ctx.needs_input_grad[1] else None
         else:
             y = ops.conv_bwd_data(x, w, spec, tuple(out_hw), wscale, in_scale=s, out_scale=d)
         ctx.spec, ctx.transposed, ctx.wscale = spec, transposed, wscale
@@ -351,7 +358,7 @@ class ModConvFn(Function):
             gs, gx = ops.mul_reduce(dxs, x, scale=s, want_scaled=True)
         if ctx.needs_input_grad[1]:
             if not tr:
-                gw = ops.conv_wgrad(gy, x, spec, O, I, ws, small_scale=d, big_scale=s)
+                gw = ops.conv_wgrad(gy, x, spec, O, I, ws, small_scale=d, big_scale=s, big_v=ctx.v)
             else:
                 gw = ops.conv_wgrad(x, gy, spec, O, I, ws, small_scale=s, big_scale=d)
         if ctx.has_d and ctx.needs_input_grad[3]:
@@ -370,8 +377,9 @@ class ModConvActFn(Function):
         x = ops.nhwc(x)
         s, d = s.contiguous(), d.contiguous()
         residual = None if residual is None else ops.nhwc(residual)
-        y = ops.conv_fwd(x, w, spec, wscale, in_scale=s, out_scale=d, residual=residual, bias=bias, act=True, slope=slope,
-                         gain=gain)
+        y, v = ops.conv_fwd(x, w, spec, wscale, keep_v=True, in_scale=s, out_scale=d, residual=residual, bias=bias, act=True,
+                            slope=slope, gain=gain)
+        ctx.v = v if ctx.needs_input_grad[1] else None  # Winograd-transformed s*x, reused by the weight gradient
         ctx.cfg = (spec, wscale, slope, gain)
         ctx.has = (residual is not None, bias is not None)
         z = x.new_zeros(())
@@ -393,7 +401,7 @@ class ModConvActFn(Function):
             dxs = ops.conv_bwd_data(gpre, w, spec, tuple(x.shape[2:]), ws, in_scale=d)
             gs, gx = ops.mul_reduce(dxs, x, scale=s, want_scaled=True)
         if ctx.needs_input_grad[1]:
-            gw = ops.conv_wgrad(gpre, x, spec, O, I, ws, small_scale=d, big_scale=s)
+            gw = ops.conv_wgrad(gpre, x, spec, O, I, ws, small_scale=d, big_scale=s, big_v=ctx.v)
         if ctx.needs_input_grad[3]:
             # d * z = act^-1(y) - residual - bias  =>  gd = sum_hw gpre * z
             gd = ops.act_inv_mul_reduce(gpre, y, residual, bias, slope, gain) / d

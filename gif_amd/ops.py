@@ -105,10 +105,11 @@ def winograd_eligible(spec: ConvSpec, B, H, W, cin_act, cout_act=64, min_tiles=N
             and B * (H // 2) * (W // 2) >= min_tiles)
 
 
-def conv3x3_winograd(x, w, rows_are_out: bool, cout_act: int, wscale=1.0, **epi):
+def conv3x3_winograd(x, w, rows_are_out: bool, cout_act: int, wscale=1.0, keep_v=False, **epi):
     """act(out_scale * conv3x3_s1_p1(in_scale * x, w) + residual + bias) via Winograd F(2x2,3x3).
 
-    rows_are_out=True : forward conv with w[O,I,3,3];  False: its data gradient (taps rotated, channels swapped)."""
+    rows_are_out=True : forward conv with w[O,I,3,3];  False: its data gradient (taps rotated, channels swapped).
+    keep_v=True returns (y, V): V = the transformed (in_scale * x), reusable by conv3x3_winograd_wgrad(big=x)."""
     global _winograd_calls
     _winograd_calls += 1
     lib = _lib.load()
@@ -128,11 +129,14 @@ def conv3x3_winograd(x, w, rows_are_out: bool, cout_act: int, wscale=1.0, **epi)
     e = _epilogue(**epi)
     _lib.check(lib.gif_conv3x3_winograd_f32(x.data_ptr(), U.data_ptr(), out.data_ptr(), V.data_ptr(), B, H, W, C, cout_act,
                                             ctypes.byref(e), _stream()), "conv3x3_winograd")
-    return out
+    return (out, V) if keep_v else out
 
 
-def conv_fwd(big, w, spec: ConvSpec, wscale=1.0, **epi):
-    """small = conv2d(big, w[O,I,KH,KW]) ; returns [B, pad4(O), Hs, Ws]."""
+def conv_fwd(big, w, spec: ConvSpec, wscale=1.0, keep_v=False, **epi):
+    """small = conv2d(big, w[O,I,KH,KW]) ; returns [B, pad4(O), Hs, Ws].
+
+    keep_v=True returns (small, V) where V is the Winograd-transformed (in_scale * big) if that path ran, else None;
+    pass it to conv_wgrad(big_v=V) for the weight gradient of the same (big, in_scale)."""
     lib = _lib.load()
     big = nhwc(big)
     B, Cb, Hb, Wb = big.shape
@@ -140,7 +144,9 @@ def conv_fwd(big, w, spec: ConvSpec, wscale=1.0, **epi):
     Cs = pad4(O)
     Hs, Ws = spec.small_hw(Hb, Wb)
     if winograd_eligible(spec, B, Hb, Wb, Cb, Cs):
-        return conv3x3_winograd(big, w, True, Cs, wscale, **epi)
+        return conv3x3_winograd(big, w, True, Cs, wscale, keep_v=keep_v, **epi)
+    if keep_v:
+        return conv_fwd(big, w, spec, wscale, **epi), None
     wp = pack_weight(w, True, Cs, Cb, wscale)
     out = empty_nhwc(B, Cs, Hs, Ws, big.device)
     g = _geom(B, Hb, Wb, Cb, Hs, Ws, Cs, spec)
@@ -173,8 +179,9 @@ def pad32(c: int) -> int:
     return (c + 31) // 32 * 32
 
 
-def conv3x3_winograd_wgrad(small, big, O, I, wscale=1.0, small_scale=None, big_scale=None):
-    """dW[O,I,3,3] of the stride-1 / pad-1 3x3 conv via Winograd F(3x3,2x2) (transforms + 16 plane GEMMs + unpack)."""
+def conv3x3_winograd_wgrad(small, big, O, I, wscale=1.0, small_scale=None, big_scale=None, big_v=None):
+    """dW[O,I,3,3] of the stride-1 / pad-1 3x3 conv via Winograd F(3x3,2x2) (transforms + 16 plane GEMMs + unpack).
+    big_v: the V kept from the forward pass over the same (big, big_scale) — skips the input transform."""
     global _winograd_calls
     _winograd_calls += 1
     lib = _lib.load()
@@ -186,10 +193,13 @@ def conv3x3_winograd_wgrad(small, big, O, I, wscale=1.0, small_scale=None, big_s
     _lib.check(lib.gif_conv2d_wgrad_dims(pad32(Cs), pad32(Cb), ctypes.byref(RP), ctypes.byref(CP)), "wgrad_dims")
     nsplit = lib.gif_conv3x3_winograd_wgrad_splits(B, H, W, Cs, Cb)
     dev = small.device
-    V = torch.empty((lib.gif_winograd_workspace_floats(B, H, W, Cb),), device=dev, dtype=torch.float32)
+    nv = lib.gif_winograd_workspace_floats(B, H, W, Cb)
+    if big_v is not None and big_v.numel() != nv:
+        raise _lib.GifHipError(f"conv3x3_winograd_wgrad: cached V has {big_v.numel()} floats, expected {nv}")
+    V = big_v if big_v is not None else torch.empty((nv,), device=dev, dtype=torch.float32)
     Mg = torch.empty((lib.gif_winograd_workspace_floats(B, H, W, Cs),), device=dev, dtype=torch.float32)
     ws = torch.empty((nsplit, 16, RP.value, CP.value), device=dev, dtype=torch.float32)
-    _lib.check(lib.gif_conv3x3_winograd_wgrad_f32(big.data_ptr(), small.data_ptr(), V.data_ptr(), Mg.data_ptr(), ws.data_ptr(),
+    _lib.check(lib.gif_conv3x3_winograd_wgrad_f32(None if big_v is not None else big.data_ptr(), small.data_ptr(), V.data_ptr(), Mg.data_ptr(), ws.data_ptr(),
                                                   _p(small_scale), _p(big_scale), B, H, W, Cs, Cb, nsplit, _stream()),
                "conv3x3_winograd_wgrad")
     dw = torch.empty((O, I, 3, 3), device=dev, dtype=torch.float32)
@@ -199,8 +209,9 @@ def conv3x3_winograd_wgrad(small, big, O, I, wscale=1.0, small_scale=None, big_s
     return dw
 
 
-def conv_wgrad(small, big, spec: ConvSpec, O, I, wscale=1.0, small_scale=None, big_scale=None):
-    """dW[O,I,KH,KW] = wscale * sum small (x) big  (contiguous canonical layout)."""
+def conv_wgrad(small, big, spec: ConvSpec, O, I, wscale=1.0, small_scale=None, big_scale=None, big_v=None):
+    """dW[O,I,KH,KW] = wscale * sum small (x) big  (contiguous canonical layout).
+    big_v: optional Winograd V of (big_scale * big) kept from conv_fwd(keep_v=True)."""
     lib = _lib.load()
     small, big = nhwc(small), nhwc(big)
     B, Cs, Hs, Ws = small.shape
@@ -208,7 +219,7 @@ def conv_wgrad(small, big, spec: ConvSpec, O, I, wscale=1.0, small_scale=None, b
     assert O <= Cs and I <= Cb
     if (WINOGRAD_WGRAD and (Hb, Wb) == (Hs, Ws) and Cs >= 64 and Cb >= 64
             and winograd_eligible(spec, B, Hs, Ws, Cb, Cs, min(WINOGRAD_MIN_TILES, WINOGRAD_WGRAD_MIN_TILES))):
-        return conv3x3_winograd_wgrad(small, big, O, I, wscale, small_scale, big_scale)
+        return conv3x3_winograd_wgrad(small, big, O, I, wscale, small_scale, big_scale, big_v)
     g = _geom(B, Hb, Wb, Cb, Hs, Ws, Cs, spec)
     RP, CP = ctypes.c_int(), ctypes.c_int()
     _lib.check(lib.gif_conv2d_wgrad_dims(Cs, Cb, ctypes.byref(RP), ctypes.byref(CP)), "wgrad_dims")

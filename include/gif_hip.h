@@ -146,7 +146,8 @@ int gif_conv3x3_winograd_f32(const float* x, const float* U, float* y, float* V,
  * above): x [B,H,W,Cb] = conv input, gy [B,H,W,Cs] = output gradient, optional per-sample scales as in
  * gif_conv2d_wgrad_f32.  V / Mg = scratch of gif_winograd_workspace_floats(B,H,W,Cb / Cs) floats; ws = per-split partial
  * sums [nsplit][16][RP][CP] with (RP, CP) = gif_conv2d_wgrad_dims(pad32(Cs), pad32(Cb)); nsplit from
- * gif_conv3x3_winograd_wgrad_splits.  gif_winograd_unpack_wgrad_f32 reduces the splits, applies the output transform and
+ * gif_conv3x3_winograd_wgrad_splits.  x may be NULL when V still holds the transform of the same x (and the same
+ * big_scale) from gif_conv3x3_winograd_f32's forward pass.  gif_winograd_unpack_wgrad_f32 reduces the splits, applies the output transform and
  * scatters scale * dW into the strided canonical [R=Cs.., C=Cb.., 3, 3] view (deterministic: no atomics). */
 int gif_conv3x3_winograd_wgrad_splits(int B, int H, int W, int Cs, int Cb);
 int gif_conv3x3_winograd_wgrad_f32(const float* x, const float* gy, float* V, float* Mg, float* ws,

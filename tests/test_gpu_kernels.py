@@ -232,6 +232,10 @@ def test_winograd_wgrad(case):
     assert_close(got2, 0.25 * ref2, 5e-5, f"winograd modulated wgrad {case}")
     again = ops.conv3x3_winograd_wgrad(dev(gy), dev(x), Co, Ci, 0.25, small_scale=dp, big_scale=sp)
     assert torch.equal(again, got2), "split-K reduction must be deterministic"
+    # the forward pass's transformed input (same x, same modulation) can stand in for the input transform
+    _, v = ops.conv3x3_winograd(dev(x), w.detach().cuda(), True, pad4(Co), keep_v=True, in_scale=sp)
+    reuse = ops.conv3x3_winograd_wgrad(dev(gy), dev(x), Co, Ci, 0.25, small_scale=dp, big_scale=sp, big_v=v)
+    assert torch.equal(reuse, got2), "wgrad from the kept V must equal the recomputed one bit for bit"
 
 
 def test_winograd_scales_and_epilogue(monkeypatch):
