@@ -153,6 +153,89 @@ __global__ void __launch_bounds__(256) blur4x4_tiled_kernel(const UpfirdnParams 
     }
 }
 
+// Sliding-window variant for tall images: one lane walks down TYL output rows of a TX-wide column strip (4 channels),
+// loading every input row of the strip ONCE (TX+3 float4) and scattering it into a ring of 4 partially accumulated
+// output rows: (TYL+3)(TX+3)/(TYL*TX) = 2.1 loads per output instead of 4.4, same tap order => bit-identical sums.
+template <int TYL, int TX>
+__global__ void __launch_bounds__(256) blur4x4_rows_kernel(const UpfirdnParams p) {
+    __shared__ float kfs[16];
+    if (threadIdx.x < 16) {
+        int a = threadIdx.x >> 2, b = threadIdx.x & 3;
+        kfs[threadIdx.x] = p.k[p.flip ? (3 - a) * 4 + (3 - b) : a * 4 + b];
+    }
+    __syncthreads();
+    float kf[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) kf[i] = kfs[i];
+    const int C4 = p.C >> 2;
+    const int nyb = (p.Ho + TYL - 1) / TYL, nxb = (p.Wo + TX - 1) / TX;
+    const long total = (long)p.B * nyb * nxb * C4;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 bias4 = zero4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        int c4 = (int)(idx % C4);
+        long t = idx / C4;
+        int xb = (int)(t % nxb);
+        t /= nxb;
+        int yb = (int)(t % nyb);
+        int b = (int)(t / nyb);
+        const int oy0 = yb * TYL, ox0 = xb * TX;
+        const float* xb_ = p.x + (size_t)b * p.Hi * p.Wi * p.C + c4 * 4;
+        if (p.bias) bias4 = *reinterpret_cast<const float4*>(p.bias + c4 * 4);
+        float4 acc[4][TX];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < TX; ++j) acc[i][j] = zero4;
+        static_assert((TYL + 3 + 3) / 4 * 4 >= TYL + 3, "row loop covers the halo");
+        for (int r4 = 0; r4 < TYL + 3; r4 += 4) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = r4 + q;  // input row oy0 + r - pady0 feeds output rows oy0 + r - a, a = 0..3
+                const int iy = oy0 + r - p.pady0;
+                const bool rok = r < TYL + 3 && (unsigned)iy < (unsigned)p.Hi;
+                float4 v[TX + 3];
+#pragma unroll
+                for (int c = 0; c < TX + 3; ++c) {
+                    const int ix = ox0 + c - p.padx0;
+                    const bool ok = rok && (unsigned)ix < (unsigned)p.Wi;
+                    v[c] = *reinterpret_cast<const float4*>(xb_ + (ok ? ((size_t)iy * p.Wi + ix) * p.C : 0));
+                    if (!ok) v[c] = zero4;
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const int slot = (q - a) & 3;  // ring slot of output row r - a
+#pragma unroll
+                    for (int tx = 0; tx < TX; ++tx)
+#pragma unroll
+                        for (int bb = 0; bb < 4; ++bb) acc[slot][tx] = f4fma(kf[a * 4 + bb], v[tx + bb], acc[slot][tx]);
+                }
+                // output row r - 3 is complete
+                const int done = (q - 3) & 3;
+                const int oy = oy0 + r - 3;
+                if (r >= 3 && r - 3 < TYL && oy < p.Ho) {
+#pragma unroll
+                    for (int tx = 0; tx < TX; ++tx) {
+                        const int ox = ox0 + tx;
+                        if (ox >= p.Wo) continue;
+                        size_t o = (((size_t)b * p.Ho + oy) * p.Wo + ox) * p.C + c4 * 4;
+                        float4 vv = acc[done][tx];
+                        if (p.residual) vv = f4add(vv, *reinterpret_cast<const float4*>(p.residual + o));
+                        if (p.bias) vv = f4add(vv, bias4);
+                        if (p.act) {
+                            vv.x = lrelu(vv.x, p.slope, p.gain); vv.y = lrelu(vv.y, p.slope, p.gain);
+                            vv.z = lrelu(vv.z, p.slope, p.gain); vv.w = lrelu(vv.w, p.slope, p.gain);
+                        }
+                        *reinterpret_cast<float4*>(p.y + o) = vv;
+                    }
+                }
+#pragma unroll
+                for (int tx = 0; tx < TX; ++tx) acc[done][tx] = zero4;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // bias + leaky ReLU (FusedLeakyReLU.forward, stylegan2_common_layers.py:32-39)
 // ---------------------------------------------------------------------------------------------------------
@@ -441,6 +524,12 @@ int gif_upfirdn2d_f32(const float* x, const float* k, float* y, int B, int Hi, i
     p.gain = e ? e->gain : 1.f;
     p.B = B; p.Hi = Hi; p.Wi = Wi; p.C = C; p.Ho = Ho; p.Wo = Wo; p.up = up; p.down = down;
     p.padx0 = padx0; p.pady0 = pady0; p.KH = KH; p.KW = KW; p.flip = flip;
+    if (up == 1 && down == 1 && KH == 4 && KW == 4 && (long)B * ((Ho + 15) / 16) * ((Wo + 3) / 4) * (C / 4) >= 256L * 256 * 2) {
+        // enough columns strips to fill the chip with 16-row sliding windows
+        long total = (long)B * ((Ho + 15) / 16) * ((Wo + 3) / 4) * (C / 4);
+        blur4x4_rows_kernel<16, 4><<<ew_grid(total), 256, 0, gif::as_stream(stream)>>>(p);
+        return gif::check_launch("upfirdn2d(blur rows)");
+    }
     if (up == 1 && down == 1 && KH == 4 && KW == 4) {
         constexpr int TY = 2, TX = 4;
         long total = (long)B * ((Ho + TY - 1) / TY) * ((Wo + TX - 1) / TX) * (C / 4);
