@@ -104,7 +104,10 @@ def roofline_objects(ops, steps):
     `achieved` is what the MFMA pipe actually executed per second (<= peak); for the Winograd GEMMs the ALGORITHMIC
     (direct-convolution) rate, which is 36/16 of that, is reported next to it as `algorithmic_achieved`."""
     fams = {
-        0: ("conv_gather_mfma_glds (direct fwd / dgrad / transposed conv, fp32 MFMA)", 1.0, "conv_gather_mfma_glds"),
+        0: ("conv_gather_mfma_glds (direct fwd / dgrad / stride-2 / transposed conv on the LDS-DMA kernel, Cin >= 32)", 1.0,
+            "conv_gather_mfma_glds"),
+        5: ("conv_gather_mfma (register-staged kernel of the Cin < 32 layers: condition-noise convs, 9-channel D input)", 1.0,
+            None),
         1: ("conv_wgrad_mfma (direct weight gradient)", 1.0, None),
         2: ("wino_gemm_mfma (Winograd F(2x2,3x3) fwd / dgrad GEMM + fused output transform and epilogue)",
             WINOGRAD_EXECUTED, "wino_gemm_mfma"),
@@ -130,7 +133,8 @@ def roofline_objects(ops, steps):
     if objs:
         dom = max(objs, key=lambda f: objs[f]["gpu_ms_per_step"])
         out["roofline"] = objs.pop(dom)
-        names = {0: "roofline_conv_direct", 1: "roofline_wgrad_direct", 2: "roofline_conv_winograd", 3: "roofline_wgrad_winograd"}
+        names = {0: "roofline_conv_direct", 1: "roofline_wgrad_direct", 2: "roofline_conv_winograd", 3: "roofline_wgrad_winograd",
+                 5: "roofline_conv_direct_small_cin"}
         for fam, o in objs.items():
             out[names[fam]] = o
     ms, by, n = ops.prof_read(4)
@@ -197,7 +201,7 @@ def main():
 
     data = [batch() for _ in range(min(args.steps, 4))]  # synthetic batches resident in HBM before the timed region
     if not args.no_prof:
-        for fam in range(5):
+        for fam in range(6):
             ops.prof_read(fam)
         ops.prof_enable(True)
     sync()

@@ -32,9 +32,10 @@ inline hipStream_t as_stream(gif_stream_t s) { return reinterpret_cast<hipStream
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- kernel profiling (runtime.hip): HIP events around launches, grouped in families ----
-// 0 direct conv fwd/dgrad (flops), 1 direct wgrad (flops), 2 Winograd GEMM fwd/dgrad (ALGORITHMIC direct-conv flops; the
-// kernel executes 16/36 of them), 3 Winograd wgrad GEMM (same convention), 4 Winograd transforms (HBM bytes)
-#define GIF_PROF_FAMILIES 5
+// 0 direct conv fwd/dgrad on the LDS-DMA kernel (Cin >= 32; flops), 1 direct wgrad (flops), 2 Winograd GEMM fwd/dgrad
+// (ALGORITHMIC direct-conv flops; the kernel executes 16/36 of them), 3 Winograd wgrad GEMM (same convention),
+// 4 Winograd transforms (HBM bytes), 5 direct conv fwd/dgrad on the register-staged kernel (Cin < 32; flops)
+#define GIF_PROF_FAMILIES 6
 struct ProfScope {
     int family;
     hipStream_t stream;

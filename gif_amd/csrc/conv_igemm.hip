@@ -648,7 +648,7 @@ int gif_conv2d_fwd_f32(const float* big, const float* wp, float* small, const gi
     gif_conv2d_pack_dims(p.Co, p.Ci, &p.RP, &p.CP);
     p.M = p.B * p.Hp * p.Wp;
     double flops = 2.0 * p.M * (double)p.Co * p.Ci * p.ntaps;
-    gif::ProfScope prof(0, flops, gif::as_stream(stream), p.M, p.Co, p.Ci, p.ntaps * 10 + g->stride);
+    gif::ProfScope prof(p.Ci >= 32 ? 0 : 5, flops, gif::as_stream(stream), p.M, p.Co, p.Ci, p.ntaps * 10 + g->stride);
     if (int rc = launch(p, gif::as_stream(stream))) return rc;
     return gif::check_launch("conv2d_fwd");
 }
@@ -697,7 +697,7 @@ int gif_conv2d_bwd_data_f32(const float* small, const float* wp, float* big, con
     // algorithmic FLOPs of a transposed conv: every small-side pixel scatters through every tap
     double flops = 2.0 * g->B * (double)g->Hs * g->Ws * g->KH * g->KW * (double)g->Cs * g->Cb;
     {
-        gif::ProfScope prof(0, flops, s, g->B * g->Hb * g->Wb, base.Co, base.Ci, -(g->KH * g->KW * 10 + g->stride));
+        gif::ProfScope prof(base.Ci >= 32 ? 0 : 5, flops, s, g->B * g->Hb * g->Wb, base.Co, base.Ci, -(g->KH * g->KW * 10 + g->stride));
         for (int i = 0; i < nph; ++i)
             if (int rc = launch(ph[i], s)) return rc;
     }

@@ -220,7 +220,8 @@ int gif_sqnorm_per_sample_f32(const float* g, float* out, int B, int64_t n, gif_
  * Kernel timing for bench.py's roofline line: when enabled, every conv launch is bracketed by HIP
  * events on its own stream; gif_prof_read() synchronises those events and returns accumulated
  * milliseconds / work / launch count per kernel family:
- *   0 direct conv fwd+dgrad (FLOPs)          1 direct wgrad (FLOPs)
+ *   0 direct conv fwd+dgrad, LDS-DMA kernel (Cin >= 32; FLOPs)   5 same, register-staged kernel (Cin < 32)
+ *   1 direct wgrad (FLOPs)
  *   2 Winograd GEMM fwd+dgrad                3 Winograd wgrad GEMM
  *     (2, 3: ALGORITHMIC direct-convolution FLOPs; the kernels execute 16/36 of them)
  *   4 Winograd input / gradient transforms (HBM bytes: tensor read once + transformed planes written once)
