@@ -231,7 +231,8 @@ def main():
             "config": {"workload": f"GIF run-29 G+D training iteration, {args.res}x{args.res}, batch {B}/GPU, "
                                    f"R1 every {args.r1_every}th step, fp32 MFMA (BASELINE configs[1]/[3] shape)",
                        "global_batch": world * B, "resolution": args.res, "parallelism": f"dp{world}",
-                       "algorithmic_tflop_per_image": fl_img / 1e12},
+                       "algorithmic_tflop_per_image": fl_img / 1e12,
+                       "peak_hbm_allocated_gb": torch.cuda.max_memory_allocated() / 2 ** 30},
             "step_mfma_roofline": {"achieved": step_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                    "frac": step_tflops / PEAK_F32_MFMA_TFLOPS,
                                    "note": "whole step (incl. HBM-bound kernels, optimiser, host) vs fp32 MFMA peak, per GPU"},
