@@ -180,14 +180,12 @@ def main():
     G, G_ema, D = G.to(dev), G_ema.to(dev), D.to(dev)
     trainer = GifTrainer(G, D, G_ema, step=res_step, alpha=1.0, r1_every=args.r1_every)
 
-    gen = torch.Generator(device=dev).manual_seed(1234 + rank)  # every rank draws its own synthetic batch
+    from gif_amd.data import SyntheticBatches
     B = args.batch
+    batches = SyntheticBatches(B, args.res, args.vocab, dev, seed=1234, rank=rank)  # every rank draws its own data
 
     def batch():
-        real = torch.rand(B, 3, args.res, args.res, device=dev, generator=gen) * 2 - 1
-        cond = torch.rand(B, 6, args.res, args.res, device=dev, generator=gen) * 2 - 1
-        idx = torch.randint(0, args.vocab, (B,), device=dev, generator=gen)
-        return real, cond, idx
+        return next(batches)
 
     it = 0
     for _ in range(args.warmup):

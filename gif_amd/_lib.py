@@ -49,6 +49,8 @@ PROTOTYPES = {
     "gif_conv3x3_winograd_wgrad_splits": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "gif_conv3x3_winograd_wgrad_f32": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "gif_winograd_unpack_wgrad_f32": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_float, P]),
+    "gif_resize_f32": (c_int, [P, P, c_i64, c_int, c_int, c_int, c_int, c_int, P]),
+    "gif_resize_bwd_f32": (c_int, [P, P, c_i64, c_int, c_int, c_int, c_int, c_int, P]),
     "gif_upfirdn2d_f32": (c_int, [P, P, P] + [c_int] * 13 + [EP, P]),
     "gif_bias_act_f32": (c_int, [P, P, P, P, c_i64, c_int, c_float, c_float, P]),
     "gif_colsum_partial_floats": (c_i64, [c_i64, c_int]),

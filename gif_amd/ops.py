@@ -380,6 +380,27 @@ def rasterize(face_vertices, depth, tri, out3, h, w, face_colors=None):
     _lib.check(rc, "rasterize")
 
 
+def resize(x, out_hw, mode: str, backward_to=None):
+    """NCHW fp32 resize (bilinear / bicubic, align_corners=False).  backward_to=(Hi, Wi): apply the adjoint to x instead."""
+    lib = _lib.load()
+    if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4:
+        raise _lib.GifHipError("resize: need a 4-D fp32 device tensor (no CPU fallback)")
+    if mode not in ("bilinear", "bicubic"):
+        raise _lib.GifHipError(f"resize: mode {mode!r} not supported (bilinear | bicubic)")
+    x = x.contiguous()
+    B, C, H, W = x.shape
+    m = 0 if mode == "bilinear" else 1
+    if backward_to is None:
+        Ho, Wo = out_hw
+        y = torch.empty((B, C, Ho, Wo), device=x.device, dtype=torch.float32)
+        _lib.check(lib.gif_resize_f32(x.data_ptr(), y.data_ptr(), B * C, H, W, Ho, Wo, m, _stream()), "resize")
+        return y
+    Hi, Wi = backward_to
+    gx = torch.empty((B, C, Hi, Wi), device=x.device, dtype=torch.float32)
+    _lib.check(lib.gif_resize_bwd_f32(x.data_ptr(), gx.data_ptr(), B * C, Hi, Wi, H, W, m, _stream()), "resize_bwd")
+    return gx
+
+
 def prof_enable(on: bool):
     _lib.load().gif_prof_enable(1 if on else 0)
 

@@ -217,6 +217,17 @@ int gif_mbstd_bwd_f32(const float* x, const float* gy, float* gx, int B, int H, 
 int gif_sqnorm_per_sample_f32(const float* g, float* out, int B, int64_t n, gif_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Image resize — replaces fast_image_reshape() dataset_loaders.py:26-34 (F.interpolate, mode 'bilinear' or 'bicubic',
+ * align_corners=False, no antialias) of the input / visualisation pipeline (generate_random_samples.py:190-191).
+ * x [planes,Hi,Wi] -> y [planes,Ho,Wo] with planes = B*C of an NCHW fp32 tensor; mode 0 bilinear, 1 bicubic (A=-0.75,
+ * border-clamped taps).  The backward scatters the same weights with fp32 atomics into gx (zeroed inside).
+ * ---------------------------------------------------------------------------------------------- */
+int gif_resize_f32(const float* x, float* y, int64_t planes, int Hi, int Wi, int Ho, int Wo, int mode,
+                   gif_stream_t stream);
+int gif_resize_bwd_f32(const float* gy, float* gx, int64_t planes, int Hi, int Wi, int Ho, int Wo, int mode,
+                       gif_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Kernel timing for bench.py's roofline line: when enabled, every conv launch is bracketed by HIP
  * events on its own stream; gif_prof_read() synchronises those events and returns accumulated
  * milliseconds / work / launch count per kernel family:

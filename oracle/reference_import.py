@@ -71,3 +71,22 @@ def reference_modules():
     finally:
         os.chdir(cwd)
     return stg2_generator.StyledGenerator, stg2_discriminator.Discriminator, stylegan2_common_layers
+
+
+def reference_fast_image_reshape():
+    """The real dataset_loaders.fast_image_reshape (dataset_loaders.py:26-34).  dataset_loaders imports torchvision and lmdb
+    at module level (absent here, unused by this function): two more empty stub modules."""
+    install_stubs()
+    for name in ("torchvision", "torchvision.transforms", "torchvision.transforms.functional", "lmdb"):
+        if name not in sys.modules:
+            _stub(name)
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    sys.modules["torchvision.transforms"].functional = sys.modules["torchvision.transforms.functional"]
+    cwd = os.getcwd()
+    try:
+        os.chdir(REF_ROOT)
+        with contextlib.redirect_stdout(io.StringIO()):
+            import dataset_loaders
+    finally:
+        os.chdir(cwd)
+    return dataset_loaders.fast_image_reshape

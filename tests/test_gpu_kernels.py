@@ -511,3 +511,52 @@ def test_texture_map_vs_reference_golden():
     assert np.abs(gi - g["grad_img"]).max() <= 2e-4 * np.abs(g["grad_img"]).max(), "gradient w.r.t. the source image"
     with pytest.raises(Exception, match="FLAME"):
         fts(img, torch.zeros(2, 159, device="cuda"))
+
+
+# ------------------------------------------------------------------------------------------------ input pipeline (8(f).3)
+def test_fast_image_reshape_vs_reference_goldens_and_oracle():
+    """HIP resize behind the reference's fast_image_reshape signature: goldens of the real reference, the oracle on larger
+    seeded inputs, first- and second-order gradients vs ATen on the host."""
+    from golden.make_resize_golden import CASES
+    from gif_amd.data import fast_image_reshape
+    from oracle import resize_ref as R
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "resize_golden.npz"))
+    for name, B, C, H, W, ho, wo, mode, clamp in CASES:
+        got = fast_image_reshape(torch.from_numpy(g[name + "_x"]).cuda(), ho, wo, non_diff_allowed=clamp, mode=mode)
+        assert got.shape == (B, C, wo, ho)
+        assert_close(got, torch.from_numpy(g[name + "_y"]), 2e-6, f"resize golden {name}")
+    x = torch.rand(4, 3, 512, 512, generator=torch.Generator().manual_seed(7)) * 2 - 1
+    for mode, size in (("bicubic", 256), ("bilinear", 256), ("bicubic", 300)):
+        ref = R.fast_image_reshape(x, size, size, mode=mode)
+        assert_close(fast_image_reshape(x.cuda(), size, size, mode=mode), ref, 2e-6, f"resize {mode} 512->{size}")
+    xs = torch.rand(2, 3, 12, 9, generator=torch.Generator().manual_seed(8))
+    wgt = torch.randn(2, 3, 20, 15, generator=torch.Generator().manual_seed(9))
+    for mode in ("bicubic", "bilinear"):
+        xr = xs.clone().requires_grad_(True)
+        (F.interpolate(xr, size=(20, 15), mode=mode) * wgt).sum().backward()
+        xg = xs.cuda().requires_grad_(True)
+        y = fast_image_reshape(xg, 15, 20, mode=mode)  # (height_out, width_out) -> rows = width_out, like the reference
+        (gx,) = torch.autograd.grad((y * wgt.cuda()).sum(), xg, create_graph=True)
+        assert_close(gx, xr.grad, 5e-6, f"resize backward {mode}")
+        # the map is linear: d/d(wgt-like cotangent) of <gx, v> is resize(v)
+        v = torch.randn_like(xs).cuda()
+        yv = fast_image_reshape(v, 15, 20, mode=mode)
+        gy = torch.ones_like(y, requires_grad=True)
+        (gx2,) = torch.autograd.grad(fast_image_reshape(xg, 15, 20, mode=mode), xg, gy, create_graph=True)
+        (ggy,) = torch.autograd.grad((gx2 * v).sum(), gy)
+        assert_close(ggy, yv, 5e-6, f"resize double backward {mode}")
+    with pytest.raises(Exception):
+        fast_image_reshape(xs, 4, 4)  # CPU tensor: no fallback
+
+
+def test_synthetic_batches_are_device_resident_and_rank_distinct():
+    from gif_amd.data import SyntheticBatches
+    a = SyntheticBatches(4, 64, 1000, torch.device("cuda"), rank=0)
+    b = SyntheticBatches(4, 64, 1000, torch.device("cuda"), rank=1)
+    real, cond, idx = next(a)
+    assert real.shape == (4, 3, 64, 64) and cond.shape == (4, 6, 64, 64) and idx.shape == (4,) and idx.dtype == torch.int64
+    assert real.is_cuda and cond.is_cuda and idx.is_cuda
+    assert real.min() >= -1 and real.max() <= 1 and int(idx.max()) < 1000
+    assert not torch.equal(real, next(b)[0]), "ranks must draw different data"
+    a2 = SyntheticBatches(4, 64, 1000, torch.device("cuda"), rank=0)
+    assert torch.equal(real, next(a2)[0]), "same seed and rank: reproducible"
