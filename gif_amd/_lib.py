@@ -49,6 +49,9 @@ PROTOTYPES = {
     "gif_conv3x3_winograd_wgrad_splits": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "gif_conv3x3_winograd_wgrad_f32": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "gif_winograd_unpack_wgrad_f32": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_float, P]),
+    "gif_texture_pair_loss_partials": (c_int, [c_i64]),
+    "gif_texture_pair_loss_f32": (c_int, [P, P, P, P, P, P, P, c_int, c_i64, P]),
+    "gif_texture_pair_loss_bwd_f32": (c_int, [P, P, P, P, P, P, P, c_int, c_i64, P]),
     "gif_resize_f32": (c_int, [P, P, c_i64, c_int, c_int, c_int, c_int, c_int, P]),
     "gif_resize_bwd_f32": (c_int, [P, P, c_i64, c_int, c_int, c_int, c_int, c_int, P]),
     "gif_upfirdn2d_f32": (c_int, [P, P, P] + [c_int] * 13 + [EP, P]),

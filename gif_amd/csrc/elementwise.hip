@@ -651,3 +651,101 @@ int gif_sqnorm_per_sample_f32(const float* g, float* out, int B, int64_t n, gif_
     return gif::check_launch("sqnorm");
 }
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// texture-interpolation loss core (InterpolatedTextureLoss.pairwise_texture_loss, loss_functions/losses.py:147-160, with
+// the common-visibility masking of its call site :171-174 folded in):
+//   loss = mean_{c,h,w} sigmoid(((a - b) * ma * mb)^2) * f          a, b [C,H,W]; ma, mb [H,W] u8 or null; f [H,W]
+// Two-stage deterministic reduction; the backward is one pointwise pass (gb = -ga).
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ void __launch_bounds__(256) tex_pair_loss_stage1(const float* __restrict__ a, const float* __restrict__ b,
+                                                            const uint8_t* __restrict__ ma, const uint8_t* __restrict__ mb,
+                                                            const float* __restrict__ f, float* __restrict__ partial,
+                                                            long n, long HW) {
+    __shared__ float red[256];
+    float acc = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long hw = i % HW;
+        float d = a[i] - b[i];
+        if (ma && !ma[hw]) d = 0.f;
+        if (mb && !mb[hw]) d = 0.f;
+        acc += sigmoidf_(d * d) * f[hw];
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ void __launch_bounds__(256) tex_pair_loss_stage2(const float* __restrict__ partial, float* __restrict__ loss,
+                                                            int nblk, float inv_n) {
+    __shared__ float red[256];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += 256) acc += partial[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss = red[0] * inv_n;
+}
+
+__global__ void __launch_bounds__(256) tex_pair_loss_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                                const uint8_t* __restrict__ ma, const uint8_t* __restrict__ mb,
+                                                                const float* __restrict__ f, const float* __restrict__ gloss,
+                                                                float* __restrict__ ga, long n, long HW, float inv_n) {
+    const float g = *gloss * inv_n;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long hw = i % HW;
+        float d = a[i] - b[i];
+        bool vis = true;
+        if (ma && !ma[hw]) vis = false;
+        if (mb && !mb[hw]) vis = false;
+        float out = 0.f;
+        if (vis) {
+            const float s = sigmoidf_(d * d);
+            out = g * f[hw] * s * (1.f - s) * 2.f * d;
+        }
+        ga[i] = out;
+    }
+}
+
+inline int tex_pair_blocks(long n) {
+    long b = (n + 255) / 256;
+    return (int)(b > 1024 ? 1024 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+extern "C" {
+
+int gif_texture_pair_loss_partials(int64_t n) { return tex_pair_blocks(n); }
+
+int gif_texture_pair_loss_f32(const float* a, const float* b, const uint8_t* ma, const uint8_t* mb, const float* f,
+                              float* partial, float* loss, int C, int64_t HW, gif_stream_t stream) {
+    GIF_REQUIRE(a && b && f && partial && loss && C > 0 && HW > 0, "texture_pair_loss: bad arguments");
+    const long n = (long)C * HW;
+    const int nblk = tex_pair_blocks(n);
+    hipStream_t s = gif::as_stream(stream);
+    tex_pair_loss_stage1<<<nblk, 256, 0, s>>>(a, b, ma, mb, f, partial, n, HW);
+    tex_pair_loss_stage2<<<1, 256, 0, s>>>(partial, loss, nblk, 1.0f / (float)n);
+    return gif::check_launch("texture_pair_loss");
+}
+
+int gif_texture_pair_loss_bwd_f32(const float* a, const float* b, const uint8_t* ma, const uint8_t* mb, const float* f,
+                                  const float* gloss, float* ga, int C, int64_t HW, gif_stream_t stream) {
+    GIF_REQUIRE(a && b && f && gloss && ga && C > 0 && HW > 0, "texture_pair_loss_bwd: bad arguments");
+    const long n = (long)C * HW;
+    tex_pair_loss_bwd_kernel<<<tex_pair_blocks(n), 256, 0, gif::as_stream(stream)>>>(a, b, ma, mb, f, gloss, ga, n, HW,
+                                                                                      1.0f / (float)n);
+    return gif::check_launch("texture_pair_loss_bwd");
+}
+}

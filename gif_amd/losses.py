@@ -85,3 +85,79 @@ class PathLengthRegularizor:
         mean = self.pl_moving_mean + self.pl_decay * (pl_lengths.mean().detach() - self.pl_moving_mean)
         self.pl_moving_mean = mean
         return (pl_lengths - mean).pow(2).mean()
+
+
+# --------------------------------------------------------------------------------------------------------
+# texture-interpolation loss (loss_functions/losses.py:127-243) — the FLAME-free core
+# --------------------------------------------------------------------------------------------------------
+class _TexPairLossFn(Function):
+    """mean(sigmoid(((a - b) * ma * mb)^2) * f): one fused HIP reduction + one pointwise backward (once differentiable)."""
+
+    @staticmethod
+    def forward(ctx, a, b, ma, mb, f):
+        ctx.save_for_backward(a, b, f)
+        ctx.masks = (ma, mb)
+        return ops.texture_pair_loss(a, b, ma, mb, f)
+
+    @staticmethod
+    def backward(ctx, gloss):
+        a, b, f = ctx.saved_tensors
+        ga = ops.texture_pair_loss(a, b, ctx.masks[0], ctx.masks[1], f, gloss=gloss)
+        return (ga if ctx.needs_input_grad[0] else None), (-ga if ctx.needs_input_grad[1] else None), None, None, None
+
+
+class InterpolatedTextureLoss:
+    """Mirror of InterpolatedTextureLoss (loss_functions/losses.py:127-243): generated images of DIFFERENT expressions/poses
+    but the same identity must agree in UV texture space wherever both see the surface.
+
+    The reference constructor loads the licensed FLAME texture space, a face-region mask image and builds the FLAME
+    renderer (`OverLayViz`) — none of which exist in this repository.  Here they are injected:
+      face_region_only_mask  [1,1,h,w] float in [0,1]  (reference: cnst.face_region_mask_file / 255)
+      flm_tex_dec            gif_amd.texture_space.FlameTextureSpace (or any callable images, flame_params -> textures, masks)
+      render_condition       callable flame_batch -> (rend_flm, norma_map_img) in [-1,1]  (reference: OverLayViz + clamp*2-1)
+    `pairwise_texture_loss` and `texture_pairs_loss` (the loop of tex_sp_intrp_loss) run on the fused HIP kernel."""
+
+    def __init__(self, max_images_in_batch, face_region_only_mask, flm_tex_dec=None, render_condition=None):
+        self.face_region_only_mask = face_region_only_mask.to(torch.float32)
+        self.flm_tex_dec = flm_tex_dec
+        self.render_condition = render_condition
+        self.max_num = max_images_in_batch - 1
+        self.pairs = np.array([(i, j) for i in range(self.max_num) for j in range(i + 1, self.max_num)])
+
+    def _face_mask(self, like):
+        from .data import fast_image_reshape
+        if self.face_region_only_mask.device != like.device:
+            self.face_region_only_mask = self.face_region_only_mask.to(like.device)
+        if self.face_region_only_mask.shape[-1] != like.shape[-1]:  # reference :151-152 (bicubic, (shape[1], shape[2]))
+            return fast_image_reshape(self.face_region_only_mask, like.shape[1], like.shape[2])
+        return self.face_region_only_mask
+
+    def pairwise_texture_loss(self, tx1, tx2):
+        """tx1, tx2 [3,T,T] (already multiplied by the common visibility mask, as at the reference's call site)."""
+        return _TexPairLossFn.apply(tx1, tx2, None, None, self._face_mask(tx1)[0])
+
+    def texture_pairs_loss(self, textures, tx_masks, random_pairs=None):
+        """The loop of tex_sp_intrp_loss (:166-176) on textures [N,3,T,T] and visibility masks [N,1,T,T]: the masking
+        `textures[i] * (mask_i * mask_j)` is folded into the kernel.  random_pairs=None draws them like the reference
+        (np.random.choice(len(pairs), max_num, replace=False))."""
+        if random_pairs is None:
+            random_pairs = self.pairs[np.random.choice(len(self.pairs), self.max_num, replace=False)]
+        f = self._face_mask(textures[0])[0]
+        loss = 0
+        for i, j in random_pairs:
+            loss = loss + _TexPairLossFn.apply(textures[i], textures[j], tx_masks[i], tx_masks[j], f)
+        return 16 * loss / len(random_pairs)
+
+    def tex_sp_intrp_loss(self, flame_batch, generator, step, alpha, max_ids, normal_maps_as_cond=True,
+                          use_posed_constant_input=False, rendered_flame_as_condition=True):
+        if self.flm_tex_dec is None or self.render_condition is None:
+            raise ops._lib.GifHipError("tex_sp_intrp_loss needs a FLAME texture decoder and a condition renderer (FLAME assets "
+                                       "are not part of this repository): pass flm_tex_dec= and render_condition=, or call "
+                                       "texture_pairs_loss(textures, tx_masks) directly")
+        flame_batch = flame_batch[:self.max_num]
+        rend_flm, norma_map_img = self.render_condition(flame_batch)
+        gen_in = torch.cat((rend_flm, norma_map_img), dim=1)
+        fixed_identities = torch.ones(flame_batch.shape[0], dtype=torch.long, device=gen_in.device) * np.random.randint(0, max_ids)
+        generated_image = generator(gen_in, pose=None, step=step, alpha=alpha, input_indices=fixed_identities)[-1]
+        textures, tx_masks = self.flm_tex_dec(generated_image, flame_batch)
+        return self.texture_pairs_loss(textures, tx_masks)

@@ -380,6 +380,40 @@ def rasterize(face_vertices, depth, tri, out3, h, w, face_colors=None):
     _lib.check(rc, "rasterize")
 
 
+def _mask_u8(m, hw):
+    if m is None:
+        return None
+    m = m.reshape(-1)
+    if m.numel() != hw:
+        raise _lib.GifHipError(f"texture_pair_loss: visibility mask has {m.numel()} elements, expected {hw}")
+    return (m != 0).to(torch.uint8).contiguous()
+
+
+def texture_pair_loss(a, b, ma, mb, f, gloss=None):
+    """mean(sigmoid(((a-b)*ma*mb)^2) * f) over [C,H,W]; with gloss (device scalar) returns d/da instead (d/db = -d/da)."""
+    lib = _lib.load()
+    if not (a.is_cuda and b.is_cuda and f.is_cuda) or a.dtype != torch.float32 or a.dim() != 3 or a.shape != b.shape:
+        raise _lib.GifHipError("texture_pair_loss: need two fp32 device textures [C,H,W] of the same shape (no CPU fallback)")
+    a, b = a.contiguous(), b.contiguous()
+    C, H, W = a.shape
+    HW = H * W
+    f = f.to(torch.float32).reshape(-1).contiguous()
+    if f.numel() != HW:
+        raise _lib.GifHipError(f"texture_pair_loss: face mask has {f.numel()} elements, expected {HW}")
+    ma, mb = _mask_u8(ma, HW), _mask_u8(mb, HW)
+    if gloss is None:
+        partial = torch.empty((lib.gif_texture_pair_loss_partials(C * HW),), device=a.device, dtype=torch.float32)
+        loss = torch.empty((), device=a.device, dtype=torch.float32)
+        _lib.check(lib.gif_texture_pair_loss_f32(a.data_ptr(), b.data_ptr(), _p(ma), _p(mb), f.data_ptr(), partial.data_ptr(),
+                                                 loss.data_ptr(), C, HW, _stream()), "texture_pair_loss")
+        return loss
+    ga = torch.empty_like(a)
+    gloss = gloss.to(torch.float32).contiguous()
+    _lib.check(lib.gif_texture_pair_loss_bwd_f32(a.data_ptr(), b.data_ptr(), _p(ma), _p(mb), f.data_ptr(), gloss.data_ptr(),
+                                                 ga.data_ptr(), C, HW, _stream()), "texture_pair_loss_bwd")
+    return ga
+
+
 def resize(x, out_hw, mode: str, backward_to=None):
     """NCHW fp32 resize (bilinear / bicubic, align_corners=False).  backward_to=(Hi, Wi): apply the adjoint to x instead."""
     lib = _lib.load()

@@ -217,6 +217,20 @@ int gif_mbstd_bwd_f32(const float* x, const float* gy, float* gx, int B, int H, 
 int gif_sqnorm_per_sample_f32(const float* g, float* out, int B, int64_t n, gif_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Texture-interpolation loss core — replaces InterpolatedTextureLoss.pairwise_texture_loss (loss_functions/losses.py:
+ * 147-160) together with the common-visibility masking of its call site (:171-174):
+ *   loss = mean_{c,h,w} sigmoid(((a - b) * ma * mb)^2) * f
+ * a, b [C,H,W] fp32 textures; ma, mb [H,W] uint8 visibility masks or NULL; f [H,W] fp32 face-region mask;
+ * partial = gif_texture_pair_loss_partials(C*HW) floats of scratch; loss / gloss = DEVICE scalars (no host sync).
+ * The backward writes ga = d loss / d a * gloss (d loss / d b = -ga).  Deterministic two-stage reduction.
+ * ---------------------------------------------------------------------------------------------- */
+int gif_texture_pair_loss_partials(int64_t n);
+int gif_texture_pair_loss_f32(const float* a, const float* b, const uint8_t* ma, const uint8_t* mb, const float* f,
+                              float* partial, float* loss, int C, int64_t HW, gif_stream_t stream);
+int gif_texture_pair_loss_bwd_f32(const float* a, const float* b, const uint8_t* ma, const uint8_t* mb, const float* f,
+                                  const float* gloss, float* ga, int C, int64_t HW, gif_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Image resize — replaces fast_image_reshape() dataset_loaders.py:26-34 (F.interpolate, mode 'bilinear' or 'bicubic',
  * align_corners=False, no antialias) of the input / visualisation pipeline (generate_random_samples.py:190-191).
  * x [planes,Hi,Wi] -> y [planes,Ho,Wo] with planes = B*C of an NCHW fp32 tensor; mode 0 bilinear, 1 bicubic (A=-0.75,

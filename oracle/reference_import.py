@@ -90,3 +90,18 @@ def reference_fast_image_reshape():
     finally:
         os.chdir(cwd)
     return dataset_loaders.fast_image_reshape
+
+
+def reference_losses():
+    """The real loss_functions.losses module (grad_penalty_loss :87-99, PathLengthRegularizor :102-124,
+    InterpolatedTextureLoss.pairwise_texture_loss :147-160 ...).  Importable once dataset_loaders' absent dependencies
+    are stubbed; classes whose constructors read licensed FLAME files are used through their unbound methods only."""
+    reference_fast_image_reshape()
+    cwd = os.getcwd()
+    try:
+        os.chdir(REF_ROOT)
+        with contextlib.redirect_stdout(io.StringIO()):
+            from loss_functions import losses
+    finally:
+        os.chdir(cwd)
+    return losses

@@ -560,3 +560,33 @@ def test_synthetic_batches_are_device_resident_and_rank_distinct():
     assert not torch.equal(real, next(b)[0]), "ranks must draw different data"
     a2 = SyntheticBatches(4, 64, 1000, torch.device("cuda"), rank=0)
     assert torch.equal(real, next(a2)[0]), "same seed and rank: reproducible"
+
+
+def test_texture_interpolation_loss_vs_reference_goldens_and_oracle_grads():
+    """InterpolatedTextureLoss core on the fused HIP kernel: values produced by the REAL reference methods (pairwise loss and
+    the whole tex_sp_intrp_loss loop, same-size and resized face mask) and gradients vs the oracle's autograd."""
+    from gif_amd.losses import InterpolatedTextureLoss
+    from oracle import texture_loss_ref as R
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "texture_loss_golden.npz"))
+    tex_h, msk_h = torch.from_numpy(g["textures"]), torch.from_numpy(g["tx_masks"])
+    for tag in ("same", "big"):
+        face_h = torch.from_numpy(g[f"face_{tag}"])
+        crit = InterpolatedTextureLoss(6, face_h.cuda())
+        assert len(crit.pairs) == 10 and crit.max_num == 5
+        tex = tex_h.cuda().requires_grad_(True)
+        pw = crit.pairwise_texture_loss(tex[0], tex[1])
+        assert abs(pw.item() - float(g[f"pair01_{tag}"])) < 2e-6 * abs(float(g[f"pair01_{tag}"])) + 1e-7
+        pairs = g[f"loop_pairs_{tag}"]
+        loss = crit.texture_pairs_loss(tex, msk_h.cuda(), pairs)
+        assert abs(loss.item() - float(g[f"loop_{tag}"])) < 3e-6 * abs(float(g[f"loop_{tag}"]))
+        loss.backward()
+        tex_r = tex_h.clone().requires_grad_(True)
+        R.texture_pairs_loss(face_h, tex_r, msk_h, pairs).backward()
+        assert_close(tex.grad, tex_r.grad, 5e-6, f"texture loss grad ({tag})")
+        np.random.seed(3)
+        drawn = crit.texture_pairs_loss(tex.detach(), msk_h.cuda())  # pairs drawn like the reference
+        np.random.seed(3)
+        ref_pairs = crit.pairs[np.random.choice(len(crit.pairs), crit.max_num, replace=False)]
+        assert abs(drawn.item() - R.texture_pairs_loss(face_h, tex_h, msk_h, ref_pairs).item()) < 1e-5
+    with pytest.raises(Exception, match="FLAME"):
+        crit.tex_sp_intrp_loss(torch.zeros(6, 236, device="cuda"), None, 6, 1.0, 10)
