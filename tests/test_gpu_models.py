@@ -314,3 +314,29 @@ def test_goldens_with_every_eligible_layer_on_winograd(monkeypatch):
     assert (diff.norm() / ref.norm()).item() < 1e-3, "grad wrt image, relative L2"
     assert (diff > 3e-4 * ref.abs().max()).float().mean().item() < 0.01, "grad wrt image: too many outliers"
     assert diff.max().item() < 1e-2 * ref.abs().max().item()
+
+
+def test_path_length_regulariser_value_parity_with_reference_class(monkeypatch):
+    """a13: PathLengthRegularizor(reference_semantics=True) against penalties / moving means produced by the REAL reference
+    class on a stand-in generator, fed the very same random draws (tests/golden/make_pathlen_golden.py)."""
+    import numpy as np
+    from golden.make_pathlen_golden import standin_generator, standin_weights
+    from gif_amd import losses
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "pathlen_golden.npz"))
+    draws = [torch.from_numpy(g[f"draw{i}"]) for i in range(4)]
+    A, bias = standin_weights()
+    gen = standin_generator(A.cuda(), bias.cuda())
+
+    def replay(*a, **k):
+        t = draws.pop(0).to(k.get("device", "cpu"))
+        assert tuple(t.shape) == tuple(a[0] if isinstance(a[0], (tuple, list, torch.Size)) else a)
+        return t.requires_grad_(k.get("requires_grad", False))
+
+    monkeypatch.setattr(torch, "randn", replay)
+    reg = losses.PathLengthRegularizor(reference_semantics=True)
+    idx = torch.tensor([0, 1, 2], device="cuda")
+    for k in range(2):
+        pen = reg.path_length_reg(gen, 1, 1.0, idx)
+        assert abs(pen.item() - g["penalty"][k]) < 1e-5 * g["penalty"][k], (k, pen.item(), g["penalty"][k])
+        assert abs(float(reg.pl_moving_mean) - g["moving_mean"][k]) < 1e-5 * g["moving_mean"][k]
+        assert not pen.requires_grad, "reference semantics: no create_graph => the penalty carries no gradient"
