@@ -3,13 +3,15 @@
 // The same layers as conv_igemm.hip serves (ModulatedConv2d :343-347, EqualConv2d :176 of
 // model/stylegan2_common_layers.py, and their stride-1 data gradients), computed with 16 instead of 36 multiplies per
 // 2x2 output tile:   Y = A^T [ sum_ci (G g G^T) .* (B^T d B) ] A.
-// Three kernels:
-//   1. wino_input_transform : x [B,H,W,C] (times the per-sample modulation s[b,c] — free here) -> V [16][tiles][C]
+// Kernels:
+//   0. wino_gy_transform    : (wgrad only, F(3x3,2x2)) 2x2 tiles of the output gradient -> Mg [16][tiles_pad][C_pad]; the
+//      16 plane GEMMs of the weight gradient run in conv_wgrad.hip (conv_wgrad_mfma, "planes" mode)
+//   1. wino_input_transform : x [B,H,W,C] (times the per-sample modulation s[b,c] — free here) -> V [16][tiles_pad][C_pad]
 //   2. wino_weight_transform: canonical weight view (any strides, optional 180-degree flip for the dgrad) -> U [16][RP][CP]
 //   3. wino_gemm_mfma       : for each of the 16 positions p a dense GEMM  M_p[tile,co] = sum_ci V_p[tile,ci] U_p[co,ci]
 //      on v_mfma_f32_32x32x2_f32 with LDS-DMA staging (same unpadded-row + XOR-swizzle scheme as conv_gather_mfma_glds;
-//      no gather, no bounds: V is a dense matrix), and the OUTPUT TRANSFORM FUSED: after the K loop of position p the
-//      accumulators are folded into the four 2x2-output accumulators with the +-1/0 coefficients of A^T (x) A^T, so the
+//      no gather, no bounds: V is a dense padded matrix; 3-stage ring), and the OUTPUT TRANSFORM FUSED: the accumulators of
+//      position p are folded, in the MFMA shadow of position p+1 (ping-pong accumulator sets), into the four 2x2-output accumulators with the +-1/0 coefficients of A^T (x) A^T, so the
 //      16x-larger M tensor never exists.  The epilogue (demodulation, noise residual, bias, leaky ReLU) is the shared
 //      LDS-transposed float4 epilogue, run once per output position (a,b) of the 2x2 tile.
 // HBM traffic: V is 4x the input (written once, read once); MFMA work is 4/9 of the direct convolution.
