@@ -11,8 +11,8 @@
 //   3. wino_gemm_mfma       : for each of the 16 positions p a dense GEMM  M_p[tile,co] = sum_ci V_p[tile,ci] U_p[co,ci]
 //      on v_mfma_f32_32x32x2_f32 with LDS-DMA staging (same unpadded-row + XOR-swizzle scheme as conv_gather_mfma_glds;
 //      no gather, no bounds: V is a dense padded matrix; 3-stage ring), and the OUTPUT TRANSFORM FUSED: the accumulators of
-//      position p are folded, in the MFMA shadow of position p+1 (ping-pong accumulator sets), into the four 2x2-output accumulators with the +-1/0 coefficients of A^T (x) A^T, so the
-//      16x-larger M tensor never exists.  The epilogue (demodulation, noise residual, bias, leaky ReLU) is the shared
+//      position p are folded, in the MFMA shadow of position p+1 (ping-pong accumulator sets), into the four 2x2-output
+//      accumulators with the +-1/0 coefficients of A^T (x) A^T, so the 16x-larger M tensor never exists.  The epilogue (demodulation, noise residual, bias, leaky ReLU) is the shared
 //      LDS-transposed float4 epilogue, run once per output position (a,b) of the 2x2 tile.
 // HBM traffic: V is 4x the input (written once, read once); MFMA work is 4/9 of the direct convolution.
 #include "common.h"
