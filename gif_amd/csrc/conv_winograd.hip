@@ -15,6 +15,8 @@
 //      accumulators with the +-1/0 coefficients of A^T (x) A^T, so the 16x-larger M tensor never exists.  The epilogue (demodulation, noise residual, bias, leaky ReLU) is the shared
 //      LDS-transposed float4 epilogue, run once per output position (a,b) of the 2x2 tile.
 // HBM traffic: V is 4x the input (written once, read once); MFMA work is 4/9 of the direct convolution.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -192,21 +194,25 @@ __device__ __forceinline__ float wino_coef(int a, int xi) {
     return a == 0 ? (xi < 3 ? 1.f : 0.f) : (xi == 0 ? 0.f : (xi == 1 ? 1.f : -1.f));
 }
 
-__global__ void __launch_bounds__(256, 2) wino_gemm_mfma(const WinoParams p) {
+// WN = waves along N: 2 -> 256 threads, block 128 x 64, two workgroups per CU; 4 -> 512 threads, block 128 x 128, one
+// workgroup per CU (same 2 waves per SIMD) with a third fewer DMA bytes per MFMA (V tile shared by 128 couts).
+template <int WN>
+__global__ void __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) wino_gemm_mfma(const WinoParams p) {
+    constexpr int THREADS = 128 * WN, BN = 32 * WN, PROWS = THREADS / 8;  // PROWS = tile rows one DMA pass covers
     constexpr int LD = WBK, CH = WBK / 4, RB = 64 / WBK, RPW = 64 / CH;
     constexpr int MT = 2;
-    constexpr int A_IT = WBM / 32, B_IT = WBN / 32;
+    constexpr int A_IT = WBM / PROWS, B_IT = BN / PROWS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                       // [NSTAGE][WBM][LD]
-    float* Bs = smem + WNSTAGE * WBM * LD;  // [NSTAGE][WBN][LD]
+    float* Bs = smem + WNSTAGE * WBM * LD;  // [NSTAGE][BN][LD]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
-    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 32;
+    const int wm0 = (wave / WN) * 64, wn0 = (wave % WN) * 32;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
-    const int m0 = tm * WBM, n0 = tn * WBN;
+    const int m0 = tm * WBM, n0 = tn * BN;
     const int t_row = tid / CH;
     const int src_c4 = ((tid % CH) ^ ((t_row / RB) % CH)) * 4;
     const int fsw = (li / RB) % CH;
@@ -216,7 +222,7 @@ __global__ void __launch_bounds__(256, 2) wino_gemm_mfma(const WinoParams p) {
     // Both operands are dense, padded matrices: per-lane 32-bit element offsets + one wave-uniform pointer per stage.
     const unsigned a_off = (unsigned)(m0 + t_row) * (unsigned)p.CP + (unsigned)src_c4;
     const unsigned b_off = (unsigned)(n0 + t_row) * (unsigned)p.CP + (unsigned)src_c4;
-    const size_t pass_stride = (size_t)32 * p.CP;  // 32 rows per 256-lane pass
+    const size_t pass_stride = (size_t)PROWS * p.CP;  // tile rows per DMA pass
     const size_t planeV = (size_t)p.ntiles_pad * p.CP, planeU = (size_t)p.RP * p.CP;
     const int kchunks = p.CP / WBK;
     const int nsteps = 16 * kchunks;
@@ -226,13 +232,13 @@ __global__ void __launch_bounds__(256, 2) wino_gemm_mfma(const WinoParams p) {
 
     auto issue = [&](int buf) __attribute__((always_inline)) {
         float* Ad = As + buf * WBM * LD + wave * RPW * LD;
-        float* Bd = Bs + buf * WBN * LD + wave * RPW * LD;
+        float* Bd = Bs + buf * BN * LD + wave * RPW * LD;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it)
-            __builtin_amdgcn_global_load_lds((gptr_t)((vptr + it * pass_stride) + a_off), (lptr_t)(Ad + it * 32 * LD), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)((vptr + it * pass_stride) + a_off), (lptr_t)(Ad + it * PROWS * LD), 16, 0, 0);
 #pragma unroll
         for (int it = 0; it < B_IT; ++it)
-            __builtin_amdgcn_global_load_lds((gptr_t)((uptr + it * pass_stride) + b_off), (lptr_t)(Bd + it * 32 * LD), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)((uptr + it * pass_stride) + b_off), (lptr_t)(Bd + it * PROWS * LD), 16, 0, 0);
         vptr += WBK;
         uptr += WBK;
         ld_kc += WBK;
@@ -259,7 +265,7 @@ __global__ void __launch_bounds__(256, 2) wino_gemm_mfma(const WinoParams p) {
 
     auto compute = [&](int buf, f32x16(&acc)[MT]) __attribute__((always_inline)) {
         const float* Ab = As + buf * WBM * LD + (wm0 + li) * LD;
-        const float* Bb = Bs + buf * WBN * LD + (wn0 + li) * LD;
+        const float* Bb = Bs + buf * BN * LD + (wn0 + li) * LD;
 #pragma unroll
         for (int kk = 0; kk < WBK / 8; ++kk) {
             const int c = ((kk * 2 + lh) ^ fsw) * 4;
@@ -300,11 +306,15 @@ __global__ void __launch_bounds__(256, 2) wino_gemm_mfma(const WinoParams p) {
     // 3-stage ring: the DMA of stage s+2 is issued before the MFMAs of stage s.  `s_waitcnt vmcnt(NI)` (NI = DMA
     // instructions per stage and wave) lets the newest stage stay in flight; the last two stages drain with vmcnt(0).
     constexpr int NI = A_IT + B_IT;
-    static_assert(NI == 6, "the s_waitcnt immediate below encodes vmcnt(6)");
+    static_assert((WN == 2 && NI == 6) || (WN == 4 && NI == 4), "the s_waitcnt immediates below encode vmcnt(NI)");
     int cur = 0, step = 0;
     auto advance = [&]() __attribute__((always_inline)) {
-        if (step + 2 < nsteps) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (step + 2 < nsteps) {
+            if (WN == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
         cur = cur == 2 ? 0 : cur + 1;
         ++step;
@@ -314,7 +324,8 @@ __global__ void __launch_bounds__(256, 2) wino_gemm_mfma(const WinoParams p) {
     };
     issue(0);
     issue(1);  // nsteps >= 16
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if (WN == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
     for (int pp = 0; pp < 8; ++pp) {
@@ -344,9 +355,9 @@ __global__ void __launch_bounds__(256, 2) wino_gemm_mfma(const WinoParams p) {
     fold(15, accB);
 
     // ---- epilogue: for each output position (a,b): transpose through LDS, then coalesced float4 rows
-    constexpr int LDC = WBN + 4;
-    float* Cs = smem;  // [WBM][LDC]  (128*68*4 = 34.8 KB of the 72 KB of staging)
-    constexpr int C4_ROW = WBN / 4, EROWS = 256 / C4_ROW, E_IT = WBM / EROWS;
+    constexpr int LDC = BN + 4;
+    float* Cs = smem;  // [WBM][LDC]  (34.8 of the 72 KB / 67.6 of the 96 KB of staging)
+    constexpr int C4_ROW = BN / 4, EROWS = THREADS / C4_ROW, E_IT = WBM / EROWS;
     const int e_row0 = tid / C4_ROW, e_c = (tid % C4_ROW) * 4;
     const int n = n0 + e_c;
     f32x4 bias4 = (f32x4)(0.f);
@@ -481,14 +492,29 @@ int gif_conv3x3_winograd_f32(const float* x, const float* U, float* y, float* V,
     p.B = B; p.H = H; p.W = W; p.Co = Co;
     p.ntiles = (int)ntiles; p.ntiles_pad = (int)ntiles_pad; p.TH = H / 2; p.TW = W / 2;
     p.tiles_m = (int)(ntiles_pad / WBM);
-    p.tiles_n = p.RP / WBN;
-    const size_t lds = (size_t)WNSTAGE * (WBM + WBN) * WBK * sizeof(float);
+    // 128-wide N tile (8 waves) whenever the output channels fill it; GIF_WINO_WN=2 / 4 forces a variant (benchmarking)
+    static int force_wn = -1;
+    if (force_wn < 0) {
+        const char* env = getenv("GIF_WINO_WN");
+        force_wn = env ? atoi(env) : 0;
+    }
+    // measured: +1-2 % on the >= 32^2 layers, slower when the launch has fewer than ~512 workgroups of 512 threads
+    const bool wide = force_wn == 4 ? (p.RP % 128 == 0)
+                                    : (force_wn == 2 ? false : (Co % 128 == 0 && (long)p.tiles_m * (p.RP / 128) >= 512));
+    const int bn = wide ? 128 : 64;
+    p.tiles_n = p.RP / bn;
+    const size_t lds = (size_t)WNSTAGE * (WBM + bn) * WBK * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_gemm_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_gemm_mfma<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)((size_t)WNSTAGE * (WBM + 64) * WBK * sizeof(float)));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_gemm_mfma<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)((size_t)WNSTAGE * (WBM + 128) * WBK * sizeof(float)));
         attr = true;
     }
-    hipLaunchKernelGGL(wino_gemm_mfma, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(256), lds, s, p);
+    const dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
+    if (wide) hipLaunchKernelGGL(wino_gemm_mfma<4>, grid, dim3(512), lds, s, p);
+    else hipLaunchKernelGGL(wino_gemm_mfma<2>, grid, dim3(256), lds, s, p);
     return gif::check_launch("conv3x3_winograd");
 }
 }
