@@ -54,6 +54,7 @@ struct GatherParams {
     int tiles_m, tiles_n;
     int stab_nb, stab_stride;  // LDS table of per-sample input scales (LDS-DMA kernel): samples per tile, row stride
     const float* zero;         // 16 zero bytes in HBM: source of the LDS-DMA lanes that fall outside the tensor
+    int m_begin;               // first GEMM row of this launch (a launch may cover only rows [m_begin, M))
 };
 
 // XCD-aware, bijective block remap (cdna guide T1): consecutive logical tiles share an XCD's L2.
@@ -168,7 +169,7 @@ __global__ void __launch_bounds__(256) conv_gather_mfma(const GatherParams p) {
 
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = p.m_begin + tm * BM, n0 = tn * BN;
     const int HWp = p.Hp * p.Wp;
 
     const int t_row = tid / F4_ROW, t_c4 = (tid % F4_ROW) * 4;
@@ -335,7 +336,7 @@ __global__ void __launch_bounds__(256) conv_gather_mfma_glds(const GatherParams 
     const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = p.m_begin + tm * BM, n0 = tn * BN;
     const int HWp = p.Hp * p.Wp;
     // this lane fills LDS row tid/CH + RPP*it, physical 16-B chunk tid%CH, with the LOGICAL chunk (tid%CH)^f(row),
     // f(row) = (row / RB) % CH: the 16 rows of a ds_read_b128 lane group then hit 16 distinct 16-B slots
@@ -501,7 +502,7 @@ inline TileCfg pick_cfg(int cout, int cin) {
 
 template <typename K>
 int launch_kernel(K kern, GatherParams& p, int BM, int BN, int BK, hipStream_t s, bool& attr_set) {
-    p.tiles_m = gif::cdiv(p.M, BM);
+    p.tiles_m = gif::cdiv(p.M - p.m_begin, BM);
     p.tiles_n = p.RP / BN;
     size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
     if (!attr_set) {
@@ -522,7 +523,7 @@ int launch_simple(GatherParams& p, hipStream_t s) {
 template <int BM, int BN, int WMv, int WNv, bool SCALE, int BK>
 int launch_glds_impl(GatherParams& p, hipStream_t s) {
     static size_t attr_bytes = 0;
-    p.tiles_m = gif::cdiv(p.M, BM);
+    p.tiles_m = gif::cdiv(p.M - p.m_begin, BM);
     p.tiles_n = p.RP / BN;
     size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
     p.stab_nb = 0;
@@ -582,6 +583,27 @@ int launch(GatherParams& p, hipStream_t s) {
         // 144-step K loop; 64x64 tiles give 4x the workgroups (and 32 KB of LDS: 4 per CU) at a quarter of the latency
         const long tiles128 = (long)gif::cdiv(p.M, 128) * (p.RP / 128);
         if (glds && tiles128 < 384 && launch_glds<64, 64, 2, 2>(p, s) == 0) return 0;
+        if (glds && conv_variant() != 3) {
+            // Tile quantisation: 512 workgroups of this kernel are resident (2 per CU), so T tiles cost ceil(T / 512) rounds.
+            // The odd-sized phase grids of the transposed convolutions (129^2, 65^2, 33^2 pixels) give e.g. 4161 or 1092
+            // tiles = 8.13 / 2.13 rounds: the nearly empty last round costs 10-30 %.  Split such launches: the full rounds
+            // on 128x128 tiles, the remaining rows on 64x64 tiles (4x the workgroups, a quarter of the latency each).
+            const long slots = 512, tn = p.RP / 128;
+            const long full = tiles128 / slots, rem = tiles128 % slots;
+            if (full >= 1 && rem > 0 && rem * 2 <= slots && slots % tn == 0) {
+                const int M = p.M;
+                const int m_bulk = (int)(full * slots / tn) * 128;
+                p.M = m_bulk;
+                if (launch_glds<128, 128, 2, 2>(p, s) == 0) {
+                    p.M = M;
+                    p.m_begin = m_bulk;
+                    int rc = launch_glds<64, 64, 2, 2>(p, s);
+                    p.m_begin = 0;
+                    return rc;
+                }
+                p.M = M;
+            }
+        }
         if (glds && launch_glds<128, 128, 2, 2>(p, s) == 0) return 0;
         return launch_simple<128, 128, 32, 2, 2>(p, s);
     }

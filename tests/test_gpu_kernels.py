@@ -590,3 +590,34 @@ def test_texture_interpolation_loss_vs_reference_goldens_and_oracle_grads():
         assert abs(drawn.item() - R.texture_pairs_loss(face_h, tex_h, msk_h, ref_pairs).item()) < 1e-5
     with pytest.raises(Exception, match="FLAME"):
         crit.tex_sp_intrp_loss(torch.zeros(6, 236, device="cuda"), None, 6, 1.0, 10)
+
+
+def test_conv_launch_split_on_tile_quantisation():
+    """Launches whose 128-row tile count is a little above a multiple of the 512 resident workgroups are split into a bulk
+    launch (128x128 tiles) and a tail launch (64x64 tiles) over disjoint row ranges: forward conv, the four phases of a
+    transposed stride-2 conv, and a modulated conv with a fused epilogue must all still match ATen."""
+    from gif_amd import ops
+    g = torch.Generator().manual_seed(21)
+    # forward: M = 257*259 = 66563 rows = 520.02 tiles of 128
+    x = torch.randn(1, 128, 257, 259, generator=g)
+    w = torch.randn(128, 128, 3, 3, generator=g) / 34
+    s_, d_ = torch.rand(1, 128, generator=g) + 0.5, torch.rand(1, 128, generator=g) + 0.5
+    bias = torch.randn(128, generator=g)
+    ops_w = ops.WINOGRAD
+    ops.WINOGRAD = False  # this test is about the direct kernels
+    try:
+        ref = F.conv2d(x, w, padding=1)
+        assert_close(host(ops.conv_fwd(dev(x), w.cuda(), ops.ConvSpec(3, 3, 1, 1))), ref, TOL, "split fwd")
+        ref2 = 2 ** 0.5 * F.leaky_relu(F.conv2d(x * s_[:, :, None, None], w, padding=1) * d_[:, :, None, None]
+                                       + bias[None, :, None, None], 0.2)
+        got2 = ops.conv_fwd(dev(x), w.cuda(), ops.ConvSpec(3, 3, 1, 1), in_scale=s_.cuda(), out_scale=d_.cuda(),
+                            bias=bias.cuda(), act=True)
+        assert_close(host(got2), ref2, TOL, "split modulated fwd + epilogue")
+        # transposed stride 2: phases of 182x182 / 182x181 / ... pixels x batch 2 = ~518 tiles each
+        xs = torch.randn(2, 128, 181, 181, generator=g)
+        wt = torch.randn(128, 128, 3, 3, generator=g) / 34
+        ref3 = F.conv_transpose2d(xs, wt, stride=2)
+        got3 = ops.conv_bwd_data(dev(xs), wt.cuda(), ops.ConvSpec(3, 3, 2, 0), (363, 363))
+        assert_close(host(got3), ref3, TOL, "split transposed conv")
+    finally:
+        ops.WINOGRAD = ops_w
