@@ -312,7 +312,7 @@ __global__ void __launch_bounds__(256) conv_gather_mfma(const GatherParams p) {
 __device__ __attribute__((aligned(16))) float g_zero_page[4];
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool SCALE, int BK>
-__global__ void __launch_bounds__(256) conv_gather_mfma_glds(const GatherParams p) {
+__device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, const int nwg) {
     constexpr int LD = BK;             // unpadded LDS row (floats)
     constexpr int CH = BK / 4;         // 16-byte chunks per row
     constexpr int RB = 64 / BK;        // rows per 256-byte LDS bank row (2 for 128-byte rows)
@@ -334,7 +334,7 @@ __global__ void __launch_bounds__(256) conv_gather_mfma_glds(const GatherParams 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
     const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = xcd_remap(bid, nwg);
     const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
     const int m0 = p.m_begin + tm * BM, n0 = tn * BN;
     const int HWp = p.Hp * p.Wp;
@@ -488,6 +488,28 @@ __global__ void __launch_bounds__(256) conv_gather_mfma_glds(const GatherParams 
     conv_epilogue<BM, BN, LD, MT, NT>(p, acc, smem, m0, n0, wm0, wn0, tid, li, lh, HWp);
 }
 
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool SCALE, int BK>
+__global__ void __launch_bounds__(256) conv_gather_mfma_glds(const GatherParams p) {
+    glds_body<BM, BN, WAVES_M, WAVES_N, SCALE, BK>(p, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Up to 4 independent problems (the output-parity phases of a small transposed convolution) in ONE launch: each phase
+// alone would fill a fraction of the chip (e.g. 104 workgroups), together they run side by side.
+struct MultiParams {
+    GatherParams ph[4];
+    int wg_end[4];  // exclusive prefix sums of the phases' workgroup counts
+    int nph;
+};
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool SCALE, int BK>
+__global__ void __launch_bounds__(256) conv_gather_mfma_glds_multi(const MultiParams mp) {
+    const int b = (int)blockIdx.x;
+    int k = 0;
+    while (k + 1 < mp.nph && b >= mp.wg_end[k]) ++k;  // wave-uniform
+    const int begin = k ? mp.wg_end[k - 1] : 0;
+    glds_body<BM, BN, WAVES_M, WAVES_N, SCALE, BK>(mp.ph[k], b - begin, mp.wg_end[k] - begin);
+}
+
 struct TileCfg {
     int BM, BN, BK;
 };
@@ -550,6 +572,52 @@ int launch_glds_impl(GatherParams& p, hipStream_t s) {
     }
     p.zero = zero_page;
     hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(256), lds, s, p);
+    return 0;
+}
+
+// all phases in one launch (64x64 tiles); returns -100 if the configuration does not fit
+template <bool SCALE>
+int launch_glds_multi(GatherParams* ph, int nph, hipStream_t s) {
+    constexpr int BM = 64, BN = 64, BK = 32;
+    static size_t attr_bytes = 0;
+    static const float* zero_page = nullptr;
+    if (!zero_page) {
+        void* zp = nullptr;
+        if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero_page)) != hipSuccess) return -101;
+        zero_page = static_cast<const float*>(zp);
+    }
+    MultiParams mp{};
+    size_t lds_max = 0;
+    int total = 0;
+    for (int i = 0; i < nph; ++i) {
+        GatherParams& p = ph[i];
+        p.tiles_m = gif::cdiv(p.M - p.m_begin, BM);
+        p.tiles_n = p.RP / BN;
+        size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
+        p.stab_nb = 0;
+        p.stab_stride = 0;
+        if (SCALE) {
+            const int HWp = p.Hp * p.Wp;
+            int nb = (BM - 1) / HWp + 2;
+            if (nb > p.B) nb = p.B;
+            p.stab_nb = nb;
+            p.stab_stride = p.CP + 4;
+            lds += (size_t)nb * p.stab_stride * sizeof(float);
+        }
+        if (lds > lds_max) lds_max = lds;
+        p.zero = zero_page;
+        total += p.tiles_m * p.tiles_n;
+        mp.ph[i] = p;
+        mp.wg_end[i] = total;
+    }
+    mp.nph = nph;
+    if (lds_max > 160 * 1024) return -100;
+    auto kern = conv_gather_mfma_glds_multi<BM, BN, 2, 2, SCALE, BK>;
+    if (lds_max > attr_bytes) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+        attr_bytes = lds_max;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), lds_max, s, mp);
     return 0;
 }
 
@@ -720,8 +788,21 @@ int gif_conv2d_bwd_data_f32(const float* small, const float* wp, float* big, con
     double flops = 2.0 * g->B * (double)g->Hs * g->Ws * g->KH * g->KW * (double)g->Cs * g->Cb;
     {
         gif::ProfScope prof(base.Ci >= 32 ? 0 : 5, flops, s, g->B * g->Hb * g->Wb, base.Co, base.Ci, -(g->KH * g->KW * 10 + g->stride));
-        for (int i = 0; i < nph; ++i)
-            if (int rc = launch(ph[i], s)) return rc;
+        // small transposed convs: every phase alone would sit on the 64x64-tile path with a partly filled chip
+        bool merged = false;
+        if (nph > 1 && conv_variant() == 0) {
+            const TileCfg c = pick_cfg(base.Co, base.Ci);
+            bool small_all = c.BN == 128 && c.BK == 32;
+            for (int i = 0; i < nph && small_all; ++i)
+                small_all = (long)gif::cdiv(ph[i].M, 128) * (ph[i].RP / 128) < 384 &&
+                            (long)ph[i].B * ph[i].Hi * ph[i].Wi * ph[i].Ci < (1L << 31) &&
+                            (long)ph[i].B * ph[i].Ho * ph[i].Wo * ph[i].Co < (1L << 31);
+            if (small_all)
+                merged = (base.in_scale ? launch_glds_multi<true>(ph, nph, s) : launch_glds_multi<false>(ph, nph, s)) == 0;
+        }
+        if (!merged)
+            for (int i = 0; i < nph; ++i)
+                if (int rc = launch(ph[i], s)) return rc;
     }
     return gif::check_launch("conv2d_bwd_data");
 }
