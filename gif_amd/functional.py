@@ -142,7 +142,13 @@ class BiasActBwdFn(Function):
 
     @staticmethod
     def forward(ctx, gy, y, want_gbias, slope, gain):
-        gx, gb = ops.bias_act_bwd(gy, y, want_gbias, slope, gain)
+        if slope == 1.0 and gain == 1.0:
+            # identity activation (bias only, e.g. the last condition-noise conv): gx IS gy — no elementwise pass, the bias
+            # gradient is one column-sum read of gy
+            gx = ops.nhwc(gy).view_as(gy)
+            gb = ops.colsum(gy) if want_gbias else None
+        else:
+            gx, gb = ops.bias_act_bwd(gy, y, want_gbias, slope, gain)
         ctx.slope, ctx.gain = slope, gain
         ctx.save_for_backward(y)
         if gb is None:

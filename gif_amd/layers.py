@@ -256,10 +256,11 @@ class NoiseInjection(nn.Module):
         h = noise
         for idx in (0, 2, 4):
             conv = self.noise_conv[idx]
-            h = GF.conv2d(h, conv.weight, 1, 1)
             last = idx == 4
-            # bias (+ReLU): leaky_relu with slope 0 / gain 1; the last conv has no activation (slope 1)
-            h = GF.bias_act(h, _pad_vec(conv.bias, h.shape[1]), None, 1.0 if last else 0.0, 1.0)
+            # bias (+ReLU) run in the conv kernel's epilogue: leaky_relu with slope 0 / gain 1 is the ReLU; the last conv
+            # has no activation (slope 1 = identity)
+            h = GF.conv2d_bias_act(h, conv.weight, _pad_vec(conv.bias, pad4(conv.weight.shape[0])), 1, 1, 1.0,
+                                   1.0 if last else 0.0, 1.0)
         return h
 
     def forward(self, image, noise):
