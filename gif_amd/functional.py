@@ -23,34 +23,38 @@ from .ops import ConvSpec
 # plain convolution family (twice differentiable)
 # --------------------------------------------------------------------------------------------------------
 class Conv2dFn(Function):
-    """transposed=False: y = conv2d(x, w*wscale); True: y = conv_transpose2d(x, w*wscale) to size out_hw.
-    w is the canonical FORWARD-conv weight [O,I,KH,KW] in both cases."""
+    """transposed=False: y = conv2d(x, w*wscale); True: y = conv_transpose2d(x, w*wscale) to size out_hw; optional
+    `residual` (same shape as y) is added in the kernel's epilogue.  w is the canonical FORWARD-conv weight [O,I,KH,KW]
+    in both cases."""
 
     @staticmethod
-    def forward(ctx, x, w, spec, transposed, out_hw, wscale):
+    def forward(ctx, x, w, spec, transposed, out_hw, wscale, residual=None):
         x = ops.nhwc(x)
         ctx.spec, ctx.transposed, ctx.wscale = spec, transposed, wscale
         ctx.save_for_backward(x, w)
         ctx.v = None
+        epi = {} if residual is None else {"residual": ops.nhwc(residual)}
         if not transposed:
             # keep the Winograd-transformed input for the weight gradient (same x): saves one HBM-bound transform pass
-            y, v = ops.conv_fwd(x, w, spec, wscale, keep_v=True)
+            y, v = ops.conv_fwd(x, w, spec, wscale, keep_v=True, **epi)
             ctx.v = v if ctx.needs_input_grad[1] else None
             return y
-        return ops.conv_bwd_data(x, w, spec, tuple(out_hw), wscale)
+        return ops.conv_bwd_data(x, w, spec, tuple(out_hw), wscale, **epi)
 
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
         spec, tr, ws = ctx.spec, ctx.transposed, ctx.wscale
-        gx = gw = None
+        gx = gw = gr = None
         if ctx.needs_input_grad[0]:
-            gx = Conv2dFn.apply(gy, w, spec, not tr, tuple(x.shape[2:]), ws)
+            gx = Conv2dFn.apply(gy, w, spec, not tr, tuple(x.shape[2:]), ws, None)
             assert gx.shape == x.shape, (gx.shape, x.shape)
         if ctx.needs_input_grad[1]:
             O, I = w.shape[:2]
             gw = WgradFn.apply(gy, x, spec, O, I, ws, ctx.v) if not tr else WgradFn.apply(x, gy, spec, O, I, ws)
-        return gx, gw, None, None, None, None
+        if ctx.needs_input_grad[6]:
+            gr = gy
+        return gx, gw, None, None, None, None, gr
 
 
 class WgradFn(Function):
@@ -68,52 +72,61 @@ class WgradFn(Function):
         small, big = ctx.saved_tensors
         gs = gb = None
         if ctx.needs_input_grad[0]:
-            gs = Conv2dFn.apply(big, ggw, ctx.spec, False, None, ctx.wscale)
+            gs = Conv2dFn.apply(big, ggw, ctx.spec, False, None, ctx.wscale, None)
         if ctx.needs_input_grad[1]:
-            gb = Conv2dFn.apply(small, ggw, ctx.spec, True, tuple(big.shape[2:]), ctx.wscale)
+            gb = Conv2dFn.apply(small, ggw, ctx.spec, True, tuple(big.shape[2:]), ctx.wscale, None)
         return gs, gb, None, None, None, None, None
 
 
 class ConvBiasActFn(Function):
     """y = gain*lrelu(conv2d(x, w*wscale) + bias): bias and activation run in the conv kernel's epilogue (ConvLayer =
     EqualConv2d + FusedLeakyReLU, stylegan2_common_layers.py:752-799).  The backward is composed of BiasActBwdFn,
-    Conv2dFn and WgradFn, hence differentiable to any order (R1)."""
+    Conv2dFn and WgradFn, hence differentiable to any order (R1).
+
+    passthrough=True returns (y, x'), x' an alias of x for a SECOND consumer of x (the ResBlock's skip branch): that
+    consumer's gradient then arrives here, in this node's backward, and is added by the data-gradient kernel's epilogue
+    (`residual`) instead of by a separate gradient-accumulation pass over two full-resolution tensors."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, spec, wscale, slope, gain):
+    def forward(ctx, x, w, bias, spec, wscale, slope, gain, passthrough=False):
+        ctx.set_materialize_grads(False)  # an unused output (y or the alias) arrives as None, not as a zero tensor
         x = ops.nhwc(x)
         y, v = ops.conv_fwd(x, w, spec, wscale, keep_v=True, bias=bias, act=True, slope=slope, gain=gain)
         ctx.v = v if ctx.needs_input_grad[1] else None  # Winograd-transformed x, reused by the weight gradient
         ctx.cfg = (spec, wscale, slope, gain, bias is not None)
         ctx.save_for_backward(x, w, y)
-        return y
+        return (y, x.view_as(x)) if passthrough else y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, g_alias=None):
         x, w, y = ctx.saved_tensors
         spec, ws, slope, gain, has_bias = ctx.cfg
         want_b = has_bias and ctx.needs_input_grad[2]
-        gpre, gb = BiasActBwdFn.apply(gy, y, want_b, slope, gain)
-        gx = gw = None
-        if ctx.needs_input_grad[0]:
-            gx = Conv2dFn.apply(gpre, w, spec, True, tuple(x.shape[2:]), ws)
-        if ctx.needs_input_grad[1]:
-            gw = WgradFn.apply(gpre, x, spec, w.shape[0], w.shape[1], ws, ctx.v)
-        return gx, gw, (gb if want_b else None), None, None, None, None
+        gx = gw = gb = None
+        if gy is not None:
+            gpre, gb = BiasActBwdFn.apply(gy, y, want_b, slope, gain)
+            if ctx.needs_input_grad[0]:
+                gx = Conv2dFn.apply(gpre, w, spec, True, tuple(x.shape[2:]), ws, g_alias)
+            if ctx.needs_input_grad[1]:
+                gw = WgradFn.apply(gpre, x, spec, w.shape[0], w.shape[1], ws, ctx.v)
+        elif ctx.needs_input_grad[0]:
+            gx = g_alias
+        return gx, gw, (gb if want_b else None), None, None, None, None, None
 
 
-def conv2d_bias_act(x, w, bias, stride=1, pad=0, wscale=1.0, slope=0.2, gain=2 ** 0.5):
-    return ConvBiasActFn.apply(x, w, bias, ConvSpec(w.shape[2], w.shape[3], stride, pad), wscale, slope, gain)
+def conv2d_bias_act(x, w, bias, stride=1, pad=0, wscale=1.0, slope=0.2, gain=2 ** 0.5, passthrough=False):
+    """passthrough=True: returns (y, alias of x) — see ConvBiasActFn."""
+    return ConvBiasActFn.apply(x, w, bias, ConvSpec(w.shape[2], w.shape[3], stride, pad), wscale, slope, gain, bool(passthrough))
 
 
 def conv2d(x, w, stride=1, pad=0, wscale=1.0):
     """x [B,C,H,W] with C == pad4(w.shape[1]); returns [B, pad4(O), Ho, Wo]."""
-    return Conv2dFn.apply(x, w, ConvSpec(w.shape[2], w.shape[3], stride, pad), False, None, wscale)
+    return Conv2dFn.apply(x, w, ConvSpec(w.shape[2], w.shape[3], stride, pad), False, None, wscale, None)
 
 
 def conv_transpose2d(x, w, stride, pad, out_hw, wscale=1.0):
     """Adjoint of conv2d(., w): x [B, pad4(O), Hs, Ws] -> [B, pad4(I), *out_hw]."""
-    return Conv2dFn.apply(x, w, ConvSpec(w.shape[2], w.shape[3], stride, pad), True, tuple(out_hw), wscale)
+    return Conv2dFn.apply(x, w, ConvSpec(w.shape[2], w.shape[3], stride, pad), True, tuple(out_hw), wscale, None)
 
 
 # --------------------------------------------------------------------------------------------------------

@@ -356,19 +356,23 @@ class ConvLayer(nn.Sequential):
             layers.append(FusedLeakyReLU(out_channel) if bias else ScaledLeakyReLU(0.2))
         super().__init__(*layers)
 
-    def forward(self, input):
+    def forward(self, input, passthrough=False):
+        """passthrough=True (fused, non-downsampling layers only): returns (out, input') with input' an alias of the
+        input for a second consumer — see functional.ConvBiasActFn."""
         mods = list(self)
         if isinstance(mods[0], Blur):
+            assert not passthrough
             input = mods[0](input)
             mods = mods[1:]
         conv = mods[0]
         if len(mods) == 2 and isinstance(mods[1], FusedLeakyReLU) and conv.bias is None:
             act = mods[1]  # EqualConv2d + FusedLeakyReLU => bias and lrelu run in the conv kernel's epilogue
             return GF.conv2d_bias_act(input, conv.weight, _pad_vec(act.bias, pad4(conv.weight.shape[0])), conv.stride,
-                                      conv.padding, conv.scale, act.negative_slope, act.scale)
+                                      conv.padding, conv.scale, act.negative_slope, act.scale, passthrough)
+        first = input
         for m in mods:
             input = m(input)
-        return input
+        return (input, first) if passthrough else input
 
 
 class ResBlock(nn.Module):
@@ -381,6 +385,9 @@ class ResBlock(nn.Module):
         self.skip = ConvLayer(in_channel, out_channel, 1, downsample=True, activate=False, bias=False)
 
     def forward(self, input):
-        out = self.conv2(self.conv1(input))
-        skip = self.skip(input)
+        # the skip branch consumes the alias handed back by conv1: its input gradient is then accumulated inside conv1's
+        # data-gradient kernel instead of by a separate add over two full-resolution tensors
+        out, input_alias = self.conv1(input, passthrough=True)
+        out = self.conv2(out)
+        skip = self.skip(input_alias)
         return GF.bias_act(out, None, skip, 1.0, 1 / math.sqrt(2))

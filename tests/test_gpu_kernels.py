@@ -621,3 +621,46 @@ def test_conv_launch_split_on_tile_quantisation():
         assert_close(host(got3), ref3, TOL, "split transposed conv")
     finally:
         ops.WINOGRAD = ops_w
+
+
+def test_conv_bias_act_passthrough_accumulates_in_the_dgrad_kernel():
+    """ConvBiasActFn(passthrough=True) hands back an alias of x for a second consumer; that consumer's gradient must come out
+    ADDED to the conv's data gradient (fused as the dgrad kernel's residual), to first and second order."""
+    from gif_amd import functional as GF
+    g = torch.Generator().manual_seed(31)
+    x0 = torch.randn(2, 64, 12, 12, generator=g)
+    w0 = torch.randn(64, 64, 3, 3, generator=g) / 24
+    b0 = torch.randn(64, generator=g) * 0.1
+    m = torch.randn(2, 64, 12, 12, generator=g)      # weights of the second consumer: z = sum(m * x^2)
+    t = torch.randn(2, 64, 12, 12, generator=g)
+
+    def run(passthrough):
+        x = dev(x0).requires_grad_(True)
+        w, b = w0.cuda().requires_grad_(True), b0.cuda().requires_grad_(True)
+        if passthrough:
+            y, xa = GF.conv2d_bias_act(x, w, b, 1, 1, 0.5, passthrough=True)
+        else:
+            y, xa = GF.conv2d_bias_act(x, w, b, 1, 1, 0.5), x
+        loss = (y * dev(t)).sum() + (dev(m) * xa * xa).sum()
+        (gx,) = torch.autograd.grad(loss, x, create_graph=True)
+        gw, gb, ggx = torch.autograd.grad((gx * gx).sum(), [w, b, x], allow_unused=True)
+        return gx.detach(), gw, gb, ggx
+
+    a, bb = run(True), run(False)
+    for got, ref, what in zip(a, bb, ("gx", "d|gx|^2/dw", "d|gx|^2/db", "d|gx|^2/dx")):
+        if ref is None:
+            assert got is None or float(got.abs().max()) == 0.0, what
+        else:
+            assert_close(got, ref, 1e-5, f"passthrough {what}")
+    # reference value of gx on the host
+    xr = x0.clone().requires_grad_(True)
+    yr = 2 ** 0.5 * F.leaky_relu(F.conv2d(xr, w0 * 0.5, padding=1) + b0[None, :, None, None], 0.2)
+    ((yr * t).sum() + (m * xr * xr).sum()).backward()
+    assert_close(host(a[0]), xr.grad, TOL, "passthrough gx vs ATen")
+    # the alias alone (y unused) and y alone (alias unused) still differentiate
+    x = dev(x0).requires_grad_(True)
+    y, xa = GF.conv2d_bias_act(x, w0.cuda(), b0.cuda(), 1, 1, 0.5, passthrough=True)
+    (g1,) = torch.autograd.grad((xa * dev(m)).sum(), x, retain_graph=True)
+    assert_close(host(g1), m, 1e-6, "alias-only gradient")
+    (g2,) = torch.autograd.grad((y * dev(t)).sum(), x)
+    assert float((g2 - (a[0] - 2 * dev(m) * dev(x0))).abs().max()) < 1e-4
