@@ -165,7 +165,7 @@ class BiasActBwdFn(Function):
         ctx.slope, ctx.gain = slope, gain
         ctx.save_for_backward(y)
         if gb is None:
-            gb = gx.new_zeros(())
+            gb = gx.new_empty(())  # 0-dim placeholder (never read): no fill kernel
             ctx.mark_non_differentiable(gb)
         return gx, gb
 
@@ -356,7 +356,8 @@ class ModConvFn(Function):
         else:
             y = ops.conv_bwd_data(x, w, spec, tuple(out_hw), wscale, in_scale=s, out_scale=d)
         ctx.spec, ctx.transposed, ctx.wscale = spec, transposed, wscale
-        ctx.save_for_backward(x, w, s, d if d is not None else x.new_zeros(()), y if d is not None else x.new_zeros(()))
+        none = x.new_empty(())  # placeholder for absent tensors (never read): no fill kernel
+        ctx.save_for_backward(x, w, s, d if d is not None else none, y if d is not None else none)
         ctx.has_d = d is not None
         return y
 
@@ -401,7 +402,7 @@ class ModConvActFn(Function):
         ctx.v = v if ctx.needs_input_grad[1] else None  # Winograd-transformed s*x, reused by the weight gradient
         ctx.cfg = (spec, wscale, slope, gain)
         ctx.has = (residual is not None, bias is not None)
-        z = x.new_zeros(())
+        z = x.new_empty(())  # placeholder for absent tensors (never read): no fill kernel
         ctx.save_for_backward(x, w, s, d, y, residual if residual is not None else z, bias if bias is not None else z)
         return y
 
