@@ -88,13 +88,16 @@ def cpu_baseline(res, step_idx, batch, threads, timeout_s=240):
                 "sample": f"cpu baseline did not finish within {timeout_s}s ({type(e).__name__})"}
 
 
-# PMC passes (separate rocprofv3 --pmc runs, profiles/r1_pmc_winograd.md / r1_pmc_dominant_kernels.md) on the largest layer
-# shape (128->128 3x3 @256x256, batch 32): HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (KiB, gfx950 corrections)
+# HBM bytes per launch, averaged over every launch of the family in the bench step: separate rocprofv3 --pmc passes
+# (FETCH_SIZE, WRITE_SIZE; KiB; 2*FETCH + WRITE, gfx950 corrections) over `bench.py --steps 1 --warmup 1`,
+# profiles/r1_pmc_step.md.  PMC counters cannot be collected from inside the timed run, so these are the committed values.
+PMC_TRAFFIC_PER_LAUNCH = {0: 0.597e9, 2: 3.00e9}
 PMC_TRAFFIC = {
     "wino_gemm_mfma": {"hbm_bytes": 5.63e9, "algorithmic_bytes": 5.37e9, "mfma_busy": 0.58,
-                       "note": "V planes read once (4.29 GB) + output written once (1.07 GB); top layer, 2.9 ms"},
+                       "note": "largest layer (128->128 @256^2, batch 32), profiles/r1_pmc_winograd.md: V planes read once "
+                               "(4.29 GB) + output written once (1.07 GB); 2.9 ms"},
     "conv_gather_mfma_glds": {"hbm_bytes": 3.68e9, "algorithmic_bytes": 2.15e9, "mfma_busy": 0.824,
-                              "note": "direct 3x3 conv, same shape"},
+                              "note": "direct 3x3 conv on the same shape, profiles/r1_pmc_dominant_kernels.md"},
 }
 WINOGRAD_EXECUTED = 16.0 / 36.0  # MFMA FLOPs a Winograd F(2x2,3x3)/F(3x3,2x2) GEMM executes per algorithmic FLOP
 
@@ -127,6 +130,9 @@ def roofline_objects(ops, steps):
             o["algorithmic_achieved"] = alg
             o["algorithmic_frac"] = alg / PEAK_F32_MFMA_TFLOPS
             o["note"] = "achieved = executed MFMA FLOP/s (16/36 of the algorithmic direct-convolution FLOPs)"
+        if fam in PMC_TRAFFIC_PER_LAUNCH:
+            o["traffic"] = PMC_TRAFFIC_PER_LAUNCH[fam]
+            o["traffic_note"] = "HBM bytes per launch (family average), rocprofv3 --pmc passes in profiles/r1_pmc_step.md"
         if pmc:
             o["traffic_probe"] = PMC_TRAFFIC[pmc]
         objs[fam] = o
