@@ -346,6 +346,131 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ ws, float* __restr
     dw[r * sr + c * sc + ky * sky + kx * skx] = scale * acc;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Small-channel weight gradient (the condition-noise convs 6->12->24: Cs <= 32, Cb <= 16, 3x3, stride 1, pad 1).
+// On the 32x32-tile kernel above these layers run at 5-11 TFLOP/s: nine launches-worth of 32x32x2 MFMAs of which
+// (12..24)x(8..12) entries are real.  Here ONE wave owns all 9 taps: per group of 4 consecutive pixels it loads gy[4 px][Cs]
+// and the nine shifted x[4 px][Cb] straight from global memory (64-byte segments, L1/L2 resident: no LDS) as the A / B operands
+// of v_mfma_f32_16x16x4_f32 (i = cout, j = cin, k = pixel) and accumulates 9 taps x 2 cout tiles = 18 accumulators.
+// 1024-thread workgroups: 16 waves share a pixel range; their accumulators are reduced through LDS in a fixed order and
+// written as one split of the usual [split][tap][RP][CP] workspace (deterministic, same unpack kernel).
+// ------------------------------------------------------------------------------------------------------------------
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+struct SmallWgradParams {
+    const float* sm;  // gy [B,H,W,Cs]
+    const float* bg;  // x  [B,H,W,Cb]
+    float* ws;        // [nsplit][9][RP][CP]
+    int B, H, W, Cs, Cb, RP, CP;
+    long Ntot, chunk;  // pixels, pixels per split (multiple of 64)
+};
+
+__global__ void __launch_bounds__(1024) conv_wgrad_small_mfma(const SmallWgradParams p) {
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [8][18][256] floats = 147 KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, k = lane >> 4;
+    const long n_begin = (long)blockIdx.x * p.chunk;
+    long n_end = n_begin + p.chunk;
+    if (n_end > p.Ntot) n_end = p.Ntot;
+    f32x4v acc[9][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) acc[t][ct] = (f32x4v)(0.f);
+    const bool cin_ok = c < p.Cb;
+    const bool co_ok[2] = {c < p.Cs, 16 + c < p.Cs};
+    // this lane's pixel: n = n_begin + (quad index)*4 + k ; waves take quads round-robin (16 waves => +64 pixels per step)
+    long n = n_begin + wave * 4 + k;
+    int x, y, b;
+    {
+        long hw = (long)p.H * p.W;
+        b = (int)(n / hw);
+        long r = n - (long)b * hw;
+        y = (int)(r / p.W);
+        x = (int)(r - (long)y * p.W);
+    }
+    float a_cur[2], b_cur[9];
+    auto load = [&](float (&av)[2], float (&bv)[9]) __attribute__((always_inline)) {
+        const bool ok = n < n_end;
+        const float* sp = p.sm + n * p.Cs + c;
+        av[0] = (ok && co_ok[0]) ? sp[0] : 0.f;
+        av[1] = (ok && co_ok[1]) ? sp[16] : 0.f;
+        const float* bp = p.bg + n * p.Cb + c;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const bool in = ok && cin_ok && (unsigned)(y + dy) < (unsigned)p.H && (unsigned)(x + dx) < (unsigned)p.W;
+                bv[(dy + 1) * 3 + dx + 1] = in ? bp[((long)dy * p.W + dx) * p.Cb] : 0.f;
+            }
+    };
+    auto advance = [&]() __attribute__((always_inline)) {
+        n += 64;
+        x += 64;
+        while (x >= p.W) { x -= p.W; ++y; }
+        while (y >= p.H) { y -= p.H; ++b; }
+    };
+    const long steps = (n_end - n_begin + 63) / 64;
+    load(a_cur, b_cur);
+    for (long s = 0; s < steps; ++s) {
+        float a_nxt[2], b_nxt[9];
+        advance();
+        load(a_nxt, b_nxt);  // prefetch of the next group runs under this group's 18 MFMAs
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+                acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[ct], b_cur[t], acc[t][ct], 0, 0, 0);
+        a_cur[0] = a_nxt[0]; a_cur[1] = a_nxt[1];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) b_cur[t] = b_nxt[t];
+    }
+    // fixed-order tree over the 16 waves: waves [h, 2h) hand their accumulators to waves [0, h)
+    for (int h = 8; h >= 1; h >>= 1) {
+        if (wave >= h && wave < 2 * h) {
+            float* dst = red + (size_t)(wave - h) * 18 * 256;
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+                    *reinterpret_cast<f32x4v*>(dst + (t * 2 + ct) * 256 + lane * 4) = acc[t][ct];
+        }
+        __syncthreads();
+        if (wave < h) {
+            const float* src = red + (size_t)wave * 18 * 256;
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+                    acc[t][ct] += *reinterpret_cast<const f32x4v*>(src + (t * 2 + ct) * 256 + lane * 4);
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+        // C/D layout of the 16x16 MFMA: column j = lane & 15, rows i = 4*(lane >> 4) + r
+        float* out = p.ws + (size_t)blockIdx.x * 9 * p.RP * p.CP;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = ct * 16 + 4 * k + r;
+                    out[((size_t)t * p.RP + row) * p.CP + c] = acc[t][ct][r];
+                }
+    }
+}
+
+inline bool small_wgrad_ok(const gif_conv_geom* g, bool scaled) {
+    static int off = -1;
+    if (off < 0) {
+        const char* e = getenv("GIF_SMALL_WGRAD");
+        off = (e && atoi(e) == 0) ? 1 : 0;
+    }
+    return !off && !scaled && g->KH == 3 && g->KW == 3 && g->stride == 1 && g->pad == 1 && g->Hs == g->Hb && g->Ws == g->Wb &&
+           g->Cs <= 32 && g->Cb <= 16 && (long)g->B * g->Hs * g->Ws >= 65536;
+}
+
 // Winograd F(3x3,2x2) output transform fused with the split reduction: dW = A'^T dU A' with
 // A'^T = [1 1 1 0; 0 1 -1 0; 0 1 1 -1] (the F(3,2) matrix with the sign of the input transform's last row folded in,
 // because V was produced by the F(2,3) input transform whose last row is the negative of F(3,2)'s).
@@ -417,6 +542,8 @@ int gif_conv2d_wgrad_dims(int Cs, int Cb, int* RP, int* CP) {
 
 int gif_conv2d_wgrad_splits(const gif_conv_geom* g) {
     if (!g || g->B <= 0) return 1;
+    if (small_wgrad_ok(g, false)) return 256;  // one 16-wave workgroup per CU (conv_wgrad_small_mfma); scaled calls never
+                                               // reach that kernel and simply use 256 splits of the generic one
     int RP, CP;
     wgrad_dims(g->Cs, g->Cb, &RP, &CP);
     long tiles = (long)(RP / tile_of(g->Cs)) * (CP / tile_of(g->Cb)) * g->KH * g->KW;
@@ -464,6 +591,23 @@ int gif_conv2d_wgrad_f32(const float* small, const float* big, float* ws, const 
     }
     p.zero = zero_page;
     double flops = 2.0 * p.Ntot * (double)g->Cs * g->Cb * p.T;
+    if (small_wgrad_ok(g, small_scale || big_scale)) {
+        gif::ProfScope prof(1, flops, s, (int)p.Ntot, g->Cs, g->Cb, p.T * 10 + g->stride);
+        SmallWgradParams q{};
+        q.sm = small; q.bg = big; q.ws = ws;
+        q.B = g->B; q.H = g->Hs; q.W = g->Ws; q.Cs = g->Cs; q.Cb = g->Cb; q.RP = p.RP; q.CP = p.CP;
+        q.Ntot = p.Ntot;
+        long ch = (p.Ntot + nsplit - 1) / nsplit;
+        q.chunk = (ch + 63) / 64 * 64;
+        const size_t lds = (size_t)8 * 18 * 256 * sizeof(float);
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_small_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr = true;
+        }
+        hipLaunchKernelGGL(conv_wgrad_small_mfma, dim3((unsigned)nsplit), dim3(1024), lds, s, q);
+        return gif::check_launch("conv2d_wgrad(small)");
+    }
     {
         gif::ProfScope prof(1, flops, s, (int)p.Ntot, g->Cs, g->Cb, p.T * 10 + g->stride + (small_scale || big_scale ? 100 : 0));
         const char* env = getenv("GIF_CONV_VARIANT");

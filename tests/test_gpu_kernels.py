@@ -664,3 +664,19 @@ def test_conv_bias_act_passthrough_accumulates_in_the_dgrad_kernel():
     assert_close(host(g1), m, 1e-6, "alias-only gradient")
     (g2,) = torch.autograd.grad((y * dev(t)).sum(), x)
     assert float((g2 - (a[0] - 2 * dev(m) * dev(x0))).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("case", [(2, 6, 12, 192, 192), (1, 12, 24, 260, 254), (3, 16, 32, 150, 150), (2, 4, 8, 181, 183)])
+def test_small_channel_wgrad_kernel(case):
+    """conv_wgrad_small_mfma (all 9 taps in one wave on 16x16x4 MFMAs, no LDS staging) — the condition-noise convs' weight
+    gradients — vs autograd of the direct convolution; ragged widths, channel counts below the MFMA tile, determinism."""
+    from gif_amd import ops
+    B, Ci, Co, H, W = case
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    gy = torch.randn(B, Co, H, W, generator=g)
+    w = torch.zeros(Co, Ci, 3, 3, requires_grad=True)
+    (ref,) = torch.autograd.grad(F.conv2d(x, w, padding=1), w, gy)
+    got = ops.conv_wgrad(dev(gy), dev(x), ops.ConvSpec(3, 3, 1, 1), Co, Ci, 0.5)
+    assert_close(got, 0.5 * ref, 5e-5, f"small-channel wgrad {case}")
+    assert torch.equal(got, ops.conv_wgrad(dev(gy), dev(x), ops.ConvSpec(3, 3, 1, 1), Co, Ci, 0.5))
