@@ -77,6 +77,80 @@ __global__ void __launch_bounds__(256) upfirdn2d_kernel(const UpfirdnParams p) {
     }
 }
 
+// 4x4 FIR with decimation by 2 (up = 1, down = 2; the ResBlock skip path: blur + 1x1 stride-2 conv reads every second
+// blurred pixel only) and with zero insertion by 2 (up = 2, down = 1; its adjoint, and the ToRGB skip up-sampling):
+// fully unrolled, no divisions; the up = 2 kernel touches only the 2x2 taps whose parity matches the output pixel.
+template <int UP, int DOWN>
+__global__ void __launch_bounds__(256) fir4x4_resample_kernel(const UpfirdnParams p) {
+    static_assert((UP == 1 && DOWN == 2) || (UP == 2 && DOWN == 1), "decimate-by-2 or interpolate-by-2");
+    __shared__ float kfs[16];
+    if (threadIdx.x < 16) {
+        int a = threadIdx.x >> 2, b = threadIdx.x & 3;
+        kfs[threadIdx.x] = p.k[p.flip ? (3 - a) * 4 + (3 - b) : a * 4 + b];
+    }
+    __syncthreads();
+    float kf[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) kf[i] = kfs[i];
+    const int C4 = p.C >> 2;
+    const long total = (long)p.B * p.Ho * p.Wo * C4;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        int c4 = (int)(idx % C4);
+        long pix = idx / C4;
+        int ox = (int)(pix % p.Wo);
+        long t = pix / p.Wo;
+        int oy = (int)(t % p.Ho);
+        int b = (int)(t / p.Ho);
+        const float* xb = p.x + (size_t)b * p.Hi * p.Wi * p.C + c4 * 4;
+        float4 acc = zero4;
+        if (DOWN == 2) {
+            const int iy0 = oy * 2 - p.pady0, ix0 = ox * 2 - p.padx0;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int iy = iy0 + a;
+                const bool rok = (unsigned)iy < (unsigned)p.Hi;
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) {
+                    const int ix = ix0 + bb;
+                    const bool ok = rok && (unsigned)ix < (unsigned)p.Wi;
+                    float4 xv = *reinterpret_cast<const float4*>(xb + (ok ? ((size_t)iy * p.Wi + ix) * p.C : 0));
+                    if (!ok) xv = zero4;
+                    acc = f4fma(kf[a * 4 + bb], xv, acc);
+                }
+            }
+        } else {
+            // u = oy + a - pady0 must be even: a = a0, a0 + 2 with a0 = (oy + pady0) & 1 ; input row (u >> 1)
+            const int a0 = (oy + p.pady0) & 1, b0 = (ox + p.padx0) & 1;
+#pragma unroll
+            for (int ia = 0; ia < 2; ++ia) {
+                const int a = a0 + 2 * ia;
+                const int u = oy + a - p.pady0;
+                const int iy = u >> 1;
+                const bool rok = u >= 0 && iy < p.Hi;
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib) {
+                    const int bb = b0 + 2 * ib;
+                    const int v = ox + bb - p.padx0;
+                    const int ix = v >> 1;
+                    const bool ok = rok && v >= 0 && ix < p.Wi;
+                    float4 xv = *reinterpret_cast<const float4*>(xb + (ok ? ((size_t)iy * p.Wi + ix) * p.C : 0));
+                    if (!ok) xv = zero4;
+                    acc = f4fma(kf[a * 4 + bb], xv, acc);
+                }
+            }
+        }
+        size_t o = (size_t)pix * p.C + c4 * 4;
+        if (p.residual) acc = f4add(acc, *reinterpret_cast<const float4*>(p.residual + o));
+        if (p.bias) acc = f4add(acc, *reinterpret_cast<const float4*>(p.bias + c4 * 4));
+        if (p.act) {
+            acc.x = lrelu(acc.x, p.slope, p.gain); acc.y = lrelu(acc.y, p.slope, p.gain);
+            acc.z = lrelu(acc.z, p.slope, p.gain); acc.w = lrelu(acc.w, p.slope, p.gain);
+        }
+        *reinterpret_cast<float4*>(p.y + o) = acc;
+    }
+}
+
 // Fast path for the blur (up = down = 1, 4x4 FIR): one lane produces a TY x TX patch of output pixels for 4
 // channels, so every input float4 is loaded once per patch ((TY+3)*(TX+3) loads for TY*TX outputs: 4.4 loads
 // per output instead of 16).  Lanes are consecutive along the channel axis => fully coalesced 16-B accesses.
@@ -537,6 +611,14 @@ int gif_upfirdn2d_f32(const float* x, const float* k, float* y, int B, int Hi, i
         return gif::check_launch("upfirdn2d(blur)");
     }
     long total = (long)B * Ho * Wo * (C / 4);
+    if (KH == 4 && KW == 4 && up == 1 && down == 2) {
+        fir4x4_resample_kernel<1, 2><<<ew_grid(total), 256, 0, gif::as_stream(stream)>>>(p);
+        return gif::check_launch("upfirdn2d(down 2)");
+    }
+    if (KH == 4 && KW == 4 && up == 2 && down == 1) {
+        fir4x4_resample_kernel<2, 1><<<ew_grid(total), 256, 0, gif::as_stream(stream)>>>(p);
+        return gif::check_launch("upfirdn2d(up 2)");
+    }
     upfirdn2d_kernel<<<ew_grid(total), 256, 0, gif::as_stream(stream)>>>(p);
     return gif::check_launch("upfirdn2d");
 }

@@ -362,6 +362,14 @@ class ConvLayer(nn.Sequential):
         mods = list(self)
         if isinstance(mods[0], Blur):
             assert not passthrough
+            nxt = mods[1]
+            if (isinstance(nxt, EqualConv2d) and nxt.weight.shape[2] == 1 and nxt.weight.shape[3] == 1 and nxt.stride == 2
+                    and nxt.padding == 0 and len(mods) == 2 and nxt.bias is None):
+                # blur followed by a 1x1 stride-2 conv (the ResBlock skip): the conv only ever reads every second blurred
+                # pixel, so blur AND decimate in one FIR pass (a quarter of the outputs) and run the 1x1 conv at stride 1 —
+                # the same taps for the kept pixels, i.e. the same function, without the full-resolution blurred tensor
+                input = upfirdn2d(input, mods[0].kernel, up=1, down=2, pad=mods[0].pad)
+                return GF.conv2d(input, nxt.weight, 1, 0, wscale=nxt.scale)
             input = mods[0](input)
             mods = mods[1:]
         conv = mods[0]

@@ -280,7 +280,8 @@ def test_conv_wgrad_with_scales():
 
 # ------------------------------------------------------------------------------------------------ FIR / pointwise
 @pytest.mark.parametrize("cfg", [(1, 1, (2, 2), 16), (1, 1, (1, 1), 17), (2, 1, (2, 1), 8), (1, 2, (1, 1), 16),
-                                 (1, 1, (-1, 2), 9), (2, 2, (3, 0), 8), (1, 1, (1, 1), 33)])
+                                 (1, 1, (-1, 2), 9), (2, 2, (3, 0), 8), (1, 1, (1, 1), 33), (1, 2, (1, 1), 17), (2, 1, (1, 1), 9),
+                                 (1, 2, (2, 2), 31), (2, 1, (3, 1), 12)])
 def test_upfirdn2d_fwd_bwd(cfg):
     from gif_amd import functional as GF
     from oracle import stylegan2_ref as R
