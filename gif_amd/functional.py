@@ -119,9 +119,9 @@ def conv2d_bias_act(x, w, bias, stride=1, pad=0, wscale=1.0, slope=0.2, gain=2 *
     return ConvBiasActFn.apply(x, w, bias, ConvSpec(w.shape[2], w.shape[3], stride, pad), wscale, slope, gain, bool(passthrough))
 
 
-def conv2d(x, w, stride=1, pad=0, wscale=1.0):
-    """x [B,C,H,W] with C == pad4(w.shape[1]); returns [B, pad4(O), Ho, Wo]."""
-    return Conv2dFn.apply(x, w, ConvSpec(w.shape[2], w.shape[3], stride, pad), False, None, wscale, None)
+def conv2d(x, w, stride=1, pad=0, wscale=1.0, residual=None):
+    """x [B,C,H,W] with C == pad4(w.shape[1]); returns [B, pad4(O), Ho, Wo] (+ residual, added in the kernel epilogue)."""
+    return Conv2dFn.apply(x, w, ConvSpec(w.shape[2], w.shape[3], stride, pad), False, None, wscale, residual)
 
 
 def conv_transpose2d(x, w, stride, pad, out_hw, wscale=1.0):

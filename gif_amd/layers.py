@@ -356,9 +356,11 @@ class ConvLayer(nn.Sequential):
             layers.append(FusedLeakyReLU(out_channel) if bias else ScaledLeakyReLU(0.2))
         super().__init__(*layers)
 
-    def forward(self, input, passthrough=False):
+    def forward(self, input, passthrough=False, out_scale=1.0, residual=None):
         """passthrough=True (fused, non-downsampling layers only): returns (out, input') with input' an alias of the
-        input for a second consumer — see functional.ConvBiasActFn."""
+        input for a second consumer — see functional.ConvBiasActFn.
+        out_scale / residual (ResBlock): the layer's result is multiplied by out_scale (folded into the activation gain or
+        the weight scale — no extra pass) and, for the blur + 1x1 layer, `residual` is added in the conv epilogue."""
         mods = list(self)
         if isinstance(mods[0], Blur):
             assert not passthrough
@@ -369,14 +371,16 @@ class ConvLayer(nn.Sequential):
                 # pixel, so blur AND decimate in one FIR pass (a quarter of the outputs) and run the 1x1 conv at stride 1 —
                 # the same taps for the kept pixels, i.e. the same function, without the full-resolution blurred tensor
                 input = upfirdn2d(input, mods[0].kernel, up=1, down=2, pad=mods[0].pad)
-                return GF.conv2d(input, nxt.weight, 1, 0, wscale=nxt.scale)
+                return GF.conv2d(input, nxt.weight, 1, 0, wscale=nxt.scale * out_scale, residual=residual)
             input = mods[0](input)
             mods = mods[1:]
+        assert residual is None, "residual is only fused into the blur + 1x1 layer"
         conv = mods[0]
         if len(mods) == 2 and isinstance(mods[1], FusedLeakyReLU) and conv.bias is None:
             act = mods[1]  # EqualConv2d + FusedLeakyReLU => bias and lrelu run in the conv kernel's epilogue
             return GF.conv2d_bias_act(input, conv.weight, _pad_vec(act.bias, pad4(conv.weight.shape[0])), conv.stride,
-                                      conv.padding, conv.scale, act.negative_slope, act.scale, passthrough)
+                                      conv.padding, conv.scale, act.negative_slope, act.scale * out_scale, passthrough)
+        assert out_scale == 1.0, "out_scale needs one of the fused layer forms"
         first = input
         for m in mods:
             input = m(input)
@@ -384,7 +388,7 @@ class ConvLayer(nn.Sequential):
 
 
 class ResBlock(nn.Module):
-    """Reference :802-820; (out + skip)/sqrt(2) is one fused kernel."""
+    """Reference :802-820; (out + skip)/sqrt(2) runs in the conv epilogues (no elementwise pass)."""
 
     def __init__(self, in_channel, out_channel, blur_kernel=[1, 3, 3, 1]):
         super().__init__()
@@ -395,7 +399,9 @@ class ResBlock(nn.Module):
     def forward(self, input):
         # the skip branch consumes the alias handed back by conv1: its input gradient is then accumulated inside conv1's
         # data-gradient kernel instead of by a separate add over two full-resolution tensors
+        # (conv2(conv1(x)) + skip(x)) / sqrt(2) without a separate add/scale pass: 1/sqrt(2) is folded into conv2's
+        # activation gain and into the skip conv's weight scale, and the skip conv adds conv2's output in its epilogue
         out, input_alias = self.conv1(input, passthrough=True)
-        out = self.conv2(out)
-        skip = self.skip(input_alias)
-        return GF.bias_act(out, None, skip, 1.0, 1 / math.sqrt(2))
+        r = 1 / math.sqrt(2)
+        out = self.conv2(out, out_scale=r)
+        return self.skip(input_alias, out_scale=r, residual=out)
