@@ -92,16 +92,17 @@ __global__ void __launch_bounds__(256) fir4x4_resample_kernel(const UpfirdnParam
     float kf[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) kf[i] = kfs[i];
-    const int C4 = p.C >> 2;
-    const long total = (long)p.B * p.Ho * p.Wo * C4;
+    // grid: x over (ox, c4) of one output row, y over (b, oy): the row decomposition is block-uniform (scalar ALU) and the
+    // per-lane index math is two 32-bit operations (64-bit div/mod per output made this kernel ALU- instead of HBM-bound)
+    const unsigned C4 = (unsigned)p.C >> 2;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        int c4 = (int)(idx % C4);
-        long pix = idx / C4;
-        int ox = (int)(pix % p.Wo);
-        long t = pix / p.Wo;
-        int oy = (int)(t % p.Ho);
-        int b = (int)(t / p.Ho);
+    const unsigned row = blockIdx.y;
+    const int b = (int)(row / (unsigned)p.Ho), oy = (int)(row - (unsigned)b * (unsigned)p.Ho);
+    const unsigned row_items = (unsigned)p.Wo * C4;
+    for (unsigned it = blockIdx.x * blockDim.x + threadIdx.x; it < row_items; it += gridDim.x * blockDim.x) {
+        const int ox = (int)(it / C4);
+        const int c4 = (int)(it - (unsigned)ox * C4);
+        const long pix = ((long)b * p.Ho + oy) * p.Wo + ox;
         const float* xb = p.x + (size_t)b * p.Hi * p.Wi * p.C + c4 * 4;
         float4 acc = zero4;
         if (DOWN == 2) {
@@ -611,13 +612,14 @@ int gif_upfirdn2d_f32(const float* x, const float* k, float* y, int B, int Hi, i
         return gif::check_launch("upfirdn2d(blur)");
     }
     long total = (long)B * Ho * Wo * (C / 4);
-    if (KH == 4 && KW == 4 && up == 1 && down == 2) {
-        fir4x4_resample_kernel<1, 2><<<ew_grid(total), 256, 0, gif::as_stream(stream)>>>(p);
-        return gif::check_launch("upfirdn2d(down 2)");
-    }
-    if (KH == 4 && KW == 4 && up == 2 && down == 1) {
-        fir4x4_resample_kernel<2, 1><<<ew_grid(total), 256, 0, gif::as_stream(stream)>>>(p);
-        return gif::check_launch("upfirdn2d(up 2)");
+    if (KH == 4 && KW == 4 && (long)B * Ho <= 65535 && ((up == 1 && down == 2) || (up == 2 && down == 1))) {
+        const long row_items = (long)Wo * (C / 4);
+        long gx = (row_items + 255) / 256;
+        if (gx > 64) gx = 64;
+        const dim3 grid((unsigned)gx, (unsigned)((long)B * Ho));
+        if (down == 2) fir4x4_resample_kernel<1, 2><<<grid, 256, 0, gif::as_stream(stream)>>>(p);
+        else fir4x4_resample_kernel<2, 1><<<grid, 256, 0, gif::as_stream(stream)>>>(p);
+        return gif::check_launch("upfirdn2d(resample by 2)");
     }
     upfirdn2d_kernel<<<ew_grid(total), 256, 0, gif::as_stream(stream)>>>(p);
     return gif::check_launch("upfirdn2d");
