@@ -47,18 +47,19 @@ __global__ void __launch_bounds__(256) wino_input_transform(const float* __restr
     const long ntiles = (long)B * TH * TW;
     const long total = ntiles * C4;
     const size_t plane = (size_t)ntiles_pad * CP;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c4 = (int)(idx % C4);
-        const long tile = idx / C4;
+    // 32-bit index math (callers guarantee ntiles_pad * CP < 2^31): 64-bit div/mod costs ~60 instructions each
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < (unsigned)total; idx += gridDim.x * blockDim.x) {
+        const unsigned tile = idx / (unsigned)C4;
+        const int c4 = (int)(idx - tile * (unsigned)C4);
         float* vout = V + (size_t)tile * CP + c4 * 4;
         if (c4 * 4 >= C) {  // channel padding
 #pragma unroll
             for (int q = 0; q < 16; ++q) *reinterpret_cast<f32x4*>(vout + q * plane) = (f32x4)(0.f);
             continue;
         }
-        const int tx = (int)(tile % TW);
-        const long t2 = tile / TW;
-        const int ty = (int)(t2 % TH), b = (int)(t2 / TH);
+        const unsigned t2 = tile / (unsigned)TW;
+        const int tx = (int)(tile - t2 * (unsigned)TW);
+        const int b = (int)(t2 / (unsigned)TH), ty = (int)(t2 - (unsigned)b * (unsigned)TH);
         const float* xb = x + ((size_t)b * H * W) * C + c4 * 4;
         f32x4 d[4][4];
 #pragma unroll
@@ -103,18 +104,19 @@ __global__ void __launch_bounds__(256) wino_gy_transform(const float* __restrict
     const long ntiles = (long)B * TH * TW;
     const long total = ntiles * C4;
     const size_t plane = (size_t)ntiles_pad * CP;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c4 = (int)(idx % C4);
-        const long tile = idx / C4;
+    // 32-bit index math (callers guarantee ntiles_pad * CP < 2^31): 64-bit div/mod costs ~60 instructions each
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < (unsigned)total; idx += gridDim.x * blockDim.x) {
+        const unsigned tile = idx / (unsigned)C4;
+        const int c4 = (int)(idx - tile * (unsigned)C4);
         float* out = Mg + (size_t)tile * CP + c4 * 4;
         if (c4 * 4 >= C) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) *reinterpret_cast<f32x4*>(out + q * plane) = (f32x4)(0.f);
             continue;
         }
-        const int tx = (int)(tile % TW);
-        const long t2 = tile / TW;
-        const int ty = (int)(t2 % TH), b = (int)(t2 / TH);
+        const unsigned t2 = tile / (unsigned)TW;
+        const int tx = (int)(tile - t2 * (unsigned)TW);
+        const int b = (int)(t2 / (unsigned)TH), ty = (int)(t2 - (unsigned)b * (unsigned)TH);
         const float* g0 = gy + (((size_t)b * H + 2 * ty) * W + 2 * tx) * C + c4 * 4;
         f32x4 s = (f32x4)(1.f);
         if (scale) s = *reinterpret_cast<const f32x4*>(scale + (size_t)b * C + c4 * 4);
