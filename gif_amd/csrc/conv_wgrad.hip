@@ -305,6 +305,20 @@ void wgrad_launch(dim3 grid, int threads, hipStream_t s, const WgradParams& p) {
 // rows RP multiple of 32 or 128, cols CP multiple of 8 or 32 — so pad further to the tile here.
 inline int tile_of(int c) { return c <= 32 ? 32 : 128; }
 
+// 256x128 tiles (wave tile 128x64: 6 LDS operand reads per 8 MFMAs instead of 4 per 4 — the operand reads, one ds_read_b32 per
+// MFMA operand in this [pixel][channel] layout, are what caps the 128x128 kernel) whenever the row count allows it and the
+// operands go through the plain LDS-DMA path.  GIF_WGRAD_BIG=0 disables it.
+inline bool wgrad_big_tile(int Cs, int Cb, bool scaled, long Ntot) {
+    static int off = -1;
+    if (off < 0) {
+        const char* e = getenv("GIF_WGRAD_BIG");
+        off = (e && atoi(e) == 0) ? 1 : 0;
+    }
+    // (below ~16K reduction rows the halved workgroup count costs more than the operand reuse gains: measured)
+    return !off && !scaled && Ntot >= 16384 && tile_of(Cs) == 128 && tile_of(Cb) == 128 && ((Cs + 127) / 128 * 128) % 256 == 0;
+}
+inline int tile_rows(int Cs, int Cb, bool scaled, long Ntot) { return wgrad_big_tile(Cs, Cb, scaled, Ntot) ? 256 : tile_of(Cs); }
+
 __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int R, int C, int KH,
                                    int KW, int RP, int CP, long sr, long sc, long sky, long skx, float scale) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -546,8 +560,9 @@ int gif_conv2d_wgrad_splits(const gif_conv_geom* g) {
                                                // reach that kernel and simply use 256 splits of the generic one
     int RP, CP;
     wgrad_dims(g->Cs, g->Cb, &RP, &CP);
-    long tiles = (long)(RP / tile_of(g->Cs)) * (CP / tile_of(g->Cb)) * g->KH * g->KW;
+    // (scaled launches of the same geometry use 128-row tiles: they simply get half the splits they could use)
     long Ntot = (long)g->B * g->Hs * g->Ws;
+    long tiles = (long)(RP / tile_rows(g->Cs, g->Cb, false, Ntot)) * (CP / tile_of(g->Cb)) * g->KH * g->KW;
     // 2 workgroups fit per CU (64 KB LDS each) => 512 concurrent slots on 256 CUs: fill k full rounds of 512
     // and never spill a few blocks into an extra, almost empty round (floor, not ceil)
     long want = tiles >= 1024 ? 1 : 1024 / tiles;
@@ -579,8 +594,9 @@ int gif_conv2d_wgrad_f32(const float* small, const float* big, float* ws, const 
     p.chunk = (chunk + BKP_MAX - 1) / BKP_MAX * BKP_MAX;
     if (p.chunk < BKP_MAX) p.chunk = BKP_MAX;
     const int bp = tile_of(g->Cs), bq = tile_of(g->Cb);
+    const bool big_tile = wgrad_big_tile(g->Cs, g->Cb, small_scale || big_scale, p.Ntot) && !getenv("GIF_CONV_VARIANT");
     p.tiles_q = p.CP / bq;
-    p.tiles_pq = (p.RP / bp) * p.tiles_q;
+    p.tiles_pq = (p.RP / (big_tile ? 256 : bp)) * p.tiles_q;
     dim3 grid((unsigned)(p.tiles_pq * p.T * nsplit));
     hipStream_t s = gif::as_stream(stream);
     static const float* zero_page = nullptr;
@@ -621,7 +637,9 @@ int gif_conv2d_wgrad_f32(const float* small, const float* big, float* ws, const 
         if (p.stab_nb > g->B) p.stab_nb = g->B;
         const bool tab = (small_scale || big_scale) && variant != 1 && HWs % 16 == 0 &&
                          (size_t)p.stab_nb * 256 * sizeof(float) <= 64 * 1024;
-        if (bp == 128 && bq == 128 && tab) {
+        if (big_tile) {
+            wgrad_launch<256, 128, 2, 2, true, 16>(grid, 256, s, p);
+        } else if (bp == 128 && bq == 128 && tab) {
             // modulated wgrad (x*s, dy*d): LDS-DMA operands + scale table
             wgrad_launch<128, 128, 2, 2, true, 16, true>(grid, 256, s, p);
         } else if (bp == 128 && bq == 128 && glds && variant != 7) {
@@ -652,8 +670,8 @@ int gif_conv3x3_winograd_wgrad_splits(int B, int H, int W, int Cs, int Cb) {
     if (B <= 0 || H <= 0 || W <= 0 || Cs <= 0 || Cb <= 0) return 1;
     int RP, CP;
     wgrad_dims(Cs, Cb, &RP, &CP);
-    long tiles = (long)(RP / tile_of(Cs)) * (CP / tile_of(Cb)) * 16;
     long Ntot = (long)B * (H / 2) * (W / 2);
+    long tiles = (long)(RP / tile_rows(Cs, Cb, false, Ntot)) * (CP / tile_of(Cb)) * 16;
     long want = tiles >= 1024 ? 1 : 1024 / tiles;
     long max_by_work = (Ntot + 4 * BKP_MAX - 1) / (4 * BKP_MAX);
     long max_by_mem = (128L << 20) / (16L * RP * CP * 4);
@@ -699,8 +717,9 @@ int gif_conv3x3_winograd_wgrad_f32(const float* x, const float* gy, float* V, fl
     p.chunk = (chunk + BKP_MAX - 1) / BKP_MAX * BKP_MAX;
     if (p.chunk < BKP_MAX) p.chunk = BKP_MAX;
     const int bp = tile_of(CsP), bq = tile_of(CbP);
+    const bool big = wgrad_big_tile(CsP, CbP, false, ntiles);
     p.tiles_q = p.CP / bq;
-    p.tiles_pq = (p.RP / bp) * p.tiles_q;
+    p.tiles_pq = (p.RP / (big ? 256 : bp)) * p.tiles_q;
     dim3 grid((unsigned)(p.tiles_pq * p.T * nsplit));
     static const float* zero_page = nullptr;
     if (!zero_page) {
@@ -709,7 +728,8 @@ int gif_conv3x3_winograd_wgrad_f32(const float* x, const float* gy, float* V, fl
         zero_page = static_cast<const float*>(zp);
     }
     p.zero = zero_page;
-    if (bp == 128 && bq == 128) wgrad_launch<128, 128, 2, 2, true, 16>(grid, 256, s, p);
+    if (big) wgrad_launch<256, 128, 2, 2, true, 16>(grid, 256, s, p);
+    else if (bp == 128 && bq == 128) wgrad_launch<128, 128, 2, 2, true, 16>(grid, 256, s, p);
     else if (bp == 128 && bq == 32) wgrad_launch<128, 32, 4, 1, true, 32>(grid, 256, s, p);
     else if (bp == 32 && bq == 128) wgrad_launch<32, 128, 1, 4, true, 32>(grid, 256, s, p);
     else wgrad_launch<32, 32, 1, 1, true, 32>(grid, 64, s, p);
