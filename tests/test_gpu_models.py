@@ -340,3 +340,48 @@ def test_path_length_regulariser_value_parity_with_reference_class(monkeypatch):
         assert abs(pen.item() - g["penalty"][k]) < 1e-5 * g["penalty"][k], (k, pen.item(), g["penalty"][k])
         assert abs(float(reg.pl_moving_mean) - g["moving_mean"][k]) < 1e-5 * g["moving_mean"][k]
         assert not pen.requires_grad, "reference semantics: no create_graph => the penalty carries no gradient"
+
+
+def test_training_trajectory_vs_oracle_trainer():
+    """a14 end to end: two full iterations (the second an R1 iteration) of gif_amd.train_step.GifTrainer against the CPU
+    restatement of train.py:82-250 (oracle/train_ref.py) from the same seeded weights and the same batches: losses of both
+    iterations, parameters after the Adam steps and the EMA generator.
+
+    Adam with beta1 = 0 moves every weight by ~lr * sign(grad) on its first step, so an entry whose gradient is within rounding
+    of zero may move the other way: parameters are compared on the fraction of entries that agree, losses on their values."""
+    from oracle import stylegan2_ref as R
+    from oracle.train_ref import RefTrainer
+    from gif_amd.train_step import GifTrainer
+    torch.manual_seed(0)
+    G, G_ema, D = _build_g(vocab=16), _build_g(vocab=16), _build_d(32)
+    g_sd = R.seeded_state_dict(G.state_dict(), 61)
+    d_sd = R.seeded_state_dict(D.state_dict(), 62)
+    G.load_state_dict(g_sd, strict=True)
+    G_ema.load_state_dict(g_sd, strict=True)
+    D.load_state_dict(d_sd, strict=True)
+    ref = RefTrainer(g_sd, d_sd, res_step=3, size=32, r1_every=2)
+    tr = GifTrainer(G.cuda(), D.cuda(), G_ema.cuda(), step=3, alpha=1.0, r1_every=2)
+    gen = torch.Generator().manual_seed(63)
+    for i in range(2):
+        real = torch.rand(4, 3, 32, 32, generator=gen) * 2 - 1
+        cond = torch.rand(4, 6, 32, 32, generator=gen) * 2 - 1
+        idx = torch.randint(0, 16, (4,), generator=gen)
+        d_ref, g_ref = ref.step(i, real, cond, idx)
+        d_got, g_got = tr.step(i, real.cuda(), cond.cuda(), idx.cuda())
+        assert abs(d_got.item() - d_ref.item()) < 2e-3 * max(1.0, abs(d_ref.item())), (i, d_got.item(), d_ref.item())
+        assert abs(g_got.item() - g_ref.item()) < 2e-3 * max(1.0, abs(g_ref.item())), (i, g_got.item(), g_ref.item())
+    lr_g, lr_d = 0.002 * 4 / 5, 0.002 * 16 / 17
+    for model, leaves, lr in ((G, ref.g, lr_g), (D, ref.d, lr_d)):
+        sd = model.state_dict()
+        agree, total = 0, 0
+        for k, v in leaves.items():
+            if not v.requires_grad:
+                continue
+            diff = (sd[k].detach().cpu() - v.detach()).abs()
+            agree += int((diff <= 0.05 * lr).sum())
+            total += diff.numel()
+            assert diff.max().item() <= 4.2 * lr, (k, diff.max().item())  # at most two sign flips of lr-sized steps
+        assert agree / total > 0.995, (agree, total)
+    decay = 0.5 ** (32 / 10000)
+    w_ema = G_ema.state_dict()["generator.progression.2.st_cv2.conv.weight"].cpu()
+    assert (w_ema - ref.g_ema["generator.progression.2.st_cv2.conv.weight"]).abs().max().item() < 4.2 * lr_g * (1 - decay) * 2 + 1e-6
