@@ -681,3 +681,44 @@ def test_small_channel_wgrad_kernel(case):
     got = ops.conv_wgrad(dev(gy), dev(x), ops.ConvSpec(3, 3, 1, 1), Co, Ci, 0.5)
     assert_close(got, 0.5 * ref, 5e-5, f"small-channel wgrad {case}")
     assert torch.equal(got, ops.conv_wgrad(dev(gy), dev(x), ops.ConvSpec(3, 3, 1, 1), Co, Ci, 0.5))
+
+
+@pytest.mark.parametrize("case", [
+    ("winograd 128->128 @256^2", 128, 128, 3, 1, 1, 256),
+    ("winograd 512->512 @64^2", 512, 512, 3, 1, 1, 64),
+    ("stride-2 128->256 @257^2", 128, 256, 3, 2, 0, 257),
+    ("1x1 12->128 @256^2", 12, 128, 1, 1, 0, 256),
+])
+def test_full_size_conv_linearity_and_adjointness(case):
+    """BASELINE sizes (batch 32, the benchmark's layer shapes) have no CPU reference that finishes in seconds; what must hold
+    at any size is checked instead: linearity of the forward op, and that forward, data gradient and weight gradient are
+    adjoints of ONE bilinear map:  <conv(x, w), g> == <x, dgrad(g, w)> == <w, wgrad(g, x)>  (dot products in float64)."""
+    from gif_amd import ops
+    name, Ci, Co, K, s, p, H = case
+    B = 32
+    spec = ops.ConvSpec(K, K, s, p)
+    gen = torch.Generator(device="cuda").manual_seed(51)
+    x1 = torch.randn(B, Ci, H, H, device="cuda", generator=gen).contiguous(memory_format=torch.channels_last)
+    x2 = torch.randn(B, Ci, H, H, device="cuda", generator=gen).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(Co, Ci, K, K, device="cuda", generator=gen) / (K * Ci ** 0.5)
+    y1 = ops.conv_fwd(x1, w, spec)
+    y2 = ops.conv_fwd(x2, w, spec)
+    y12 = ops.conv_fwd(2.0 * x1 - 3.0 * x2, w, spec)
+    lin = 2.0 * y1 - 3.0 * y2
+    assert ((y12 - lin).abs().max() / lin.abs().max()).item() < 2e-5, f"{name}: linearity"
+    del y2, y12, lin, x2
+    g = torch.randn(y1.shape, device="cuda", generator=gen).contiguous(memory_format=torch.channels_last)
+
+    def dot(a, b):
+        return (a.double() * b.double()).sum().item()
+
+    lhs = dot(y1, g)
+    gx = ops.conv_bwd_data(g, w, spec, (H, H))
+    mid = dot(x1, gx)
+    gw = ops.conv_wgrad(g, x1, spec, Co, Ci)
+    rhs = dot(w, gw)
+    scale = (y1.double().norm() * g.double().norm()).item()
+    assert abs(lhs - mid) < 2e-6 * scale, f"{name}: <conv(x), g> vs <x, dgrad(g)>: {lhs} {mid}"
+    assert abs(lhs - rhs) < 2e-6 * scale, f"{name}: <conv(x), g> vs <w, wgrad(g, x)>: {lhs} {rhs}"
+    assert gx.shape == x1.shape and gw.shape == w.shape
+    assert torch.equal(gw, ops.conv_wgrad(g, x1, spec, Co, Ci)), f"{name}: wgrad must be deterministic"
