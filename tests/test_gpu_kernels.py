@@ -722,3 +722,33 @@ def test_full_size_conv_linearity_and_adjointness(case):
     assert abs(lhs - rhs) < 2e-6 * scale, f"{name}: <conv(x), g> vs <w, wgrad(g, x)>: {lhs} {rhs}"
     assert gx.shape == x1.shape and gw.shape == w.shape
     assert torch.equal(gw, ops.conv_wgrad(g, x1, spec, Co, Ci)), f"{name}: wgrad must be deterministic"
+
+
+def test_rasterize_bit_exact_at_benchmark_batch():
+    """Config 3 size: 32 poses of the bundled body mesh (V=6890, F=13776) at 256x256 — depth bits, face indices and
+    barycentric bits of the HIP rasteriser against the C oracle, plus idempotence of a second launch."""
+    from gif_amd import standard_rasterize as sr
+    from oracle import rasterize_oracle as ro
+    g, v, f = _body()
+    rng = np.random.RandomState(7)
+    vs = []
+    for i in range(32):
+        a, b = rng.uniform(-0.8, 0.8), rng.uniform(-0.3, 0.3)
+        Ry = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], np.float32)
+        Rx = np.array([[1, 0, 0], [0, np.cos(b), -np.sin(b)], [0, np.sin(b), np.cos(b)]], np.float32)
+        vs.append((v[0] @ (Ry @ Rx).T * np.float32(rng.uniform(0.8, 1.2))).astype(np.float32))
+    v32 = np.stack(vs)
+    f32 = np.repeat(f, 32, 0)
+    h = w = 256
+    fv = ro.face_vertices(ro.to_image_space(v32, h, w), f32)
+    d0, t0, b0 = ro.new_buffers(32, h, w)
+    ro.standard_rasterize(fv, d0, t0, b0, h, w)
+    fvt = torch.from_numpy(fv).cuda()
+    d1, t1, b1 = sr.new_buffers(32, h, w, "cuda")
+    sr.standard_rasterize(fvt, d1, t1, b1, h, w)
+    assert np.array_equal(t1.cpu().numpy(), t0), "face indices"
+    assert np.array_equal(d1.cpu().numpy().view(np.uint32), d0.view(np.uint32)), "depth bits"
+    assert np.array_equal(b1.cpu().numpy().view(np.uint32), b0.view(np.uint32)), "barycentric bits"
+    assert (t0 >= 0).mean() > 0.05
+    sr.standard_rasterize(fvt, d1, t1, b1, h, w)
+    assert np.array_equal(t1.cpu().numpy(), t0) and np.array_equal(d1.cpu().numpy().view(np.uint32), d0.view(np.uint32))
