@@ -66,6 +66,9 @@ PROTOTYPES = {
     "gif_mbstd_fwd_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "gif_mbstd_bwd_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "gif_sqnorm_per_sample_f32": (c_int, [P, P, c_int, c_i64, P]),
+    "gif_adam_chunk_floats": (c_int, []),
+    "gif_adam_ema_step_f32": (c_int, [P, c_int, P, P, P, c_float, c_float, c_float, c_float, ctypes.c_double, ctypes.c_double,
+                                      c_float, c_int, P]),
     "gif_prof_enable": (c_int, [c_int]),
     "gif_prof_read": (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64)]),
 }

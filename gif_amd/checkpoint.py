@@ -25,6 +25,8 @@ def strip_module_prefix(state_dict):
 
 def checkpoint_dict(trainer):
     """The reference's 5-entry checkpoint dict, DataParallel-style keys (train.py:257-261)."""
+    if hasattr(trainer, "flush"):
+        trainer.flush()  # complete a discriminator update deferred behind the generator forward (overlap_comm)
     return {"generator_running": add_module_prefix(trainer.G_ema.state_dict()),
             "generator": add_module_prefix(trainer.G.state_dict()),
             "g_optimizer": trainer.g_optim.state_dict(),

@@ -31,6 +31,18 @@ inline hipStream_t as_stream(gif_stream_t s) { return reinterpret_cast<hipStream
 
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// ---- per-device launch state (runtime.hip).  The library may be driven for several devices of one process (tensors on
+// cuda:1, DataParallel-style hosts) and from several threads (forward thread + autograd thread): nothing device-specific is
+// cached in a plain static.
+constexpr int kMaxDevices = 64;
+int current_device();           // hipGetDevice(), validated against kMaxDevices
+const float* zero_page16();     // 16 zero bytes in the CURRENT device's memory (source of out-of-range LDS-DMA lanes)
+// "this kernel may use `bytes` of dynamic LDS on the current device": hipFuncSetAttribute once per (kernel, device, size step)
+struct LdsAttr {
+    unsigned long granted[kMaxDevices] = {};
+    void ensure(const void* kernel, size_t bytes);
+};
+
 // ---- kernel profiling (runtime.hip): HIP events around launches, grouped in families ----
 // 0 direct conv fwd/dgrad on the LDS-DMA kernel (Cin >= 32; flops), 1 direct wgrad (flops), 2 Winograd GEMM fwd/dgrad
 // (ALGORITHMIC direct-conv flops; the kernel executes 16/36 of them), 3 Winograd wgrad GEMM (same convention),

@@ -309,8 +309,6 @@ __global__ void __launch_bounds__(256) conv_gather_mfma(const GatherParams p) {
 // Out-of-image / out-of-range lanes read a 16-byte zero page instead of being masked.
 // SCALE: input modulation (ModulatedConv2d's s[b,ci], or d[b,co] in its dgrad) through an LDS table, see below.
 // ------------------------------------------------------------------------------------------------------------------
-__device__ __attribute__((aligned(16))) float g_zero_page[4];
-
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool SCALE, int BK>
 __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, const int nwg) {
     constexpr int LD = BK;             // unpadded LDS row (floats)
@@ -523,14 +521,11 @@ inline TileCfg pick_cfg(int cout, int cin) {
 }
 
 template <typename K>
-int launch_kernel(K kern, GatherParams& p, int BM, int BN, int BK, hipStream_t s, bool& attr_set) {
+int launch_kernel(K kern, GatherParams& p, int BM, int BN, int BK, hipStream_t s, gif::LdsAttr& attr) {
     p.tiles_m = gif::cdiv(p.M - p.m_begin, BM);
     p.tiles_n = p.RP / BN;
     size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    attr.ensure(reinterpret_cast<const void*>(kern), lds);
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
     return 0;
@@ -538,13 +533,13 @@ int launch_kernel(K kern, GatherParams& p, int BM, int BN, int BK, hipStream_t s
 
 template <int BM, int BN, int BK, int WMv, int WNv>
 int launch_simple(GatherParams& p, hipStream_t s) {
-    static bool attr = false;
+    static gif::LdsAttr attr;
     return launch_kernel(conv_gather_mfma<BM, BN, BK, WMv, WNv>, p, BM, BN, BK, s, attr);
 }
 
 template <int BM, int BN, int WMv, int WNv, bool SCALE, int BK>
 int launch_glds_impl(GatherParams& p, hipStream_t s) {
-    static size_t attr_bytes = 0;
+    static gif::LdsAttr attr;
     p.tiles_m = gif::cdiv(p.M - p.m_begin, BM);
     p.tiles_n = p.RP / BN;
     size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
@@ -560,17 +555,10 @@ int launch_glds_impl(GatherParams& p, hipStream_t s) {
     }
     if (lds > 160 * 1024) return -100;  // caller falls back to the register-staged kernel
     auto kern = conv_gather_mfma_glds<BM, BN, WMv, WNv, SCALE, BK>;
-    if (lds > attr_bytes) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_bytes = lds;
-    }
-    static const float* zero_page = nullptr;  // passed as a kernel argument: a GOT load inside the K loop costs a scalar
-    if (!zero_page) {                          // memory round trip + s_waitcnt per stage
-        void* zp = nullptr;
-        if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero_page)) != hipSuccess) return -101;
-        zero_page = static_cast<const float*>(zp);
-    }
-    p.zero = zero_page;
+    attr.ensure(reinterpret_cast<const void*>(kern), lds);
+    // passed as a kernel argument: a GOT load inside the K loop costs a scalar memory round trip + s_waitcnt per stage
+    p.zero = gif::zero_page16();
+    if (!p.zero) return -101;
     hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(256), lds, s, p);
     return 0;
 }
@@ -579,13 +567,9 @@ int launch_glds_impl(GatherParams& p, hipStream_t s) {
 template <bool SCALE>
 int launch_glds_multi(GatherParams* ph, int nph, hipStream_t s) {
     constexpr int BM = 64, BN = 64, BK = 32;
-    static size_t attr_bytes = 0;
-    static const float* zero_page = nullptr;
-    if (!zero_page) {
-        void* zp = nullptr;
-        if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero_page)) != hipSuccess) return -101;
-        zero_page = static_cast<const float*>(zp);
-    }
+    static gif::LdsAttr attr;
+    const float* zero_page = gif::zero_page16();
+    if (!zero_page) return -101;
     MultiParams mp{};
     size_t lds_max = 0;
     int total = 0;
@@ -613,10 +597,7 @@ int launch_glds_multi(GatherParams* ph, int nph, hipStream_t s) {
     mp.nph = nph;
     if (lds_max > 160 * 1024) return -100;
     auto kern = conv_gather_mfma_glds_multi<BM, BN, 2, 2, SCALE, BK>;
-    if (lds_max > attr_bytes) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
-        attr_bytes = lds_max;
-    }
+    attr.ensure(reinterpret_cast<const void*>(kern), lds_max);
     hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), lds_max, s, mp);
     return 0;
 }

@@ -46,8 +46,6 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + idx;
 }
 
-__device__ __attribute__((aligned(16))) float g_wgrad_zero_page[4];
-
 // GLDS = true (no per-sample scales): both operand tiles go global -> LDS directly (global_load_lds_dwordx4, lane-linear
 // destination == the [pixel][channel] tile layout), no staging registers / ds_write; invalid lanes read a zero page.
 // TAB = true (GLDS with per-sample scales, needs Hs*Ws % BKP == 0 so that a stage never straddles two samples): the
@@ -291,13 +289,10 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const 
 
 template <int BP, int BQ, int WP_, int WQ_, bool GLDS, int BKP, bool TAB = false>
 void wgrad_launch(dim3 grid, int threads, hipStream_t s, const WgradParams& p) {
-    static size_t attr_bytes = 0;
+    static gif::LdsAttr attr;
     const size_t lds = (size_t)(2 * BKP * (BP + BQ) + (TAB ? p.stab_nb * (BP + BQ) : 0)) * sizeof(float);
     auto kern = conv_wgrad_mfma<BP, BQ, WP_, WQ_, GLDS, BKP, TAB>;
-    if (lds > attr_bytes) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_bytes = lds;
-    }
+    attr.ensure(reinterpret_cast<const void*>(kern), lds);
     hipLaunchKernelGGL(kern, grid, dim3(threads), lds, s, p);
 }
 
@@ -599,13 +594,8 @@ int gif_conv2d_wgrad_f32(const float* small, const float* big, float* ws, const 
     p.tiles_pq = (p.RP / (big_tile ? 256 : bp)) * p.tiles_q;
     dim3 grid((unsigned)(p.tiles_pq * p.T * nsplit));
     hipStream_t s = gif::as_stream(stream);
-    static const float* zero_page = nullptr;
-    if (!zero_page) {
-        void* zp = nullptr;
-        GIF_REQUIRE(hipGetSymbolAddress(&zp, HIP_SYMBOL(g_wgrad_zero_page)) == hipSuccess, "conv2d_wgrad: zero page lookup failed");
-        zero_page = static_cast<const float*>(zp);
-    }
-    p.zero = zero_page;
+    p.zero = gif::zero_page16();
+    GIF_REQUIRE(p.zero, "conv2d_wgrad: zero page lookup failed");
     double flops = 2.0 * p.Ntot * (double)g->Cs * g->Cb * p.T;
     if (small_wgrad_ok(g, small_scale || big_scale)) {
         gif::ProfScope prof(1, flops, s, (int)p.Ntot, g->Cs, g->Cb, p.T * 10 + g->stride);
@@ -616,11 +606,8 @@ int gif_conv2d_wgrad_f32(const float* small, const float* big, float* ws, const 
         long ch = (p.Ntot + nsplit - 1) / nsplit;
         q.chunk = (ch + 63) / 64 * 64;
         const size_t lds = (size_t)8 * 18 * 256 * sizeof(float);
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_small_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr = true;
-        }
+        static gif::LdsAttr attr;
+        attr.ensure(reinterpret_cast<const void*>(conv_wgrad_small_mfma), lds);
         hipLaunchKernelGGL(conv_wgrad_small_mfma, dim3((unsigned)nsplit), dim3(1024), lds, s, q);
         return gif::check_launch("conv2d_wgrad(small)");
     }
@@ -721,13 +708,8 @@ int gif_conv3x3_winograd_wgrad_f32(const float* x, const float* gy, float* V, fl
     p.tiles_q = p.CP / bq;
     p.tiles_pq = (p.RP / (big ? 256 : bp)) * p.tiles_q;
     dim3 grid((unsigned)(p.tiles_pq * p.T * nsplit));
-    static const float* zero_page = nullptr;
-    if (!zero_page) {
-        void* zp = nullptr;
-        GIF_REQUIRE(hipGetSymbolAddress(&zp, HIP_SYMBOL(g_wgrad_zero_page)) == hipSuccess, "winograd_wgrad: zero page lookup failed");
-        zero_page = static_cast<const float*>(zp);
-    }
-    p.zero = zero_page;
+    p.zero = gif::zero_page16();
+    GIF_REQUIRE(p.zero, "winograd_wgrad: zero page lookup failed");
     if (big) wgrad_launch<256, 128, 2, 2, true, 16>(grid, 256, s, p);
     else if (bp == 128 && bq == 128) wgrad_launch<128, 128, 2, 2, true, 16>(grid, 256, s, p);
     else if (bp == 128 && bq == 32) wgrad_launch<128, 32, 4, 1, true, 32>(grid, 256, s, p);

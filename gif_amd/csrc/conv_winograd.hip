@@ -506,14 +506,9 @@ int gif_conv3x3_winograd_f32(const float* x, const float* U, float* y, float* V,
     const int bn = wide ? 128 : 64;
     p.tiles_n = p.RP / bn;
     const size_t lds = (size_t)WNSTAGE * (WBM + bn) * WBK * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_gemm_mfma<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)((size_t)WNSTAGE * (WBM + 64) * WBK * sizeof(float)));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_gemm_mfma<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)((size_t)WNSTAGE * (WBM + 128) * WBK * sizeof(float)));
-        attr = true;
-    }
+    static gif::LdsAttr attr2, attr4;
+    if (wide) attr4.ensure(reinterpret_cast<const void*>(wino_gemm_mfma<4>), lds);
+    else attr2.ensure(reinterpret_cast<const void*>(wino_gemm_mfma<2>), lds);
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
     if (wide) hipLaunchKernelGGL(wino_gemm_mfma<4>, grid, dim3(512), lds, s, p);
     else hipLaunchKernelGGL(wino_gemm_mfma<2>, grid, dim3(256), lds, s, p);

@@ -11,6 +11,37 @@ namespace gif {
 
 static thread_local char g_err[512] = "";
 
+__device__ __attribute__((aligned(16))) float g_zero_page[4];
+
+int current_device() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) return 0;
+    return d;
+}
+
+const float* zero_page16() {
+    static std::mutex mu;
+    static const float* page[kMaxDevices] = {};
+    const int d = current_device();
+    std::lock_guard<std::mutex> lk(mu);
+    if (!page[d]) {
+        void* zp = nullptr;
+        if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero_page)) != hipSuccess) return nullptr;
+        page[d] = static_cast<const float*>(zp);
+    }
+    return page[d];
+}
+
+void LdsAttr::ensure(const void* kernel, size_t bytes) {
+    static std::mutex mu;
+    const int d = current_device();
+    std::lock_guard<std::mutex> lk(mu);
+    if (bytes > granted[d]) {
+        (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        granted[d] = bytes;
+    }
+}
+
 void set_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);

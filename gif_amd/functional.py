@@ -7,8 +7,11 @@ Two families:
     ConvBiasActFn / BlurBiasActFn fuse bias (+ condition noise) + leaky ReLU into the producing kernel's epilogue
     and keep that property (their backward is composed of the Functions above).
   * ModConvFn / ModConvActFn — the generator's modulated convolution (ModulatedConv2d.forward,
-    stylegan2_common_layers.py:307-349) as ONE fused op: y = [act](d[b,co] * conv(s[b,ci] * x, W) [+ noise + bias]);
-    once differentiable (the generator never needs a double backward in the shipped configurations).
+    stylegan2_common_layers.py:307-349) as ONE fused op: y = [act](d[b,co] * conv(s[b,ci] * x, W) [+ noise + bias]).
+    The first-order backward is a handful of raw fused launches.  When the backward itself is recorded
+    (create_graph=True: the StyleGAN2-form path-length regulariser, DIRECT_GRAD_REG of train.py:209-215) the gradients are
+    instead produced by differentiating a composition of the any-order Functions above (_modconv_composite), so the
+    generator is differentiable to any order as well — slower, but never silently wrong.
   * BilinearDownFn — the condition pyramid; _TextureMapFn lives in gif_amd/texture_space.py.
 All tensors are logical NCHW with NHWC memory (ops.nhwc).
 """
@@ -338,14 +341,41 @@ def minibatch_stddev(x, group, Cy):
 
 
 # --------------------------------------------------------------------------------------------------------
-# generator: fused modulated convolution (once differentiable)
+# generator: fused modulated convolution
 # --------------------------------------------------------------------------------------------------------
+def _modconv_composite(x, w, s, d, spec, transposed, out_hw, wscale, residual=None, bias=None, act=None):
+    """The modulated convolution written with the any-order Functions only (Conv2dFn, BiasActFn, torch broadcasting):
+    act(d * conv(s * x, w) + residual + bias).  Same algebra as the fused kernels; used to BUILD A GRAPH of the backward
+    when a double backward is requested."""
+    z = Conv2dFn.apply(x * s[:, :, None, None], w, spec, transposed, out_hw, wscale, None)
+    if d is not None:
+        z = z * d[:, :, None, None]
+    if act is None:
+        return z
+    slope, gain = act
+    return BiasActFn.apply(z, bias, residual, slope, gain)
+
+
+def _recorded_backward(inputs, needs, gy, build):
+    """Gradients of build(*inputs) w.r.t. the inputs flagged in `needs`, contracted with gy, WITH history (create_graph):
+    the forward is re-run through differentiable Functions inside the backward pass."""
+    with torch.enable_grad():
+        y = build()
+        idx = [i for i, (t, n) in enumerate(zip(inputs, needs)) if n and t is not None and t.requires_grad]
+        grads = torch.autograd.grad(y, [inputs[i] for i in idx], gy, create_graph=True, allow_unused=True)
+    out = [None] * len(inputs)
+    for i, g in zip(idx, grads):
+        out[i] = g
+    return out
+
+
 class ModConvFn(Function):
     """y = d * conv(s * x, w * wscale) with per-sample s [B,Cin] (modulation) and d [B,Cout] (demodulation, or None).
     transposed=True runs the stride-2 up-sampling branch (conv_transpose2d, stylegan2_common_layers.py:322-330)."""
 
     @staticmethod
     def forward(ctx, x, w, s, d, spec, transposed, out_hw, wscale):
+        x_in, s_in, d_in = x, s, d  # saved as given (a layout copy made in here would cut the graph of a recorded backward)
         x = ops.nhwc(x)
         s = s.contiguous()
         d = None if d is None else d.contiguous()
@@ -356,8 +386,9 @@ class ModConvFn(Function):
         else:
             y = ops.conv_bwd_data(x, w, spec, tuple(out_hw), wscale, in_scale=s, out_scale=d)
         ctx.spec, ctx.transposed, ctx.wscale = spec, transposed, wscale
+        ctx.out_hw = tuple(y.shape[2:])
         none = x.new_empty(())  # placeholder for absent tensors (never read): no fill kernel
-        ctx.save_for_backward(x, w, s, d if d is not None else none, y if d is not None else none)
+        ctx.save_for_backward(x_in, w, s_in, d_in if d is not None else none, y if d is not None else none)
         ctx.has_d = d is not None
         return y
 
@@ -366,7 +397,13 @@ class ModConvFn(Function):
         x, w, s, d, y = ctx.saved_tensors
         d = d if ctx.has_d else None
         spec, tr, ws = ctx.spec, ctx.transposed, ctx.wscale
-        gy = ops.nhwc(gy)
+        if torch.is_grad_enabled():  # create_graph=True: the gradients must carry history
+            gx, gw, gs, gd = _recorded_backward(
+                (x, w, s, d), ctx.needs_input_grad[:4], gy,
+                lambda: _modconv_composite(x, w, s, d, spec, tr, ctx.out_hw, ws))
+            return gx, gw, gs, gd, None, None, None, None
+        x, s, gy = ops.nhwc(x), s.contiguous(), ops.nhwc(gy)
+        d = None if d is None else d.contiguous()
         O, I = w.shape[:2]
         gx = gs = gd = gw = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
@@ -390,10 +427,12 @@ class ModConvFn(Function):
 class ModConvActFn(Function):
     """y = gain*lrelu(d * conv(s * x, w*wscale) + residual + bias): the whole StyledConv (same-resolution branch,
     stylegan2_common_layers.py:479-486) as ONE MFMA kernel launch — modulation on the A-tile load, demodulation,
-    condition-noise add, bias and leaky ReLU in the epilogue.  Once differentiable (generator)."""
+    condition-noise add, bias and leaky ReLU in the epilogue.  First-order backward = raw fused launches; a recorded
+    backward (create_graph=True) differentiates _modconv_composite instead."""
 
     @staticmethod
     def forward(ctx, x, w, s, d, residual, bias, spec, wscale, slope, gain):
+        saved_in = (x, s, d, residual)  # saved as given (see ModConvFn.forward)
         x = ops.nhwc(x)
         s, d = s.contiguous(), d.contiguous()
         residual = None if residual is None else ops.nhwc(residual)
@@ -403,7 +442,8 @@ class ModConvActFn(Function):
         ctx.cfg = (spec, wscale, slope, gain)
         ctx.has = (residual is not None, bias is not None)
         z = x.new_empty(())  # placeholder for absent tensors (never read): no fill kernel
-        ctx.save_for_backward(x, w, s, d, y, residual if residual is not None else z, bias if bias is not None else z)
+        x_in, s_in, d_in, r_in = saved_in
+        ctx.save_for_backward(x_in, w, s_in, d_in, y, r_in if residual is not None else z, bias if bias is not None else z)
         return y
 
     @staticmethod
@@ -414,6 +454,13 @@ class ModConvActFn(Function):
         residual = residual if has_res else None
         bias = bias if has_bias else None
         O, I = w.shape[:2]
+        if torch.is_grad_enabled():  # create_graph=True: the gradients must carry history
+            gx, gw, gs, gd, gr, gb = _recorded_backward(
+                (x, w, s, d, residual, bias), ctx.needs_input_grad[:6], gy,
+                lambda: _modconv_composite(x, w, s, d, spec, False, None, ws, residual, bias, (slope, gain)))
+            return gx, gw, gs, gd, gr, gb, None, None, None, None
+        x, s, d = ops.nhwc(x), s.contiguous(), d.contiguous()
+        residual = None if residual is None else ops.nhwc(residual)
         want_b = has_bias and ctx.needs_input_grad[5]
         gpre, gb = ops.bias_act_bwd(gy, y, want_b, slope, gain)
         gx = gs = gd = gw = None

@@ -7,6 +7,7 @@ backward: every D layer is an any-order autograd Function, gif_amd/functional.py
 import numpy as np
 import torch
 from torch.autograd import Function, grad
+from torch.autograd.function import once_differentiable
 
 from . import ops
 
@@ -100,6 +101,7 @@ class _TexPairLossFn(Function):
         return ops.texture_pair_loss(a, b, ma, mb, f)
 
     @staticmethod
+    @once_differentiable  # raw kernel launch: a double backward raises instead of returning a history-free gradient
     def backward(ctx, gloss):
         a, b, f = ctx.saved_tensors
         ga = ops.texture_pair_loss(a, b, ctx.masks[0], ctx.masks[1], f, gloss=gloss)

@@ -5,6 +5,7 @@ Conventions: activations are torch tensors of LOGICAL shape [B,C,H,W] whose memo
 torch is used for device memory and streams only — all arithmetic is in libgif_hip.so.
 """
 import ctypes
+import functools
 import os
 from typing import NamedTuple, Optional
 
@@ -16,7 +17,27 @@ CL = torch.channels_last
 
 
 def _stream():
+    # current stream of the CURRENT device; _device_guard makes that the operands' device
     return torch.cuda.current_stream().cuda_stream
+
+
+def _device_guard(fn):
+    """Run `fn` with the operands' device current (launch + stream + per-device kernel state all follow it) and refuse
+    operands that span devices.  One process per GPU never takes the slow branch."""
+    @functools.wraps(fn)
+    def wrapped(*args, **kw):
+        dev = None
+        for a in args + tuple(kw.values()):
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                if dev is None:
+                    dev = a.device
+                elif a.device != dev:
+                    raise _lib.GifHipError(f"{fn.__name__}: operands on different devices ({dev} and {a.device})")
+        if dev is None or dev.index == torch.cuda.current_device():
+            return fn(*args, **kw)
+        with torch.cuda.device(dev):
+            return fn(*args, **kw)
+    return wrapped
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -433,6 +454,13 @@ def resize(x, out_hw, mode: str, backward_to=None):
     gx = torch.empty((B, C, Hi, Wi), device=x.device, dtype=torch.float32)
     _lib.check(lib.gif_resize_bwd_f32(x.data_ptr(), gx.data_ptr(), B * C, Hi, Wi, H, W, m, _stream()), "resize_bwd")
     return gx
+
+
+for _name in ("pack_weight", "conv3x3_winograd", "conv_fwd", "conv_bwd_data", "conv3x3_winograd_wgrad", "conv_wgrad", "upfirdn2d",
+              "bias_act", "bias_act_bwd", "colsum", "mul_reduce", "bilinear_down", "act_inv_mul_reduce", "mbstd_fwd", "mbstd_bwd",
+              "sqnorm_per_sample", "rasterize", "texture_pair_loss", "resize"):
+    globals()[_name] = _device_guard(globals()[_name])
+del _name
 
 
 def prof_enable(on: bool):

@@ -57,8 +57,9 @@ def vertex_normals(vertices, faces):
     verts = vertices.contiguous().float()
     out = torch.empty_like(verts)
     lib = _lib.load()
-    _lib.check(lib.gif_vertex_normals_f32(verts.data_ptr(), f32.data_ptr(), off.data_ptr(), ent.data_ptr(), out.data_ptr(),
-                                          B, V, f32.shape[0], torch.cuda.current_stream().cuda_stream), "vertex_normals")
+    with torch.cuda.device(verts.device):  # launch on the operands' device and its current stream
+        _lib.check(lib.gif_vertex_normals_f32(verts.data_ptr(), f32.data_ptr(), off.data_ptr(), ent.data_ptr(), out.data_ptr(),
+                                              B, V, f32.shape[0], torch.cuda.current_stream().cuda_stream), "vertex_normals")
     return out
 
 

@@ -10,6 +10,7 @@ import numpy as np
 import torch
 from torch import nn
 from torch.autograd import Function
+from torch.autograd.function import once_differentiable
 
 from . import _lib
 from . import render
@@ -27,25 +28,29 @@ class _TextureMapFn(Function):
         V = verts.shape[1]
         tex = torch.empty((B, C, T, T), device=img.device, dtype=torch.float32)
         mask = torch.empty((B, 1, T, T), device=img.device, dtype=torch.uint8)
-        _lib.check(lib.gif_texture_map_f32(img.data_ptr(), verts.data_ptr(), normals.data_ptr(), cam.data_ptr(),
-                                           tmap.data_ptr(), tfaces.data_ptr(), tbc.data_ptr(), tex.data_ptr(),
-                                           mask.data_ptr(), B, C, H, W, V, T, torch.cuda.current_stream().cuda_stream),
-                   "texture_map")
+        with torch.cuda.device(img.device):  # launch on the operands' device and its current stream
+            _lib.check(lib.gif_texture_map_f32(img.data_ptr(), verts.data_ptr(), normals.data_ptr(), cam.data_ptr(),
+                                               tmap.data_ptr(), tfaces.data_ptr(), tbc.data_ptr(), tex.data_ptr(),
+                                               mask.data_ptr(), B, C, H, W, V, T, torch.cuda.current_stream().cuda_stream),
+                       "texture_map")
         ctx.save_for_backward(verts, normals, cam, tmap, tfaces, tbc)
         ctx.dims = (B, C, H, W, V, T)
+        mask = mask.view(torch.bool)  # the kernel writes 0 / 1 bytes; the reference returns a bool mask (stg2_generator.py:415)
         ctx.mark_non_differentiable(mask)
         return tex, mask
 
     @staticmethod
+    @once_differentiable  # raw kernel launch: a double backward must fail loudly, not return a history-free gradient
     def backward(ctx, gtex, _gmask):
         verts, normals, cam, tmap, tfaces, tbc = ctx.saved_tensors
         B, C, H, W, V, T = ctx.dims
         lib = _lib.load()
         gtex = gtex.contiguous()
         gimg = torch.empty((B, C, H, W), device=gtex.device, dtype=torch.float32)
-        _lib.check(lib.gif_texture_map_bwd_f32(gtex.data_ptr(), verts.data_ptr(), normals.data_ptr(), cam.data_ptr(),
-                                               tmap.data_ptr(), tfaces.data_ptr(), tbc.data_ptr(), gimg.data_ptr(), B, C, H,
-                                               W, V, T, torch.cuda.current_stream().cuda_stream), "texture_map_bwd")
+        with torch.cuda.device(gtex.device):
+            _lib.check(lib.gif_texture_map_bwd_f32(gtex.data_ptr(), verts.data_ptr(), normals.data_ptr(), cam.data_ptr(),
+                                                   tmap.data_ptr(), tfaces.data_ptr(), tbc.data_ptr(), gimg.data_ptr(), B, C, H,
+                                                   W, V, T, torch.cuda.current_stream().cuda_stream), "texture_map_bwd")
         return gimg, None, None, None, None, None, None, None
 
 

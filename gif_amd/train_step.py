@@ -4,17 +4,18 @@ gradient bucket per optimiser step (torch.distributed backend "nccl" == RCCL ove
 
 Semantics kept from the reference: non-saturating logistic losses, R1 (weight 5.0) on the real images every
 16th iteration, Adam(lr=0.002*r, betas=(0, 0.99**r)) with r = 16/17 (D) and 4/5 (G), EMA generator with decay
-0.5**(32/10000) over named parameters, G frozen during the D step and vice versa.
-Semantics that change with DataParallel -> per-rank replicas: parameters/buffers are never
-re-broadcast after init; minibatch-stddev groups are formed inside the per-rank batch.
+0.5**(32/10000) over named parameters, G frozen during the D step and vice versa, the optional generator
+regularisers PATH_LEN_REG / DIRECT_GRAD_REG (train.py:203-215) and the embedding L2 term (:217-220).
+Semantics that change with DataParallel -> per-rank replicas: parameters and buffers are broadcast
+from rank 0 ONCE, at construction (DataParallel re-broadcasts them on every forward); minibatch-stddev groups are
+formed inside the per-rank batch.
 """
-import math
-
 import torch
 import torch.distributed as dist
 import torch.nn.functional as F
 
 from . import losses
+from .optim import FlatAdam
 
 
 def requires_grad(model, flag=True):  # my_utils/generic_utils.py:58-60
@@ -30,67 +31,176 @@ def accumulate(model1, model2, decay=0.999):  # my_utils/generic_utils.py:63-76 
     torch._foreach_add_(p1, p2, alpha=1 - decay)
 
 
-class FlatGradBucket:
-    """All parameter gradients of a model live in ONE contiguous fp32 buffer (p.grad are views into it), so the
-    data-parallel exchange is exactly one all-reduce(sum)/world per optimiser step — D: 28.86 M floats = 115.5 MB,
-    G: 31.63 M = 126.5 MB — instead of DataParallel's per-forward broadcast + per-backward reduce.
-    Parameters that receive no gradient in a step (e.g. G blocks above `step`) simply stay zero in the bucket."""
+def _dist_on(group=None):
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
 
-    def __init__(self, params, process_group=None):
-        self.params = [p for p in params]
+
+@torch.no_grad()
+def broadcast_module_state(modules, src=0, group=None):
+    """Make every rank's replica identical to rank `src`'s: all parameters AND buffers (the frozen ImgEmbedding code
+    book is a buffer drawn with torch.randn per process).  What DDP does at construction; no-op without a process
+    group of size > 1."""
+    if not _dist_on(group):
+        return
+    for m in modules:
+        for t in list(m.parameters()) + list(m.buffers()):
+            dist.broadcast(t.data, src=src, group=group)
+
+
+class FlatGradBucket:
+    """All ACTIVE parameter gradients of a model live in ONE contiguous fp32 buffer (p.grad are views into it), so the
+    data-parallel exchange is exactly one all-reduce per optimiser step — D: 28.86 M floats = 115.5 MB, G at 256x256:
+    31.24 M = 125.0 MB — instead of DataParallel's per-forward broadcast + per-backward reduce.
+
+    `active`: optional predicate over the parameters; inactive ones (G blocks above the current resolution `step`,
+    which receive no gradient) stay OUT of the bucket with p.grad = None, exactly like in the reference — Adam then
+    skips them and creates no state for them — and they do not ride along in the all-reduce.
+
+    The aliasing p.grad -> bucket is re-established by zero() and verified before every all-reduce: model.zero_grad()
+    / optimizer.zero_grad(set_to_none=True) or a model.to() after construction would otherwise silently detach it."""
+
+    ALIGN = 64  # floats: every view starts on a 256-byte boundary (vectorised optimiser / RCCL paths)
+
+    def __init__(self, params, process_group=None, active=None):
+        params = list(params)
+        self.params = [p for p in params if active is None or active(p)]
+        self.inactive = [p for p in params if not (active is None or active(p))]
         self.group = process_group
-        align = 64  # floats: every view starts on a 256-byte boundary (vectorised optimiser / RCCL paths)
-        offs, n = [], 0
+        self.offsets, n = [], 0
         for p in self.params:
-            offs.append(n)
-            n += (p.numel() + align - 1) // align * align
+            self.offsets.append(n)
+            n += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
         dev = self.params[0].device
         self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
-        for p, off in zip(self.params, offs):
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+        self.views = [self.flat[off:off + p.numel()].view_as(p) for p, off in zip(self.params, self.offsets)]
+        self._pending = None
+        self.attach()
+
+    def attach(self):
+        """(Re-)alias every active p.grad to its bucket view; a gradient that lives elsewhere is moved in first."""
+        for p, v in zip(self.params, self.views):
+            g = p.grad
+            if g is None or g.data_ptr() != v.data_ptr():
+                if g is not None:
+                    v.copy_(g)
+                p.grad = v
+        for p in self.inactive:
+            p.grad = None
 
     def zero(self):
+        self.wait()
         self.flat.zero_()
+        self.attach()
 
-    def all_reduce_mean(self):
-        if dist.is_available() and dist.is_initialized():
-            ws = dist.get_world_size(self.group)
-            if ws > 1:
-                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+    def all_reduce_mean(self, async_op=False):
+        """Average the bucket over the process group.  async_op=True only ENQUEUES the collective (it runs on the
+        backend's own stream behind the work already queued on the current stream) — call wait() before the bucket is
+        read; everything launched in between overlaps with the exchange."""
+        if not _dist_on(self.group):
+            return
+        self.attach()  # a detached p.grad would leave its gradient out of the exchange
+        ws = dist.get_world_size(self.group)
+        if dist.get_backend(self.group) == "nccl":  # RCCL: the mean is taken inside the collective, no separate pass
+            work = dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op)
+            self._pending = (work, None) if async_op else None
+        else:  # gloo (CPU tests) has no AVG
+            work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+            if async_op:
+                self._pending = (work, ws)
+            else:
                 self.flat.div_(ws)
+
+    def wait(self):
+        if self._pending is not None:
+            work, div = self._pending
+            self._pending = None
+            work.wait()
+            if div:
+                self.flat.div_(div)
+
+
+def _g_param_active(generator, step):
+    """Predicate: does this generator parameter receive a gradient at resolution `step`?  Blocks / ToRGB layers above
+    `step` are never executed (Generator.forward breaks at i == step, stg2_generator.py:205-206)."""
+    dead = set()
+    gen = getattr(generator, "generator", None)
+    if gen is not None:
+        for lst in (gen.progression, gen.to_rgb):
+            for i, m in enumerate(lst):
+                if i > step:
+                    dead.update(id(p) for p in m.parameters())
+    return lambda p: id(p) not in dead
 
 
 class GifTrainer:
-    """Holds G, D, the EMA generator, both Adam optimisers and the two gradient buckets; step() is one iteration."""
+    """Holds G, D, the EMA generator, both Adam optimisers and the two gradient buckets; step() is one iteration.
+
+    Multi-GPU (one process per GPU, torch.distributed initialised by the caller): construction broadcasts rank 0's
+    G / D / G_ema parameters and buffers to every rank; each optimiser step all-reduces one flat bucket.  With
+    overlap_comm (default when a process group of size > 1 exists) the discriminator's all-reduce + Adam update are
+    deferred to the point where D is next needed (the D forward of the G step), so the exchange runs under the
+    generator forward; flush() completes anything pending (call it before reading D's weights, e.g. to checkpoint)."""
 
     def __init__(self, generator, discriminator, g_running, step=6, alpha=1.0, r1_every=16, gen_reg_type='None',
                  embedding_reg_weight=0.0, lr=0.002, fused_adam=None, process_group=None,
-                 reuse_generator_forward=False):
+                 reuse_generator_forward=False, overlap_comm=None, sync_initial_state=True):
         self.G, self.D, self.G_ema = generator, discriminator, g_running
         self.res_step, self.alpha, self.r1_every = step, alpha, r1_every
         self.gen_reg_type = gen_reg_type.upper()
         self.embedding_reg_weight = embedding_reg_weight
+        self.group = process_group
+        if sync_initial_state:
+            broadcast_module_state((generator, discriminator, g_running), 0, process_group)
         g_ratio, d_ratio = 4 / (4 + 1), 16 / (16 + 1)  # train.py:364-381
         on_gpu = next(generator.parameters()).is_cuda
-        fused = on_gpu if fused_adam is None else fused_adam
-        self.g_bucket = FlatGradBucket(generator.parameters(), process_group)
+        self.g_bucket = FlatGradBucket(generator.parameters(), process_group, _g_param_active(generator, step))
         self.d_bucket = FlatGradBucket(discriminator.parameters(), process_group)
-        self.g_optim = torch.optim.Adam(generator.parameters(), lr=lr * g_ratio, betas=(0.0, 0.99 ** g_ratio), fused=fused)
-        self.d_optim = torch.optim.Adam(discriminator.parameters(), lr=lr * d_ratio, betas=(0.0, 0.99 ** d_ratio), fused=fused)
+        hip_adam = on_gpu if fused_adam is None else fused_adam
+        if hip_adam:  # one HIP launch per optimiser step over the flat buffers (+ the EMA of the generator)
+            self.g_optim = FlatAdam(generator.parameters(), lr=lr * g_ratio, betas=(0.0, 0.99 ** g_ratio),
+                                    bucket=self.g_bucket, ema_params=[p for _, p in g_running.named_parameters()])
+            self.d_optim = FlatAdam(discriminator.parameters(), lr=lr * d_ratio, betas=(0.0, 0.99 ** d_ratio),
+                                    bucket=self.d_bucket)
+        else:
+            self.g_optim = torch.optim.Adam(generator.parameters(), lr=lr * g_ratio, betas=(0.0, 0.99 ** g_ratio))
+            self.d_optim = torch.optim.Adam(discriminator.parameters(), lr=lr * d_ratio, betas=(0.0, 0.99 ** d_ratio))
         self.pl_reg = losses.PathLengthRegularizor() if self.gen_reg_type == 'PATH_LEN_REG' else None
         # Optional (off by default, NOT used by bench.py): the reference runs the generator twice per iteration on
         # identical inputs and identical weights (train.py:157 and :197 — G only changes at :243).  With this flag the
         # forward is executed once with autograd enabled; the D step consumes fake.detach(), the G step back-propagates
         # through the same graph.  Bit-identical losses and updates, one generator forward (9 % of the FLOPs) less.
         self.reuse_generator_forward = reuse_generator_forward
+        self.overlap_comm = _dist_on(process_group) if overlap_comm is None else overlap_comm
+        self._d_update_pending = False
         self.g_running_decay = 0.5 ** (32 / (10 * 1000))
         self.G_ema.train(False)
         requires_grad(self.G, False)  # train.py:68
         requires_grad(self.D, True)
 
+    # ---- optimiser updates -------------------------------------------------------------------------------------
+    def _finish_d_update(self):
+        if self._d_update_pending:
+            self._d_update_pending = False
+            self.d_bucket.wait()
+            self.d_optim.step()
+
+    def flush(self):
+        """Complete a deferred discriminator update (overlap_comm)."""
+        self._finish_d_update()
+
+    def _g_update(self):
+        self.g_bucket.all_reduce_mean()
+        if isinstance(self.g_optim, FlatAdam):
+            self.g_optim.step(ema_decay=self.g_running_decay)  # Adam + generic_utils.accumulate in one launch
+        else:
+            self.g_optim.step()
+            accumulate(self.G_ema, self.G, self.g_running_decay)
+
+    # ---- the two halves of an iteration ------------------------------------------------------------------------
     def d_step(self, i, real_image, cond, input_indices, fake=None):
         """train.py:82-178"""
         G, D = self.G, self.D
+        self._finish_d_update()
         requires_grad(D, True)
         self.d_bucket.zero()
         r1_step = bool(self.r1_every) and (i + 1) % self.r1_every == 0
@@ -107,8 +217,12 @@ class GifTrainer:
         fake_scores, _ = D([fake.detach()], condition=cond, step=self.res_step, alpha=self.alpha)
         fake_loss = F.softplus(fake_scores).mean()
         (real_loss + fake_loss).backward()
-        self.d_bucket.all_reduce_mean()
-        self.d_optim.step()
+        if self.overlap_comm:
+            self.d_bucket.all_reduce_mean(async_op=True)
+            self._d_update_pending = True  # completed right before D is used again
+        else:
+            self.d_bucket.all_reduce_mean()
+            self.d_optim.step()
         return (real_loss + fake_loss).detach()
 
     def g_step(self, cond, input_indices, fake=None):
@@ -117,19 +231,27 @@ class GifTrainer:
         requires_grad(G, True)
         requires_grad(D, False)
         self.g_bucket.zero()
+        direct_reg = self.gen_reg_type == 'DIRECT_GRAD_REG'
+        if direct_reg:
+            cond = cond.detach().requires_grad_(True)
+            fake = None  # the regulariser differentiates the images w.r.t. THIS condition tensor
         if fake is None:
             fake = G(cond, None, step=self.res_step, alpha=self.alpha, input_indices=input_indices)
+        self._finish_d_update()  # the exchange of D's gradients ran under the generator forward above
         pred, _ = D(fake, condition=cond.detach(), step=self.res_step, alpha=self.alpha)
         loss = F.softplus(-pred).mean()
         if self.pl_reg is not None:
             loss = loss + 2 * self.pl_reg.path_length_reg(G, step=self.res_step, alpha=self.alpha,
                                                           input_indices=input_indices, cond=cond)
+        elif direct_reg:
+            # train.py:209-215: changes of the condition should change the image as little as possible.  The reference
+            # adds the per-sample [B] penalty to the scalar loss and calls .backward() on the result, which only works
+            # for batch 1; here the penalty is averaged over the batch (identical for batch 1).
+            loss = loss + 1e-8 * 8 * losses.grad_penalty_loss([cond], torch.pow(fake[-1], 2), step=None).mean()
         if self.embedding_reg_weight:
             loss = loss + self.embedding_reg_weight * losses.l2_reg(G.z_to_w)
         loss.backward()
-        self.g_bucket.all_reduce_mean()
-        self.g_optim.step()
-        accumulate(self.G_ema, G, self.g_running_decay)
+        self._g_update()
         requires_grad(G, False)
         return loss.detach()
 

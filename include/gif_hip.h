@@ -254,6 +254,27 @@ int gif_resize_bwd_f32(const float* gy, float* gx, int64_t planes, int Hi, int W
 int gif_prof_enable(int on);
 int gif_prof_read(int family, double* ms, double* flops, int64_t* launches);
 
+/* ------------------------------------------------------------------------------------------------
+ * Fused Adam (+ EMA generator) over the flat gradient bucket — replaces torch.optim.Adam.step() (train.py:173, :243;
+ * Adam(lr, betas=(0, 0.99**r)): no weight decay, no amsgrad) and generic_utils.accumulate (my_utils/generic_utils.py:63-76)
+ * by one launch.  grad / exp_avg / exp_avg_sq are flat buffers sharing one offset table; parameters (and the EMA copies,
+ * `ema` may be NULL per chunk) are addressed through a DEVICE array of chunks, each at most gif_adam_chunk_floats() elements.
+ *   m += (g - m)*(1 - beta1);  v = v*beta2 + (1 - beta2)*g*g;  p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+ *   ema = ema*ema_decay + (1 - ema_decay)*p      (has_ema != 0)
+ * bias_correction1/2 = 1 - beta^step are computed by the caller (host, double).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct gif_adam_chunk {
+    float* param;        /* first element of this chunk in the parameter tensor */
+    float* ema;          /* same element of the EMA copy, or NULL */
+    int64_t flat_offset; /* offset of the chunk in the flat grad / exp_avg / exp_avg_sq buffers */
+    int32_t n;           /* elements in this chunk (<= gif_adam_chunk_floats()) */
+    int32_t reserved;
+} gif_adam_chunk;
+int gif_adam_chunk_floats(void);
+int gif_adam_ema_step_f32(const gif_adam_chunk* chunks, int nchunks, const float* grad_flat, float* exp_avg_flat,
+                          float* exp_avg_sq_flat, float lr, float beta1, float beta2, float eps, double bias_correction1,
+                          double bias_correction2, float ema_decay, int has_ema, gif_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

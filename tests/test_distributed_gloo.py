@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from gif_amd.train_step import FlatGradBucket, accumulate, flops_per_image
+from gif_amd.train_step import FlatGradBucket, accumulate, broadcast_module_state, flops_per_image
 
 
 def _free_port():
@@ -100,3 +100,91 @@ def test_bucket_single_process_and_ema():
     for p, q0, q1 in zip(m.parameters(), before, m2.parameters()):
         assert torch.allclose(p, 0.75 * q0 + 0.25 * q1)
     assert abs(flops_per_image(256, 16) / 1e12 - 1.181) < 2e-3
+
+
+def _worker_sync(rank, world, port, q):
+    """Per-rank DIFFERENT initial weights and buffers (the reference sets no seed, train.py): the broadcast at trainer
+    construction must make the replicas identical; the active-subset bucket must keep parameters without a gradient out of
+    the exchange (p.grad None, untouched by Adam); the asynchronous all-reduce must give the same numbers as the blocking one."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)
+    m = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.LeakyReLU(0.2), torch.nn.Linear(16, 1))
+    m.unused = torch.nn.Parameter(torch.randn(5))
+    m.register_buffer("codebook", torch.randn(7, 3))  # like ImgEmbedding.embd_weight: a randn BUFFER
+    before = torch.cat([p.detach().reshape(-1) for p in m.parameters()] + [m.codebook.reshape(-1)]).clone()
+    broadcast_module_state((m,), 0)
+    synced = torch.cat([p.detach().reshape(-1) for p in m.parameters()] + [m.codebook.reshape(-1)]).clone()
+    bucket = FlatGradBucket(m.parameters(), active=lambda p: p is not m.unused)
+    opt = torch.optim.Adam(m.parameters(), lr=0.01, betas=(0.0, 0.99))
+    g = torch.Generator().manual_seed(7)
+    x_all = torch.randn(2, 8, 8, generator=g)
+    flats = []
+    for step in range(2):
+        x = x_all[step, rank * 4:(rank + 1) * 4]
+        if step == 1:
+            opt.zero_grad(set_to_none=True)  # detaches p.grad from the bucket: zero() must re-attach
+        bucket.zero()
+        torch.nn.functional.softplus(-m(x)).mean().backward()
+        bucket.all_reduce_mean(async_op=(step == 1))
+        bucket.wait()
+        flats.append(bucket.flat.clone())
+        opt.step()
+    ok_alias = all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(bucket.params, bucket.views))
+    q.put((rank, before.tolist(), synced.tolist(), [f.tolist() for f in flats],
+           torch.cat([p.detach().reshape(-1) for p in m.parameters()]).tolist(), m.unused.grad is None, ok_alias,
+           len(opt.state.get(m.unused, {}))))
+    dist.destroy_process_group()
+
+
+def test_initial_state_broadcast_active_subset_and_async_allreduce():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_sync, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, b0, s0, f0, p0, none0, alias0, st0), (r1, b1, s1, f1, p1, none1, alias1, st1) = res
+    assert b0 != b1, "the ranks really started from different weights"
+    assert s0 == s1 == b0, "after the broadcast every rank holds rank 0's parameters AND buffers"
+    assert f0 == f1, "all-reduced buckets agree (blocking on step 0, asynchronous on step 1)"
+    assert p0 == p1, "replicas stay identical through the Adam steps"
+    assert none0 and none1, "a parameter outside the active set keeps grad None (as in the reference)"
+    assert alias0 and alias1, "p.grad aliases the bucket again after zero_grad(set_to_none=True)"
+    assert st0 == 0 and st1 == 0, "Adam created no state for the gradient-less parameter"
+    # single-process check of the exchanged numbers: mean over ranks == gradient of the global-batch mean loss
+    torch.manual_seed(100)
+    m = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.LeakyReLU(0.2), torch.nn.Linear(16, 1))
+    g = torch.Generator().manual_seed(7)
+    x_all = torch.randn(2, 8, 8, generator=g)
+    torch.nn.functional.softplus(-m(x_all[0])).mean().backward()
+    ref = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
+    got = torch.tensor(f0[0])
+    # bucket views are 64-float aligned: compare view by view
+    off, k = 0, 0
+    for p in m.parameters():
+        n = p.numel()
+        assert torch.allclose(got[off:off + n], ref[k:k + n], atol=1e-6)
+        off += (n + 63) // 64 * 64
+        k += n
+
+
+def test_bucket_moves_a_detached_gradient_back_in():
+    """A gradient that was accumulated OUTSIDE the bucket (after zero_grad(set_to_none=True) without bucket.zero()) is not
+    lost: attach() (called by all_reduce_mean / FlatAdam.step) copies it into the bucket and re-aliases p.grad."""
+    m = _model()
+    b = FlatGradBucket(m.parameters())
+    for p in m.parameters():
+        p.grad = None
+    m(torch.ones(2, 8)).sum().backward()
+    stray = {id(p): p.grad.clone() for p in m.parameters() if p.grad is not None}
+    assert all(p.grad is None or p.grad.data_ptr() != v.data_ptr() for p, v in zip(b.params, b.views))
+    b.attach()
+    for p, v in zip(b.params, b.views):
+        assert p.grad.data_ptr() == v.data_ptr()
+        if id(p) in stray:
+            assert torch.equal(v, stray[id(p)])
