@@ -9,6 +9,8 @@ A "step" is one full GIF training iteration (train.py:82-250): D step (D fwd rea
 Adam) + G step (G fwd, D fwd, backward, Adam, EMA), R1 on every 16th iteration, run-29 model configuration
 (6-channel rendered condition, 9-channel D input, n_mlp=8, 69 158-entry embedding buffer), synthetic 256x256
 batches generated on device, random-init weights, fp32 (the reference's dtype) on the fp32 MFMA path.
+Other BASELINE configs as extra lines: `--batch 16` (config 2), `--render-cond [--gen-reg PATH_LEN_REG]` (config 3: the
+condition is rasterised from a posed mesh INSIDE the timed region).
 Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` and `cpu_baseline` objects.
 """
 import argparse
@@ -28,6 +30,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PMC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # written by tools/pmc_to_json.py from rocprofv3 --pmc passes
 
 
 def parse():
@@ -35,21 +38,26 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE: 32)")
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE: 32; config 2: 16)")
     ap.add_argument("--res", type=int, default=256)
     ap.add_argument("--vocab", type=int, default=69158)
     ap.add_argument("--r1-every", type=int, default=16)
+    ap.add_argument("--render-cond", action="store_true",
+                    help="config 3: rasterise the 6-channel condition from a posed mesh inside the timed region")
+    ap.add_argument("--gen-reg", type=str, default="None", help="None | PATH_LEN_REG | DIRECT_GRAD_REG (train.py:203-215)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=1)
-    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(host cores, 16)")
+    ap.add_argument("--cpu-batch", type=int, default=4, help="CPU baseline batch (BASELINE.md §3: 4; 32 does not fit)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores (BASELINE.md §3)")
+    ap.add_argument("--cpu-timeout", type=int, default=420)
     ap.add_argument("--cpu-baseline-worker", type=str, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--no-prof", action="store_true", help="skip per-kernel HIP-event timing")
     return ap.parse_args()
 
 
 def cpu_baseline_worker(res, step_idx, batch, threads):
-    """Runs in a child process: oracle ("port") timed on `threads` host cores — one full G+D training iteration
-    (no R1) at the benchmark resolution on a small batch (batch 32 needs ~80 GB of activations on the CPU)."""
+    """Runs in a child process: oracle ("port") timed on `threads` host cores — two full G+D training iterations at the
+    benchmark resolution on a small batch (batch 32 needs ~80 GB of activations on the CPU): a plain iteration and an R1
+    iteration, weighted 15:1 like the benchmark's R1-every-16th schedule."""
     torch.set_num_threads(threads)
     from oracle import stylegan2_ref as R
     from oracle.train_ref import RefTrainer
@@ -59,20 +67,26 @@ def cpu_baseline_worker(res, step_idx, batch, threads):
         g = StyledGenerator(embedding_vocab_size=64, rendered_flame_ascondition=True, normal_maps_as_cond=True)
         d = Discriminator(size=res, num_color_chnls=9)
     tr = RefTrainer(R.seeded_state_dict(g.state_dict(), 1), R.seeded_state_dict(d.state_dict(), 2), res_step=step_idx,
-                    size=res, r1_every=0)
+                    size=res, r1_every=2)
     gen = torch.Generator().manual_seed(0)
     real = torch.rand(batch, 3, res, res, generator=gen) * 2 - 1
     cond = torch.rand(batch, 6, res, res, generator=gen) * 2 - 1
     idx = torch.randint(0, 64, (batch,), generator=gen)
     t0 = time.time()
-    tr.step(0, real, cond, idx)
-    dt = time.time() - t0
-    print(json.dumps({"value": batch / dt, "unit": "images/s", "cores": threads, "kind": "port",
-                      "sample": f"1 full G+D train step (no R1) at {res}x{res}, batch {batch}, oracle/train_ref.py "
-                                f"(torch CPU fp32, {threads} threads of {os.cpu_count()} host cores), {dt:.1f} s"}))
+    tr.step(0, real, cond, idx)  # i = 0: no R1
+    t_plain = time.time() - t0
+    t0 = time.time()
+    tr.step(1, real, cond, idx)  # i = 1: R1 iteration (r1_every = 2 here)
+    t_r1 = time.time() - t0
+    per_step = (15 * t_plain + t_r1) / 16
+    print(json.dumps({"value": batch / per_step, "unit": "images/s", "cores": threads, "kind": "port",
+                      "sample": f"2 full G+D train steps at {res}x{res}, batch {batch}, oracle/train_ref.py (torch CPU fp32, "
+                                f"{threads} threads of {os.cpu_count()} host cores): plain {t_plain:.1f} s, R1 iteration "
+                                f"{t_r1:.1f} s; value = batch / ((15*plain + R1)/16)",
+                      "plain_step_s": t_plain, "r1_step_s": t_r1}))
 
 
-def cpu_baseline(res, step_idx, batch, threads, timeout_s=240):
+def cpu_baseline(res, step_idx, batch, threads, timeout_s):
     """Bounded: a child process with a fixed thread count and a hard timeout, so bench.py always finishes in minutes."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", f"{res},{step_idx},{batch},{threads}"]
@@ -88,69 +102,113 @@ def cpu_baseline(res, step_idx, batch, threads, timeout_s=240):
                 "sample": f"cpu baseline did not finish within {timeout_s}s ({type(e).__name__})"}
 
 
-# HBM bytes per launch, averaged over every launch of the family in the bench step: separate rocprofv3 --pmc passes
-# (FETCH_SIZE, WRITE_SIZE; KiB; 2*FETCH + WRITE, gfx950 corrections) over `bench.py --steps 1 --warmup 1`,
-# profiles/r1_pmc_step.md.  PMC counters cannot be collected from inside the timed run, so these are the committed values.
-PMC_TRAFFIC_PER_LAUNCH = {0: 0.597e9, 2: 3.00e9}
-PMC_TRAFFIC = {
-    "wino_gemm_mfma": {"hbm_bytes": 5.63e9, "algorithmic_bytes": 5.37e9, "mfma_busy": 0.58,
-                       "note": "largest layer (128->128 @256^2, batch 32), profiles/r1_pmc_winograd.md: V planes read once "
-                               "(4.29 GB) + output written once (1.07 GB); 2.9 ms"},
-    "conv_gather_mfma_glds": {"hbm_bytes": 3.68e9, "algorithmic_bytes": 2.15e9, "mfma_busy": 0.824,
-                              "note": "direct 3x3 conv on the same shape, profiles/r1_pmc_dominant_kernels.md"},
-}
 WINOGRAD_EXECUTED = 16.0 / 36.0  # MFMA FLOPs a Winograd F(2x2,3x3)/F(3x3,2x2) GEMM executes per algorithmic FLOP
 
+# family id -> (description, executed MFMA fraction of the algorithmic FLOPs, key in profiles/pmc_traffic.json)
+FAMILIES = {
+    0: ("conv_gather_mfma_glds (direct fwd / dgrad / stride-2 / transposed conv on the LDS-DMA kernel, Cin >= 32)", 1.0,
+        "conv_gather_mfma_glds"),
+    5: ("conv_gather_mfma (register-staged kernel of the Cin < 32 layers: condition-noise convs, 9-channel D input)", 1.0,
+        "conv_gather_mfma"),
+    1: ("conv_wgrad_mfma (direct weight gradient)", 1.0, "conv_wgrad_mfma"),
+    2: ("wino_gemm_mfma (Winograd F(2x2,3x3) fwd / dgrad GEMM + fused output transform and epilogue)", WINOGRAD_EXECUTED,
+        "wino_gemm_mfma"),
+    3: ("conv_wgrad_mfma in planes mode (Winograd F(3x3,2x2) weight-gradient GEMM)", WINOGRAD_EXECUTED, "conv_wgrad_mfma"),
+}
+FAMILY_KEYS = {0: "roofline_conv_direct", 1: "roofline_wgrad_direct", 2: "roofline_conv_winograd", 3: "roofline_wgrad_winograd",
+               5: "roofline_conv_direct_small_cin"}
 
-def roofline_objects(ops, steps):
+
+def load_pmc():
+    """HBM bytes per launch per kernel family from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE cannot be read
+    from inside the timed run).  The file names the commit and the command it was taken at; bench.py only relays it."""
+    try:
+        with open(PMC_JSON) as fh:
+            return json.load(fh)
+    except Exception:
+        return None
+
+
+def roofline_objects(ops, steps, wall_s):
     """Per-family HIP-event timings -> the `roofline` object of the dominant kernel + one object per other MFMA family.
 
     `achieved` is what the MFMA pipe actually executed per second (<= peak); for the Winograd GEMMs the ALGORITHMIC
     (direct-convolution) rate, which is 36/16 of that, is reported next to it as `algorithmic_achieved`."""
-    fams = {
-        0: ("conv_gather_mfma_glds (direct fwd / dgrad / stride-2 / transposed conv on the LDS-DMA kernel, Cin >= 32)", 1.0,
-            "conv_gather_mfma_glds"),
-        5: ("conv_gather_mfma (register-staged kernel of the Cin < 32 layers: condition-noise convs, 9-channel D input)", 1.0,
-            None),
-        1: ("conv_wgrad_mfma (direct weight gradient)", 1.0, None),
-        2: ("wino_gemm_mfma (Winograd F(2x2,3x3) fwd / dgrad GEMM + fused output transform and epilogue)",
-            WINOGRAD_EXECUTED, "wino_gemm_mfma"),
-        3: ("conv_wgrad_mfma in planes mode (Winograd F(3x3,2x2) weight-gradient GEMM)", WINOGRAD_EXECUTED, None),
-    }
-    objs = {}
-    for fam, (name, exec_frac, pmc) in fams.items():
+    pmc = load_pmc()
+    objs, executed_flops, mfma_ms = {}, 0.0, 0.0
+    for fam, (name, exec_frac, pmc_key) in FAMILIES.items():
         ms, fl, n = ops.prof_read(fam)
         if n == 0 or ms <= 0:
             continue
+        executed_flops += fl * exec_frac
+        mfma_ms += ms
         alg = fl / (ms * 1e-3) / 1e12
         o = {"bound": "mfma", "kernel": name, "achieved": alg * exec_frac, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
              "frac": alg * exec_frac / PEAK_F32_MFMA_TFLOPS, "traffic": None, "launches": n, "avg_ms": ms / n,
-             "gpu_ms_per_step": ms / steps}
+             "gpu_ms_per_step": ms / steps, "algorithmic_flop_per_launch": fl / n}
         if exec_frac != 1.0:
             o["algorithmic_achieved"] = alg
             o["algorithmic_frac"] = alg / PEAK_F32_MFMA_TFLOPS
             o["note"] = "achieved = executed MFMA FLOP/s (16/36 of the algorithmic direct-convolution FLOPs)"
-        if fam in PMC_TRAFFIC_PER_LAUNCH:
-            o["traffic"] = PMC_TRAFFIC_PER_LAUNCH[fam]
-            o["traffic_note"] = "HBM bytes per launch (family average), rocprofv3 --pmc passes in profiles/r1_pmc_step.md"
-        if pmc:
-            o["traffic_probe"] = PMC_TRAFFIC[pmc]
+        fam_pmc = (pmc or {}).get("families", {}).get(pmc_key)
+        if fam_pmc:
+            o["traffic"] = fam_pmc["hbm_bytes_per_launch"]
+            o["traffic_source"] = {"file": "profiles/pmc_traffic.json", "kernels": fam_pmc.get("kernels"),
+                                   "launches_profiled": fam_pmc.get("launches"), "commit": pmc.get("commit"),
+                                   "command": pmc.get("command"),
+                                   "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (2*FETCH + WRITE, gfx950 correction), "
+                                           "family average over one profiled training iteration"}
         objs[fam] = o
     out = {}
     if objs:
         dom = max(objs, key=lambda f: objs[f]["gpu_ms_per_step"])
         out["roofline"] = objs.pop(dom)
-        names = {0: "roofline_conv_direct", 1: "roofline_wgrad_direct", 2: "roofline_conv_winograd", 3: "roofline_wgrad_winograd",
-                 5: "roofline_conv_direct_small_cin"}
         for fam, o in objs.items():
-            out[names[fam]] = o
+            out[FAMILY_KEYS[fam]] = o
     ms, by, n = ops.prof_read(4)
     if n:
-        out["roofline_winograd_transforms"] = {"bound": "hbm", "kernel": "wino_input_transform / wino_gy_transform",
-                                               "achieved": by / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                                               "frac": by / (ms * 1e-3) / 1e9 / 8000.0, "traffic": None, "launches": n,
-                                               "avg_ms": ms / n, "gpu_ms_per_step": ms / steps}
+        o = {"bound": "hbm", "kernel": "wino_input_transform / wino_gy_transform", "achieved": by / (ms * 1e-3) / 1e9,
+             "peak": 8000.0, "unit": "GB/s", "frac": by / (ms * 1e-3) / 1e9 / 8000.0, "traffic": None, "launches": n,
+             "avg_ms": ms / n, "gpu_ms_per_step": ms / steps}
+        fam_pmc = (pmc or {}).get("families", {}).get("wino_transforms")
+        if fam_pmc:
+            o["traffic"] = fam_pmc["hbm_bytes_per_launch"]
+        out["roofline_winograd_transforms"] = o
+    # what the MFMA pipe really did over the WALL time of the timed region (Winograd's skipped multiplies not counted)
+    out["executed_mfma_frac_wall"] = {
+        "executed_tflop_per_step": executed_flops / steps / 1e12,
+        "achieved": executed_flops / wall_s / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+        "frac": executed_flops / wall_s / 1e12 / PEAK_F32_MFMA_TFLOPS,
+        "mfma_kernel_ms_per_step": mfma_ms / steps,
+        "frac_while_mfma_kernels_run": executed_flops / (mfma_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS if mfma_ms else None,
+        "note": "MFMA FLOPs actually executed (direct kernels: all; Winograd GEMMs: 16/36 of the algorithmic count) / wall time "
+                "of the timed region / fp32 MFMA peak"}
     return out
+
+
+class MeshConditions:
+    """Config 3: a posed synthetic mesh of FLAME size rendered to the 6-channel condition with the HIP vertex-normal and
+    rasteriser kernels (gif_amd.render.render_condition) — called INSIDE the timed region."""
+
+    def __init__(self, batch, res, dev, seed):
+        import numpy as np
+        from gif_amd import render
+        self.render, self.res = render, res
+        m = np.load(os.path.join(ROOT, "tests", "golden", "body_mesh.npz"))
+        rng = np.random.RandomState(seed)
+        verts = []
+        for _ in range(batch):
+            a = rng.uniform(-0.4, 0.4)
+            rot = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], np.float32)
+            verts.append((m["vertices"] @ rot.T).astype(np.float32))
+        self.v = torch.from_numpy(np.stack(verts)).to(dev)
+        self.f = torch.from_numpy(m["faces"]).to(dev)
+        self.cam = torch.tensor([[0.95, 0.0, 0.35]] * batch, device=dev)
+        self.tex = (self.v - self.v.amin(dim=1, keepdim=True)) / (self.v.amax(dim=1, keepdim=True) - self.v.amin(dim=1, keepdim=True))
+
+    def __call__(self):
+        v_ndc = self.render.batch_orth_proj(self.v, self.cam)
+        return self.render.render_condition(v_ndc, self.f, self.tex, self.res, self.res)
 
 
 def main():
@@ -175,7 +233,7 @@ def main():
     from gif_amd.train_step import GifTrainer, flops_per_image
 
     res_step = {64: 4, 128: 5, 256: 6, 512: 7, 1024: 8}[args.res]
-    torch.manual_seed(0)  # identical initial replicas on every rank (no broadcast needed)
+    torch.manual_seed(1234 + rank)  # per-rank seeds on purpose: GifTrainer broadcasts rank 0's state at construction
     with contextlib.redirect_stdout(io.StringIO()):
         kw = dict(embedding_vocab_size=args.vocab, rendered_flame_ascondition=True, normal_maps_as_cond=True,
                   core_tensor_res=4, n_mlp=8)
@@ -184,18 +242,25 @@ def main():
         D = Discriminator(size=args.res, num_color_chnls=9, channel_multiplier=2)
     G_ema.load_state_dict(G.state_dict())
     G, G_ema, D = G.to(dev), G_ema.to(dev), D.to(dev)
-    trainer = GifTrainer(G, D, G_ema, step=res_step, alpha=1.0, r1_every=args.r1_every)
+    trainer = GifTrainer(G, D, G_ema, step=res_step, alpha=1.0, r1_every=args.r1_every, gen_reg_type=args.gen_reg)
 
     from gif_amd.data import SyntheticBatches
     B = args.batch
     batches = SyntheticBatches(B, args.res, args.vocab, dev, seed=1234, rank=rank)  # every rank draws its own data
+    mesh = MeshConditions(B, args.res, dev, seed=99 + rank) if args.render_cond else None
 
     def batch():
         return next(batches)
 
+    def run_step(it, b):
+        real, cond, idx = b
+        if mesh is not None:
+            cond = mesh()  # config 3: rasterised condition, inside the timed region
+        return trainer.step(it, real, cond, idx)
+
     it = 0
     for _ in range(args.warmup):
-        trainer.step(it, *batch())
+        run_step(it, batch())
         it += 1
 
     def sync():
@@ -212,8 +277,9 @@ def main():
     sync()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        trainer.step(it, *data[k % len(data)])
+        run_step(it, data[k % len(data)])
         it += 1
+    trainer.flush()
     sync()
     dt = time.perf_counter() - t0
     ops.prof_enable(False)
@@ -228,25 +294,30 @@ def main():
         value = imgs / dt
         fl_img = flops_per_image(args.res, args.r1_every)
         step_tflops = value * fl_img / 1e12 / world
+        workload = (f"GIF run-29 G+D training iteration, {args.res}x{args.res}, batch {B}/GPU, R1 every {args.r1_every}th step, "
+                    f"fp32 MFMA (BASELINE configs[1]/[3] shape)")
+        if args.render_cond:
+            workload += "; condition rasterised from a posed mesh inside the timed region (configs[2])"
+        if args.gen_reg.upper() != "NONE":
+            workload += f"; generator regulariser {args.gen_reg.upper()}"
         out = {
             "metric": f"G+D train-step images/sec at {args.res}x{args.res}, batch {B}/GPU",
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"GIF run-29 G+D training iteration, {args.res}x{args.res}, batch {B}/GPU, "
-                                   f"R1 every {args.r1_every}th step, fp32 MFMA (BASELINE configs[1]/[3] shape)",
-                       "global_batch": world * B, "resolution": args.res, "parallelism": f"dp{world}",
+            "config": {"workload": workload, "global_batch": world * B, "resolution": args.res, "parallelism": f"dp{world}",
                        "algorithmic_tflop_per_image": fl_img / 1e12,
                        "peak_hbm_allocated_gb": torch.cuda.max_memory_allocated() / 2 ** 30},
             "step_mfma_roofline": {"achieved": step_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                    "frac": step_tflops / PEAK_F32_MFMA_TFLOPS,
-                                   "note": "whole step (incl. HBM-bound kernels, optimiser, host) vs fp32 MFMA peak, per GPU"},
+                                   "note": "whole step, ALGORITHMIC direct-convolution FLOPs (Winograd executes fewer: see "
+                                           "executed_mfma_frac_wall) incl. HBM-bound kernels, optimiser, host; per GPU"},
         }
         if not args.no_prof:
-            out.update(roofline_objects(ops, args.steps))
+            out.update(roofline_objects(ops, args.steps, dt))
         if world == 1 and not args.no_cpu_baseline:
-            threads = args.cpu_threads or min(os.cpu_count() or 1, 16)
-            out["cpu_baseline"] = cpu_baseline(args.res, res_step, args.cpu_batch, threads)
+            threads = args.cpu_threads or (os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline(args.res, res_step, args.cpu_batch, threads, args.cpu_timeout)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

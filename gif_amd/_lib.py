@@ -31,6 +31,9 @@ PROTOTYPES = {
     "gif_rasterize_workspace_bytes": (c_i64, [c_int, c_int, c_int]),
     "gif_rasterize_f32": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P]),
     "gif_rasterize_colors_f32": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P, P]),
+    "gif_rasterize_workspace_bytes_f64": (c_i64, [c_int, c_int, c_int]),
+    "gif_rasterize_f64": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P]),
+    "gif_rasterize_colors_f64": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P, P]),
     "gif_vertex_normals_f32": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),
     "gif_texture_map_f32": (c_int, [P] * 9 + [c_int] * 6 + [P]),
     "gif_texture_map_bwd_f32": (c_int, [P] * 8 + [c_int] * 6 + [P]),

@@ -6,7 +6,7 @@
 // Gradients, exp_avg and exp_avg_sq live in flat buffers that share one offset table (train_step.FlatGradBucket); the
 // parameters (and EMA parameters) stay wherever torch allocated them and are reached through a chunk table, so model.to(),
 // load_state_dict() or checkpoint code never see a re-bound storage.
-// Arithmetic follows torch's single-tensor Adam: m += (g - m) * (1 - b1); v = v * b2 + (1 - b2) * g * g;
+// Arithmetic follows torch's single-tensor Adam: m = lerp(m, g, 1 - b1); v = v * b2 + (1 - b2) * g * g;
 // p -= step_size * m / (sqrt(v) / sqrt(bc2) + eps), step_size = lr / bc1 (bias corrections computed on the host in double).
 #include "common.h"
 
@@ -24,7 +24,8 @@ struct AdamArgs {
 };
 
 __device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v, const AdamArgs& a) {
-    m = m + (g - m) * (1.f - a.b1);
+    const float w = 1.f - a.b1;  // exp_avg.lerp_(grad, 1 - beta1), ATen's two-sided formula (exact at beta1 = 0: m = g)
+    m = w < 0.5f ? m + w * (g - m) : g - (g - m) * (1.f - w);
     v = v * a.b2 + (1.f - a.b2) * g * g;
     const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
     p = p - a.step_size * (m / denom);

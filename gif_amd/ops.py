@@ -389,15 +389,20 @@ def sqnorm_per_sample(g):
 
 
 def rasterize(face_vertices, depth, tri, out3, h, w, face_colors=None):
+    """float32 or float64 buffers (all floating tensors of one dtype, like the reference's AT_DISPATCH_FLOATING_TYPES)."""
     lib = _lib.load()
     B, F = face_vertices.shape[:2]
-    ws = torch.empty((max(B * h * w, 1),), device=face_vertices.device, dtype=torch.int64)
+    f64 = face_vertices.dtype == torch.float64
+    ws_bytes = (lib.gif_rasterize_workspace_bytes_f64 if f64 else lib.gif_rasterize_workspace_bytes)(B, h, w)
+    ws = torch.empty((max(ws_bytes // 8, 1),), device=face_vertices.device, dtype=torch.int64)
+    plain, colors = (lib.gif_rasterize_f64, lib.gif_rasterize_colors_f64) if f64 else (lib.gif_rasterize_f32,
+                                                                                        lib.gif_rasterize_colors_f32)
     if face_colors is None:
-        rc = lib.gif_rasterize_f32(face_vertices.data_ptr(), depth.data_ptr(), tri.data_ptr(), out3.data_ptr(), B, F, h, w,
-                                   ws.data_ptr(), _stream())
+        rc = plain(face_vertices.data_ptr(), depth.data_ptr(), tri.data_ptr(), out3.data_ptr(), B, F, h, w, ws.data_ptr(),
+                   _stream())
     else:
-        rc = lib.gif_rasterize_colors_f32(face_vertices.data_ptr(), face_colors.data_ptr(), depth.data_ptr(), tri.data_ptr(),
-                                          out3.data_ptr(), B, F, h, w, ws.data_ptr(), _stream())
+        rc = colors(face_vertices.data_ptr(), face_colors.data_ptr(), depth.data_ptr(), tri.data_ptr(), out3.data_ptr(), B, F,
+                    h, w, ws.data_ptr(), _stream())
     _lib.check(rc, "rasterize")
 
 

@@ -3,7 +3,8 @@
 Mirrors (same names, argument order, in-place semantics, return value):
   standard_rasterize / standard_rasterize_colors   my_utils/standard_rasterize_cuda/standard_rasterize_cuda.cpp:26-40, :59-75
   face_vertices / get_visibility / get_visibility_z my_utils/standard_rasterize_cuda/visibility.py:9-100
-The kernels are gif_amd/csrc/rasterize.hip (HIP, gfx950) behind the C ABI gif_rasterize[_colors]_f32.
+The kernels are gif_amd/csrc/rasterize.hip (HIP, gfx950) behind the C ABI gif_rasterize[_colors]_f32 / _f64 (the reference
+dispatches both floating types).
 Like the reference's CHECK_INPUT (.cpp:21-23) every tensor must be a contiguous device tensor, else an
 exception is raised; buffers are caller-allocated, caller-initialised, mutated in place and returned.
 """
@@ -18,24 +19,35 @@ def _check(t, name, dtype):
     if not t.is_contiguous():
         raise RuntimeError(f"{name} must be contiguous")
     if t.dtype != dtype:
-        raise _lib.GifHipError(f"{name} must be {dtype} (this build implements the float32 path), got {t.dtype}")
+        raise _lib.GifHipError(f"{name} must be {dtype}, got {t.dtype}")
+
+
+def _float_dtype(face_vertices):
+    """float32 or float64, taken from face_vertices like the reference's AT_DISPATCH_FLOATING_TYPES(face_vertices.type(), ...)
+    (standard_rasterize_cuda_kernel.cu:252,295); every other floating buffer must match it."""
+    dt = face_vertices.dtype if isinstance(face_vertices, torch.Tensor) else None
+    if dt not in (torch.float32, torch.float64):
+        raise _lib.GifHipError(f"face_vertices must be float32 or float64, got {dt}")
+    return dt
 
 
 def standard_rasterize(face_vertices, depth_buffer, triangle_buffer, baryw_buffer, height, width):
-    _check(face_vertices, "face_vertices", torch.float32)
-    _check(depth_buffer, "depth_buffer", torch.float32)
+    ft = _float_dtype(face_vertices)
+    _check(face_vertices, "face_vertices", ft)
+    _check(depth_buffer, "depth_buffer", ft)
     _check(triangle_buffer, "triangle_buffer", torch.int32)
-    _check(baryw_buffer, "baryw_buffer", torch.float32)
+    _check(baryw_buffer, "baryw_buffer", ft)
     ops.rasterize(face_vertices, depth_buffer, triangle_buffer, baryw_buffer, int(height), int(width))
     return [depth_buffer, triangle_buffer, baryw_buffer]
 
 
 def standard_rasterize_colors(face_vertices, face_colors, depth_buffer, triangle_buffer, images, height, width):
-    _check(face_vertices, "face_vertices", torch.float32)
-    _check(face_colors, "face_colors", torch.float32)
-    _check(depth_buffer, "depth_buffer", torch.float32)
+    ft = _float_dtype(face_vertices)
+    _check(face_vertices, "face_vertices", ft)
+    _check(face_colors, "face_colors", ft)
+    _check(depth_buffer, "depth_buffer", ft)
     _check(triangle_buffer, "triangle_buffer", torch.int32)
-    _check(images, "images", torch.float32)
+    _check(images, "images", ft)
     if face_colors.shape != face_vertices.shape:
         raise _lib.GifHipError("face_colors must have the shape of face_vertices [B,F,3,3]")
     ops.rasterize(face_vertices, depth_buffer, triangle_buffer, images, int(height), int(width), face_colors=face_colors)

@@ -42,9 +42,15 @@ def broadcast_module_state(modules, src=0, group=None):
     group of size > 1."""
     if not _dist_on(group):
         return
+    via_host = dist.get_backend(group) != "nccl"  # gloo (tests): move device tensors through the host explicitly
     for m in modules:
         for t in list(m.parameters()) + list(m.buffers()):
-            dist.broadcast(t.data, src=src, group=group)
+            if via_host and t.is_cuda:
+                h = t.data.cpu()
+                dist.broadcast(h, src=src, group=group)
+                t.data.copy_(h)
+            else:
+                dist.broadcast(t.data, src=src, group=group)
 
 
 class FlatGradBucket:
@@ -103,6 +109,10 @@ class FlatGradBucket:
         if dist.get_backend(self.group) == "nccl":  # RCCL: the mean is taken inside the collective, no separate pass
             work = dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op)
             self._pending = (work, None) if async_op else None
+        elif self.flat.is_cuda:  # gloo with a device bucket (tests only): through the host, synchronously
+            h = self.flat.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            self.flat.copy_(h.div_(ws))
         else:  # gloo (CPU tests) has no AVG
             work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
             if async_op:

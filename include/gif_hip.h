@@ -46,6 +46,19 @@ int gif_rasterize_colors_f32(const float* face_vertices, const float* face_color
                              int32_t* tri, float* images, int B, int F, int H, int W, void* workspace,
                              gif_stream_t stream);
 
+/* float64 variants: the reference dispatches both floating types (AT_DISPATCH_FLOATING_TYPES,
+ * standard_rasterize_cuda_kernel.cu:252,295).  Same contract with double buffers; `workspace` holds
+ * gif_rasterize_workspace_bytes_f64 bytes (a uint64 depth key + a uint32 face key per pixel).  NOTE: the reference's own
+ * double path funnels the depth through fminf (.cu:19-29: the CAS loop of atomicMin(double*) calls fminf), i.e. it stores
+ * FLOAT-rounded depths and then almost never finds `depth == zp`, so it leaves the face / barycentric buffers unwritten;
+ * this implementation computes what that code intends: true double-precision minimum depth and its face. */
+int64_t gif_rasterize_workspace_bytes_f64(int B, int H, int W);
+int gif_rasterize_f64(const double* face_vertices, double* depth, int32_t* tri, double* bary, int B, int F,
+                      int H, int W, void* workspace, gif_stream_t stream);
+int gif_rasterize_colors_f64(const double* face_vertices, const double* face_colors, double* depth,
+                             int32_t* tri, double* images, int B, int F, int H, int W, void* workspace,
+                             gif_stream_t stream);
+
 /* Per-vertex normals — replaces vertex_normals() model/mesh_and_3d_helpers.py:5-37 (condition-render pipeline,
  * SURVEY §8(f) row 1).  verts [B,V,3]; faces [F,3] int32 (topology shared by the batch); csr_off [V+1] / csr_ent [3F]:
  * vertex -> entries (face*4 + corner), ordered corner 1, corner 2, corner 0 with faces ascending (the order of the

@@ -34,6 +34,11 @@ def lib():
         _LIB.oracle_rasterize.restype = None
         _LIB.oracle_rasterize_colors.argtypes = [fp, fp, fp, ip, fp] + [ctypes.c_int] * 4
         _LIB.oracle_rasterize_colors.restype = None
+        dp = ctypes.POINTER(ctypes.c_double)
+        _LIB.oracle_rasterize_f64.argtypes = [dp, dp, ip, dp] + [ctypes.c_int] * 4
+        _LIB.oracle_rasterize_f64.restype = None
+        _LIB.oracle_rasterize_colors_f64.argtypes = [dp, dp, dp, ip, dp] + [ctypes.c_int] * 4
+        _LIB.oracle_rasterize_colors_f64.restype = None
     return _LIB
 
 
@@ -45,18 +50,30 @@ def _i(a):
     return a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
 
 
+def _d(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
 def standard_rasterize(face_verts, depth, tri, bary, h, w):
-    """In-place on C-contiguous float32/int32 numpy buffers, like standard_rasterize_cuda.cpp:26-40."""
-    assert face_verts.dtype == np.float32 and face_verts.flags.c_contiguous
+    """In-place on C-contiguous float32 (or float64) / int32 numpy buffers, like standard_rasterize_cuda.cpp:26-40."""
+    assert face_verts.dtype in (np.float32, np.float64) and face_verts.flags.c_contiguous
+    assert depth.dtype == face_verts.dtype and bary.dtype == face_verts.dtype
     B, F = face_verts.shape[:2]
-    lib().oracle_rasterize(_f(face_verts), _f(depth), _i(tri), _f(bary), B, F, h, w)
+    if face_verts.dtype == np.float64:
+        lib().oracle_rasterize_f64(_d(face_verts), _d(depth), _i(tri), _d(bary), B, F, h, w)
+    else:
+        lib().oracle_rasterize(_f(face_verts), _f(depth), _i(tri), _f(bary), B, F, h, w)
     return depth, tri, bary
 
 
 def standard_rasterize_colors(face_verts, face_colors, depth, tri, images, h, w):
-    assert face_verts.dtype == np.float32 and face_colors.dtype == np.float32
+    assert face_verts.dtype in (np.float32, np.float64) and face_colors.dtype == face_verts.dtype
+    assert depth.dtype == face_verts.dtype and images.dtype == face_verts.dtype
     B, F = face_verts.shape[:2]
-    lib().oracle_rasterize_colors(_f(face_verts), _f(face_colors), _f(depth), _i(tri), _f(images), B, F, h, w)
+    if face_verts.dtype == np.float64:
+        lib().oracle_rasterize_colors_f64(_d(face_verts), _d(face_colors), _d(depth), _i(tri), _d(images), B, F, h, w)
+    else:
+        lib().oracle_rasterize_colors(_f(face_verts), _f(face_colors), _f(depth), _i(tri), _f(images), B, F, h, w)
     return depth, tri, images
 
 

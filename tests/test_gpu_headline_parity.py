@@ -1,0 +1,262 @@
+"""-m gpu: ORACLE-checked parity at the BASELINE sizes (round-1 verdict item 1: the full-size checks used to compare the HIP
+kernels with each other).
+
+(a) per-layer: the benchmark's layer shapes at batch 32 through the DEFAULT dispatch (Winograd / direct / transposed phases /
+    small-channel kernels exactly as bench.py takes them) — forward, data gradient and weight gradient against ONE ATen-CPU
+    fp32 convolution each (the GPU box's host has enough cores for a 0.3 TFLOP conv in seconds).
+(b) 256x256, batch 4, full backward: every G and D parameter gradient, the R1 penalty and the gradients through its double
+    backward against oracle/stylegan2_ref.py (the restatement that is pinned to the real reference).
+(c) BASELINE config 3 at its stated size: mesh -> HIP vertex normals + rasteriser -> 6-channel condition -> GifTrainer.step
+    at 256x256, batch 32, R1 iteration; per-sample images / scores / R1 penalties of one minibatch-stddev group against the
+    oracle, and the trainer's first-step losses against the values assembled from those per-sample quantities.
+Tolerances are the small-size tests' (CONV_CASES): 2e-5 of the tensor max for forward / dgrad, 5e-5 for wgrad (fp32 sums of
+2 M products), 3e-4 for whole-model gradients."""
+import contextlib
+import io
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_util import assert_close, dev, host, pad4, rel_err
+
+pytestmark = pytest.mark.gpu
+
+B_HEAD = 32  # BASELINE batch per GPU
+
+# (name, Cin, Cout, K, stride, pad, Hin, transposed)
+LAYER_SHAPES = [
+    ("3x3 128->128 @256^2 (G st_cv2 / D conv1)", 128, 128, 3, 1, 1, 256, False),
+    ("3x3 256->256 @128^2", 256, 256, 3, 1, 1, 128, False),
+    ("3x3 512->512 @64^2", 512, 512, 3, 1, 1, 64, False),
+    ("3x3 stride-2 128->256 on the blurred 257^2 map (D conv2)", 128, 256, 3, 2, 0, 257, False),
+    ("transposed 3x3 stride-2 256->128, 128^2 -> 257^2 (G up-sampling)", 256, 128, 3, 2, 0, 128, True),
+    ("3x3 24->128 @256^2 (condition-noise conv 3)", 24, 128, 3, 1, 1, 256, False),
+]
+
+
+@pytest.mark.parametrize("shape", LAYER_SHAPES, ids=[s[0].split(" (")[0].replace(" ", "_") for s in LAYER_SHAPES])
+def test_benchmark_layer_vs_aten_cpu(shape):
+    """fwd / dgrad / wgrad of one benchmark layer, batch 32, default dispatch, vs ATen CPU fp32."""
+    from gif_amd import functional as GF
+    name, Ci, Co, K, st, pd, H, transposed = shape
+    g = torch.Generator().manual_seed(100 + LAYER_SHAPES.index(shape))
+    B = B_HEAD
+    x = torch.randn(B, Ci, H, H, generator=g)
+    if not transposed:
+        w = torch.randn(Co, Ci, K, K, generator=g)
+        wscale = 1 / math.sqrt(Ci * K * K)
+        Ho = (H + 2 * pd - K) // st + 1
+    else:
+        # conv_transpose2d(x, W^T, stride 2): the underlying forward conv maps Cout -> Cin, canonical weight [Ci, Co, K, K]
+        w = torch.randn(Ci, Co, K, K, generator=g)
+        wscale = 1 / math.sqrt(Ci * K * K)
+        Ho = (H - 1) * st + K - 2 * pd
+    gy = torch.randn(B, Co, Ho, Ho, generator=g)
+    # ---- ATen CPU reference (one conv call + its autograd)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    if not transposed:
+        yr = F.conv2d(xr, wr * wscale, stride=st, padding=pd)
+    else:
+        yr = F.conv_transpose2d(xr, wr * wscale, stride=st, padding=pd)
+    gxr, gwr = torch.autograd.grad(yr, (xr, wr), gy)
+    # ---- HIP path through the autograd Functions the models use
+    xd = dev(x, requires_grad=True)
+    wd = w.cuda().requires_grad_(True)
+    if not transposed:
+        yd = GF.conv2d(xd, wd, st, pd, wscale=wscale)
+    else:
+        yd = GF.conv_transpose2d(xd, wd, st, pd, (Ho, Ho), wscale=wscale)
+    gxd, gwd = torch.autograd.grad(yd, (xd, wd), dev(gy))
+    assert_close(host(yd, Co), yr, 2e-5, f"{name}: forward")
+    assert_close(host(gxd, Ci), gxr, 2e-5, f"{name}: data gradient")
+    assert_close(gwd, gwr, 5e-5, f"{name}: weight gradient")
+
+
+def test_benchmark_modulated_layers_vs_aten_cpu():
+    """The generator's two modulated forms at the benchmark size, batch 32, default dispatch: the fused StyledConv
+    (128->128 @256^2: modulation, demodulation, condition-noise residual, bias, leaky ReLU in one launch) and the up-sampling
+    modulated transposed conv (256->128, 128^2 -> 257^2) — forward and every gradient vs an ATen-CPU composition."""
+    from gif_amd import functional as GF
+    g = torch.Generator().manual_seed(77)
+    B = B_HEAD
+    # ---- fused same-resolution StyledConv
+    Ci = Co = 128
+    H = 256
+    x = torch.randn(B, Ci, H, H, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g)
+    s, d = torch.rand(B, Ci, generator=g) + 0.5, torch.rand(B, Co, generator=g) + 0.5
+    res, bias = torch.randn(B, Co, H, H, generator=g), torch.randn(Co, generator=g) * 0.1
+    gy = torch.randn(B, Co, H, H, generator=g)
+    wscale = 1 / math.sqrt(Ci * 9)
+    leaves = [t.clone().requires_grad_(True) for t in (x, w, s, d, res, bias)]
+    xr, wr, sr, dr, rr, br = leaves
+    yr = 2 ** 0.5 * F.leaky_relu(F.conv2d(xr * sr[:, :, None, None], wr * wscale, padding=1) * dr[:, :, None, None]
+                                 + rr + br[None, :, None, None], 0.2)
+    refs = torch.autograd.grad(yr, leaves, gy)
+    xd, rd = dev(x, True), dev(res, True)
+    wd, sd_, dd, bd = (t.cuda().requires_grad_(True) for t in (w, s, d, bias))
+    yd = GF.modulated_conv2d_act(xd, wd, sd_, dd, rd, bd, 1, wscale)
+    gots = torch.autograd.grad(yd, (xd, wd, sd_, dd, rd, bd), dev(gy))
+    assert_close(host(yd), yr, 2e-5, "fused StyledConv forward")
+    for nm, got, ref, tol in zip(("x", "w", "s", "d", "residual", "bias"), gots, refs, (2e-5, 5e-5, 5e-5, 5e-5, 2e-5, 5e-5)):
+        assert_close(got, ref, tol, f"fused StyledConv grad {nm}")
+    del leaves, refs, gots, yr, yd, xd, rd
+    # ---- up-sampling branch: modulated conv_transpose2d, stride 2 (the blur that follows is covered by the FIR tests)
+    Ci, Co, H = 256, 128, 128
+    x = torch.randn(B, Ci, H, H, generator=g)
+    wt = torch.randn(Ci, Co, 3, 3, generator=g)  # canonical forward-conv weight of the underlying conv (Co -> Ci)
+    s, d = torch.rand(B, Ci, generator=g) + 0.5, torch.rand(B, Co, generator=g) + 0.5
+    Ho = 2 * H + 1
+    gy = torch.randn(B, Co, Ho, Ho, generator=g)
+    wscale = 1 / math.sqrt(Ci * 9)
+    leaves = [t.clone().requires_grad_(True) for t in (x, wt, s, d)]
+    xr, wr, sr, dr = leaves
+    yr = F.conv_transpose2d(xr * sr[:, :, None, None], wr * wscale, stride=2) * dr[:, :, None, None]
+    refs = torch.autograd.grad(yr, leaves, gy)
+    xd = dev(x, True)
+    wd, sd_, dd = (t.cuda().requires_grad_(True) for t in (wt, s, d))
+    yd = GF.modulated_conv2d(xd, wd, sd_, dd, stride=2, pad=0, transposed=True, out_hw=(Ho, Ho), wscale=wscale)
+    gots = torch.autograd.grad(yd, (xd, wd, sd_, dd), dev(gy))
+    assert_close(host(yd), yr, 2e-5, "modulated transposed conv forward")
+    for nm, got, ref, tol in zip(("x", "w", "s", "d"), gots, refs, (2e-5, 5e-5, 5e-5, 5e-5)):
+        assert_close(got, ref, tol, f"modulated transposed conv grad {nm}")
+
+
+def _build(res, vocab=64):
+    from gif_amd.discriminator import Discriminator
+    from gif_amd.generator import StyledGenerator
+    with contextlib.redirect_stdout(io.StringIO()):
+        g = StyledGenerator(embedding_vocab_size=vocab, rendered_flame_ascondition=True, normal_maps_as_cond=True)
+        d = Discriminator(size=res, num_color_chnls=9)
+    return g, d
+
+
+def _leaves(sd):
+    return {k: (v.clone().requires_grad_(True) if (not k.endswith('kernel') and 'embd_weight' not in k) else v.clone())
+            for k, v in sd.items()}
+
+
+def test_full_backward_256_batch4_vs_oracle():
+    """(b) one D loss (with R1 on the real images) and one G loss at 256x256, batch 4: EVERY parameter gradient of both
+    networks against the CPU oracle's autograd, plus the R1 penalty values."""
+    from gif_amd import losses
+    from oracle import stylegan2_ref as R
+    torch.manual_seed(0)
+    G, D = _build(256, vocab=16)
+    g_sd = R.seeded_state_dict(G.state_dict(), 41)
+    d_sd = R.seeded_state_dict(D.state_dict(), 42)
+    G.load_state_dict(g_sd, strict=True)
+    D.load_state_dict(d_sd, strict=True)
+    gen = torch.Generator().manual_seed(43)
+    B = 4
+    real = torch.rand(B, 3, 256, 256, generator=gen) * 2 - 1
+    cond = torch.rand(B, 6, 256, 256, generator=gen) * 2 - 1
+    idx = torch.randint(0, 16, (B,), generator=gen)
+    # ---- oracle
+    gl, dl = _leaves(g_sd), _leaves(d_sd)
+    real_r = real.clone().requires_grad_(True)
+    fake_r = R.generator_forward(gl, cond, 6, idx)
+    rs = R.discriminator_forward(dl, real_r, cond, 256)
+    r1_r = R.grad_penalty_loss([real_r], rs)
+    d_loss_r = F.softplus(-rs).mean() + r1_r.mean() + F.softplus(R.discriminator_forward(dl, fake_r.detach(), cond, 256)).mean()
+    d_keys = [k for k, v in dl.items() if v.requires_grad]
+    d_grads_r = dict(zip(d_keys, torch.autograd.grad(d_loss_r, [dl[k] for k in d_keys])))
+    g_loss_r = F.softplus(-R.discriminator_forward(dl, fake_r, cond, 256)).mean()
+    g_keys = [k for k, v in gl.items() if v.requires_grad]
+    g_grads_r = dict(zip(g_keys, torch.autograd.grad(g_loss_r, [gl[k] for k in g_keys], allow_unused=True)))
+    # ---- HIP
+    G, D = G.cuda(), D.cuda()
+    condd, idxd = cond.cuda(), idx.cuda()
+    real_d = real.cuda().requires_grad_(True)
+    fake_d = G(condd, None, step=6, alpha=1, input_indices=idxd)
+    assert (fake_d[0].detach().cpu() - fake_r.detach()).abs().max().item() < 1e-3, "north-star: G output L_inf < 1e-3"
+    rs_d, _ = D([real_d], condition=condd)
+    r1_d = losses.grad_penalty_loss([real_d], rs_d, step=None)
+    assert_close(r1_d, r1_r, 3e-4, "R1 penalties at 256x256")
+    d_loss_d = F.softplus(-rs_d).mean() + r1_d.mean() + F.softplus(D([fake_d[0].detach()], condition=condd)[0]).mean()
+    assert abs(d_loss_d.item() - d_loss_r.item()) < 1e-4 * max(1.0, abs(d_loss_r.item()))
+    d_named = dict(D.named_parameters())
+    d_grads_d = dict(zip(d_keys, torch.autograd.grad(d_loss_d, [d_named[k] for k in d_keys])))
+    g_loss_d = F.softplus(-D(fake_d, condition=condd)[0]).mean()
+    assert abs(g_loss_d.item() - g_loss_r.item()) < 1e-4 * max(1.0, abs(g_loss_r.item()))
+    g_named = dict(G.named_parameters())
+    g_grads_d = dict(zip(g_keys, torch.autograd.grad(g_loss_d, [g_named[k] for k in g_keys], allow_unused=True)))
+    worst = ("", 0.0)
+    for keys, got, ref, what in ((d_keys, d_grads_d, d_grads_r, "D"), (g_keys, g_grads_d, g_grads_r, "G")):
+        for k in keys:
+            if ref[k] is None:  # blocks above step 6 receive no gradient on either side
+                assert got[k] is None or got[k].abs().max().item() == 0, k
+                continue
+            e = rel_err(got[k], ref[k])
+            if e > worst[1]:
+                worst = (f"{what}.{k}", e)
+            assert e <= 3e-4, f"{what} grad {k}: rel err {e:.3e}"
+    print(f"worst parameter-gradient error at 256x256, batch 4: {worst[0]} {worst[1]:.2e}")
+
+
+def test_config3_at_stated_size_vs_oracle():
+    """(c) BASELINE config 3: rendered condition -> full G+D training iteration at 256x256, batch 32, R1 iteration."""
+    from gif_amd import losses, render
+    from gif_amd.train_step import GifTrainer
+    from oracle import stylegan2_ref as R
+    mesh = np.load(os.path.join(os.path.dirname(__file__), "golden", "body_mesh.npz"))
+    B, RES = 32, 256
+    rng = np.random.RandomState(0)
+    verts = []
+    for i in range(B):  # small random rotations about y, as a stand-in for FLAME pose variation
+        a = rng.uniform(-0.4, 0.4)
+        Rm = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], np.float32)
+        verts.append((mesh["vertices"] @ Rm.T).astype(np.float32))
+    v = torch.from_numpy(np.stack(verts)).cuda()
+    f = torch.from_numpy(mesh["faces"]).cuda()
+    cam = torch.tensor([[0.95, 0.0, 0.35]] * B, device="cuda")
+    v_ndc = render.batch_orth_proj(v, cam)
+    tex = (v - v.amin(dim=1, keepdim=True)) / (v.amax(dim=1, keepdim=True) - v.amin(dim=1, keepdim=True))
+    cond = render.render_condition(v_ndc, f, tex, RES, RES)
+    assert cond.shape == (B, 6, RES, RES) and (cond[:, 3:].abs().sum(dim=(1, 2, 3)) > 0).all()
+    torch.manual_seed(0)
+    G, D = _build(RES, vocab=64)
+    G_ema, _ = _build(RES, vocab=64)
+    g_sd = R.seeded_state_dict(G.state_dict(), 51)
+    d_sd = R.seeded_state_dict(D.state_dict(), 52)
+    G.load_state_dict(g_sd, strict=True)
+    G_ema.load_state_dict(g_sd, strict=True)
+    D.load_state_dict(d_sd, strict=True)
+    G, G_ema, D = G.cuda(), G_ema.cuda(), D.cuda()
+    gen = torch.Generator(device="cuda").manual_seed(53)
+    real = torch.rand(B, 3, RES, RES, device="cuda", generator=gen) * 2 - 1
+    idx = torch.randint(0, 64, (B,), device="cuda", generator=gen)
+    # per-sample quantities of the first D step, HIP
+    real_d = real.clone().requires_grad_(True)
+    with torch.no_grad():
+        fake = G(cond, None, step=6, alpha=1, input_indices=idx)[0]
+        fs = D([fake], condition=cond)[0]
+    rs = D([real_d], condition=cond)[0]
+    r1 = losses.grad_penalty_loss([real_d], rs, step=None).detach()
+    rs = rs.detach()
+    # the oracle on ONE minibatch-stddev group: view(4, B/4, ...) groups samples {b, b+8, b+16, b+24}
+    sel = torch.tensor([0, 8, 16, 24])
+    c4, i4, r4 = cond[sel.cuda()].cpu(), idx[sel.cuda()].cpu(), real[sel.cuda()].cpu().requires_grad_(True)
+    with torch.no_grad():
+        fake_o = R.generator_forward(g_sd, c4, 6, i4)
+        fs_o = R.discriminator_forward(d_sd, fake_o, c4, RES)
+    rs_o = R.discriminator_forward(d_sd, r4, c4, RES)
+    r1_o = R.grad_penalty_loss([r4], rs_o).detach()
+    assert (fake[sel.cuda()].cpu() - fake_o).abs().max().item() < 1e-3, "G images of the group vs oracle (north-star bound)"
+    assert_close(fake[sel.cuda()], fake_o, 1e-4, "G images of the group")
+    assert_close(fs[sel.cuda()], fs_o, 3e-4, "D(fake) scores of the group")
+    assert_close(rs[sel.cuda()], rs_o.detach(), 3e-4, "D(real) scores of the group")
+    assert_close(r1[sel.cuda()], r1_o, 5e-4, "R1 penalties of the group")
+    d_expected = (F.softplus(-rs).mean() + r1.mean() + F.softplus(fs).mean()).item()
+    # the training iteration itself (R1 iteration: i + 1 divisible by 16)
+    tr = GifTrainer(G, D, G_ema, step=6, r1_every=16)
+    w0 = D.convs[1].conv1[0].weight.detach().clone()
+    d_loss, g_loss = tr.step(15, real, cond, idx)
+    torch.cuda.synchronize()
+    assert abs(d_loss.item() - d_expected) < 1e-4 * max(1.0, abs(d_expected)), (d_loss.item(), d_expected)
+    assert torch.isfinite(g_loss).item()
+    assert (D.convs[1].conv1[0].weight - w0).abs().max().item() > 0, "discriminator parameters must move"

@@ -1,0 +1,370 @@
+"""-m gpu: round-2 additions — any-order generator (StyleGAN2-form path-length regulariser, DIRECT_GRAD_REG), fused HIP
+Adam+EMA vs torch.optim.Adam, wrapping tolerance of the drop-in boundary (nn.DataParallel(...).module, tensors carrying
+ad-hoc attributes), float64 rasteriser, and the REAL trainer in two data-parallel processes on one GPU."""
+import contextlib
+import io
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_util import assert_close, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _build_g(vocab=16):
+    from gif_amd.generator import StyledGenerator
+    with contextlib.redirect_stdout(io.StringIO()):
+        return StyledGenerator(embedding_vocab_size=vocab, rendered_flame_ascondition=True, normal_maps_as_cond=True)
+
+
+def _build_d(size):
+    from gif_amd.discriminator import Discriminator
+    return Discriminator(size=size, num_color_chnls=9)
+
+
+def _leaves(sd):
+    return {k: (v.clone().requires_grad_(True) if (not k.endswith('kernel') and 'embd_weight' not in k) else v.clone())
+            for k, v in sd.items()}
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# a13: twice-differentiable generator
+# ------------------------------------------------------------------------------------------------------------------------
+def _setup_g32(seed):
+    from oracle import stylegan2_ref as R
+    torch.manual_seed(0)
+    g = _build_g()
+    sd = R.seeded_state_dict(g.state_dict(), seed)
+    g.load_state_dict(sd, strict=True)
+    return g.cuda(), sd
+
+
+def test_path_length_stylegan2_form_gradients_vs_oracle(monkeypatch):
+    """PathLengthRegularizor(reference_semantics=False): the penalty is back-propagated THROUGH the generator's backward
+    (create_graph=True).  Value, moving mean and the gradient of the penalty w.r.t. generator parameters against the CPU
+    oracle's autograd on a 32x32 generator fed the same draws."""
+    from gif_amd import losses
+    from oracle import stylegan2_ref as R
+    g, sd = _setup_g32(71)
+    gen = torch.Generator().manual_seed(72)
+    B = 2
+    cond = torch.rand(B, 6, 32, 32, generator=gen) * 2 - 1
+    style = torch.randn(B, 512, generator=gen)
+    noise = torch.randn(B, 3, 32, 32, generator=gen)
+    # ---- oracle: StyleGAN2 form (per-image noise scale, create_graph, per-sample lengths, EMA of the mean length)
+    leaves = _leaves(sd)
+    z = style.clone().requires_grad_(True)
+    fake_r = R.generator_forward(leaves, cond, 3, z)
+    n_r = noise / np.sqrt(32 * 32)
+    (pg_r,) = torch.autograd.grad((fake_r * n_r).sum(), z, create_graph=True)
+    len_r = torch.sqrt(pg_r.pow(2).sum(1))
+    mean_r = 0 + 0.01 * (len_r.mean().detach() - 0)
+    pen_r = (len_r - mean_r).pow(2).mean()
+    keys = ['generator.progression.1.st_cv1.conv.weight', 'generator.progression.3.st_cv2.conv.weight',
+            'generator.progression.2.st_cv2.conv.modulation.weight', 'generator.progression.3.st_cv2.noise.noise_conv.4.weight',
+            'generator.to_rgb.3.conv.weight', 'generator.progression.2.st_cv1.activate.bias', 'z_to_w.8.weight',
+            'generator.const_input.input']
+    grads_r = torch.autograd.grad(pen_r, [leaves[k] for k in keys])
+    # ---- HIP: the regulariser class itself, with its two torch.randn draws replayed
+    draws = [style, noise]
+
+    def replay(*a, **k):
+        t = draws.pop(0)
+        shape = tuple(a[0]) if isinstance(a[0], (tuple, list, torch.Size)) else tuple(a)
+        assert tuple(t.shape) == shape, (t.shape, shape)
+        return t.to(k.get("device", "cpu")).requires_grad_(k.get("requires_grad", False))
+
+    monkeypatch.setattr(torch, "randn", replay)
+    reg = losses.PathLengthRegularizor(reference_semantics=False)
+    for p in g.parameters():
+        p.requires_grad_(True)
+    pen = reg.path_length_reg(g, step=3, alpha=1.0, input_indices=torch.zeros(B, dtype=torch.long, device="cuda"),
+                              cond=cond.cuda())
+    monkeypatch.undo()
+    assert pen.requires_grad, "StyleGAN2 form: the penalty must carry a gradient to G"
+    assert abs(pen.item() - pen_r.item()) < 2e-4 * abs(pen_r.item()), (pen.item(), pen_r.item())
+    assert abs(float(reg.pl_moving_mean) - mean_r.item()) < 2e-4 * abs(mean_r.item())
+    named = dict(g.named_parameters())
+    grads = torch.autograd.grad(pen, [named[k] for k in keys])
+    for k, got, ref in zip(keys, grads, grads_r):
+        assert ref.abs().max().item() > 0, k
+        assert_close(got, ref, 1e-3, f"d penalty / d {k} (double backward through G)")
+
+
+def test_direct_grad_reg_vs_oracle_and_in_trainer():
+    """DIRECT_GRAD_REG (train.py:209-215): gradient penalty of the squared image w.r.t. the condition, back-propagated to
+    the generator parameters — oracle autograd vs the HIP generator; then the trainer option end to end."""
+    from gif_amd import losses
+    from gif_amd.train_step import GifTrainer
+    from oracle import stylegan2_ref as R
+    g, sd = _setup_g32(81)
+    gen = torch.Generator().manual_seed(82)
+    B = 2
+    cond = torch.rand(B, 6, 32, 32, generator=gen) * 2 - 1
+    idx = torch.tensor([3, 11])
+    leaves = _leaves(sd)
+    c_r = cond.clone().requires_grad_(True)
+    fake_r = R.generator_forward(leaves, c_r, 3, idx)
+    pen_r = R.grad_penalty_loss([c_r], fake_r.pow(2))
+    keys = ['generator.progression.2.st_cv2.conv.weight', 'generator.progression.3.st_cv1.noise.noise_conv.0.weight',
+            'generator.progression.1.st_cv2.noise.noise_conv.4.bias', 'generator.to_rgb.2.conv.weight']
+    grads_r = torch.autograd.grad(pen_r.mean(), [leaves[k] for k in keys])
+    for p in g.parameters():
+        p.requires_grad_(True)
+    c_d = cond.cuda().requires_grad_(True)
+    fake_d = g(c_d, None, step=3, alpha=1, input_indices=idx.cuda())
+    pen_d = losses.grad_penalty_loss([c_d], torch.pow(fake_d[-1], 2), step=None)
+    assert_close(pen_d, pen_r.detach(), 5e-4, "DIRECT_GRAD_REG penalty")
+    named = dict(g.named_parameters())
+    grads_d = torch.autograd.grad(pen_d.mean(), [named[k] for k in keys])
+    for k, got, ref in zip(keys, grads_d, grads_r):
+        assert_close(got, ref, 1e-3, f"d direct-grad penalty / d {k}")
+    # trainer plumbing
+    torch.manual_seed(0)
+    G, G_ema, D = _build_g().cuda(), _build_g().cuda(), _build_d(32).cuda()
+    G_ema.load_state_dict(G.state_dict())
+    tr = GifTrainer(G, D, G_ema, step=3, gen_reg_type='DIRECT_GRAD_REG')
+    real = torch.rand(4, 3, 32, 32, device="cuda") * 2 - 1
+    cond4 = torch.rand(4, 6, 32, 32, device="cuda") * 2 - 1
+    d_loss, g_loss = tr.step(0, real, cond4, torch.randint(0, 16, (4,), device="cuda"))
+    assert torch.isfinite(d_loss).item() and torch.isfinite(g_loss).item()
+
+
+def test_raw_functions_refuse_a_double_backward():
+    """The two Functions that stay once-differentiable (texture map, texture pair loss) raise instead of returning a
+    gradient without history."""
+    from gif_amd import losses
+    a = torch.rand(3, 16, 16, device="cuda", requires_grad=True)
+    b = torch.rand(3, 16, 16, device="cuda")
+    f = torch.ones(16, 16, device="cuda")
+    loss = losses._TexPairLossFn.apply(a, b, None, None, f)
+    (ga,) = torch.autograd.grad(loss, a, create_graph=True)
+    with pytest.raises(RuntimeError):
+        ga.sum().backward()
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# a14: fused Adam + EMA
+# ------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("betas", [(0.0, 0.99 ** 0.8), (0.9, 0.999)])
+def test_flat_adam_matches_torch_adam_and_accumulate(betas):
+    from gif_amd.optim import FlatAdam
+    from gif_amd.train_step import FlatGradBucket, accumulate
+    torch.manual_seed(3)
+    shapes = [(512, 512, 3, 3), (1, 3, 128, 1, 1), (513,), (7, 5), (1,), (4096 * 3 + 5,), (256, 128, 3, 3)]
+
+    class Bag(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.ps = torch.nn.ParameterList([torch.nn.Parameter(torch.randn(*s)) for s in shapes])
+
+    ma, mb, ea, eb = Bag().cuda(), Bag().cuda(), Bag().cuda(), Bag().cuda()
+    mb.load_state_dict(ma.state_dict())
+    eb.load_state_dict(ea.state_dict())
+    skip = ma.ps[3]  # a parameter that never gets a gradient
+    bucket = FlatGradBucket(ma.parameters(), active=lambda p: p is not skip)
+    opt_a = FlatAdam(ma.parameters(), lr=2e-3, betas=betas, bucket=bucket, ema_params=[p for _, p in ea.named_parameters()])
+    opt_b = torch.optim.Adam(mb.parameters(), lr=2e-3, betas=betas)
+    decay = 0.5 ** (32 / 10000)
+    for it in range(4):
+        bucket.zero()
+        opt_b.zero_grad(set_to_none=True)
+        for k, (pa, pb) in enumerate(zip(ma.ps, mb.ps)):
+            if k == 3:
+                continue
+            gsrc = torch.randn_like(pa) * (10.0 ** (k % 3 - 1))
+            pa.grad.copy_(gsrc)
+            pb.grad = gsrc.clone()
+        opt_a.step(ema_decay=decay)
+        opt_b.step()
+        accumulate(eb, mb, decay)
+    for k, (pa, pb, qa, qb) in enumerate(zip(ma.ps, mb.ps, ea.ps, eb.ps)):
+        assert_close(pa, pb, 2e-6, f"parameter {k} after 4 Adam steps")
+        assert_close(qa, qb, 2e-6, f"EMA parameter {k}")
+    assert torch.equal(ma.ps[3], mb.ps[3]) and ma.ps[3].grad is None
+    # checkpoint compatibility both ways (train.py:254-265 stores optimizer.state_dict())
+    sd_a = opt_a.state_dict()
+    opt_c = torch.optim.Adam(mb.parameters(), lr=2e-3, betas=betas)
+    opt_c.load_state_dict(sd_a)
+    st = opt_c.state[mb.ps[0]]
+    assert_close(st["exp_avg_sq"], opt_b.state[mb.ps[0]]["exp_avg_sq"], 2e-6, "exp_avg_sq through FlatAdam.state_dict()")
+    assert float(st["step"]) == 4.0
+    opt_a.load_state_dict(opt_b.state_dict())
+    assert float(opt_a._step_t) == 4.0
+    assert_close(opt_a.state[ma.ps[6]]["exp_avg"], opt_b.state[mb.ps[6]]["exp_avg"], 2e-6, "exp_avg loaded from torch Adam")
+    assert opt_a.state[ma.ps[6]]["exp_avg"].data_ptr() == opt_a._m[bucket.offsets[5]:].data_ptr(), "state stays in the flat buffer"
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# boundary: wrapping tolerance and float64 rasteriser
+# ------------------------------------------------------------------------------------------------------------------------
+def test_modules_work_inside_dataparallel_wrapper_and_with_tagged_tensors():
+    """train.py:34,218,348,367 wrap G/D in nn.DataParallel and reach through `.module`; the reference's graph tracer hangs
+    `input_name` / `_self_node_tracing_name` attributes on tensors (stg2_generator.py:314)."""
+    torch.manual_seed(0)
+    g, d = _build_g().cuda(), _build_d(32).cuda()
+    gw, dw = torch.nn.DataParallel(g, device_ids=[0]), torch.nn.DataParallel(d, device_ids=[0])
+    assert gw.module.get_embddings().shape == (16, 512)
+    assert isinstance(gw.module.z_to_w, torch.nn.Module) and len(list(gw.module.parameters())) == len(list(g.parameters()))
+    cond = torch.rand(4, 6, 32, 32, device="cuda") * 2 - 1
+    cond.input_name = "rendered_flame"
+    cond._self_node_tracing_name = "cond_0"
+    idx = torch.tensor([1, 2, 3, 4], device="cuda")
+    idx.input_name = "indices"
+    with torch.no_grad():
+        bare = g(cond, None, step=3, alpha=1, input_indices=idx)
+        wrapped = gw(cond, None, step=3, alpha=1, input_indices=idx)
+    assert isinstance(wrapped, list) and torch.equal(wrapped[0], bare[0])
+    img = bare[0]
+    img.input_name = "fake"
+    with torch.no_grad():
+        s_bare = d([img], condition=cond)[0]
+        s_wrapped = dw([img], condition=cond, step=3, alpha=1)[0]
+    assert torch.equal(s_bare, s_wrapped)
+    # state_dict of the wrapper carries the 'module.' prefix the reference's checkpoints use
+    assert all(k.startswith("module.") for k in gw.state_dict())
+    g2 = torch.nn.DataParallel(_build_g().cuda(), device_ids=[0])
+    g2.load_state_dict(gw.state_dict(), strict=True)
+
+
+def test_rasteriser_float64_bit_exact_vs_oracle():
+    """The reference dispatches float and double (AT_DISPATCH_FLOATING_TYPES): the float64 entry points against the C oracle's
+    double instantiation, bit for bit (depth, face index, barycentrics, interpolated colours); dtype mixing is refused."""
+    from gif_amd import standard_rasterize as sr
+    from oracle import rasterize_oracle as ro
+    rng = np.random.RandomState(5)
+    B, V, Fc, H, W = 3, 400, 900, 96, 80
+    v = rng.uniform(-0.95, 0.95, (B, V, 3))
+    f = rng.randint(0, V, (B, Fc, 3)).astype(np.int32)
+    vi = v.copy()
+    vi[..., 0] = vi[..., 0] * W / 2 + W / 2
+    vi[..., 1] = vi[..., 1] * H / 2 + H / 2
+    vi[..., 2] = vi[..., 2] - vi[..., 2].min() + 1
+    fv = ro.face_vertices(vi, f).astype(np.float64)
+    cols = rng.uniform(0, 1, fv.shape)
+    d0 = np.zeros((B, H, W)) + 1e6
+    t0 = np.zeros((B, H, W), np.int32) - 1
+    b0 = np.zeros((B, H, W, 3))
+    ro.standard_rasterize(fv, d0, t0, b0, H, W)
+    d1 = torch.zeros(B, H, W, device="cuda", dtype=torch.float64) + 1e6
+    t1 = torch.zeros(B, H, W, device="cuda", dtype=torch.int32) - 1
+    b1 = torch.zeros(B, H, W, 3, device="cuda", dtype=torch.float64)
+    out = sr.standard_rasterize(torch.from_numpy(fv).cuda(), d1, t1, b1, H, W)
+    assert out[0] is d1 and out[1] is t1 and out[2] is b1
+    assert (t0 >= 0).sum() > 1000
+    assert np.array_equal(t1.cpu().numpy(), t0), "float64: face indices"
+    assert np.array_equal(d1.cpu().numpy().view(np.int64), d0.view(np.int64)), "float64: depth bits"
+    assert np.array_equal(b1.cpu().numpy().view(np.int64), b0.view(np.int64)), "float64: barycentric bits"
+    d2, t2, i2 = np.zeros((B, H, W)) + 1e6, np.zeros((B, H, W), np.int32) - 1, np.zeros((B, H, W, 3))
+    ro.standard_rasterize_colors(fv, cols, d2, t2, i2, H, W)
+    d3 = torch.zeros(B, H, W, device="cuda", dtype=torch.float64) + 1e6
+    t3 = torch.zeros(B, H, W, device="cuda", dtype=torch.int32) - 1
+    i3 = torch.zeros(B, H, W, 3, device="cuda", dtype=torch.float64)
+    sr.standard_rasterize_colors(torch.from_numpy(fv).cuda(), torch.from_numpy(cols).cuda(), d3, t3, i3, H, W)
+    assert np.array_equal(t3.cpu().numpy(), t2) and np.array_equal(i3.cpu().numpy().view(np.int64), i2.view(np.int64))
+    # the double result refines the float one: same winners wherever the float depths are not within rounding of a tie
+    d4, t4, b4 = sr.new_buffers(B, H, W, "cuda")
+    sr.standard_rasterize(torch.from_numpy(fv.astype(np.float32)).cuda(), d4, t4, b4, H, W)
+    assert (t4.cpu().numpy() == t0).mean() > 0.99
+    with pytest.raises(Exception):
+        sr.standard_rasterize(torch.from_numpy(fv).cuda(), d4, t4, b4, H, W)  # float64 vertices, float32 buffers
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# (e) the real trainer, two data-parallel processes on ONE GPU
+# ------------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _dp_worker(rank, world, port, q):
+    try:
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        import copy
+        from gif_amd.train_step import GifTrainer
+        torch.manual_seed(1000 + rank)  # DIFFERENT initial weights / embedding buffers per rank (the reference sets no seed)
+        G, G_ema, D = _build_g().cuda(), _build_g().cuda(), _build_d(32).cuda()
+        G_ema.load_state_dict(G.state_dict())
+        w_before = G.generator.progression[2].st_cv2.conv.weight.detach().clone()
+        tr = GifTrainer(G, D, G_ema, step=3, r1_every=2)  # broadcasts rank 0's state
+        w_synced = G.generator.progression[2].st_cv2.conv.weight.detach().clone()
+        emb_synced = G.image_embedding.embd_weight.detach().clone()
+        gen = torch.Generator().manual_seed(9)  # the GLOBAL batch of 8, identical in both processes
+        real = (torch.rand(2, 8, 3, 32, 32, generator=gen) * 2 - 1).cuda()
+        cond = (torch.rand(2, 8, 6, 32, 32, generator=gen) * 2 - 1).cuda()
+        idx = torch.randint(0, 16, (2, 8), generator=gen).cuda()
+        sl = slice(rank * 4, rank * 4 + 4)
+        # gradients of the two halves computed WITHOUT data parallelism on copies of the synced models
+        halves = []
+        for h in range(world):
+            G2, D2, E2 = copy.deepcopy(G), copy.deepcopy(D), copy.deepcopy(G_ema)
+            t2 = GifTrainer(G2, D2, E2, step=3, r1_every=2, process_group=None, overlap_comm=False, sync_initial_state=False)
+            hs = slice(h * 4, h * 4 + 4)
+            # run the D half-step by hand up to the backward (no exchange, no update)
+            import torch.nn.functional as Fn
+            from gif_amd import losses
+            t2.d_bucket.zero()
+            rs, _ = D2([real[0, hs].detach()], condition=cond[0, hs], step=3, alpha=1.0)
+            with torch.no_grad():
+                fk = G2(cond[0, hs], None, step=3, alpha=1.0, input_indices=idx[0, hs])[0]
+            fs, _ = D2([fk], condition=cond[0, hs], step=3, alpha=1.0)
+            (Fn.softplus(-rs).mean() + Fn.softplus(fs).mean()).backward()
+            halves.append(t2.d_bucket.flat.clone())
+        mean_halves = (halves[0] + halves[1]) / 2
+        # the data-parallel step: D half with the exchange deferred (overlap), then inspect the bucket
+        assert tr.overlap_comm, "a process group of size 2 exists: the D exchange is deferred behind the G forward"
+        tr.d_step(0, real[0, sl], cond[0, sl], idx[0, sl])
+        tr.d_bucket.wait()
+        exchanged = tr.d_bucket.flat.clone()
+        tr.g_step(cond[0, sl], idx[0, sl])
+        losses1 = tr.step(1, real[1, sl], cond[1, sl], idx[1, sl])  # R1 iteration
+        tr.flush()
+        torch.cuda.synchronize()
+        flat_g = torch.cat([p.detach().reshape(-1) for p in G.parameters()]).cpu()
+        flat_d = torch.cat([p.detach().reshape(-1) for p in D.parameters()]).cpu()
+        flat_e = torch.cat([p.detach().reshape(-1) for p in G_ema.parameters()]).cpu()
+        err = ((exchanged - mean_halves).abs().max() / mean_halves.abs().max()).item()
+        q.put((rank, "ok", w_before.cpu(), w_synced.cpu(), emb_synced.cpu(), err, flat_g, flat_d, flat_e,
+               [t.item() for t in losses1]))
+        dist.destroy_process_group()
+    except Exception as e:  # surface the failure in the parent instead of a silent timeout
+        import traceback
+        q.put((rank, "error", traceback.format_exc()))
+        raise
+
+
+def test_real_trainer_two_processes_one_gpu():
+    """GifTrainer in two gloo-connected processes sharing cuda:0 (RCCL refuses two ranks on one device; gloo moves the
+    device bucket through the host): initial state broadcast from different per-rank seeds, exchanged D gradients == mean of
+    the two halves' single-process gradients, replicas bit-identical after two iterations (Adam, EMA, an R1 step)."""
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+    for r in res:
+        assert r[1] == "ok", r[2]
+    (_, _, b0, s0, e0, err0, g0, d0, m0, l0), (_, _, b1, s1, e1, err1, g1, d1, m1, l1) = res
+    assert not torch.equal(b0, b1), "ranks started from different weights"
+    assert torch.equal(s0, s1) and torch.equal(s0, b0), "construction broadcast rank 0's parameters"
+    assert torch.equal(e0, e1), "construction broadcast rank 0's embedding BUFFER"
+    assert err0 < 1e-5 and err1 < 1e-5, (err0, err1)
+    assert torch.equal(g0, g1) and torch.equal(d0, d1) and torch.equal(m0, m1), "replicas bit-identical after 2 iterations"
+    assert all(np.isfinite(l0)) and all(np.isfinite(l1))
