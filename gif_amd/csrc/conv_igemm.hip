@@ -23,6 +23,8 @@
 // Both share conv_epilogue(): accumulators -> LDS -> coalesced float4 rows with out_scale / residual / bias / lrelu.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -31,14 +33,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: plain vector loads/stores, never memcpy
 
 
+// Activation / packed-weight pointers are typeless: fp32 (the reference dtype) or f16 (BASELINE config 5), chosen by the
+// kernel's element-type template parameter.  Per-sample scales and the bias are always fp32.
 struct GatherParams {
-    const float* x;
-    const float* wp;
-    float* y;
+    const void* x;
+    const void* wp;
+    void* y;
     const float* in_scale;
     const float* out_scale;
     const float* bias;
-    const float* residual;
+    const void* residual;
     int B, Hi, Wi, Ci;  // input tensor
     int Ho, Wo, Co;     // output tensor
     int Hp, Wp;         // output sub-grid of this launch
@@ -53,7 +57,7 @@ struct GatherParams {
     int M;  // B*Hp*Wp
     int tiles_m, tiles_n;
     int stab_nb, stab_stride;  // LDS table of per-sample input scales (LDS-DMA kernel): samples per tile, row stride
-    const float* zero;         // 16 zero bytes in HBM: source of the LDS-DMA lanes that fall outside the tensor
+    const void* zero;          // 16 zero bytes in HBM: source of the LDS-DMA lanes that fall outside the tensor
     int m_begin;               // first GEMM row of this launch (a launch may cover only rows [m_begin, M))
 };
 
@@ -69,9 +73,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // Epilogue shared by both kernels.  The accumulator tile is transposed through LDS (the staging buffers are free by
 // then) so that global I/O is row-wise float4: residual / out_scale / bias loads and the output store are 16 B per lane
 // and fully coalesced along the channel axis.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5).
-template <int BM, int BN, int LD, int MT, int NT>
+template <int BM, int BN, int LD, int MT, int NT, typename T = float>
 __device__ __forceinline__ void conv_epilogue(const GatherParams& p, f32x16 (&acc)[MT][NT], float* smem, int m0, int n0,
                                               int wm0, int wn0, int tid, int li, int lh, int HWp) {
+    const T* const res = static_cast<const T*>(p.residual);
+    T* const yout = static_cast<T*>(p.y);
     constexpr int THREADS = 256;
     constexpr int LDC = BN + 4;
     // the tile goes through LDS in EPI_CHUNKS row chunks so that it fits into the staging buffers' footprint
@@ -120,8 +126,8 @@ __device__ __forceinline__ void conv_epilogue(const GatherParams& p, f32x16 (&ac
                     float4 d = *reinterpret_cast<const float4*>(p.out_scale + (size_t)b * p.Co + n);
                     v.x *= d.x; v.y *= d.y; v.z *= d.z; v.w *= d.w;
                 }
-                if (p.residual) {
-                    float4 rv = *reinterpret_cast<const float4*>(p.residual + o);
+                if (res) {
+                    float4 rv = gif::load4(res + o);
                     v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
                 }
                 v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
@@ -129,7 +135,7 @@ __device__ __forceinline__ void conv_epilogue(const GatherParams& p, f32x16 (&ac
                     v.x = (v.x > 0.f ? v.x : v.x * p.slope) * p.gain; v.y = (v.y > 0.f ? v.y : v.y * p.slope) * p.gain;
                     v.z = (v.z > 0.f ? v.z : v.z * p.slope) * p.gain; v.w = (v.w > 0.f ? v.w : v.w * p.slope) * p.gain;
                 }
-                *reinterpret_cast<float4*>(p.y + o) = v;
+                gif::store4(yout + o, v);
             }
         }
     }
@@ -161,6 +167,8 @@ __global__ void __launch_bounds__(256) conv_gather_mfma(const GatherParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                // [2][BM][LD]
     float* Bs = smem + 2 * BM * LD;  // [2][BN][LD]
+    const float* const px = static_cast<const float*>(p.x);    // this kernel is fp32 only
+    const float* const pw = static_cast<const float*>(p.wp);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -206,7 +214,7 @@ __global__ void __launch_bounds__(256) conv_gather_mfma(const GatherParams p) {
         const int dy = p.dy0 + ld_a * p.ddy, dx = p.dx0 + ld_b * p.ddx;
         const int widx = (p.ky0 + ld_a * p.kstep) * p.KW + p.kx0 + ld_b * p.kstep;
         const int kc = ld_kc;
-        const float* wt = p.wp + ((size_t)widx * p.RP + n0 + t_row) * p.CP + kc + t_c4;
+        const float* wt = pw + ((size_t)widx * p.RP + n0 + t_row) * p.CP + kc + t_c4;
         const int tap_off = (dy * p.Wi + dx) * p.Ci + kc;
         const bool ch_ok = kc + t_c4 < p.Ci;
         unsigned mask = 0;
@@ -215,7 +223,7 @@ __global__ void __launch_bounds__(256) conv_gather_mfma(const GatherParams p) {
             bool ok = ((row_ok >> it) & 1u) && ch_ok && (unsigned)(a_iy0[it] + dy) < (unsigned)p.Hi &&
                       (unsigned)(a_ix0[it] + dx) < (unsigned)p.Wi;
             int off = ok ? a_base[it] + tap_off : 0;
-            st.a[it] = *reinterpret_cast<const f32x4*>(p.x + off);
+            st.a[it] = *reinterpret_cast<const f32x4*>(px + off);
             if (has_scale) st.s[it] = *reinterpret_cast<const f32x4*>(p.in_scale + (ok ? a_soff[it] + kc : 0));
             mask |= (ok ? 1u : 0u) << it;
         }
@@ -223,7 +231,7 @@ __global__ void __launch_bounds__(256) conv_gather_mfma(const GatherParams p) {
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
             bool ok = (it < B_IT - 1) || b_row_ok;
-            st.b[it] = *reinterpret_cast<const f32x4*>(ok ? wt + (size_t)it * ROWS_PER_IT * p.CP : p.wp);
+            st.b[it] = *reinterpret_cast<const f32x4*>(ok ? wt + (size_t)it * ROWS_PER_IT * p.CP : pw);
         }
         ld_kc += BK;
         if (ld_kc >= p.CP) {
@@ -309,23 +317,33 @@ __global__ void __launch_bounds__(256) conv_gather_mfma(const GatherParams p) {
 // Out-of-image / out-of-range lanes read a 16-byte zero page instead of being masked.
 // SCALE: input modulation (ModulatedConv2d's s[b,ci], or d[b,co] in its dgrad) through an LDS table, see below.
 // ------------------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool SCALE, int BK>
+// T = float: BK = 32 floats per LDS row, v_mfma_f32_32x32x2_f32, one ds_read_b128 feeds 4 MFMAs (k = 8*kk + 4*h + t).
+// T = f16  : BK = 64 halfs per LDS row — the SAME 128-byte rows, 16-byte chunks and XOR swizzle — v_mfma_f32_32x32x16_f16:
+//            one ds_read_b128 = 8 halfs = the whole operand of one MFMA (lane half h supplies k = 16*kk + 8*h .. +7),
+//            fp32 accumulators, fp32 epilogue (demodulation, bias, residual, lrelu), saturating f16 store.  The per-sample
+//            modulation table is f16 (x * s is what the f16 MFMA consumes anyway); demodulation stays fp32 in the epilogue.
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool SCALE, int BK>
 __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, const int nwg) {
-    constexpr int LD = BK;             // unpadded LDS row (floats)
-    constexpr int CH = BK / 4;         // 16-byte chunks per row
-    constexpr int RB = 64 / BK;        // rows per 256-byte LDS bank row (2 for 128-byte rows)
+    constexpr bool F16 = sizeof(T) == 2;
+    constexpr int EPC = 16 / sizeof(T);  // elements per 16-byte chunk
+    constexpr int LD = BK;             // unpadded LDS row (elements)
+    constexpr int CH = BK / EPC;       // 16-byte chunks per row
+    constexpr int RB = 256 / (BK * (int)sizeof(T));  // rows per 256-byte LDS bank row (2 for 128-byte rows)
     constexpr int RPP = 256 / CH;      // rows filled by one pass of the 256 lanes
     constexpr int RPW = 64 / CH;       // rows filled by one wave instruction (1 KiB)
-    constexpr int KG = BK / 8;         // k-groups (8 k each) per step
+    constexpr int KG = CH / 2;         // k-groups per step: two chunks (lane halves h = 0 / 1) each
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int MT = WM / 32, NT = WN / 32;
     constexpr int A_IT = BM / RPP, B_IT = (BN + RPP - 1) / RPP;
     static_assert(WAVES_M * WAVES_N == 4 && BM % RPP == 0 && (BN % RPP == 0 || BN < RPP), "tile config");
-    static_assert(BK == 32, "only 128-byte rows are validated (a 64-byte-row variant measured 8-10 % slower)");
+    static_assert(BK * sizeof(T) == 128, "only 128-byte rows are validated (a 64-byte-row variant measured 8-10 % slower)");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                // [2][BM][32]
-    float* Bs = smem + 2 * BM * LD;  // [2][BN][32]
+    T* As = reinterpret_cast<T*>(smem);  // [2][BM][LD]
+    T* Bs = As + 2 * BM * LD;            // [2][BN][LD]
+    const T* const px = static_cast<const T*>(p.x);
+    const T* const pw = static_cast<const T*>(p.wp);
+    const T* const pzero = static_cast<const T*>(p.zero);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -339,7 +357,7 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
     // this lane fills LDS row tid/CH + RPP*it, physical 16-B chunk tid%CH, with the LOGICAL chunk (tid%CH)^f(row),
     // f(row) = (row / RB) % CH: the 16 rows of a ds_read_b128 lane group then hit 16 distinct 16-B slots
     const int t_row = tid / CH;
-    const int src_c4 = ((tid % CH) ^ ((t_row / RB) % CH)) * 4;
+    const int src_c4 = ((tid % CH) ^ ((t_row / RB) % CH)) * EPC;
     const bool b_lane_ok = (BN % RPP == 0) || t_row < BN;
 
     int a_iy0[A_IT], a_ix0[A_IT], a_base[A_IT];
@@ -361,20 +379,20 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
     // samples this tile touches are parked in an LDS table and multiplied into the A fragments after the operand read
     // ("weight modulation" applied on the activation side; algebraically identical).  Filled BEFORE the first DMA so no
     // ordinary global load is outstanding while DMAs are in flight (hipcc would drain them with vmcnt(0)).
-    float* Stab = smem + 2 * (BM + BN) * LD;  // [stab_nb][stab_stride], tail of each row zeroed
+    T* Stab = As + 2 * (BM + BN) * LD;  // [stab_nb][stab_stride], tail of each row zeroed
     int s_row[MT];
     if (SCALE) {
         const int b_first = m0 / HWp;
         for (int e = tid; e < p.stab_nb * p.stab_stride; e += 256) {
             int bl = e / p.stab_stride, c = e - bl * p.stab_stride;
             int b = b_first + bl;
-            Stab[e] = (c < p.Ci && b < p.B) ? p.in_scale[(size_t)b * p.Ci + c] : 0.f;
+            Stab[e] = (T)((c < p.Ci && b < p.B) ? p.in_scale[(size_t)b * p.Ci + c] : 0.f);
         }
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             int m = m0 + wm0 + i * 32 + li;
             if (m >= p.M) m = p.M - 1;
-            s_row[i] = (m / HWp - b_first) * p.stab_stride + lh * 4;
+            s_row[i] = (m / HWp - b_first) * p.stab_stride + lh * EPC;
         }
         __syncthreads();
     }
@@ -390,20 +408,20 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
         const int kc = ld_kc;
         const int tap_off = (dy * p.Wi + dx) * p.Ci + kc;
         const bool ch_ok = kc + src_c4 < p.Ci;
-        float* Ad = As + buf * BM * LD + wave * RPW * LD;  // wave-uniform; lane l lands at +l*4 floats
-        float* Bd = Bs + buf * BN * LD + wave * RPW * LD;
+        T* Ad = As + buf * BM * LD + wave * RPW * LD;  // wave-uniform; lane l lands at +l*16 bytes
+        T* Bd = Bs + buf * BN * LD + wave * RPW * LD;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             bool ok = ((row_ok >> it) & 1u) && ch_ok && (unsigned)(a_iy0[it] + dy) < (unsigned)p.Hi &&
                       (unsigned)(a_ix0[it] + dx) < (unsigned)p.Wi;
-            const float* g = ok ? p.x + (a_base[it] + tap_off) : p.zero;
+            const T* g = ok ? px + (a_base[it] + tap_off) : pzero;
             __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Ad + it * RPP * LD), 16, 0, 0);
         }
-        const float* wt = p.wp + ((size_t)widx * p.RP + n0 + t_row) * p.CP + kc + src_c4;
+        const T* wt = pw + ((size_t)widx * p.RP + n0 + t_row) * p.CP + kc + src_c4;
         if (BN % RPP == 0 || wave * RPW < BN) {  // wave-uniform: waves beyond the B tile issue nothing
 #pragma unroll
             for (int it = 0; it < B_IT; ++it)
-                __builtin_amdgcn_global_load_lds((gptr_t)(b_lane_ok ? wt + (size_t)it * RPP * p.CP : p.zero),
+                __builtin_amdgcn_global_load_lds((gptr_t)(b_lane_ok ? wt + (size_t)it * RPP * p.CP : pzero),
                                                  (lptr_t)(Bd + it * RPP * LD), 16, 0, 0);
         }
         ld_kc += BK;
@@ -422,32 +440,44 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int fsw = (li / RB) % CH;  // f(row) of every row this lane reads (tile bases are multiples of 32)
-    // operand fragments of one k-group (8 k): register double buffer, read one group ahead of its MFMAs
-    f32x4 av[2][MT], bv[2][NT];
+    // operand fragments of one k-group: register double buffer, read one group ahead of its MFMAs (16 bytes per fragment:
+    // 4 floats or 8 halfs)
+    typedef typename std::conditional<F16, gif::f16x8_t, f32x4>::type frag_t;
+    frag_t av[2][MT], bv[2][NT];
     auto frag_read = [&](int buf, int kk, int slot, int kc) __attribute__((always_inline)) {
-        const float* Ab = As + buf * BM * LD + (wm0 + li) * LD;
-        const float* Bb = Bs + buf * BN * LD + (wn0 + li) * LD;
-        const int c = ((kk * 2 + lh) ^ fsw) * 4;
+        const T* Ab = As + buf * BM * LD + (wm0 + li) * LD;
+        const T* Bb = Bs + buf * BN * LD + (wn0 + li) * LD;
+        const int c = ((kk * 2 + lh) ^ fsw) * EPC;
 #pragma unroll
-        for (int i = 0; i < MT; ++i) av[slot][i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LD + c);
+        for (int i = 0; i < MT; ++i) av[slot][i] = *reinterpret_cast<const frag_t*>(Ab + i * 32 * LD + c);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) bv[slot][j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LD + c);
+        for (int j = 0; j < NT; ++j) bv[slot][j] = *reinterpret_cast<const frag_t*>(Bb + j * 32 * LD + c);
         if (SCALE) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i) av[slot][i] *= *reinterpret_cast<const f32x4*>(Stab + s_row[i] + kc + kk * 8);
+            for (int i = 0; i < MT; ++i) av[slot][i] *= *reinterpret_cast<const frag_t*>(Stab + s_row[i] + kc + kk * 2 * EPC);
         }
     };
     auto mfma_group = [&](int slot) __attribute__((always_inline)) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
+        if constexpr (F16) {
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[slot][i][t], bv[slot][j][t], acc[i][j], 0, 0, 0);
-        // pin: the LDS reads of the NEXT group (issued just before this call) go out ahead of these MFMAs
-        __builtin_amdgcn_sched_group_barrier(0x100, MT + NT + (SCALE ? MT : 0), 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 4 * MT * NT, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[slot][i], bv[slot][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, MT + NT + (SCALE ? MT : 0), 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[slot][i][t], bv[slot][j][t], acc[i][j], 0, 0, 0);
+            // pin: the LDS reads of the NEXT group (issued just before this call) go out ahead of these MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x100, MT + NT + (SCALE ? MT : 0), 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * MT * NT, 0);
+        }
     };
     auto next_kc = [&](int kc) { return (kc + BK >= p.CP) ? 0 : kc + BK; };
 
@@ -471,7 +501,7 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
         cur ^= 1;
         frag_read(cur, 0, KG & 1, cmp_kc);
         mfma_group((KG - 1) & 1);
-        if (KG & 1) {  // odd group count: realign the register slots (KG is even for BK = 16 / 32, kept for safety)
+        if (KG & 1) {  // odd group count: realign the register slots (KG is even here, kept for safety)
 #pragma unroll
             for (int i = 0; i < MT; ++i) av[0][i] = av[1][i];
 #pragma unroll
@@ -483,12 +513,12 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
         if (g + 1 < KG) frag_read(cur, g + 1, (g + 1) & 1, cmp_kc);
         mfma_group(g & 1);
     }
-    conv_epilogue<BM, BN, LD, MT, NT>(p, acc, smem, m0, n0, wm0, wn0, tid, li, lh, HWp);
+    conv_epilogue<BM, BN, 32, MT, NT, T>(p, acc, smem, m0, n0, wm0, wn0, tid, li, lh, HWp);
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool SCALE, int BK>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool SCALE, int BK>
 __global__ void __launch_bounds__(256) conv_gather_mfma_glds(const GatherParams p) {
-    glds_body<BM, BN, WAVES_M, WAVES_N, SCALE, BK>(p, (int)blockIdx.x, (int)gridDim.x);
+    glds_body<T, BM, BN, WAVES_M, WAVES_N, SCALE, BK>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Up to 4 independent problems (the output-parity phases of a small transposed convolution) in ONE launch: each phase
@@ -499,23 +529,26 @@ struct MultiParams {
     int nph;
 };
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool SCALE, int BK>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool SCALE, int BK>
 __global__ void __launch_bounds__(256) conv_gather_mfma_glds_multi(const MultiParams mp) {
     const int b = (int)blockIdx.x;
     int k = 0;
     while (k + 1 < mp.nph && b >= mp.wg_end[k]) ++k;  // wave-uniform
     const int begin = k ? mp.wg_end[k - 1] : 0;
-    glds_body<BM, BN, WAVES_M, WAVES_N, SCALE, BK>(mp.ph[k], b - begin, mp.wg_end[k] - begin);
+    glds_body<T, BM, BN, WAVES_M, WAVES_N, SCALE, BK>(mp.ph[k], b - begin, mp.wg_end[k] - begin);
 }
 
 struct TileCfg {
     int BM, BN, BK;
 };
 
+// fp32: BK = 32 floats (LDS-DMA kernel) or 8 (register-staged kernel of the Cin < 32 layers).
+// f16 : BK = 64 halfs, LDS-DMA kernel only (channel counts are multiples of 8 there: every 16-byte DMA chunk is 8 halfs).
+template <typename T>
 inline TileCfg pick_cfg(int cout, int cin) {
     TileCfg c;
     c.BN = cout <= 32 ? 32 : 128;
-    c.BK = cin < 32 ? 8 : 32;
+    c.BK = sizeof(T) == 2 ? 64 : (cin < 32 ? 8 : 32);
     c.BM = c.BN == 32 ? 256 : 128;
     return c;
 }
@@ -537,24 +570,29 @@ int launch_simple(GatherParams& p, hipStream_t s) {
     return launch_kernel(conv_gather_mfma<BM, BN, BK, WMv, WNv>, p, BM, BN, BK, s, attr);
 }
 
-template <int BM, int BN, int WMv, int WNv, bool SCALE, int BK>
+// LDS bytes of the per-sample scale table and its geometry (elements of T)
+template <typename T, int BM>
+inline size_t scale_table(GatherParams& p) {
+    const int HWp = p.Hp * p.Wp;
+    int nb = (BM - 1) / HWp + 2;  // samples a BM-row tile can touch
+    if (nb > p.B) nb = p.B;
+    p.stab_nb = nb;
+    p.stab_stride = p.CP + 16 / (int)sizeof(T);  // + one 16-byte chunk: consecutive samples start 4 banks apart
+    return (size_t)nb * p.stab_stride * sizeof(T);
+}
+
+template <typename T, int BM, int BN, int WMv, int WNv, bool SCALE>
 int launch_glds_impl(GatherParams& p, hipStream_t s) {
+    constexpr int BK = 128 / sizeof(T);  // 128-byte LDS rows
     static gif::LdsAttr attr;
     p.tiles_m = gif::cdiv(p.M - p.m_begin, BM);
     p.tiles_n = p.RP / BN;
-    size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
+    size_t lds = (size_t)2 * (BM + BN) * 128;
     p.stab_nb = 0;
     p.stab_stride = 0;
-    if (SCALE) {
-        const int HWp = p.Hp * p.Wp;
-        int nb = (BM - 1) / HWp + 2;  // samples a BM-row tile can touch
-        if (nb > p.B) nb = p.B;
-        p.stab_nb = nb;
-        p.stab_stride = p.CP + 4;  // +4: consecutive samples start 4 banks apart
-        lds += (size_t)nb * p.stab_stride * sizeof(float);
-    }
-    if (lds > 160 * 1024) return -100;  // caller falls back to the register-staged kernel
-    auto kern = conv_gather_mfma_glds<BM, BN, WMv, WNv, SCALE, BK>;
+    if (SCALE) lds += scale_table<T, BM>(p);
+    if (lds > 160 * 1024) return -100;  // fp32 caller falls back to the register-staged kernel
+    auto kern = conv_gather_mfma_glds<T, BM, BN, WMv, WNv, SCALE, BK>;
     attr.ensure(reinterpret_cast<const void*>(kern), lds);
     // passed as a kernel argument: a GOT load inside the K loop costs a scalar memory round trip + s_waitcnt per stage
     p.zero = gif::zero_page16();
@@ -564,9 +602,9 @@ int launch_glds_impl(GatherParams& p, hipStream_t s) {
 }
 
 // all phases in one launch (64x64 tiles); returns -100 if the configuration does not fit
-template <bool SCALE>
+template <typename T, bool SCALE>
 int launch_glds_multi(GatherParams* ph, int nph, hipStream_t s) {
-    constexpr int BM = 64, BN = 64, BK = 32;
+    constexpr int BM = 64, BN = 64, BK = 128 / sizeof(T);
     static gif::LdsAttr attr;
     const float* zero_page = gif::zero_page16();
     if (!zero_page) return -101;
@@ -577,17 +615,10 @@ int launch_glds_multi(GatherParams* ph, int nph, hipStream_t s) {
         GatherParams& p = ph[i];
         p.tiles_m = gif::cdiv(p.M - p.m_begin, BM);
         p.tiles_n = p.RP / BN;
-        size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
+        size_t lds = (size_t)2 * (BM + BN) * 128;
         p.stab_nb = 0;
         p.stab_stride = 0;
-        if (SCALE) {
-            const int HWp = p.Hp * p.Wp;
-            int nb = (BM - 1) / HWp + 2;
-            if (nb > p.B) nb = p.B;
-            p.stab_nb = nb;
-            p.stab_stride = p.CP + 4;
-            lds += (size_t)nb * p.stab_stride * sizeof(float);
-        }
+        if (SCALE) lds += scale_table<T, BM>(p);
         if (lds > lds_max) lds_max = lds;
         p.zero = zero_page;
         total += p.tiles_m * p.tiles_n;
@@ -596,16 +627,16 @@ int launch_glds_multi(GatherParams* ph, int nph, hipStream_t s) {
     }
     mp.nph = nph;
     if (lds_max > 160 * 1024) return -100;
-    auto kern = conv_gather_mfma_glds_multi<BM, BN, 2, 2, SCALE, BK>;
+    auto kern = conv_gather_mfma_glds_multi<T, BM, BN, 2, 2, SCALE, BK>;
     attr.ensure(reinterpret_cast<const void*>(kern), lds_max);
     hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), lds_max, s, mp);
     return 0;
 }
 
-template <int BM, int BN, int WMv, int WNv, int BK = 32>
+template <typename T, int BM, int BN, int WMv, int WNv>
 int launch_glds(GatherParams& p, hipStream_t s) {
-    return p.in_scale ? launch_glds_impl<BM, BN, WMv, WNv, true, BK>(p, s)
-                      : launch_glds_impl<BM, BN, WMv, WNv, false, BK>(p, s);
+    return p.in_scale ? launch_glds_impl<T, BM, BN, WMv, WNv, true>(p, s)
+                      : launch_glds_impl<T, BM, BN, WMv, WNv, false>(p, s);
 }
 
 // GIF_CONV_VARIANT=1 forces the register-staged kernel everywhere (A/B benchmarking only)
@@ -618,20 +649,27 @@ int conv_variant() {
     return v;
 }
 
+template <typename T>
 int launch(GatherParams& p, hipStream_t s) {
+    constexpr bool F16 = sizeof(T) == 2;
     if (p.M <= 0 || p.ntaps <= 0) return 0;
     if ((long)p.B * p.Hi * p.Wi * p.Ci >= (1L << 31) || (long)p.B * p.Ho * p.Wo * p.Co >= (1L << 31)) {
         gif::set_error("conv: tensors of >= 2^31 elements are not supported (32-bit offsets)");
         return GIF_ENOSUP;
     }
-    TileCfg c = pick_cfg(p.Co, p.Ci);
-    // LDS-DMA path: every BK = 32 layer (rows are 16-byte aligned in HBM because Ci % 4 == 0)
-    const bool glds = c.BK == 32 && conv_variant() != 1;
-    if (c.BN == 128 && c.BK == 32) {
+    TileCfg c = pick_cfg<T>(p.Co, p.Ci);
+    // LDS-DMA path: every layer whose K chunk is a 128-byte row (rows are 16-byte aligned in HBM: Ci % 4 == 0 for fp32,
+    // Ci % 8 == 0 for f16)
+    const bool glds = F16 || (c.BK == 32 && conv_variant() != 1);
+    auto fail_f16 = [&](int rc) {
+        if (rc != 0) gif::set_error("conv (f16): launch configuration does not fit (rc=%d)", rc);
+        return rc == 0 ? 0 : GIF_ENOSUP;
+    };
+    if (c.BN == 128 && (F16 || c.BK == 32)) {
         // low-resolution layers (4x4 .. 16x16 at batch 32): a 128x128 grid would leave most CUs idle behind a
         // 144-step K loop; 64x64 tiles give 4x the workgroups (and 32 KB of LDS: 4 per CU) at a quarter of the latency
         const long tiles128 = (long)gif::cdiv(p.M, 128) * (p.RP / 128);
-        if (glds && tiles128 < 384 && launch_glds<64, 64, 2, 2>(p, s) == 0) return 0;
+        if (glds && tiles128 < 384 && launch_glds<T, 64, 64, 2, 2>(p, s) == 0) return 0;
         if (glds && conv_variant() != 3) {
             // Tile quantisation: 512 workgroups of this kernel are resident (2 per CU), so T tiles cost ceil(T / 512) rounds.
             // The odd-sized phase grids of the transposed convolutions (129^2, 65^2, 33^2 pixels) give e.g. 4161 or 1092
@@ -643,25 +681,33 @@ int launch(GatherParams& p, hipStream_t s) {
                 const int M = p.M;
                 const int m_bulk = (int)(full * slots / tn) * 128;
                 p.M = m_bulk;
-                if (launch_glds<128, 128, 2, 2>(p, s) == 0) {
+                if (launch_glds<T, 128, 128, 2, 2>(p, s) == 0) {
                     p.M = M;
                     p.m_begin = m_bulk;
-                    int rc = launch_glds<64, 64, 2, 2>(p, s);
+                    int rc = launch_glds<T, 64, 64, 2, 2>(p, s);
                     p.m_begin = 0;
                     return rc;
                 }
                 p.M = M;
             }
         }
-        if (glds && launch_glds<128, 128, 2, 2>(p, s) == 0) return 0;
-        return launch_simple<128, 128, 32, 2, 2>(p, s);
+        if (glds) {
+            int rc = launch_glds<T, 128, 128, 2, 2>(p, s);
+            if (rc == 0) return 0;
+            if constexpr (F16) return fail_f16(rc);
+        }
+        if constexpr (!F16) return launch_simple<128, 128, 32, 2, 2>(p, s);
     }
-    if (c.BN == 128 && c.BK == 8) return launch_simple<128, 128, 8, 2, 2>(p, s);
-    if (c.BN == 32 && c.BK == 32) {
-        if (glds && launch_glds<256, 32, 4, 1>(p, s) == 0) return 0;
-        return launch_simple<256, 32, 32, 4, 1>(p, s);
+    if constexpr (F16) {
+        return fail_f16(launch_glds<T, 256, 32, 4, 1>(p, s));
+    } else {
+        if (c.BN == 128 && c.BK == 8) return launch_simple<128, 128, 8, 2, 2>(p, s);
+        if (c.BN == 32 && c.BK == 32) {
+            if (glds && launch_glds<T, 256, 32, 4, 1>(p, s) == 0) return 0;
+            return launch_simple<256, 32, 32, 4, 1>(p, s);
+        }
+        return launch_simple<256, 32, 8, 4, 1>(p, s);
     }
-    return launch_simple<256, 32, 8, 4, 1>(p, s);
 }
 
 int check_geom(const gif_conv_geom* g, const char* who) {
@@ -690,23 +736,27 @@ void fill_epilogue(GatherParams& p, const gif_conv_epilogue* e) {
 }
 
 
-}  // namespace
-
-extern "C" {
-
-int gif_conv2d_pack_dims(int cout, int cin, int* RP, int* CP) {
-    GIF_REQUIRE(cout > 0 && cin > 0 && RP && CP, "pack_dims: bad arguments");
-    TileCfg c = pick_cfg(cout, cin);
+template <typename T>
+void pack_dims(int cout, int cin, int* RP, int* CP) {
+    TileCfg c = pick_cfg<T>(cout, cin);
     *RP = (cout + c.BN - 1) / c.BN * c.BN;
     *CP = (cin + c.BK - 1) / c.BK * c.BK;
+}
+
+template <typename T>
+int check_channels(const gif_conv_geom* g, const char* who) {
+    if (sizeof(T) == 2)
+        GIF_REQUIRE(g->Cb % 8 == 0 && g->Cs % 8 == 0, "%s: f16 channel counts must be multiples of 8 (Cb=%d Cs=%d)", who, g->Cb, g->Cs);
     return 0;
 }
 
-int gif_conv2d_fwd_f32(const float* big, const float* wp, float* small, const gif_conv_geom* g,
-                       const gif_conv_epilogue* e, gif_stream_t stream) {
-    if (int rc = check_geom(g, "conv2d_fwd")) return rc;
+template <typename T>
+int conv2d_fwd_impl(const void* big, const void* wp, void* small, const gif_conv_geom* g, const gif_conv_epilogue* e,
+                    gif_stream_t stream, const char* who) {
+    if (int rc = check_geom(g, who)) return rc;
+    if (int rc = check_channels<T>(g, who)) return rc;
     if (g->B == 0) return 0;
-    GIF_REQUIRE(big && wp && small, "conv2d_fwd: null pointer");
+    GIF_REQUIRE(big && wp && small, "%s: null pointer", who);
     GatherParams p{};
     p.x = big; p.wp = wp; p.y = small;
     fill_epilogue(p, e);
@@ -716,26 +766,29 @@ int gif_conv2d_fwd_f32(const float* big, const float* wp, float* small, const gi
     p.nky = g->KH; p.nkx = g->KW; p.ntaps = g->KH * g->KW;
     p.dy0 = -g->pad; p.ddy = 1; p.dx0 = -g->pad; p.ddx = 1;
     p.ky0 = 0; p.kx0 = 0; p.kstep = 1; p.KW = g->KW;
-    gif_conv2d_pack_dims(p.Co, p.Ci, &p.RP, &p.CP);
+    pack_dims<T>(p.Co, p.Ci, &p.RP, &p.CP);
     p.M = p.B * p.Hp * p.Wp;
     double flops = 2.0 * p.M * (double)p.Co * p.Ci * p.ntaps;
-    gif::ProfScope prof(p.Ci >= 32 ? 0 : 5, flops, gif::as_stream(stream), p.M, p.Co, p.Ci, p.ntaps * 10 + g->stride);
-    if (int rc = launch(p, gif::as_stream(stream))) return rc;
-    return gif::check_launch("conv2d_fwd");
+    const int fam = sizeof(T) == 2 ? 6 : (p.Ci >= 32 ? 0 : 5);
+    gif::ProfScope prof(fam, flops, gif::as_stream(stream), p.M, p.Co, p.Ci, p.ntaps * 10 + g->stride);
+    if (int rc = launch<T>(p, gif::as_stream(stream))) return rc;
+    return gif::check_launch(who);
 }
 
-int gif_conv2d_bwd_data_f32(const float* small, const float* wp, float* big, const gif_conv_geom* g,
-                            const gif_conv_epilogue* e, gif_stream_t stream) {
-    if (int rc = check_geom(g, "conv2d_bwd_data")) return rc;
+template <typename T>
+int conv2d_bwd_data_impl(const void* small, const void* wp, void* big, const gif_conv_geom* g, const gif_conv_epilogue* e,
+                         gif_stream_t stream, const char* who) {
+    if (int rc = check_geom(g, who)) return rc;
+    if (int rc = check_channels<T>(g, who)) return rc;
     if (g->B == 0) return 0;
-    GIF_REQUIRE(small && wp && big, "conv2d_bwd_data: null pointer");
+    GIF_REQUIRE(small && wp && big, "%s: null pointer", who);
     hipStream_t s = gif::as_stream(stream);
     GatherParams base{};
     base.x = small; base.wp = wp; base.y = big;
     fill_epilogue(base, e);
     base.B = g->B; base.Hi = g->Hs; base.Wi = g->Ws; base.Ci = g->Cs;
     base.Ho = g->Hb; base.Wo = g->Wb; base.Co = g->Cb;
-    gif_conv2d_pack_dims(base.Co, base.Ci, &base.RP, &base.CP);
+    pack_dims<T>(base.Co, base.Ci, &base.RP, &base.CP);
     const int st = g->stride;
     auto pmod = [st](int a) { return ((a % st) + st) % st; };
     // Build the (up to 4) output-parity phases; phases with no tap (e.g. 1x1 stride 2) are zero-filled.
@@ -761,30 +814,67 @@ int gif_conv2d_bwd_data_f32(const float* small, const float* wp, float* big, con
             ph[nph++] = p;
         }
     if (need_zero) {
-        GIF_REQUIRE(!(e && (e->bias || e->residual || e->act)), "conv2d_bwd_data: epilogue unsupported with empty phases");
-        hipError_t me = hipMemsetAsync(big, 0, (size_t)g->B * g->Hb * g->Wb * g->Cb * sizeof(float), s);
-        if (me != hipSuccess) { gif::set_error("conv2d_bwd_data memset: %s", hipGetErrorString(me)); return (int)me; }
+        GIF_REQUIRE(!(e && (e->bias || e->residual || e->act)), "%s: epilogue unsupported with empty phases", who);
+        hipError_t me = hipMemsetAsync(big, 0, (size_t)g->B * g->Hb * g->Wb * g->Cb * sizeof(T), s);
+        if (me != hipSuccess) { gif::set_error("%s memset: %s", who, hipGetErrorString(me)); return (int)me; }
     }
     // algorithmic FLOPs of a transposed conv: every small-side pixel scatters through every tap
     double flops = 2.0 * g->B * (double)g->Hs * g->Ws * g->KH * g->KW * (double)g->Cs * g->Cb;
     {
-        gif::ProfScope prof(base.Ci >= 32 ? 0 : 5, flops, s, g->B * g->Hb * g->Wb, base.Co, base.Ci, -(g->KH * g->KW * 10 + g->stride));
+        const int fam = sizeof(T) == 2 ? 6 : (base.Ci >= 32 ? 0 : 5);
+        gif::ProfScope prof(fam, flops, s, g->B * g->Hb * g->Wb, base.Co, base.Ci, -(g->KH * g->KW * 10 + g->stride));
         // small transposed convs: every phase alone would sit on the 64x64-tile path with a partly filled chip
         bool merged = false;
         if (nph > 1 && conv_variant() == 0) {
-            const TileCfg c = pick_cfg(base.Co, base.Ci);
-            bool small_all = c.BN == 128 && c.BK == 32;
+            const TileCfg c = pick_cfg<T>(base.Co, base.Ci);
+            bool small_all = c.BN == 128 && (sizeof(T) == 2 || c.BK == 32);
             for (int i = 0; i < nph && small_all; ++i)
                 small_all = (long)gif::cdiv(ph[i].M, 128) * (ph[i].RP / 128) < 384 &&
                             (long)ph[i].B * ph[i].Hi * ph[i].Wi * ph[i].Ci < (1L << 31) &&
                             (long)ph[i].B * ph[i].Ho * ph[i].Wo * ph[i].Co < (1L << 31);
             if (small_all)
-                merged = (base.in_scale ? launch_glds_multi<true>(ph, nph, s) : launch_glds_multi<false>(ph, nph, s)) == 0;
+                merged = (base.in_scale ? launch_glds_multi<T, true>(ph, nph, s) : launch_glds_multi<T, false>(ph, nph, s)) == 0;
         }
         if (!merged)
             for (int i = 0; i < nph; ++i)
-                if (int rc = launch(ph[i], s)) return rc;
+                if (int rc = launch<T>(ph[i], s)) return rc;
     }
-    return gif::check_launch("conv2d_bwd_data");
+    return gif::check_launch(who);
+}
+
+}  // namespace
+
+extern "C" {
+
+int gif_conv2d_pack_dims(int cout, int cin, int* RP, int* CP) {
+    GIF_REQUIRE(cout > 0 && cin > 0 && RP && CP, "pack_dims: bad arguments");
+    pack_dims<float>(cout, cin, RP, CP);
+    return 0;
+}
+
+int gif_conv2d_pack_dims_f16(int cout, int cin, int* RP, int* CP) {
+    GIF_REQUIRE(cout > 0 && cin > 0 && RP && CP, "pack_dims_f16: bad arguments");
+    pack_dims<gif::f16>(cout, cin, RP, CP);
+    return 0;
+}
+
+int gif_conv2d_fwd_f32(const float* big, const float* wp, float* small, const gif_conv_geom* g,
+                       const gif_conv_epilogue* e, gif_stream_t stream) {
+    return conv2d_fwd_impl<float>(big, wp, small, g, e, stream, "conv2d_fwd");
+}
+
+int gif_conv2d_bwd_data_f32(const float* small, const float* wp, float* big, const gif_conv_geom* g,
+                            const gif_conv_epilogue* e, gif_stream_t stream) {
+    return conv2d_bwd_data_impl<float>(small, wp, big, g, e, stream, "conv2d_bwd_data");
+}
+
+int gif_conv2d_fwd_f16(const void* big, const void* wp, void* small, const gif_conv_geom* g, const gif_conv_epilogue* e,
+                       gif_stream_t stream) {
+    return conv2d_fwd_impl<gif::f16>(big, wp, small, g, e, stream, "conv2d_fwd_f16");
+}
+
+int gif_conv2d_bwd_data_f16(const void* small, const void* wp, void* big, const gif_conv_geom* g,
+                            const gif_conv_epilogue* e, gif_stream_t stream) {
+    return conv2d_bwd_data_impl<gif::f16>(small, wp, big, g, e, stream, "conv2d_bwd_data_f16");
 }
 }

@@ -487,7 +487,7 @@ int gif_conv3x3_winograd_f32(const float* x, const float* U, float* y, float* V,
     p.V = V; p.U = U; p.y = y;
     p.out_scale = e ? e->out_scale : nullptr;
     p.bias = e ? e->bias : nullptr;
-    p.residual = e ? e->residual : nullptr;
+    p.residual = e ? static_cast<const float*>(e->residual) : nullptr;
     p.act = e ? e->act : 0;
     p.slope = e ? e->slope : 0.f;
     p.gain = e ? e->gain : 1.f;

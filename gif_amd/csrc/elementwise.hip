@@ -23,17 +23,19 @@ __device__ __forceinline__ float lrelu(float v, float slope, float gain) { retur
 //   y[oy,ox] = sum_{a,b} kf[a,b] * xp[oy*down + a, ox*down + b],   xp[u,v] = x[(u-pady0)/up, (v-padx0)/up]
 //   when divisible and in range, else 0;  kf = k flipped when flip (the reference flips, :64).
 // ---------------------------------------------------------------------------------------------------------
+template <typename T>
 struct UpfirdnParams {
-    const float* x;
+    const T* x;
     const float* k;
-    float* y;
+    T* y;
     const float* bias;
-    const float* residual;
+    const T* residual;
     int B, Hi, Wi, C, Ho, Wo, up, down, padx0, pady0, KH, KW, flip, act;
     float slope, gain;
 };
 
-__global__ void __launch_bounds__(256) upfirdn2d_kernel(const UpfirdnParams p) {
+template <typename T>
+__global__ void __launch_bounds__(256) upfirdn2d_kernel(const UpfirdnParams<T> p) {
     __shared__ float kf[16];
     if (threadIdx.x < p.KH * p.KW) {
         int a = threadIdx.x / p.KW, b = threadIdx.x % p.KW;
@@ -51,7 +53,7 @@ __global__ void __launch_bounds__(256) upfirdn2d_kernel(const UpfirdnParams p) {
         int oy = (int)(t % p.Ho);
         int b = (int)(t / p.Ho);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float* xb = p.x + (size_t)b * p.Hi * p.Wi * p.C + c4 * 4;
+        const T* xb = p.x + (size_t)b * p.Hi * p.Wi * p.C + c4 * 4;
         for (int a = 0; a < p.KH; ++a) {
             int u = oy * p.down + a - p.pady0;
             if (u < 0) continue;
@@ -62,26 +64,26 @@ __global__ void __launch_bounds__(256) upfirdn2d_kernel(const UpfirdnParams p) {
                 if (v < 0) continue;
                 int ix = v / p.up;
                 if (ix * p.up != v || ix >= p.Wi) continue;
-                float4 xv = *reinterpret_cast<const float4*>(xb + ((size_t)iy * p.Wi + ix) * p.C);
+                float4 xv = gif::load4(xb + ((size_t)iy * p.Wi + ix) * p.C);
                 acc = f4fma(kf[a * p.KW + bb], xv, acc);
             }
         }
         size_t o = (size_t)pix * p.C + c4 * 4;
-        if (p.residual) acc = f4add(acc, *reinterpret_cast<const float4*>(p.residual + o));
+        if (p.residual) acc = f4add(acc, gif::load4(p.residual + o));
         if (p.bias) acc = f4add(acc, *reinterpret_cast<const float4*>(p.bias + c4 * 4));
         if (p.act) {
             acc.x = lrelu(acc.x, p.slope, p.gain); acc.y = lrelu(acc.y, p.slope, p.gain);
             acc.z = lrelu(acc.z, p.slope, p.gain); acc.w = lrelu(acc.w, p.slope, p.gain);
         }
-        *reinterpret_cast<float4*>(p.y + o) = acc;
+        gif::store4(p.y + o, acc);
     }
 }
 
 // 4x4 FIR with decimation by 2 (up = 1, down = 2; the ResBlock skip path: blur + 1x1 stride-2 conv reads every second
 // blurred pixel only) and with zero insertion by 2 (up = 2, down = 1; its adjoint, and the ToRGB skip up-sampling):
 // fully unrolled, no divisions; the up = 2 kernel touches only the 2x2 taps whose parity matches the output pixel.
-template <int UP, int DOWN>
-__global__ void __launch_bounds__(256) fir4x4_resample_kernel(const UpfirdnParams p) {
+template <typename T, int UP, int DOWN>
+__global__ void __launch_bounds__(256) fir4x4_resample_kernel(const UpfirdnParams<T> p) {
     static_assert((UP == 1 && DOWN == 2) || (UP == 2 && DOWN == 1), "decimate-by-2 or interpolate-by-2");
     __shared__ float kfs[16];
     if (threadIdx.x < 16) {
@@ -103,7 +105,7 @@ __global__ void __launch_bounds__(256) fir4x4_resample_kernel(const UpfirdnParam
         const int ox = (int)(it / C4);
         const int c4 = (int)(it - (unsigned)ox * C4);
         const long pix = ((long)b * p.Ho + oy) * p.Wo + ox;
-        const float* xb = p.x + (size_t)b * p.Hi * p.Wi * p.C + c4 * 4;
+        const T* xb = p.x + (size_t)b * p.Hi * p.Wi * p.C + c4 * 4;
         float4 acc = zero4;
         if (DOWN == 2) {
             const int iy0 = oy * 2 - p.pady0, ix0 = ox * 2 - p.padx0;
@@ -115,7 +117,7 @@ __global__ void __launch_bounds__(256) fir4x4_resample_kernel(const UpfirdnParam
                 for (int bb = 0; bb < 4; ++bb) {
                     const int ix = ix0 + bb;
                     const bool ok = rok && (unsigned)ix < (unsigned)p.Wi;
-                    float4 xv = *reinterpret_cast<const float4*>(xb + (ok ? ((size_t)iy * p.Wi + ix) * p.C : 0));
+                    float4 xv = gif::load4(xb + (ok ? ((size_t)iy * p.Wi + ix) * p.C : 0));
                     if (!ok) xv = zero4;
                     acc = f4fma(kf[a * 4 + bb], xv, acc);
                 }
@@ -135,28 +137,28 @@ __global__ void __launch_bounds__(256) fir4x4_resample_kernel(const UpfirdnParam
                     const int v = ox + bb - p.padx0;
                     const int ix = v >> 1;
                     const bool ok = rok && v >= 0 && ix < p.Wi;
-                    float4 xv = *reinterpret_cast<const float4*>(xb + (ok ? ((size_t)iy * p.Wi + ix) * p.C : 0));
+                    float4 xv = gif::load4(xb + (ok ? ((size_t)iy * p.Wi + ix) * p.C : 0));
                     if (!ok) xv = zero4;
                     acc = f4fma(kf[a * 4 + bb], xv, acc);
                 }
             }
         }
         size_t o = (size_t)pix * p.C + c4 * 4;
-        if (p.residual) acc = f4add(acc, *reinterpret_cast<const float4*>(p.residual + o));
+        if (p.residual) acc = f4add(acc, gif::load4(p.residual + o));
         if (p.bias) acc = f4add(acc, *reinterpret_cast<const float4*>(p.bias + c4 * 4));
         if (p.act) {
             acc.x = lrelu(acc.x, p.slope, p.gain); acc.y = lrelu(acc.y, p.slope, p.gain);
             acc.z = lrelu(acc.z, p.slope, p.gain); acc.w = lrelu(acc.w, p.slope, p.gain);
         }
-        *reinterpret_cast<float4*>(p.y + o) = acc;
+        gif::store4(p.y + o, acc);
     }
 }
 
 // Fast path for the blur (up = down = 1, 4x4 FIR): one lane produces a TY x TX patch of output pixels for 4
 // channels, so every input float4 is loaded once per patch ((TY+3)*(TX+3) loads for TY*TX outputs: 4.4 loads
 // per output instead of 16).  Lanes are consecutive along the channel axis => fully coalesced 16-B accesses.
-template <int TY, int TX>
-__global__ void __launch_bounds__(256) blur4x4_tiled_kernel(const UpfirdnParams p) {
+template <typename T, int TY, int TX>
+__global__ void __launch_bounds__(256) blur4x4_tiled_kernel(const UpfirdnParams<T> p) {
     __shared__ float kfs[16];
     if (threadIdx.x < 16) {
         int a = threadIdx.x >> 2, b = threadIdx.x & 3;
@@ -177,7 +179,7 @@ __global__ void __launch_bounds__(256) blur4x4_tiled_kernel(const UpfirdnParams 
         int yb = (int)(t % nyb);
         int b = (int)(t / nyb);
         const int oy0 = yb * TY, ox0 = xb * TX;
-        const float* xb_ = p.x + (size_t)b * p.Hi * p.Wi * p.C + c4 * 4;
+        const T* xb_ = p.x + (size_t)b * p.Hi * p.Wi * p.C + c4 * 4;
         float4 acc[TY][TX];
 #pragma unroll
         for (int i = 0; i < TY; ++i)
@@ -191,7 +193,7 @@ __global__ void __launch_bounds__(256) blur4x4_tiled_kernel(const UpfirdnParams 
             for (int c = 0; c < TX + 3; ++c) {
                 const int ix = ox0 + c - p.padx0;
                 const bool ok = rok && (unsigned)ix < (unsigned)p.Wi;
-                float4 v = *reinterpret_cast<const float4*>(xb_ + (ok ? ((size_t)iy * p.Wi + ix) * p.C : 0));
+                float4 v = gif::load4(xb_ + (ok ? ((size_t)iy * p.Wi + ix) * p.C : 0));
                 if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int ty = 0; ty < TY; ++ty) {
@@ -216,13 +218,13 @@ __global__ void __launch_bounds__(256) blur4x4_tiled_kernel(const UpfirdnParams 
                 if (ox >= p.Wo) continue;
                 size_t o = (((size_t)b * p.Ho + oy) * p.Wo + ox) * p.C + c4 * 4;
                 float4 v = acc[ty][tx];
-                if (p.residual) v = f4add(v, *reinterpret_cast<const float4*>(p.residual + o));
+                if (p.residual) v = f4add(v, gif::load4(p.residual + o));
                 if (p.bias) v = f4add(v, *reinterpret_cast<const float4*>(p.bias + c4 * 4));
                 if (p.act) {
                     v.x = lrelu(v.x, p.slope, p.gain); v.y = lrelu(v.y, p.slope, p.gain);
                     v.z = lrelu(v.z, p.slope, p.gain); v.w = lrelu(v.w, p.slope, p.gain);
                 }
-                *reinterpret_cast<float4*>(p.y + o) = v;
+                gif::store4(p.y + o, v);
             }
         }
     }
@@ -231,8 +233,8 @@ __global__ void __launch_bounds__(256) blur4x4_tiled_kernel(const UpfirdnParams 
 // Sliding-window variant for tall images: one lane walks down TYL output rows of a TX-wide column strip (4 channels),
 // loading every input row of the strip ONCE (TX+3 float4) and scattering it into a ring of 4 partially accumulated
 // output rows: (TYL+3)(TX+3)/(TYL*TX) = 2.1 loads per output instead of 4.4, same tap order => bit-identical sums.
-template <int TYL, int TX>
-__global__ void __launch_bounds__(256) blur4x4_rows_kernel(const UpfirdnParams p) {
+template <typename T, int TYL, int TX>
+__global__ void __launch_bounds__(256) blur4x4_rows_kernel(const UpfirdnParams<T> p) {
     __shared__ float kfs[16];
     if (threadIdx.x < 16) {
         int a = threadIdx.x >> 2, b = threadIdx.x & 3;
@@ -255,7 +257,7 @@ __global__ void __launch_bounds__(256) blur4x4_rows_kernel(const UpfirdnParams p
         int yb = (int)(t % nyb);
         int b = (int)(t / nyb);
         const int oy0 = yb * TYL, ox0 = xb * TX;
-        const float* xb_ = p.x + (size_t)b * p.Hi * p.Wi * p.C + c4 * 4;
+        const T* xb_ = p.x + (size_t)b * p.Hi * p.Wi * p.C + c4 * 4;
         if (p.bias) bias4 = *reinterpret_cast<const float4*>(p.bias + c4 * 4);
         float4 acc[4][TX];
 #pragma unroll
@@ -274,7 +276,7 @@ __global__ void __launch_bounds__(256) blur4x4_rows_kernel(const UpfirdnParams p
                 for (int c = 0; c < TX + 3; ++c) {
                     const int ix = ox0 + c - p.padx0;
                     const bool ok = rok && (unsigned)ix < (unsigned)p.Wi;
-                    v[c] = *reinterpret_cast<const float4*>(xb_ + (ok ? ((size_t)iy * p.Wi + ix) * p.C : 0));
+                    v[c] = gif::load4(xb_ + (ok ? ((size_t)iy * p.Wi + ix) * p.C : 0));
                     if (!ok) v[c] = zero4;
                 }
 #pragma unroll
@@ -295,13 +297,13 @@ __global__ void __launch_bounds__(256) blur4x4_rows_kernel(const UpfirdnParams p
                         if (ox >= p.Wo) continue;
                         size_t o = (((size_t)b * p.Ho + oy) * p.Wo + ox) * p.C + c4 * 4;
                         float4 vv = acc[done][tx];
-                        if (p.residual) vv = f4add(vv, *reinterpret_cast<const float4*>(p.residual + o));
+                        if (p.residual) vv = f4add(vv, gif::load4(p.residual + o));
                         if (p.bias) vv = f4add(vv, bias4);
                         if (p.act) {
                             vv.x = lrelu(vv.x, p.slope, p.gain); vv.y = lrelu(vv.y, p.slope, p.gain);
                             vv.z = lrelu(vv.z, p.slope, p.gain); vv.w = lrelu(vv.w, p.slope, p.gain);
                         }
-                        *reinterpret_cast<float4*>(p.y + o) = vv;
+                        gif::store4(p.y + o, vv);
                     }
                 }
 #pragma unroll
@@ -314,16 +316,17 @@ __global__ void __launch_bounds__(256) blur4x4_rows_kernel(const UpfirdnParams p
 // ---------------------------------------------------------------------------------------------------------
 // bias + leaky ReLU (FusedLeakyReLU.forward, stylegan2_common_layers.py:32-39)
 // ---------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) bias_act_kernel(const float* __restrict__ x, const float* __restrict__ bias,
-                                                       const float* __restrict__ res, float* __restrict__ y,
+template <typename T>
+__global__ void __launch_bounds__(256) bias_act_kernel(const T* __restrict__ x, const float* __restrict__ bias,
+                                                       const T* __restrict__ res, T* __restrict__ y,
                                                        long n4, int C4, float slope, float gain) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-        float4 v = reinterpret_cast<const float4*>(x)[i];
-        if (res) v = f4add(v, reinterpret_cast<const float4*>(res)[i]);
+        float4 v = gif::load4(x + 4 * i);
+        if (res) v = f4add(v, gif::load4(res + 4 * i));
         if (bias) v = f4add(v, reinterpret_cast<const float4*>(bias)[i % C4]);
         v.x = lrelu(v.x, slope, gain); v.y = lrelu(v.y, slope, gain);
         v.z = lrelu(v.z, slope, gain); v.w = lrelu(v.w, slope, gain);
-        reinterpret_cast<float4*>(y)[i] = v;
+        gif::store4(y + 4 * i, v);
     }
 }
 
@@ -332,11 +335,11 @@ __global__ void __launch_bounds__(256) bias_act_kernel(const float* __restrict__
 // MODE 0: v = x ; MODE 1 (bias_act backward): v = gy * gain * (y > 0 ? 1 : slope), also stored to gx.
 // MODE 2 (mul): v = a*b, optional scaled output s[b,c]*a.
 // MODE 3: v = a * (inv_act(b) - res - bias[c]) with inv_act the inverse of gain*lrelu(., slope) (fused-epilogue modconv).
-template <int MODE>
+template <int MODE, typename T>
 __global__ void __launch_bounds__(256)
-colsum_stage1(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out_ew,
+colsum_stage1(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out_ew,
               const float* __restrict__ scale, float* __restrict__ partial, long nrows, int C4, long rows_per_block,
-              float slope, float gain, int want_sum, const float* __restrict__ res = nullptr,
+              float slope, float gain, int want_sum, const T* __restrict__ res = nullptr,
               const float* __restrict__ bias = nullptr) {
     __shared__ float4 red[256];
     const int R = 256 / C4;  // row lanes (C4 <= 256)
@@ -356,19 +359,19 @@ colsum_stage1(const float* __restrict__ a, const float* __restrict__ b, float* _
     if (active) {
         for (long r = r0 + rl; r < r1; r += R) {
             long i = (base + r) * C4 + col;
-            float4 v = reinterpret_cast<const float4*>(a)[i];
+            float4 v = gif::load4(a + 4 * i);
             if (MODE == 1) {
-                float4 yv = reinterpret_cast<const float4*>(b)[i];
+                float4 yv = gif::load4(b + 4 * i);
                 v.x *= gain * (yv.x > 0.f ? 1.f : slope); v.y *= gain * (yv.y > 0.f ? 1.f : slope);
                 v.z *= gain * (yv.z > 0.f ? 1.f : slope); v.w *= gain * (yv.w > 0.f ? 1.f : slope);
-                reinterpret_cast<float4*>(out_ew)[i] = v;
+                gif::store4(out_ew + 4 * i, v);
             } else if (MODE == 2) {
-                float4 bv = reinterpret_cast<const float4*>(b)[i];
-                if (out_ew) reinterpret_cast<float4*>(out_ew)[i] = make_float4(sc.x * v.x, sc.y * v.y, sc.z * v.z, sc.w * v.w);
+                float4 bv = gif::load4(b + 4 * i);
+                if (out_ew) gif::store4(out_ew + 4 * i, make_float4(sc.x * v.x, sc.y * v.y, sc.z * v.z, sc.w * v.w));
                 v.x *= bv.x; v.y *= bv.y; v.z *= bv.z; v.w *= bv.w;
             } else if (MODE == 3) {
-                float4 yv = reinterpret_cast<const float4*>(b)[i];
-                float4 rv = res ? reinterpret_cast<const float4*>(res)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 yv = gif::load4(b + 4 * i);
+                float4 rv = res ? gif::load4(res + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
                 v.x *= yv.x * (yv.x > 0.f ? ig : igs) - rv.x - bs.x; v.y *= yv.y * (yv.y > 0.f ? ig : igs) - rv.y - bs.y;
                 v.z *= yv.z * (yv.z > 0.f ? ig : igs) - rv.z - bs.z; v.w *= yv.w * (yv.w > 0.f ? ig : igs) - rv.w - bs.w;
             }
@@ -579,21 +582,17 @@ inline int ew_grid(long n) {
     return (int)b;
 }
 
-}  // namespace
-
-extern "C" {
-
-int gif_upfirdn2d_f32(const float* x, const float* k, float* y, int B, int Hi, int Wi, int C, int Ho, int Wo, int up,
-                      int down, int padx0, int pady0, int KH, int KW, int flip, const gif_conv_epilogue* e,
-                      gif_stream_t stream) {
+template <typename T>
+int upfirdn2d_impl(const T* x, const float* k, T* y, int B, int Hi, int Wi, int C, int Ho, int Wo, int up, int down, int padx0,
+                   int pady0, int KH, int KW, int flip, const gif_conv_epilogue* e, gif_stream_t stream) {
     GIF_REQUIRE(x && k && y, "upfirdn2d: null pointer");
     GIF_REQUIRE(B >= 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 4 == 0, "upfirdn2d: bad dims (C=%d)", C);
     GIF_REQUIRE(up >= 1 && down >= 1 && KH >= 1 && KW >= 1 && KH * KW <= 16, "upfirdn2d: bad up/down/kernel");
     if (B == 0) return 0;
-    UpfirdnParams p{};
+    UpfirdnParams<T> p{};
     p.x = x; p.k = k; p.y = y;
     p.bias = e ? e->bias : nullptr;
-    p.residual = e ? e->residual : nullptr;
+    p.residual = e ? static_cast<const T*>(e->residual) : nullptr;
     p.act = e ? e->act : 0;
     p.slope = e ? e->slope : 0.f;
     p.gain = e ? e->gain : 1.f;
@@ -602,13 +601,13 @@ int gif_upfirdn2d_f32(const float* x, const float* k, float* y, int B, int Hi, i
     if (up == 1 && down == 1 && KH == 4 && KW == 4 && (long)B * ((Ho + 15) / 16) * ((Wo + 3) / 4) * (C / 4) >= 256L * 256 * 2) {
         // enough columns strips to fill the chip with 16-row sliding windows
         long total = (long)B * ((Ho + 15) / 16) * ((Wo + 3) / 4) * (C / 4);
-        blur4x4_rows_kernel<16, 4><<<ew_grid(total), 256, 0, gif::as_stream(stream)>>>(p);
+        blur4x4_rows_kernel<T, 16, 4><<<ew_grid(total), 256, 0, gif::as_stream(stream)>>>(p);
         return gif::check_launch("upfirdn2d(blur rows)");
     }
     if (up == 1 && down == 1 && KH == 4 && KW == 4) {
         constexpr int TY = 2, TX = 4;
         long total = (long)B * ((Ho + TY - 1) / TY) * ((Wo + TX - 1) / TX) * (C / 4);
-        blur4x4_tiled_kernel<TY, TX><<<ew_grid(total), 256, 0, gif::as_stream(stream)>>>(p);
+        blur4x4_tiled_kernel<T, TY, TX><<<ew_grid(total), 256, 0, gif::as_stream(stream)>>>(p);
         return gif::check_launch("upfirdn2d(blur)");
     }
     long total = (long)B * Ho * Wo * (C / 4);
@@ -617,21 +616,108 @@ int gif_upfirdn2d_f32(const float* x, const float* k, float* y, int B, int Hi, i
         long gx = (row_items + 255) / 256;
         if (gx > 64) gx = 64;
         const dim3 grid((unsigned)gx, (unsigned)((long)B * Ho));
-        if (down == 2) fir4x4_resample_kernel<1, 2><<<grid, 256, 0, gif::as_stream(stream)>>>(p);
-        else fir4x4_resample_kernel<2, 1><<<grid, 256, 0, gif::as_stream(stream)>>>(p);
+        if (down == 2) fir4x4_resample_kernel<T, 1, 2><<<grid, 256, 0, gif::as_stream(stream)>>>(p);
+        else fir4x4_resample_kernel<T, 2, 1><<<grid, 256, 0, gif::as_stream(stream)>>>(p);
         return gif::check_launch("upfirdn2d(resample by 2)");
     }
-    upfirdn2d_kernel<<<ew_grid(total), 256, 0, gif::as_stream(stream)>>>(p);
+    upfirdn2d_kernel<T><<<ew_grid(total), 256, 0, gif::as_stream(stream)>>>(p);
     return gif::check_launch("upfirdn2d");
+}
+
+template <typename T>
+int bias_act_impl(const T* x, const float* bias, const T* residual, T* y, int64_t npix, int C, float slope, float gain,
+                  gif_stream_t stream) {
+    GIF_REQUIRE(x && y && npix >= 0 && C > 0 && C % 4 == 0, "bias_act: bad arguments (C=%d)", C);
+    if (npix == 0) return 0;
+    long n4 = npix * (C / 4);
+    bias_act_kernel<T><<<ew_grid(n4), 256, 0, gif::as_stream(stream)>>>(x, bias, residual, y, n4, C / 4, slope, gain);
+    return gif::check_launch("bias_act");
+}
+
+template <typename T>
+int bias_act_bwd_impl(const T* gy, const T* y, T* gx, float* gbias, float* partial, int64_t npix, int C, float slope, float gain,
+                      gif_stream_t stream) {
+    GIF_REQUIRE(gy && y && gx && npix >= 0 && C > 0 && C % 4 == 0 && C <= 1024, "bias_act_bwd: bad arguments (C=%d)", C);
+    GIF_REQUIRE(!gbias || partial, "bias_act_bwd: gbias needs a partial buffer");
+    if (npix == 0) return 0;
+    hipStream_t s = gif::as_stream(stream);
+    int C4 = C / 4;
+    int nblk = colsum_blocks(npix, C4);
+    long rpb = (npix + nblk - 1) / nblk;
+    colsum_stage1<1, T><<<dim3(nblk, 1), 256, 0, s>>>(gy, y, gx, nullptr, partial, npix, C4, rpb, slope, gain, gbias != nullptr);
+    if (gbias) colsum_stage2<<<dim3(gif::cdiv(C, 64), 1), 256, 0, s>>>(partial, gbias, nblk, C);
+    return gif::check_launch("bias_act_bwd");
+}
+
+template <typename T>
+int colsum_impl(const T* x, float* out, float* partial, int64_t npix, int C, gif_stream_t stream) {
+    GIF_REQUIRE(x && out && partial && npix >= 0 && C > 0 && C % 4 == 0 && C <= 1024, "colsum: bad arguments (C=%d)", C);
+    hipStream_t s = gif::as_stream(stream);
+    int C4 = C / 4;
+    int nblk = colsum_blocks(npix, C4);
+    long rpb = (npix + nblk - 1) / nblk;
+    colsum_stage1<0, T><<<dim3(nblk, 1), 256, 0, s>>>(x, nullptr, nullptr, nullptr, partial, npix, C4, rpb, 0.f, 1.f, 1);
+    colsum_stage2<<<dim3(gif::cdiv(C, 64), 1), 256, 0, s>>>(partial, out, nblk, C);
+    return gif::check_launch("colsum");
+}
+
+inline int mul_reduce_chunks(int64_t HW) { return colsum_blocks(HW, 32) > 64 ? 64 : colsum_blocks(HW, 32); }
+
+template <typename T>
+int mul_reduce_impl(const T* a, const T* b, const float* scale, T* scaled, float* out, float* partial, int B, int64_t HW,
+                    int C, gif_stream_t stream) {
+    GIF_REQUIRE(a && b && out && partial && B >= 0 && HW > 0 && C > 0 && C % 4 == 0 && C <= 1024,
+                "mul_reduce: bad arguments (C=%d)", C);
+    GIF_REQUIRE(!scaled || scale, "mul_reduce: scaled output needs scale");
+    if (B == 0) return 0;
+    hipStream_t s = gif::as_stream(stream);
+    int nchunk = mul_reduce_chunks(HW);
+    long rpb = (HW + nchunk - 1) / nchunk;
+    colsum_stage1<2, T><<<dim3(nchunk, B), 256, 0, s>>>(a, b, scaled, scale, partial, HW, C / 4, rpb, 0.f, 1.f, 1);
+    colsum_stage2<<<dim3(gif::cdiv(C, 64), B), 256, 0, s>>>(partial, out, nchunk, C);
+    return gif::check_launch("mul_reduce");
+}
+
+template <typename T>
+int act_inv_mul_reduce_impl(const T* g, const T* y, const T* residual, const float* bias, float* out, float* partial, int B,
+                            int64_t HW, int C, float slope, float gain, gif_stream_t stream) {
+    GIF_REQUIRE(g && y && out && partial && B >= 0 && HW > 0 && C > 0 && C % 4 == 0 && C <= 1024,
+                "act_inv_mul_reduce: bad arguments (C=%d)", C);
+    GIF_REQUIRE(slope > 0.f && gain > 0.f, "act_inv_mul_reduce: activation must be invertible (slope, gain > 0)");
+    if (B == 0) return 0;
+    hipStream_t s = gif::as_stream(stream);
+    int nchunk = mul_reduce_chunks(HW);
+    long rpb = (HW + nchunk - 1) / nchunk;
+    colsum_stage1<3, T><<<dim3(nchunk, B), 256, 0, s>>>(g, y, static_cast<T*>(nullptr), nullptr, partial, HW, C / 4, rpb, slope, gain,
+                                                         1, residual, bias);
+    colsum_stage2<<<dim3(gif::cdiv(C, 64), B), 256, 0, s>>>(partial, out, nchunk, C);
+    return gif::check_launch("act_inv_mul_reduce");
+}
+
+}  // namespace
+
+extern "C" {
+
+int gif_upfirdn2d_f32(const float* x, const float* k, float* y, int B, int Hi, int Wi, int C, int Ho, int Wo, int up,
+                      int down, int padx0, int pady0, int KH, int KW, int flip, const gif_conv_epilogue* e,
+                      gif_stream_t stream) {
+    return upfirdn2d_impl<float>(x, k, y, B, Hi, Wi, C, Ho, Wo, up, down, padx0, pady0, KH, KW, flip, e, stream);
+}
+int gif_upfirdn2d_f16(const void* x, const float* k, void* y, int B, int Hi, int Wi, int C, int Ho, int Wo, int up,
+                      int down, int padx0, int pady0, int KH, int KW, int flip, const gif_conv_epilogue* e,
+                      gif_stream_t stream) {
+    return upfirdn2d_impl<gif::f16>(static_cast<const gif::f16*>(x), k, static_cast<gif::f16*>(y), B, Hi, Wi, C, Ho, Wo, up, down,
+                                    padx0, pady0, KH, KW, flip, e, stream);
 }
 
 int gif_bias_act_f32(const float* x, const float* bias, const float* residual, float* y, int64_t npix, int C,
                      float slope, float gain, gif_stream_t stream) {
-    GIF_REQUIRE(x && y && npix >= 0 && C > 0 && C % 4 == 0, "bias_act: bad arguments (C=%d)", C);
-    if (npix == 0) return 0;
-    long n4 = npix * (C / 4);
-    bias_act_kernel<<<ew_grid(n4), 256, 0, gif::as_stream(stream)>>>(x, bias, residual, y, n4, C / 4, slope, gain);
-    return gif::check_launch("bias_act");
+    return bias_act_impl<float>(x, bias, residual, y, npix, C, slope, gain, stream);
+}
+int gif_bias_act_f16(const void* x, const float* bias, const void* residual, void* y, int64_t npix, int C, float slope,
+                     float gain, gif_stream_t stream) {
+    return bias_act_impl<gif::f16>(static_cast<const gif::f16*>(x), bias, static_cast<const gif::f16*>(residual),
+                                   static_cast<gif::f16*>(y), npix, C, slope, gain, stream);
 }
 
 int64_t gif_colsum_partial_floats(int64_t npix, int C) {
@@ -641,58 +727,42 @@ int64_t gif_colsum_partial_floats(int64_t npix, int C) {
 
 int gif_bias_act_bwd_f32(const float* gy, const float* y, float* gx, float* gbias, float* partial, int64_t npix, int C,
                          float slope, float gain, gif_stream_t stream) {
-    GIF_REQUIRE(gy && y && gx && npix >= 0 && C > 0 && C % 4 == 0 && C <= 1024, "bias_act_bwd: bad arguments (C=%d)", C);
-    GIF_REQUIRE(!gbias || partial, "bias_act_bwd: gbias needs a partial buffer");
-    if (npix == 0) return 0;
-    hipStream_t s = gif::as_stream(stream);
-    int C4 = C / 4;
-    int nblk = colsum_blocks(npix, C4);
-    long rpb = (npix + nblk - 1) / nblk;
-    colsum_stage1<1><<<dim3(nblk, 1), 256, 0, s>>>(gy, y, gx, nullptr, partial, npix, C4, rpb, slope, gain, gbias != nullptr);
-    if (gbias) colsum_stage2<<<dim3(gif::cdiv(C, 64), 1), 256, 0, s>>>(partial, gbias, nblk, C);
-    return gif::check_launch("bias_act_bwd");
+    return bias_act_bwd_impl<float>(gy, y, gx, gbias, partial, npix, C, slope, gain, stream);
+}
+int gif_bias_act_bwd_f16(const void* gy, const void* y, void* gx, float* gbias, float* partial, int64_t npix, int C,
+                         float slope, float gain, gif_stream_t stream) {
+    return bias_act_bwd_impl<gif::f16>(static_cast<const gif::f16*>(gy), static_cast<const gif::f16*>(y), static_cast<gif::f16*>(gx),
+                                       gbias, partial, npix, C, slope, gain, stream);
 }
 
 int gif_colsum_f32(const float* x, float* out, float* partial, int64_t npix, int C, gif_stream_t stream) {
-    GIF_REQUIRE(x && out && partial && npix >= 0 && C > 0 && C % 4 == 0 && C <= 1024, "colsum: bad arguments (C=%d)", C);
-    hipStream_t s = gif::as_stream(stream);
-    int C4 = C / 4;
-    int nblk = colsum_blocks(npix, C4);
-    long rpb = (npix + nblk - 1) / nblk;
-    colsum_stage1<0><<<dim3(nblk, 1), 256, 0, s>>>(x, nullptr, nullptr, nullptr, partial, npix, C4, rpb, 0.f, 1.f, 1);
-    colsum_stage2<<<dim3(gif::cdiv(C, 64), 1), 256, 0, s>>>(partial, out, nblk, C);
-    return gif::check_launch("colsum");
+    return colsum_impl<float>(x, out, partial, npix, C, stream);
+}
+int gif_colsum_f16(const void* x, float* out, float* partial, int64_t npix, int C, gif_stream_t stream) {
+    return colsum_impl<gif::f16>(static_cast<const gif::f16*>(x), out, partial, npix, C, stream);
 }
 
-int gif_mul_reduce_chunks(int64_t HW) { return colsum_blocks(HW, 32) > 64 ? 64 : colsum_blocks(HW, 32); }
+int gif_mul_reduce_chunks(int64_t HW) { return mul_reduce_chunks(HW); }
 
 int gif_mul_reduce_f32(const float* a, const float* b, const float* scale, float* scaled, float* out, float* partial,
                        int B, int64_t HW, int C, gif_stream_t stream) {
-    GIF_REQUIRE(a && b && out && partial && B >= 0 && HW > 0 && C > 0 && C % 4 == 0 && C <= 1024,
-                "mul_reduce: bad arguments (C=%d)", C);
-    GIF_REQUIRE(!scaled || scale, "mul_reduce: scaled output needs scale");
-    if (B == 0) return 0;
-    hipStream_t s = gif::as_stream(stream);
-    int nchunk = gif_mul_reduce_chunks(HW);
-    long rpb = (HW + nchunk - 1) / nchunk;
-    colsum_stage1<2><<<dim3(nchunk, B), 256, 0, s>>>(a, b, scaled, scale, partial, HW, C / 4, rpb, 0.f, 1.f, 1);
-    colsum_stage2<<<dim3(gif::cdiv(C, 64), B), 256, 0, s>>>(partial, out, nchunk, C);
-    return gif::check_launch("mul_reduce");
+    return mul_reduce_impl<float>(a, b, scale, scaled, out, partial, B, HW, C, stream);
+}
+int gif_mul_reduce_f16(const void* a, const void* b, const float* scale, void* scaled, float* out, float* partial, int B,
+                       int64_t HW, int C, gif_stream_t stream) {
+    return mul_reduce_impl<gif::f16>(static_cast<const gif::f16*>(a), static_cast<const gif::f16*>(b), scale,
+                                     static_cast<gif::f16*>(scaled), out, partial, B, HW, C, stream);
 }
 
 int gif_act_inv_mul_reduce_f32(const float* g, const float* y, const float* residual, const float* bias, float* out,
                                float* partial, int B, int64_t HW, int C, float slope, float gain, gif_stream_t stream) {
-    GIF_REQUIRE(g && y && out && partial && B >= 0 && HW > 0 && C > 0 && C % 4 == 0 && C <= 1024,
-                "act_inv_mul_reduce: bad arguments (C=%d)", C);
-    GIF_REQUIRE(slope > 0.f && gain > 0.f, "act_inv_mul_reduce: activation must be invertible (slope, gain > 0)");
-    if (B == 0) return 0;
-    hipStream_t s = gif::as_stream(stream);
-    int nchunk = gif_mul_reduce_chunks(HW);
-    long rpb = (HW + nchunk - 1) / nchunk;
-    colsum_stage1<3><<<dim3(nchunk, B), 256, 0, s>>>(g, y, nullptr, nullptr, partial, HW, C / 4, rpb, slope, gain, 1, residual,
-                                                      bias);
-    colsum_stage2<<<dim3(gif::cdiv(C, 64), B), 256, 0, s>>>(partial, out, nchunk, C);
-    return gif::check_launch("act_inv_mul_reduce");
+    return act_inv_mul_reduce_impl<float>(g, y, residual, bias, out, partial, B, HW, C, slope, gain, stream);
+}
+int gif_act_inv_mul_reduce_f16(const void* g, const void* y, const void* residual, const float* bias, float* out,
+                               float* partial, int B, int64_t HW, int C, float slope, float gain, gif_stream_t stream) {
+    return act_inv_mul_reduce_impl<gif::f16>(static_cast<const gif::f16*>(g), static_cast<const gif::f16*>(y),
+                                             static_cast<const gif::f16*>(residual), bias, out, partial, B, HW, C, slope, gain,
+                                             stream);
 }
 
 int gif_bilinear_down_f32(const float* x, float* y, int B, int R, int S, int C, int backward, gif_stream_t stream) {

@@ -110,7 +110,7 @@ typedef struct {
     const float* in_scale;  /* [B, Cin]  or NULL */
     const float* out_scale; /* [B, Cout] or NULL */
     const float* bias;      /* [Cout]    or NULL */
-    const float* residual;  /* same shape as output or NULL (added before the activation) */
+    const void* residual;   /* same shape AND element type as the output, or NULL (added before the activation) */
     int32_t act;            /* 0: identity, 1: gain * leaky_relu(., slope) */
     float slope, gain;
 } gif_conv_epilogue;

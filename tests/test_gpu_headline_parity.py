@@ -92,16 +92,25 @@ def test_benchmark_modulated_layers_vs_aten_cpu():
     res, bias = torch.randn(B, Co, H, H, generator=g), torch.randn(Co, generator=g) * 0.1
     gy = torch.randn(B, Co, H, H, generator=g)
     wscale = 1 / math.sqrt(Ci * 9)
-    leaves = [t.clone().requires_grad_(True) for t in (x, w, s, d, res, bias)]
-    xr, wr, sr, dr, rr, br = leaves
-    yr = 2 ** 0.5 * F.leaky_relu(F.conv2d(xr * sr[:, :, None, None], wr * wscale, padding=1) * dr[:, :, None, None]
-                                 + rr + br[None, :, None, None], 0.2)
-    refs = torch.autograd.grad(yr, leaves, gy)
     xd, rd = dev(x, True), dev(res, True)
     wd, sd_, dd, bd = (t.cuda().requires_grad_(True) for t in (w, s, d, bias))
     yd = GF.modulated_conv2d_act(xd, wd, sd_, dd, rd, bd, 1, wscale)
     gots = torch.autograd.grad(yd, (xd, wd, sd_, dd, rd, bd), dev(gy))
-    assert_close(host(yd), yr, 2e-5, "fused StyledConv forward")
+    y_hip = host(yd)
+    # ATen-CPU reference.  The leaky-ReLU backward only depends on the SIGN of the output; of 268 M pre-activations a few
+    # hundred lie within fp32 rounding of zero, where the CPU and the HIP forward may land on different sides — each such
+    # element would move ~1000 entries of the (otherwise linear) gradients by up to 1e-1 of their max and say nothing about
+    # the kernels.  So the reference backward uses the mask of the HIP forward (whose values are checked right here), which
+    # makes every gradient below an exactly linear function of gy that must agree to accumulation-order rounding.
+    leaves = [t.clone().requires_grad_(True) for t in (x, w, s, d, res, bias)]
+    xr, wr, sr, dr, rr, br = leaves
+    zr = F.conv2d(xr * sr[:, :, None, None], wr * wscale, padding=1) * dr[:, :, None, None] + rr + br[None, :, None, None]
+    yr = 2 ** 0.5 * F.leaky_relu(zr, 0.2)
+    assert_close(y_hip, yr.detach(), 2e-5, "fused StyledConv forward")
+    flips = ((y_hip > 0) != (yr.detach() > 0)).float().mean().item()
+    assert flips < 1e-5, f"sign of the activation differs on a fraction {flips:.2e} of the outputs"
+    mask = torch.where(y_hip > 0, torch.tensor(1.0), torch.tensor(0.2)) * 2 ** 0.5
+    refs = torch.autograd.grad(zr * mask, leaves, gy)
     for nm, got, ref, tol in zip(("x", "w", "s", "d", "residual", "bias"), gots, refs, (2e-5, 5e-5, 5e-5, 5e-5, 2e-5, 5e-5)):
         assert_close(got, ref, tol, f"fused StyledConv grad {nm}")
     del leaves, refs, gots, yr, yd, xd, rd
