@@ -30,6 +30,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_f16 dense peak (not the 2:1-sparse figure)
 PMC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # written by tools/pmc_to_json.py from rocprofv3 --pmc passes
 
 
@@ -45,6 +46,9 @@ def parse():
     ap.add_argument("--render-cond", action="store_true",
                     help="config 3: rasterise the 6-channel condition from a posed mesh inside the timed region")
     ap.add_argument("--gen-reg", type=str, default="None", help="None | PATH_LEN_REG | DIRECT_GRAD_REG (train.py:203-215)")
+    ap.add_argument("--dtype", type=str, default="f32", choices=["f32", "f16"],
+                    help="activation dtype: f32 = the reference's (headline); f16 = BASELINE configs[4] (f16 activations, fp32 "
+                         "weights / demodulation / accumulation, loss scaling) — use with --res 1024 --batch 8")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4, help="CPU baseline batch (BASELINE.md §3: 4; 32 does not fit)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = calibrate: fastest of {all host cores, 64, 32, 16}")
@@ -150,9 +154,13 @@ FAMILIES = {
     2: ("wino_gemm_mfma (Winograd F(2x2,3x3) fwd / dgrad GEMM + fused output transform and epilogue)", WINOGRAD_EXECUTED,
         "wino_gemm_mfma"),
     3: ("conv_wgrad_mfma in planes mode (Winograd F(3x3,2x2) weight-gradient GEMM)", WINOGRAD_EXECUTED, "conv_wgrad_mfma"),
+    6: ("conv_gather_mfma_glds<f16> (f16 fwd / dgrad / stride-2 / transposed conv, v_mfma_f32_32x32x16_f16)", 1.0,
+        "conv_gather_mfma_glds_f16"),
+    7: ("conv_wgrad_mfma<f16> (f16 weight gradient, fp32 accumulation)", 1.0, "conv_wgrad_mfma_f16"),
 }
 FAMILY_KEYS = {0: "roofline_conv_direct", 1: "roofline_wgrad_direct", 2: "roofline_conv_winograd", 3: "roofline_wgrad_winograd",
-               5: "roofline_conv_direct_small_cin"}
+               5: "roofline_conv_direct_small_cin", 6: "roofline_conv_f16", 7: "roofline_wgrad_f16"}
+FAMILY_PEAK = {6: PEAK_F16_MFMA_TFLOPS, 7: PEAK_F16_MFMA_TFLOPS}
 
 
 def load_pmc():
@@ -171,20 +179,22 @@ def roofline_objects(ops, steps, wall_s):
     `achieved` is what the MFMA pipe actually executed per second (<= peak); for the Winograd GEMMs the ALGORITHMIC
     (direct-convolution) rate, which is 36/16 of that, is reported next to it as `algorithmic_achieved`."""
     pmc = load_pmc()
-    objs, executed_flops, mfma_ms = {}, 0.0, 0.0
+    objs, executed_flops, executed_peak_s, mfma_ms = {}, 0.0, 0.0, 0.0
     for fam, (name, exec_frac, pmc_key) in FAMILIES.items():
         ms, fl, n = ops.prof_read(fam)
         if n == 0 or ms <= 0:
             continue
+        peak = FAMILY_PEAK.get(fam, PEAK_F32_MFMA_TFLOPS)
         executed_flops += fl * exec_frac
+        executed_peak_s += fl * exec_frac / (peak * 1e12)  # seconds this work takes at the peak of the MFMA type it ran on
         mfma_ms += ms
         alg = fl / (ms * 1e-3) / 1e12
-        o = {"bound": "mfma", "kernel": name, "achieved": alg * exec_frac, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-             "frac": alg * exec_frac / PEAK_F32_MFMA_TFLOPS, "traffic": None, "launches": n, "avg_ms": ms / n,
+        o = {"bound": "mfma", "kernel": name, "achieved": alg * exec_frac, "peak": peak, "unit": "TFLOP/s",
+             "frac": alg * exec_frac / peak, "traffic": None, "launches": n, "avg_ms": ms / n,
              "gpu_ms_per_step": ms / steps, "algorithmic_flop_per_launch": fl / n}
         if exec_frac != 1.0:
             o["algorithmic_achieved"] = alg
-            o["algorithmic_frac"] = alg / PEAK_F32_MFMA_TFLOPS
+            o["algorithmic_frac"] = alg / peak
             o["note"] = "achieved = executed MFMA FLOP/s (16/36 of the algorithmic direct-convolution FLOPs)"
         fam_pmc = (pmc or {}).get("families", {}).get(pmc_key)
         if fam_pmc:
@@ -213,12 +223,13 @@ def roofline_objects(ops, steps, wall_s):
     # what the MFMA pipe really did over the WALL time of the timed region (Winograd's skipped multiplies not counted)
     out["executed_mfma_frac_wall"] = {
         "executed_tflop_per_step": executed_flops / steps / 1e12,
-        "achieved": executed_flops / wall_s / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-        "frac": executed_flops / wall_s / 1e12 / PEAK_F32_MFMA_TFLOPS,
+        "achieved": executed_flops / wall_s / 1e12, "unit": "TFLOP/s",
+        "frac": executed_peak_s / wall_s,
         "mfma_kernel_ms_per_step": mfma_ms / steps,
-        "frac_while_mfma_kernels_run": executed_flops / (mfma_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS if mfma_ms else None,
-        "note": "MFMA FLOPs actually executed (direct kernels: all; Winograd GEMMs: 16/36 of the algorithmic count) / wall time "
-                "of the timed region / fp32 MFMA peak"}
+        "frac_while_mfma_kernels_run": executed_peak_s / (mfma_ms * 1e-3) if mfma_ms else None,
+        "note": "MFMA FLOPs actually executed (direct kernels: all; Winograd GEMMs: 16/36 of the algorithmic count), each priced "
+                "at the dense peak of the MFMA type it ran on (fp32 157.3 TF, f16 2500 TF): time at peak / wall time of the "
+                "timed region"}
     return out
 
 
@@ -278,7 +289,8 @@ def main():
         D = Discriminator(size=args.res, num_color_chnls=9, channel_multiplier=2)
     G_ema.load_state_dict(G.state_dict())
     G, G_ema, D = G.to(dev), G_ema.to(dev), D.to(dev)
-    trainer = GifTrainer(G, D, G_ema, step=res_step, alpha=1.0, r1_every=args.r1_every, gen_reg_type=args.gen_reg)
+    trainer = GifTrainer(G, D, G_ema, step=res_step, alpha=1.0, r1_every=args.r1_every, gen_reg_type=args.gen_reg,
+                         act_dtype=torch.float16 if args.dtype == "f16" else None)
 
     from gif_amd.data import SyntheticBatches
     B = args.batch
@@ -307,7 +319,7 @@ def main():
 
     data = [batch() for _ in range(min(args.steps, 4))]  # synthetic batches resident in HBM before the timed region
     if not args.no_prof:
-        for fam in range(6):
+        for fam in range(8):
             ops.prof_read(fam)
         ops.prof_enable(True)
     sync()
@@ -330,8 +342,11 @@ def main():
         value = imgs / dt
         fl_img = flops_per_image(args.res, args.r1_every)
         step_tflops = value * fl_img / 1e12 / world
+        f16 = args.dtype == "f16"
+        peak = PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS
         workload = (f"GIF run-29 G+D training iteration, {args.res}x{args.res}, batch {B}/GPU, R1 every {args.r1_every}th step, "
-                    f"fp32 MFMA (BASELINE configs[1]/[3] shape)")
+                    + ("f16 activations / f16 MFMA with fp32 accumulation, fp32 weights + demodulation, dynamic loss scaling "
+                       "(BASELINE configs[4])" if f16 else "fp32 MFMA (BASELINE configs[1]/[3] shape)"))
         if args.render_cond:
             workload += "; condition rasterised from a posed mesh inside the timed region (configs[2])"
         if args.gen_reg.upper() != "NONE":
@@ -340,17 +355,20 @@ def main():
             "metric": f"G+D train-step images/sec at {args.res}x{args.res}, batch {B}/GPU",
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": workload, "global_batch": world * B, "resolution": args.res, "parallelism": f"dp{world}",
                        "algorithmic_tflop_per_image": fl_img / 1e12,
                        "peak_hbm_allocated_gb": torch.cuda.max_memory_allocated() / 2 ** 30},
-            "step_mfma_roofline": {"achieved": step_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": step_tflops / PEAK_F32_MFMA_TFLOPS,
+            "step_mfma_roofline": {"achieved": step_tflops, "peak": peak, "unit": "TFLOP/s",
+                                   "frac": step_tflops / peak,
                                    "note": "whole step, ALGORITHMIC direct-convolution FLOPs (Winograd executes fewer: see "
                                            "executed_mfma_frac_wall) incl. HBM-bound kernels, optimiser, host; per GPU"},
         }
         if not args.no_prof:
             out.update(roofline_objects(ops, args.steps, dt))
+        if f16:
+            out["loss_scaler"] = {"g_scale": trainer.g_scaler.scale.item(), "d_scale": trainer.d_scaler.scale.item(),
+                                  "skipped_g_steps": trainer.g_scaler.skipped.item(), "skipped_d_steps": trainer.d_scaler.skipped.item()}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.res, res_step, args.cpu_batch, args.cpu_threads, args.cpu_timeout)
         print(json.dumps(out), flush=True)

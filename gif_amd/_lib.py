@@ -69,9 +69,22 @@ PROTOTYPES = {
     "gif_mbstd_fwd_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "gif_mbstd_bwd_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "gif_sqnorm_per_sample_f32": (c_int, [P, P, c_int, c_i64, P]),
+    "gif_conv2d_pack_dims_f16": (c_int, [c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "gif_pack_weight_f16": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_float, P]),
+    "gif_conv2d_fwd_f16": (c_int, [P, P, P, GP, EP, P]),
+    "gif_conv2d_bwd_data_f16": (c_int, [P, P, P, GP, EP, P]),
+    "gif_conv2d_wgrad_dims_f16": (c_int, [c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "gif_conv2d_wgrad_splits_f16": (c_int, [GP]),
+    "gif_conv2d_wgrad_f16": (c_int, [P, P, P, P, P, GP, c_int, P]),
+    "gif_upfirdn2d_f16": (c_int, [P, P, P] + [c_int] * 13 + [EP, P]),
+    "gif_bias_act_f16": (c_int, [P, P, P, P, c_i64, c_int, c_float, c_float, P]),
+    "gif_bias_act_bwd_f16": (c_int, [P, P, P, P, P, c_i64, c_int, c_float, c_float, P]),
+    "gif_colsum_f16": (c_int, [P, P, P, c_i64, c_int, P]),
+    "gif_mul_reduce_f16": (c_int, [P, P, P, P, P, P, c_int, c_i64, c_int, P]),
+    "gif_act_inv_mul_reduce_f16": (c_int, [P, P, P, P, P, P, c_int, c_i64, c_int, c_float, c_float, P]),
     "gif_adam_chunk_floats": (c_int, []),
     "gif_adam_ema_step_f32": (c_int, [P, c_int, P, P, P, c_float, c_float, c_float, c_float, ctypes.c_double, ctypes.c_double,
-                                      c_float, c_int, P]),
+                                      c_float, c_int, P, P, P]),
     "gif_prof_enable": (c_int, [c_int]),
     "gif_prof_read": (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64)]),
 }

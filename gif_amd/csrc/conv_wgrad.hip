@@ -20,8 +20,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BKP_MAX = 32;  // host-side rounding unit of the pixel chunks (any BKP below divides it)
 
 struct WgradParams {
-    const float* sm;  // small side [B,Hs,Ws,Cs]
-    const float* bg;  // big side   [B,Hb,Wb,Cb]
+    const void* sm;   // small side [B,Hs,Ws,Cs]   (fp32, or f16 for the T = f16 instantiation)
+    const void* bg;   // big side   [B,Hb,Wb,Cb]
     float* ws;        // [nsplit][T][RP][CP]
     const float* ss;  // [B,Cs] or null
     const float* bs;  // [B,Cb] or null
@@ -32,7 +32,7 @@ struct WgradParams {
     long chunk;  // pixels per split (multiple of BKP)
     int tiles_q, tiles_pq;
     int stab_nb;  // LDS scale table (scaled LDS-DMA path): samples a pixel chunk can touch
-    const float* zero;  // 16 zero bytes in HBM (source of out-of-range LDS-DMA lanes), passed as an argument
+    const void* zero;   // 16 zero bytes in HBM (source of out-of-range LDS-DMA lanes), passed as an argument
     // "planes" mode (Winograd wgrad): tap t has no spatial shift but its own operand planes sm + t*sm_plane, bg + t*bg_plane
     long sm_plane, bg_plane;
 };
@@ -51,21 +51,28 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // TAB = true (GLDS with per-sample scales, needs Hs*Ws % BKP == 0 so that a stage never straddles two samples): the
 // scale vectors ss[b, r0:r0+BP) / bs[b, c0:c0+BQ) of the samples this chunk touches sit in an LDS table and are
 // multiplied into the operand fragments (the DMA cannot scale data in flight).
-template <int BP, int BQ, int WAVES_P, int WAVES_Q, bool GLDS, int BKP, bool TAB = false>
+// T = f16 (GLDS only): the same [pixel][channel] tiles in halfs (16-byte DMA chunk = 8 channels); v_mfma_f32_32x32x16_f16 wants
+// 8 consecutive K (= pixels) of ONE channel per lane, i.e. a transposed operand, which is gathered with eight 16-bit LDS reads
+// per fragment (lane = channel: the 32 lanes of a half wave read 64 contiguous bytes of one pixel row, conflict free).
+// Accumulators and the partial-sum workspace stay fp32.
+template <typename T, int BP, int BQ, int WAVES_P, int WAVES_Q, bool GLDS, int BKP, bool TAB = false>
 __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const WgradParams p) {
+    constexpr bool F16 = sizeof(T) == 2;
+    constexpr int EPC = 16 / sizeof(T);  // elements per 16-byte chunk
     constexpr int THREADS = 64 * WAVES_P * WAVES_Q;
     constexpr int WPt = BP / WAVES_P, WQt = BQ / WAVES_Q;
     constexpr int MT = WPt / 32, NT = WQt / 32;
-    constexpr int P_ROWS = THREADS / (BP / 4), Q_ROWS = THREADS / (BQ / 4);  // pixel rows per pass
+    constexpr int P_ROWS = THREADS / (BP / EPC), Q_ROWS = THREADS / (BQ / EPC);  // pixel rows per pass
     constexpr int P_IT = BKP / P_ROWS, Q_IT = BKP / Q_ROWS;
     static_assert(BKP % P_ROWS == 0 && BKP % Q_ROWS == 0 && P_IT >= 1 && Q_IT >= 1, "tile/thread mapping");
+    static_assert(!F16 || (GLDS && BKP % 16 == 0), "f16: LDS-DMA staging, 16-pixel MFMA K steps");
 
     // ONE LDS object (two separate __shared__ arrays make hipcc drain the LDS-DMA with vmcnt(0) before every ds_read)
     extern __shared__ __attribute__((aligned(16))) float wg_smem[];
-    typedef float PTile[BKP][BP];
-    typedef float QTile[BKP][BQ];
-    PTile* Ps = reinterpret_cast<PTile*>(wg_smem);                      // [2][BKP][BP]
-    QTile* Qs = reinterpret_cast<QTile*>(wg_smem + 2 * BKP * BP);       // [2][BKP][BQ]
+    typedef T PTile[BKP][BP];
+    typedef T QTile[BKP][BQ];
+    PTile* Ps = reinterpret_cast<PTile*>(wg_smem);                                        // [2][BKP][BP]
+    QTile* Qs = reinterpret_cast<QTile*>(reinterpret_cast<T*>(wg_smem) + 2 * BKP * BP);   // [2][BKP][BQ]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -80,18 +87,19 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const 
     const int r0 = tp * BP, c0 = tq * BQ;
     const bool planes = p.sm_plane != 0;
     const int ky = planes ? 0 : t / p.KW, kx = planes ? 0 : t - ky * p.KW;
-    const float* const smb = p.sm + (size_t)t * p.sm_plane;
-    const float* const bgb = p.bg + (size_t)t * p.bg_plane;
+    const T* const smb = static_cast<const T*>(p.sm) + (size_t)t * p.sm_plane;
+    const T* const bgb = static_cast<const T*>(p.bg) + (size_t)t * p.bg_plane;
+    const T* const pzero = static_cast<const T*>(p.zero);
     const int n_begin = (int)((long)split * p.chunk);
     int n_end = n_begin + (int)p.chunk;
     if (n_end > (int)p.Ntot) n_end = (int)p.Ntot;
     const unsigned HWs = (unsigned)(p.Hs * p.Ws);
 
-    const int p_row = tid / (BP / 4), p_ch = r0 + (tid % (BP / 4)) * 4;
-    const int q_row = tid / (BQ / 4), q_ch = c0 + (tid % (BQ / 4)) * 4;
+    const int p_row = tid / (BP / EPC), p_ch = r0 + (tid % (BP / EPC)) * EPC;
+    const int q_row = tid / (BQ / EPC), q_ch = c0 + (tid % (BQ / EPC)) * EPC;
     const bool p_ch_ok = p_ch < p.Cs, q_ch_ok = q_ch < p.Cb;
     const bool has_ss = !TAB && p.ss != nullptr, has_bs = !TAB && p.bs != nullptr;
-    float* Stab = wg_smem + 2 * BKP * (BP + BQ);  // [stab_nb][BP + BQ]
+    float* Stab = reinterpret_cast<float*>(reinterpret_cast<T*>(wg_smem) + 2 * BKP * (BP + BQ));  // [stab_nb][BP + BQ] fp32
     int tab_row = 0, tab_rem = 0;                 // table row / pixel offset inside the sample of the stage being computed
     if (TAB) {
         const int b_first = n_begin / (int)HWs;
@@ -146,13 +154,13 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const 
         for (int it = 0; it < P_IT; ++it) {
             bool ok = p_ch_ok && p_n[it] < n_end;
             if (GLDS) {
-                // thread tid lands at float offset 4*tid of pass `it` (== Ps[buf][p_row + it*P_ROWS][4*(tid % (BP/4))])
-                const float* g = ok ? smb + (p_n[it] * p.Cs + p_ch) : p.zero;
-                __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(&Ps[buf][it * P_ROWS][0] + wave_u * 256), 16, 0, 0);
+                // thread tid lands at byte offset 16*tid of pass `it` (== Ps[buf][p_row + it*P_ROWS][EPC*(tid % (BP/EPC))])
+                const T* g = ok ? smb + (p_n[it] * p.Cs + p_ch) : pzero;
+                __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(&Ps[buf][it * P_ROWS][0] + wave_u * (1024 / (int)sizeof(T))), 16, 0, 0);
                 p_n[it] += BKP;
                 continue;
             }
-            p_reg[it] = *reinterpret_cast<const float4*>(smb + (ok ? p_n[it] * p.Cs + p_ch : 0));
+            if constexpr (!F16) p_reg[it] = *reinterpret_cast<const float4*>(smb + (ok ? p_n[it] * p.Cs + p_ch : 0));
             if (has_ss) ps_reg[it] = *reinterpret_cast<const float4*>(p.ss + (ok ? p_b[it] * p.Cs + p_ch : 0));
             p_mask |= (ok ? 1u : 0u) << it;
             p_n[it] += BKP;
@@ -164,11 +172,12 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const 
             int iy = q_oy[it] * p.stride + ky - p.pad, ix = q_ox[it] * p.stride + kx - p.pad;
             bool ok = q_ch_ok && q_n[it] < n_end && (unsigned)iy < (unsigned)p.Hb && (unsigned)ix < (unsigned)p.Wb;
             if (GLDS) {
-                const float* g = ok ? bgb + (((q_b[it] * p.Hb + iy) * p.Wb + ix) * p.Cb + q_ch) : p.zero;
-                __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(&Qs[buf][it * Q_ROWS][0] + wave_u * 256), 16, 0, 0);
+                const T* g = ok ? bgb + (((q_b[it] * p.Hb + iy) * p.Wb + ix) * p.Cb + q_ch) : pzero;
+                __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(&Qs[buf][it * Q_ROWS][0] + wave_u * (1024 / (int)sizeof(T))), 16, 0, 0);
             } else {
-                q_reg[it] = *reinterpret_cast<const float4*>(
-                    bgb + (ok ? ((q_b[it] * p.Hb + iy) * p.Wb + ix) * p.Cb + q_ch : 0));
+                if constexpr (!F16)
+                    q_reg[it] = *reinterpret_cast<const float4*>(
+                        bgb + (ok ? ((q_b[it] * p.Hb + iy) * p.Wb + ix) * p.Cb + q_ch : 0));
                 if (has_bs) qs_reg[it] = *reinterpret_cast<const float4*>(p.bs + (ok ? q_b[it] * p.Cb + q_ch : 0));
                 q_mask |= (ok ? 1u : 0u) << it;
             }
@@ -188,7 +197,8 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const 
         }
     };
     auto store_lds = [&](int buf) __attribute__((always_inline)) {
-        if (GLDS) return;  // the DMA already wrote the tiles
+        if constexpr (GLDS) return;  // the DMA already wrote the tiles
+        else {
 #pragma unroll
         for (int it = 0; it < P_IT; ++it) {
             float4 v = p_reg[it];
@@ -203,6 +213,7 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const 
             if (!((q_mask >> it) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
             *reinterpret_cast<float4*>(&Qs[buf][q_row + it * Q_ROWS][(tid % (BQ / 4)) * 4]) = v;
         }
+        }
     };
 
     f32x16 acc[MT][NT];
@@ -214,6 +225,43 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     auto compute = [&](int buf) __attribute__((always_inline)) {
+        if constexpr (F16) {
+            float psv[MT], qsv[NT];
+            if (TAB) {
+                const float* row = Stab + tab_row * (BP + BQ);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) psv[i] = row[wp0 + i * 32 + li];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) qsv[j] = row[BP + wq0 + j * 32 + li];
+                tab_rem += BKP;
+                if (tab_rem >= (int)HWs) { tab_rem -= (int)HWs; ++tab_row; }
+            }
+#pragma unroll
+            for (int ks = 0; ks < BKP / 16; ++ks) {
+                gif::f16x8_t af[MT], bf[NT];
+                const int k0 = 16 * ks + 8 * lh;  // this lane half's 8 pixels of the K step
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) af[i][e] = Ps[buf][k0 + e][wp0 + i * 32 + li];
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bf[j][e] = Qs[buf][k0 + e][wq0 + j * 32 + li];
+                if (TAB) {
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) af[i] *= (gif::f16)psv[i];
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) bf[j] *= (gif::f16)qsv[j];
+                }
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+            return;
+        } else {
         // operand fragments of k-step ks+1 are fetched from LDS before the MFMAs of k-step ks (register double buffer)
         float av[2][MT], bv[2][NT];
         float psv[MT], qsv[NT];
@@ -254,6 +302,7 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const 
             __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);  // DS reads
             __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);  // MFMA
         }
+        }
     };
 
     if (n_begin < n_end) {
@@ -287,11 +336,11 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const 
         }
 }
 
-template <int BP, int BQ, int WP_, int WQ_, bool GLDS, int BKP, bool TAB = false>
+template <typename T, int BP, int BQ, int WP_, int WQ_, bool GLDS, int BKP, bool TAB = false>
 void wgrad_launch(dim3 grid, int threads, hipStream_t s, const WgradParams& p) {
     static gif::LdsAttr attr;
-    const size_t lds = (size_t)(2 * BKP * (BP + BQ) + (TAB ? p.stab_nb * (BP + BQ) : 0)) * sizeof(float);
-    auto kern = conv_wgrad_mfma<BP, BQ, WP_, WQ_, GLDS, BKP, TAB>;
+    const size_t lds = (size_t)2 * BKP * (BP + BQ) * sizeof(T) + (size_t)(TAB ? p.stab_nb * (BP + BQ) : 0) * sizeof(float);
+    auto kern = conv_wgrad_mfma<T, BP, BQ, WP_, WQ_, GLDS, BKP, TAB>;
     attr.ensure(reinterpret_cast<const void*>(kern), lds);
     hipLaunchKernelGGL(kern, grid, dim3(threads), lds, s, p);
 }
@@ -314,7 +363,8 @@ inline bool wgrad_big_tile(int Cs, int Cb, bool scaled, long Ntot) {
 }
 inline int tile_rows(int Cs, int Cb, bool scaled, long Ntot) { return wgrad_big_tile(Cs, Cb, scaled, Ntot) ? 256 : tile_of(Cs); }
 
-__global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int R, int C, int KH,
+template <typename T>
+__global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ wp, int R, int C, int KH,
                                    int KW, int RP, int CP, long sr, long sc, long sky, long skx, float scale) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     long total = (long)KH * KW * RP * CP;
@@ -326,7 +376,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
     int ky = t / KW, kx = t - ky * KW;
     float v = 0.f;
     if (r < R && c < C) v = scale * w[r * sr + c * sc + ky * sky + kx * skx];
-    wp[idx] = v;
+    wp[idx] = (T)v;
 }
 
 __global__ void unpack_wgrad_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit, int R, int C,
@@ -538,9 +588,87 @@ int gif_pack_weight_f32(const float* w, float* wp, int R, int C, int KH, int KW,
                         int64_t sc, int64_t sky, int64_t skx, float scale, gif_stream_t stream) {
     GIF_REQUIRE(w && wp && R > 0 && C > 0 && RP >= R && CP >= C && KH > 0 && KW > 0, "pack_weight: bad arguments");
     long total = (long)KH * KW * RP * CP;
-    pack_weight_kernel<<<gif::cdiv(total, 256), 256, 0, gif::as_stream(stream)>>>(w, wp, R, C, KH, KW, RP, CP, sr, sc,
-                                                                                    sky, skx, scale);
+    pack_weight_kernel<float><<<gif::cdiv(total, 256), 256, 0, gif::as_stream(stream)>>>(w, wp, R, C, KH, KW, RP, CP, sr, sc,
+                                                                                           sky, skx, scale);
     return gif::check_launch("pack_weight");
+}
+
+/* fp32 master weights -> f16 packed operand of the f16 convolution kernels (same [tap][RP][CP] layout) */
+int gif_pack_weight_f16(const float* w, void* wp, int R, int C, int KH, int KW, int RP, int CP, int64_t sr, int64_t sc,
+                        int64_t sky, int64_t skx, float scale, gif_stream_t stream) {
+    GIF_REQUIRE(w && wp && R > 0 && C > 0 && RP >= R && CP >= C && KH > 0 && KW > 0, "pack_weight_f16: bad arguments");
+    long total = (long)KH * KW * RP * CP;
+    pack_weight_kernel<gif::f16><<<gif::cdiv(total, 256), 256, 0, gif::as_stream(stream)>>>(w, static_cast<gif::f16*>(wp), R, C, KH,
+                                                                                              KW, RP, CP, sr, sc, sky, skx, scale);
+    return gif::check_launch("pack_weight_f16");
+}
+
+/* ---- f16 operands (BASELINE config 5): always 128x128 tiles on the LDS-DMA kernel (MFMA work on padded channels is cheap
+ * at the f16 rate), fp32 partial sums, the same unpack kernel. */
+int gif_conv2d_wgrad_dims_f16(int Cs, int Cb, int* RP, int* CP) {
+    GIF_REQUIRE(Cs > 0 && Cb > 0 && RP && CP, "wgrad_dims_f16: bad arguments");
+    *RP = (Cs + 127) / 128 * 128;
+    *CP = (Cb + 127) / 128 * 128;
+    return 0;
+}
+
+int gif_conv2d_wgrad_splits_f16(const gif_conv_geom* g) {
+    if (!g || g->B <= 0) return 1;
+    int RP, CP;
+    gif_conv2d_wgrad_dims_f16(g->Cs, g->Cb, &RP, &CP);
+    long Ntot = (long)g->B * g->Hs * g->Ws;
+    long tiles = (long)(RP / 128) * (CP / 128) * g->KH * g->KW;
+    long want = tiles >= 1024 ? 1 : 1024 / tiles;  // 4 workgroups of 32 KB LDS per CU
+    long max_by_work = (Ntot + 4 * BKP_MAX - 1) / (4 * BKP_MAX);
+    long max_by_mem = (128L << 20) / ((long)g->KH * g->KW * RP * CP * 4);
+    long n = want;
+    if (n > max_by_work) n = max_by_work;
+    if (n > max_by_mem) n = max_by_mem;
+    if (n < 1) n = 1;
+    return (int)n;
+}
+
+int gif_conv2d_wgrad_f16(const void* small, const void* big, float* ws, const float* small_scale, const float* big_scale,
+                         const gif_conv_geom* g, int nsplit, gif_stream_t stream) {
+    GIF_REQUIRE(g && small && big && ws && nsplit >= 1, "conv2d_wgrad_f16: bad arguments");
+    GIF_REQUIRE(g->Cb % 8 == 0 && g->Cs % 8 == 0, "conv2d_wgrad_f16: channels must be multiples of 8");
+    GIF_REQUIRE(g->KH >= 1 && g->KH <= 3 && g->KW >= 1 && g->KW <= 3 && (g->stride == 1 || g->stride == 2),
+                "conv2d_wgrad_f16: unsupported kernel/stride");
+    GIF_REQUIRE((long)g->B * g->Hs * g->Ws * g->Cs < (1L << 31) && (long)g->B * g->Hb * g->Wb * g->Cb < (1L << 31),
+                "conv2d_wgrad_f16: tensors of >= 2^31 elements are not supported (32-bit offsets)");
+    WgradParams p{};
+    p.sm = small; p.bg = big; p.ws = ws; p.ss = small_scale; p.bs = big_scale;
+    p.B = g->B; p.Hs = g->Hs; p.Ws = g->Ws; p.Cs = g->Cs; p.Hb = g->Hb; p.Wb = g->Wb; p.Cb = g->Cb;
+    p.KW = g->KW; p.stride = g->stride; p.pad = g->pad; p.T = g->KH * g->KW;
+    gif_conv2d_wgrad_dims_f16(g->Cs, g->Cb, &p.RP, &p.CP);
+    p.Ntot = (long)g->B * g->Hs * g->Ws;
+    long chunk = (p.Ntot + nsplit - 1) / nsplit;
+    p.chunk = (chunk + BKP_MAX - 1) / BKP_MAX * BKP_MAX;
+    if (p.chunk < BKP_MAX) p.chunk = BKP_MAX;
+    p.tiles_q = p.CP / 128;
+    p.tiles_pq = (p.RP / 128) * p.tiles_q;
+    dim3 grid((unsigned)(p.tiles_pq * p.T * nsplit));
+    hipStream_t s = gif::as_stream(stream);
+    p.zero = gif::zero_page16();
+    GIF_REQUIRE(p.zero, "conv2d_wgrad_f16: zero page lookup failed");
+    double flops = 2.0 * p.Ntot * (double)g->Cs * g->Cb * p.T;
+    gif::ProfScope prof(7, flops, s, (int)p.Ntot, g->Cs, g->Cb, p.T * 10 + g->stride + (small_scale || big_scale ? 100 : 0));
+    const bool scaled = small_scale || big_scale;
+    const long HWs = (long)g->Hs * g->Ws;
+    p.stab_nb = (int)((p.chunk + HWs - 1) / HWs + 1);
+    if (p.stab_nb > g->B) p.stab_nb = g->B;
+    if (!scaled) {
+        wgrad_launch<gif::f16, 128, 128, 2, 2, true, 32>(grid, 256, s, p);
+    } else {
+        // the scale table is indexed per stage: a stage must not straddle two samples
+        GIF_REQUIRE((size_t)p.stab_nb * 256 * sizeof(float) <= 64 * 1024, "conv2d_wgrad_f16: scale table too large");
+        if (HWs % 32 == 0) wgrad_launch<gif::f16, 128, 128, 2, 2, true, 32, true>(grid, 256, s, p);
+        else {
+            GIF_REQUIRE(HWs % 16 == 0, "conv2d_wgrad_f16: modulated weight gradient needs Hs*Ws %% 16 == 0 (got %ld)", HWs);
+            wgrad_launch<gif::f16, 128, 128, 2, 2, true, 16, true>(grid, 256, s, p);
+        }
+    }
+    return gif::check_launch("conv2d_wgrad_f16");
 }
 
 int gif_conv2d_wgrad_dims(int Cs, int Cb, int* RP, int* CP) {
@@ -617,21 +745,21 @@ int gif_conv2d_wgrad_f32(const float* small, const float* big, float* ws, const 
         const int variant = env ? atoi(env) : 0;
         const bool glds = !small_scale && !big_scale && variant != 1;
 #define GIF_WGRAD_LAUNCH(BP_, BQ_, WP_, WQ_, TH_)                                                                  \
-    if (glds) wgrad_launch<BP_, BQ_, WP_, WQ_, true, 32>(grid, TH_, s, p);                                        \
-    else wgrad_launch<BP_, BQ_, WP_, WQ_, false, 32>(grid, TH_, s, p)
+    if (glds) wgrad_launch<float, BP_, BQ_, WP_, WQ_, true, 32>(grid, TH_, s, p);                                        \
+    else wgrad_launch<float, BP_, BQ_, WP_, WQ_, false, 32>(grid, TH_, s, p)
         const long HWs = (long)g->Hs * g->Ws;
         p.stab_nb = (int)((p.chunk + HWs - 1) / HWs + 1);
         if (p.stab_nb > g->B) p.stab_nb = g->B;
         const bool tab = (small_scale || big_scale) && variant != 1 && HWs % 16 == 0 &&
                          (size_t)p.stab_nb * 256 * sizeof(float) <= 64 * 1024;
         if (big_tile) {
-            wgrad_launch<256, 128, 2, 2, true, 16>(grid, 256, s, p);
+            wgrad_launch<float, 256, 128, 2, 2, true, 16>(grid, 256, s, p);
         } else if (bp == 128 && bq == 128 && tab) {
             // modulated wgrad (x*s, dy*d): LDS-DMA operands + scale table
-            wgrad_launch<128, 128, 2, 2, true, 16, true>(grid, 256, s, p);
+            wgrad_launch<float, 128, 128, 2, 2, true, 16, true>(grid, 256, s, p);
         } else if (bp == 128 && bq == 128 && glds && variant != 7) {
             // 16-pixel stages: 32 KB of LDS per workgroup => 4 workgroups (16 waves) per CU; +6 % over 32-pixel stages
-            wgrad_launch<128, 128, 2, 2, true, 16>(grid, 256, s, p);
+            wgrad_launch<float, 128, 128, 2, 2, true, 16>(grid, 256, s, p);
         } else if (bp == 128 && bq == 128) { GIF_WGRAD_LAUNCH(128, 128, 2, 2, 256); }
         else if (bp == 128 && bq == 32) { GIF_WGRAD_LAUNCH(128, 32, 4, 1, 256); }
         else if (bp == 32 && bq == 128) { GIF_WGRAD_LAUNCH(32, 128, 1, 4, 256); }
@@ -710,11 +838,11 @@ int gif_conv3x3_winograd_wgrad_f32(const float* x, const float* gy, float* V, fl
     dim3 grid((unsigned)(p.tiles_pq * p.T * nsplit));
     p.zero = gif::zero_page16();
     GIF_REQUIRE(p.zero, "winograd_wgrad: zero page lookup failed");
-    if (big) wgrad_launch<256, 128, 2, 2, true, 16>(grid, 256, s, p);
-    else if (bp == 128 && bq == 128) wgrad_launch<128, 128, 2, 2, true, 16>(grid, 256, s, p);
-    else if (bp == 128 && bq == 32) wgrad_launch<128, 32, 4, 1, true, 32>(grid, 256, s, p);
-    else if (bp == 32 && bq == 128) wgrad_launch<32, 128, 1, 4, true, 32>(grid, 256, s, p);
-    else wgrad_launch<32, 32, 1, 1, true, 32>(grid, 64, s, p);
+    if (big) wgrad_launch<float, 256, 128, 2, 2, true, 16>(grid, 256, s, p);
+    else if (bp == 128 && bq == 128) wgrad_launch<float, 128, 128, 2, 2, true, 16>(grid, 256, s, p);
+    else if (bp == 128 && bq == 32) wgrad_launch<float, 128, 32, 4, 1, true, 32>(grid, 256, s, p);
+    else if (bp == 32 && bq == 128) wgrad_launch<float, 32, 128, 1, 4, true, 32>(grid, 256, s, p);
+    else wgrad_launch<float, 32, 32, 1, 1, true, 32>(grid, 64, s, p);
     return gif::check_launch("conv3x3_winograd_wgrad");
 }
 

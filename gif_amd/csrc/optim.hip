@@ -21,6 +21,8 @@ struct AdamArgs {
     float* v;
     float b1, b2, eps, step_size, bc2_sqrt, ema_decay;
     int has_ema;
+    const float* inv_scale;  // device scalar: gradients are multiplied by it (loss scaling of the f16 path), or NULL
+    const float* found_inf;  // device scalar: non-zero => a gradient overflowed, the whole update is skipped, or NULL
 };
 
 __device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v, const AdamArgs& a) {
@@ -32,6 +34,8 @@ __device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v,
 }
 
 __global__ void __launch_bounds__(256) adam_ema_kernel(const AdamArgs a) {
+    if (a.found_inf && *a.found_inf != 0.f) return;  // uniform over the grid: nobody updates (GradScaler semantics)
+    const float gs = a.inv_scale ? *a.inv_scale : 1.f;
     const gif_adam_chunk c = a.chunks[blockIdx.x];
     float* __restrict__ p = c.param;
     float* __restrict__ e = c.ema;
@@ -47,7 +51,8 @@ __global__ void __launch_bounds__(256) adam_ema_kernel(const AdamArgs a) {
         const int n4 = c.n >> 2;
         for (int i = threadIdx.x; i < n4; i += 256) {
             float4 pv = reinterpret_cast<float4*>(p)[i];
-            const float4 gv = reinterpret_cast<const float4*>(g)[i];
+            float4 gv = reinterpret_cast<const float4*>(g)[i];
+            gv.x *= gs; gv.y *= gs; gv.z *= gs; gv.w *= gs;
             float4 mv = reinterpret_cast<float4*>(m)[i];
             float4 vv = reinterpret_cast<float4*>(v)[i];
             adam_elem(pv.x, gv.x, mv.x, vv.x, a);
@@ -66,14 +71,14 @@ __global__ void __launch_bounds__(256) adam_ema_kernel(const AdamArgs a) {
         }
         for (int i = (n4 << 2) + threadIdx.x; i < c.n; i += 256) {
             float pv = p[i], mv = m[i], vv = v[i];
-            adam_elem(pv, g[i], mv, vv, a);
+            adam_elem(pv, g[i] * gs, mv, vv, a);
             p[i] = pv; m[i] = mv; v[i] = vv;
             if (ema) e[i] = e[i] * d + omd * pv;
         }
     } else {
         for (int i = threadIdx.x; i < c.n; i += 256) {
             float pv = p[i], mv = m[i], vv = v[i];
-            adam_elem(pv, g[i], mv, vv, a);
+            adam_elem(pv, g[i] * gs, mv, vv, a);
             p[i] = pv; m[i] = mv; v[i] = vv;
             if (ema) e[i] = e[i] * d + omd * pv;
         }
@@ -88,7 +93,8 @@ int gif_adam_chunk_floats(void) { return CHUNK; }
 
 int gif_adam_ema_step_f32(const gif_adam_chunk* chunks, int nchunks, const float* grad_flat, float* exp_avg_flat,
                           float* exp_avg_sq_flat, float lr, float beta1, float beta2, float eps, double bias_correction1,
-                          double bias_correction2, float ema_decay, int has_ema, gif_stream_t stream) {
+                          double bias_correction2, float ema_decay, int has_ema, const float* inv_grad_scale,
+                          const float* found_inf, gif_stream_t stream) {
     GIF_REQUIRE(chunks && grad_flat && exp_avg_flat && exp_avg_sq_flat && nchunks >= 0, "adam_ema_step: null pointer");
     GIF_REQUIRE(bias_correction1 > 0.0 && bias_correction2 > 0.0, "adam_ema_step: bias corrections must be positive");
     if (nchunks == 0) return 0;
@@ -98,6 +104,7 @@ int gif_adam_ema_step_f32(const gif_adam_chunk* chunks, int nchunks, const float
     a.step_size = (float)((double)lr / bias_correction1);
     a.bc2_sqrt = (float)sqrt(bias_correction2);
     a.ema_decay = ema_decay; a.has_ema = has_ema;
+    a.inv_scale = inv_grad_scale; a.found_inf = found_inf;
     adam_ema_kernel<<<nchunks, 256, 0, gif::as_stream(stream)>>>(a);
     return gif::check_launch("adam_ema_step");
 }

@@ -13,7 +13,7 @@ from torch.nn import functional as F
 
 from . import functional as GF
 from .layers import ConvLayer, EqualLinear, ResBlock
-from .ops import pad4
+from .ops import cpad
 
 
 class Discriminator(nn.Module):
@@ -32,11 +32,18 @@ class Discriminator(nn.Module):
         self.convs = nn.Sequential(*convs)
         self.stddev_group = 4
         self.stddev_feat = 1
+        self.act_dtype = torch.float32  # see StyledGenerator.act_dtype
         self.final_conv = ConvLayer(in_channel + 1, channels[4], 3)
         self.final_linear = nn.Sequential(
             EqualLinear(channels[4] * 4 * 4, channels[4], activation='fused_lrelu'),
             EqualLinear(channels[4], 1),
         )
+
+    def set_activation_dtype(self, dtype):
+        if dtype not in (torch.float32, torch.float16):
+            raise ValueError(f"activation dtype must be torch.float32 or torch.float16, got {dtype}")
+        self.act_dtype = dtype
+        return self
 
     def forward(self, input, condition=None, step=0, alpha=0):
         if type(input) in (list, tuple):
@@ -44,14 +51,15 @@ class Discriminator(nn.Module):
         if condition is not None:
             input = torch.cat((input, condition), dim=1)
         c = input.shape[1]
-        if pad4(c) != c:
-            input = F.pad(input, (0, 0, 0, 0, 0, pad4(c) - c))
-        out = self.convs(input.contiguous(memory_format=torch.channels_last))
+        cp = cpad(c, self.act_dtype)
+        if cp != c:
+            input = F.pad(input, (0, 0, 0, 0, 0, cp - c))
+        out = self.convs(input.to(self.act_dtype).contiguous(memory_format=torch.channels_last))
         batch, channel, height, width = out.shape
         group = min(batch, self.stddev_group)
-        # [B,C,4,4] -> [B,pad4(C+1),4,4]: channel C is the group's mean stddev (wavefront-shuffle reduction in HIP)
-        out = GF.minibatch_stddev(out, group, pad4(channel + 1))
+        # [B,C,4,4] -> [B,cpad(C+1),4,4]: channel C is the group's mean stddev (wavefront-shuffle reduction in HIP)
+        out = GF.minibatch_stddev(out, group, cpad(channel + 1, out.dtype))
         out = self.final_conv(out)
-        out = out.reshape(batch, -1)  # logical NCHW order == the reference's view(batch, -1)
+        out = out.reshape(batch, -1).float()  # logical NCHW order == the reference's view(batch, -1); the head is fp32
         out = self.final_linear(out)
         return out, None

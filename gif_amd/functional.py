@@ -177,6 +177,7 @@ class BiasActBwdFn(Function):
         (y,) = ctx.saved_tensors
         t = ggx
         if ggb is not None and ggb.dim() == 1:
+            ggb = ggb.to(y.dtype)
             t = ggb.view(1, -1, 1, 1).expand_as(y) if t is None else t + ggb.view(1, -1, 1, 1)
         if t is None:
             return None, None, None, None, None
@@ -337,6 +338,8 @@ class MbstdBwdFn(Function):
 
 
 def minibatch_stddev(x, group, Cy):
+    if x.dtype != torch.float32:  # f16 activations: the statistic of the tiny [B,512,4,4] tensor is taken in fp32
+        return MbstdFn.apply(x.float(), group, Cy).to(x.dtype)
     return MbstdFn.apply(x, group, Cy)
 
 
@@ -347,9 +350,9 @@ def _modconv_composite(x, w, s, d, spec, transposed, out_hw, wscale, residual=No
     """The modulated convolution written with the any-order Functions only (Conv2dFn, BiasActFn, torch broadcasting):
     act(d * conv(s * x, w) + residual + bias).  Same algebra as the fused kernels; used to BUILD A GRAPH of the backward
     when a double backward is requested."""
-    z = Conv2dFn.apply(x * s[:, :, None, None], w, spec, transposed, out_hw, wscale, None)
+    z = Conv2dFn.apply(x * s.to(x.dtype)[:, :, None, None], w, spec, transposed, out_hw, wscale, None)
     if d is not None:
-        z = z * d[:, :, None, None]
+        z = z * d.to(z.dtype)[:, :, None, None]
     if act is None:
         return z
     slope, gain = act

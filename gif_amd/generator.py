@@ -102,13 +102,13 @@ class Generator(nn.Module):
             else:
                 style_step = style[1] if mixing_range[0] <= i <= mixing_range[1] else style[0]
             if i == self.start_step:
-                out = self.const_input(out)
+                out = self.const_input(out).to(noise[i].dtype)  # activation dtype = dtype of the condition pyramid
             out = self.progression[i](out, style_step, noise[i])
             rgb = self.to_rgb[i](out, style_step, rgb)
             if i == step:
                 break
-        # internal RGB carries a zero 4th channel in NHWC; hand back the reference's [B,3,R,R] NCHW tensor
-        return [rgb[:, :3].contiguous()]
+        # internal RGB carries zero padding channels in NHWC; hand back the reference's fp32 [B,3,R,R] NCHW tensor
+        return [rgb[:, :3].float().contiguous()]
 
 
 class StyledGenerator(nn.Module):
@@ -122,6 +122,9 @@ class StyledGenerator(nn.Module):
         self.normal_maps_as_cond = normal_maps_as_cond
         self.w_truncation_factor = w_truncation_factor
         self.mean_w = None
+        # dtype of the synthesis network's activations in HBM: torch.float32 (reference) or torch.float16 (BASELINE config 5:
+        # f16 activations, fp32 weights / demodulation / accumulation).  set_activation_dtype() switches it.
+        self.act_dtype = torch.float32
         code_dim = 512
         self.generator = Generator(code_dim, core_tensor_res=core_tensor_res, noise_in_dims=noise_in_dims,
                                    apply_sqrt2_fac_in_eq_lin=apply_sqrt2_fac_in_eq_lin)
@@ -134,12 +137,20 @@ class StyledGenerator(nn.Module):
     def get_embddings(self):
         return self.image_embedding.get_embddings()
 
+    def set_activation_dtype(self, dtype):
+        if dtype not in (torch.float32, torch.float16):
+            raise ValueError(f"activation dtype must be torch.float32 or torch.float16, got {dtype}")
+        self.act_dtype = dtype
+        return self
+
     def _condition_pyramid(self, cond, step):
-        """noise[i] = bilinear resize of the condition to (4*2^i)^2 (reference :309-314), channel-padded NHWC."""
+        """noise[i] = bilinear resize of the condition to (4*2^i)^2 (reference :309-314), channel-padded NHWC; built in
+        fp32, each level cast to the activation dtype."""
         c = cond.shape[1]
-        if ops.pad4(c) != c:
-            cond = F.pad(cond, (0, 0, 0, 0, 0, ops.pad4(c) - c))
-        cond = cond.contiguous(memory_format=torch.channels_last)
+        cp = ops.cpad(c, self.act_dtype)
+        if cp != c:
+            cond = F.pad(cond.float(), (0, 0, 0, 0, 0, cp - c))
+        cond = cond.float().contiguous(memory_format=torch.channels_last)
         levels = []
         H, W = cond.shape[2:]
         for i in range(step + 1):
@@ -149,6 +160,8 @@ class StyledGenerator(nn.Module):
             else:  # arbitrary ratio (e.g. a 2x2 dummy condition): ATen's generic bilinear resampler
                 lvl = F.interpolate(cond, size=(size, size), mode='bilinear', align_corners=False)
                 levels.append(lvl.contiguous(memory_format=torch.channels_last))
+        if self.act_dtype != torch.float32:
+            levels = [lvl.to(self.act_dtype) for lvl in levels]
         return levels
 
     def forward(self, input, pose=None, noise=None, step=9, alpha=1, mean_style=None, style_weight=0,
@@ -183,7 +196,8 @@ class StyledGenerator(nn.Module):
         if self.rendered_flame_ascondition or self.normal_maps_as_cond:
             noise = self._condition_pyramid(input[0], step)
         elif noise is None:
-            noise = [torch.zeros(batch, 4, 4 * 2 ** i, 4 * 2 ** i, device=input[0].device) for i in range(step + 1)]
+            noise = [torch.zeros(batch, ops.cpad(1, self.act_dtype), 4 * 2 ** i, 4 * 2 ** i, device=input[0].device,
+                                 dtype=self.act_dtype) for i in range(step + 1)]
         if mean_style is not None:
             styles = [mean_style + style_weight * (style - mean_style) for style in styles]
         return self.generator(styles, pose, noise, step, alpha, input_indices=input_indices, mixing_range=mixing_range)

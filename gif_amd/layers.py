@@ -14,7 +14,7 @@ from torch import nn
 from torch.nn import functional as F
 
 from . import functional as GF
-from .ops import pad4
+from .ops import cpad, pad4
 
 
 def _pad_vec(v, n):
@@ -191,19 +191,21 @@ class ModulatedConv2d(nn.Module):
             d = torch.rsqrt((self.scale ** 2) * (s.pow(2) @ wsq.t()) + self.eps)
         return s, d
 
-    def _padded_scales(self, style, in_act):
+    def _padded_scales(self, style, in_act, dtype=torch.float32):
+        """fp32 scales padded to the activation's channel counts (multiples of 4 for fp32, 8 for f16 activations)."""
         s, d = self.scales(style)
         if in_act != self.in_channel:  # channel-padded activation: padded lanes are zero, scale is irrelevant
             s = F.pad(s, (0, in_act - self.in_channel), value=1.0)
-        if d is not None and pad4(self.out_channel) != self.out_channel:
-            d = F.pad(d, (0, pad4(self.out_channel) - self.out_channel), value=1.0)
+        out_act = cpad(self.out_channel, dtype)
+        if d is not None and out_act != self.out_channel:
+            d = F.pad(d, (0, out_act - self.out_channel), value=1.0)
         return s, d
 
     def forward_fused_act(self, input, style, residual, bias, slope=0.2, gain=2 ** 0.5):
         """act(modconv(input, style) + residual + bias) with everything after the contraction fused into the kernel
         epilogues: same-resolution branch = one MFMA launch; up-sampling branch = conv_transpose + one FIR launch."""
         batch, in_act, height, width = input.shape
-        s, d = self._padded_scales(style, in_act)
+        s, d = self._padded_scales(style, in_act, input.dtype)
         w = self.weight[0]
         if self.upsample:
             out = GF.modulated_conv2d(input, w.transpose(0, 1), s, d, stride=2, pad=0, transposed=True,
@@ -216,7 +218,7 @@ class ModulatedConv2d(nn.Module):
 
     def forward(self, input, style):
         batch, in_act, height, width = input.shape
-        s, d = self._padded_scales(style, in_act)
+        s, d = self._padded_scales(style, in_act, input.dtype)
         w = self.weight[0]  # [Cout, Cin, k, k]
         if self.upsample:
             # conv_transpose2d(x, W^T, stride 2): underlying forward conv maps Cout -> Cin, so canonical = W^T view
@@ -259,14 +261,14 @@ class NoiseInjection(nn.Module):
             last = idx == 4
             # bias (+ReLU) run in the conv kernel's epilogue: leaky_relu with slope 0 / gain 1 is the ReLU; the last conv
             # has no activation (slope 1 = identity)
-            h = GF.conv2d_bias_act(h, conv.weight, _pad_vec(conv.bias, pad4(conv.weight.shape[0])), 1, 1, 1.0,
+            h = GF.conv2d_bias_act(h, conv.weight, _pad_vec(conv.bias, cpad(conv.weight.shape[0], h.dtype)), 1, 1, 1.0,
                                    1.0 if last else 0.0, 1.0)
         return h
 
     def forward(self, image, noise):
         batch, _, height, width = image.shape
         if noise is None:
-            noise = image.new_empty(batch, pad4(self.noise_in_chalnnels), height, width).normal_()
+            noise = image.new_empty(batch, cpad(self.noise_in_chalnnels, image.dtype), height, width).normal_()
             noise[:, self.noise_in_chalnnels:] = 0
         return GF.bias_act(image, None, self.convolve(noise), 1.0, 1.0)
 
@@ -297,7 +299,8 @@ class StyledConv(nn.Module):
             return self.activate(self.noise(self.conv(input, style), noise=None))
         act = self.activate
         return self.conv.forward_fused_act(input, style, self.noise.convolve(noise),
-                                           _pad_vec(act.bias, pad4(self.conv.out_channel)), act.negative_slope, act.scale)
+                                           _pad_vec(act.bias, cpad(self.conv.out_channel, input.dtype)), act.negative_slope,
+                                           act.scale)
 
 
 class ToRGB(nn.Module):
@@ -378,7 +381,7 @@ class ConvLayer(nn.Sequential):
         conv = mods[0]
         if len(mods) == 2 and isinstance(mods[1], FusedLeakyReLU) and conv.bias is None:
             act = mods[1]  # EqualConv2d + FusedLeakyReLU => bias and lrelu run in the conv kernel's epilogue
-            return GF.conv2d_bias_act(input, conv.weight, _pad_vec(act.bias, pad4(conv.weight.shape[0])), conv.stride,
+            return GF.conv2d_bias_act(input, conv.weight, _pad_vec(act.bias, cpad(conv.weight.shape[0], input.dtype)), conv.stride,
                                       conv.padding, conv.scale, act.negative_slope, act.scale * out_scale, passthrough)
         assert out_scale == 1.0, "out_scale needs one of the fused layer forms"
         first = input

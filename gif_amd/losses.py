@@ -37,11 +37,16 @@ def l2_reg(model):  # losses.py:16-20
     return reg
 
 
-def grad_penalty_loss(inputs, outs, step):
-    """R1: sum over inputs of w * ||d sum(outs) / d input||^2 per sample (losses.py:87-99).  Returns [B]."""
+def grad_penalty_loss(inputs, outs, step, grad_scale=1.0):
+    """R1: sum over inputs of w * ||d sum(outs) / d input||^2 per sample (losses.py:87-99).  Returns [B].
+    grad_scale (not in the reference; 1.0 = reference arithmetic): the gradient is taken of grad_scale * sum(outs) and divided
+    back — used with f16 activations, whose first-backward activation gradients would otherwise underflow."""
     grad_penalty = 0
     for inp_idx, inpt in enumerate(inputs):
-        grad_real = grad(outputs=outs.sum(), inputs=inpt, create_graph=True)[0]
+        if grad_scale == 1.0:
+            grad_real = grad(outputs=outs.sum(), inputs=inpt, create_graph=True)[0]
+        else:
+            grad_real = grad(outputs=outs.sum() * grad_scale, inputs=inpt, create_graph=True)[0] / grad_scale
         if step is not None:
             w = 1 + step - inp_idx
             w = 0.05 / (w * np.log2(1 + w))

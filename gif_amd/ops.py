@@ -1,12 +1,15 @@
 """Raw (non-autograd) launches of the gfx950 kernels on torch device tensors.
 
 Conventions: activations are torch tensors of LOGICAL shape [B,C,H,W] whose memory is NHWC
-(torch.channels_last) fp32 with C % 4 == 0; everything runs on torch's current HIP stream.
+(torch.channels_last); fp32 (the reference dtype) with C % 4 == 0, or float16 (BASELINE config 5: f16 activations,
+fp32 everything else) with C % 8 == 0 — the kernel family is chosen by the activation's dtype.  Weights, biases, per-sample
+scales, FIR taps and every reduction result are fp32 in both cases.  Everything runs on torch's current HIP stream.
 torch is used for device memory and streams only — all arithmetic is in libgif_hip.so.
 """
 import ctypes
 import functools
 import os
+import weakref
 from typing import NamedTuple, Optional
 
 import torch
@@ -48,19 +51,41 @@ def pad4(c: int) -> int:
     return (c + 3) // 4 * 4
 
 
+def cpad(c: int, dtype=torch.float32) -> int:
+    """Channel count of an activation holding c logical channels: multiple of 4 (fp32: 16-byte lanes) or 8 (f16)."""
+    q = 8 if dtype == torch.float16 else 4
+    return (c + q - 1) // q * q
+
+
+def _sfx(dtype) -> str:
+    return "_f16" if dtype == torch.float16 else "_f32"
+
+
+def _fn(name: str, dtype):
+    """C entry point of the kernel family matching the activation dtype (gif_<name>_f32 / gif_<name>_f16)."""
+    return getattr(_lib.load(), "gif_" + name + _sfx(dtype))
+
+
 def nhwc(x: torch.Tensor) -> torch.Tensor:
-    """fp32, device-resident, NHWC memory.  Fails loudly on CPU tensors: there is no CPU path."""
+    """fp32 or f16, device-resident, NHWC memory.  Fails loudly on CPU tensors: there is no CPU path."""
     if not x.is_cuda:
         raise _lib.GifHipError("gif_amd kernels need device tensors (no CPU fallback); got a CPU tensor")
-    if x.dtype != torch.float32:
-        raise _lib.GifHipError(f"gif_amd kernels are fp32; got {x.dtype}")
+    if x.dtype not in (torch.float32, torch.float16):
+        raise _lib.GifHipError(f"gif_amd kernels take fp32 or f16 activations; got {x.dtype}")
     if x.dim() != 4:
         raise _lib.GifHipError(f"expected a 4-D activation, got shape {tuple(x.shape)}")
+    if x.dtype == torch.float16 and x.shape[1] % 8:
+        raise _lib.GifHipError(f"f16 activations need a channel count that is a multiple of 8, got {x.shape[1]}")
     return x.contiguous(memory_format=CL)
 
 
-def empty_nhwc(B, C, H, W, device):
-    return torch.empty((B, C, H, W), device=device, dtype=torch.float32, memory_format=CL)
+def _same_dtype(a, b, what):
+    if a.dtype != b.dtype:
+        raise _lib.GifHipError(f"{what}: operands of different dtypes ({a.dtype} and {b.dtype})")
+
+
+def empty_nhwc(B, C, H, W, device, dtype=torch.float32):
+    return torch.empty((B, C, H, W), device=device, dtype=dtype, memory_format=CL)
 
 
 class ConvSpec(NamedTuple):
@@ -85,11 +110,40 @@ def _epilogue(in_scale=None, out_scale=None, bias=None, residual=None, act=False
     return _lib.ConvEpilogue(_p(in_scale), _p(out_scale), _p(bias), _p(residual), 1 if act else 0, slope, gain)
 
 
-def pack_weight(w: torch.Tensor, rows_are_out: bool, cout_act: int, cin_act: int, scale: float = 1.0):
-    """Pack a canonical forward-conv weight view w[O,I,KH,KW] (any strides) into [T][RP][CP].
+# Packed / transformed weights are a pure function of (the parameter's current contents, view geometry, layout arguments):
+# the same weights are packed 2-3 times per training iteration (D runs three forwards, every backward re-packs for the data
+# gradient), so the results are kept until the parameter changes.  An entry is keyed on the identity of the BASE tensor (a
+# weak reference proves it is still the same object), its data pointer and in-place version counter (optimisers, copy_,
+# load_state_dict and FlatAdam all bump it) and the view geometry — never on an address alone.
+WEIGHT_CACHE = os.environ.get("GIF_WEIGHT_CACHE", "1") != "0"
+_weight_cache = {}
+_WEIGHT_CACHE_MAX = 512
 
-    rows_are_out=True : rows = O, cols = I (operand of gif_conv2d_fwd_f32)
-    rows_are_out=False: rows = I, cols = O (operand of gif_conv2d_bwd_data_f32)
+
+def _cached_weight_op(w, tag, build):
+    if not WEIGHT_CACHE:
+        return build()
+    base = w._base if w._base is not None else w
+    key = (id(base), tag, w.storage_offset(), tuple(w.shape), tuple(w.stride()))
+    state = (base.data_ptr(), base._version)
+    hit = _weight_cache.get(key)
+    if hit is not None and hit[0]() is base and hit[1] == state:
+        return hit[2]
+    out = build()
+    if len(_weight_cache) >= _WEIGHT_CACHE_MAX:
+        for k in [k for k, v in _weight_cache.items() if v[0]() is None]:
+            del _weight_cache[k]
+        if len(_weight_cache) >= _WEIGHT_CACHE_MAX:
+            _weight_cache.clear()
+    _weight_cache[key] = (weakref.ref(base), state, out)
+    return out
+
+
+def pack_weight(w: torch.Tensor, rows_are_out: bool, cout_act: int, cin_act: int, scale: float = 1.0, dtype=torch.float32):
+    """Pack a canonical forward-conv weight view w[O,I,KH,KW] (any strides) into [T][RP][CP] of `dtype` (fp32 or f16).
+
+    rows_are_out=True : rows = O, cols = I (operand of gif_conv2d_fwd)
+    rows_are_out=False: rows = I, cols = O (operand of gif_conv2d_bwd_data)
     cout_act / cin_act are the channel counts of the op's output / input ACTIVATIONS (>= canonical counts).
     """
     lib = _lib.load()
@@ -97,12 +151,18 @@ def pack_weight(w: torch.Tensor, rows_are_out: bool, cout_act: int, cin_act: int
     so, si, sky, skx = w.stride()
     R, C, sr, sc = (O, I, so, si) if rows_are_out else (I, O, si, so)
     assert R <= cout_act and C <= cin_act, (R, cout_act, C, cin_act)
-    RP, CP = ctypes.c_int(), ctypes.c_int()
-    _lib.check(lib.gif_conv2d_pack_dims(cout_act, cin_act, ctypes.byref(RP), ctypes.byref(CP)), "pack_dims")
-    wp = torch.empty((KH * KW, RP.value, CP.value), device=w.device, dtype=torch.float32)
-    _lib.check(lib.gif_pack_weight_f32(w.data_ptr(), wp.data_ptr(), R, C, KH, KW, RP.value, CP.value, sr, sc, sky, skx,
-                                       float(scale), _stream()), "pack_weight")
-    return wp
+    f16 = dtype == torch.float16
+
+    def build():
+        RP, CP = ctypes.c_int(), ctypes.c_int()
+        dims = lib.gif_conv2d_pack_dims_f16 if f16 else lib.gif_conv2d_pack_dims
+        _lib.check(dims(cout_act, cin_act, ctypes.byref(RP), ctypes.byref(CP)), "pack_dims")
+        wp = torch.empty((KH * KW, RP.value, CP.value), device=w.device, dtype=dtype)
+        _lib.check(_fn("pack_weight", dtype)(w.data_ptr(), wp.data_ptr(), R, C, KH, KW, RP.value, CP.value, sr, sc, sky, skx,
+                                             float(scale), _stream()), "pack_weight")
+        return wp
+
+    return _cached_weight_op(w, ("pack", rows_are_out, cout_act, cin_act, float(scale), dtype), build)
 
 
 # Winograd F(2x2,3x3) dispatch for stride-1 / pad-1 3x3 convs (conv_winograd.hip).  GIF_WINOGRAD=0 forces the direct
@@ -119,10 +179,10 @@ def prof_winograd_calls():
     return _winograd_calls
 
 
-def winograd_eligible(spec: ConvSpec, B, H, W, cin_act, cout_act=64, min_tiles=None):
+def winograd_eligible(spec: ConvSpec, B, H, W, cin_act, cout_act=64, min_tiles=None, dtype=torch.float32):
     # cout < 48 wastes over a quarter of the GEMM's 64-wide N tile; the direct 256x32 kernel is faster there (measured)
     min_tiles = WINOGRAD_MIN_TILES if min_tiles is None else min_tiles
-    return (WINOGRAD and tuple(spec) == (3, 3, 1, 1) and H % 2 == 0 and W % 2 == 0 and cin_act >= 32 and cout_act >= 48
+    return (WINOGRAD and dtype == torch.float32 and tuple(spec) == (3, 3, 1, 1) and H % 2 == 0 and W % 2 == 0 and cin_act >= 32 and cout_act >= 48
             and B * (H // 2) * (W // 2) >= min_tiles)
 
 
@@ -140,11 +200,16 @@ def conv3x3_winograd(x, w, rows_are_out: bool, cout_act: int, wscale=1.0, keep_v
     so, si, sky, skx = w.stride()
     R, Cc, sr, sc = (O, I, so, si) if rows_are_out else (I, O, si, so)
     assert R <= cout_act and Cc <= C, (R, cout_act, Cc, C)
-    RP, CP = ctypes.c_int(), ctypes.c_int()
-    _lib.check(lib.gif_winograd_pack_dims(cout_act, C, ctypes.byref(RP), ctypes.byref(CP)), "winograd_pack_dims")
-    U = torch.empty((16, RP.value, CP.value), device=x.device, dtype=torch.float32)
-    _lib.check(lib.gif_winograd_weight_f32(w.data_ptr(), U.data_ptr(), R, Cc, RP.value, CP.value, sr, sc, sky, skx,
-                                           0 if rows_are_out else 1, float(wscale), _stream()), "winograd_weight")
+
+    def build():
+        RP, CP = ctypes.c_int(), ctypes.c_int()
+        _lib.check(lib.gif_winograd_pack_dims(cout_act, C, ctypes.byref(RP), ctypes.byref(CP)), "winograd_pack_dims")
+        U = torch.empty((16, RP.value, CP.value), device=x.device, dtype=torch.float32)
+        _lib.check(lib.gif_winograd_weight_f32(w.data_ptr(), U.data_ptr(), R, Cc, RP.value, CP.value, sr, sc, sky, skx,
+                                               0 if rows_are_out else 1, float(wscale), _stream()), "winograd_weight")
+        return U
+
+    U = _cached_weight_op(w, ("wino", rows_are_out, cout_act, C, float(wscale)), build)
     V = torch.empty((lib.gif_winograd_workspace_floats(B, H, W, C),), device=x.device, dtype=torch.float32)
     out = empty_nhwc(B, cout_act, H, W, x.device)
     e = _epilogue(**epi)
@@ -153,46 +218,54 @@ def conv3x3_winograd(x, w, rows_are_out: bool, cout_act: int, wscale=1.0, keep_v
     return (out, V) if keep_v else out
 
 
+def _epi_check(x, epi):
+    r = epi.get("residual")
+    if r is not None:
+        _same_dtype(x, r, "conv epilogue residual")
+
+
 def conv_fwd(big, w, spec: ConvSpec, wscale=1.0, keep_v=False, **epi):
-    """small = conv2d(big, w[O,I,KH,KW]) ; returns [B, pad4(O), Hs, Ws].
+    """small = conv2d(big, w[O,I,KH,KW]) ; returns [B, cpad(O), Hs, Ws] in big's dtype.
 
     keep_v=True returns (small, V) where V is the Winograd-transformed (in_scale * big) if that path ran, else None;
     pass it to conv_wgrad(big_v=V) for the weight gradient of the same (big, in_scale)."""
-    lib = _lib.load()
     big = nhwc(big)
+    dt = big.dtype
     B, Cb, Hb, Wb = big.shape
     O = w.shape[0]
-    Cs = pad4(O)
+    Cs = cpad(O, dt)
     Hs, Ws = spec.small_hw(Hb, Wb)
-    if winograd_eligible(spec, B, Hb, Wb, Cb, Cs):
+    _epi_check(big, epi)
+    if winograd_eligible(spec, B, Hb, Wb, Cb, Cs, dtype=dt):
         return conv3x3_winograd(big, w, True, Cs, wscale, keep_v=keep_v, **epi)
     if keep_v:
         return conv_fwd(big, w, spec, wscale, **epi), None
-    wp = pack_weight(w, True, Cs, Cb, wscale)
-    out = empty_nhwc(B, Cs, Hs, Ws, big.device)
+    wp = pack_weight(w, True, Cs, Cb, wscale, dt)
+    out = empty_nhwc(B, Cs, Hs, Ws, big.device, dt)
     g = _geom(B, Hb, Wb, Cb, Hs, Ws, Cs, spec)
     e = _epilogue(**epi)
-    _lib.check(lib.gif_conv2d_fwd_f32(big.data_ptr(), wp.data_ptr(), out.data_ptr(), ctypes.byref(g), ctypes.byref(e),
-                                      _stream()), "conv2d_fwd")
+    _lib.check(_fn("conv2d_fwd", dt)(big.data_ptr(), wp.data_ptr(), out.data_ptr(), ctypes.byref(g), ctypes.byref(e),
+                                     _stream()), "conv2d_fwd")
     return out
 
 
 def conv_bwd_data(small, w, spec: ConvSpec, big_hw, wscale=1.0, **epi):
-    """big = conv_transpose2d(small, w[O,I,KH,KW]) ; returns [B, pad4(I), Hb, Wb]."""
-    lib = _lib.load()
+    """big = conv_transpose2d(small, w[O,I,KH,KW]) ; returns [B, cpad(I), Hb, Wb] in small's dtype."""
     small = nhwc(small)
+    dt = small.dtype
     B, Cs, Hs, Ws = small.shape
     I = w.shape[1]
-    Cb = pad4(I)
+    Cb = cpad(I, dt)
     Hb, Wb = big_hw
-    if (Hb, Wb) == (Hs, Ws) and winograd_eligible(spec, B, Hs, Ws, Cs, Cb):
+    _epi_check(small, epi)
+    if (Hb, Wb) == (Hs, Ws) and winograd_eligible(spec, B, Hs, Ws, Cs, Cb, dtype=dt):
         return conv3x3_winograd(small, w, False, Cb, wscale, **epi)
-    wp = pack_weight(w, False, Cb, Cs, wscale)
-    out = empty_nhwc(B, Cb, Hb, Wb, small.device)
+    wp = pack_weight(w, False, Cb, Cs, wscale, dt)
+    out = empty_nhwc(B, Cb, Hb, Wb, small.device, dt)
     g = _geom(B, Hb, Wb, Cb, Hs, Ws, Cs, spec)
     e = _epilogue(**epi)
-    _lib.check(lib.gif_conv2d_bwd_data_f32(small.data_ptr(), wp.data_ptr(), out.data_ptr(), ctypes.byref(g),
-                                           ctypes.byref(e), _stream()), "conv2d_bwd_data")
+    _lib.check(_fn("conv2d_bwd_data", dt)(small.data_ptr(), wp.data_ptr(), out.data_ptr(), ctypes.byref(g),
+                                          ctypes.byref(e), _stream()), "conv2d_bwd_data")
     return out
 
 
@@ -231,24 +304,29 @@ def conv3x3_winograd_wgrad(small, big, O, I, wscale=1.0, small_scale=None, big_s
 
 
 def conv_wgrad(small, big, spec: ConvSpec, O, I, wscale=1.0, small_scale=None, big_scale=None, big_v=None):
-    """dW[O,I,KH,KW] = wscale * sum small (x) big  (contiguous canonical layout).
+    """dW[O,I,KH,KW] = wscale * sum small (x) big  (contiguous canonical layout, fp32 for fp32 AND f16 operands).
     big_v: optional Winograd V of (big_scale * big) kept from conv_fwd(keep_v=True)."""
     lib = _lib.load()
     small, big = nhwc(small), nhwc(big)
+    _same_dtype(small, big, "conv_wgrad")
+    dt = small.dtype
+    f16 = dt == torch.float16
     B, Cs, Hs, Ws = small.shape
     _, Cb, Hb, Wb = big.shape
     assert O <= Cs and I <= Cb
     if (WINOGRAD_WGRAD and (Hb, Wb) == (Hs, Ws) and Cs >= 64 and Cb >= 64
-            and winograd_eligible(spec, B, Hs, Ws, Cb, Cs, min(WINOGRAD_MIN_TILES, WINOGRAD_WGRAD_MIN_TILES))):
+            and winograd_eligible(spec, B, Hs, Ws, Cb, Cs, min(WINOGRAD_MIN_TILES, WINOGRAD_WGRAD_MIN_TILES), dtype=dt)):
         return conv3x3_winograd_wgrad(small, big, O, I, wscale, small_scale, big_scale, big_v)
     g = _geom(B, Hb, Wb, Cb, Hs, Ws, Cs, spec)
     RP, CP = ctypes.c_int(), ctypes.c_int()
-    _lib.check(lib.gif_conv2d_wgrad_dims(Cs, Cb, ctypes.byref(RP), ctypes.byref(CP)), "wgrad_dims")
-    nsplit = lib.gif_conv2d_wgrad_splits(ctypes.byref(g))
+    dims, splits = ((lib.gif_conv2d_wgrad_dims_f16, lib.gif_conv2d_wgrad_splits_f16) if f16 else
+                    (lib.gif_conv2d_wgrad_dims, lib.gif_conv2d_wgrad_splits))
+    _lib.check(dims(Cs, Cb, ctypes.byref(RP), ctypes.byref(CP)), "wgrad_dims")
+    nsplit = splits(ctypes.byref(g))
     T = spec.KH * spec.KW
     ws = torch.empty((nsplit, T, RP.value, CP.value), device=small.device, dtype=torch.float32)
-    _lib.check(lib.gif_conv2d_wgrad_f32(small.data_ptr(), big.data_ptr(), ws.data_ptr(), _p(small_scale), _p(big_scale),
-                                        ctypes.byref(g), nsplit, _stream()), "conv2d_wgrad")
+    _lib.check(_fn("conv2d_wgrad", dt)(small.data_ptr(), big.data_ptr(), ws.data_ptr(), _p(small_scale), _p(big_scale),
+                                       ctypes.byref(g), nsplit, _stream()), "conv2d_wgrad")
     dw = torch.empty((O, I, spec.KH, spec.KW), device=small.device, dtype=torch.float32)
     so, si, sky, skx = dw.stride()
     _lib.check(lib.gif_unpack_wgrad_f32(ws.data_ptr(), dw.data_ptr(), nsplit, O, I, spec.KH, spec.KW, RP.value, CP.value,
@@ -257,74 +335,77 @@ def conv_wgrad(small, big, spec: ConvSpec, O, I, wscale=1.0, small_scale=None, b
 
 
 def upfirdn2d(x, k, up, down, pad0, out_hw, flip=True, bias=None, residual=None, act=False, slope=0.2, gain=2 ** 0.5):
-    lib = _lib.load()
     x = nhwc(x)
     B, C, Hi, Wi = x.shape
     Ho, Wo = out_hw
     KH, KW = k.shape
     k = k.contiguous()
-    y = empty_nhwc(B, C, Ho, Wo, x.device)
+    if residual is not None:
+        _same_dtype(x, residual, "upfirdn2d residual")
+    y = empty_nhwc(B, C, Ho, Wo, x.device, x.dtype)
     e = _epilogue(bias=bias, residual=residual, act=act, slope=slope, gain=gain)
-    _lib.check(lib.gif_upfirdn2d_f32(x.data_ptr(), k.data_ptr(), y.data_ptr(), B, Hi, Wi, C, Ho, Wo, up, down, pad0, pad0,
-                                     KH, KW, 1 if flip else 0, ctypes.byref(e), _stream()), "upfirdn2d")
+    _lib.check(_fn("upfirdn2d", x.dtype)(x.data_ptr(), k.data_ptr(), y.data_ptr(), B, Hi, Wi, C, Ho, Wo, up, down, pad0, pad0,
+                                         KH, KW, 1 if flip else 0, ctypes.byref(e), _stream()), "upfirdn2d")
     return y
 
 
 def bias_act(x, bias=None, residual=None, slope=0.2, gain=2 ** 0.5):
-    lib = _lib.load()
     x = nhwc(x)
     B, C, H, W = x.shape
     if residual is not None:
         residual = nhwc(residual)
         assert residual.shape == x.shape
-    y = empty_nhwc(B, C, H, W, x.device)
-    _lib.check(lib.gif_bias_act_f32(x.data_ptr(), _p(bias), _p(residual), y.data_ptr(), B * H * W, C, slope, gain,
-                                    _stream()), "bias_act")
+        _same_dtype(x, residual, "bias_act residual")
+    y = empty_nhwc(B, C, H, W, x.device, x.dtype)
+    _lib.check(_fn("bias_act", x.dtype)(x.data_ptr(), _p(bias), _p(residual), y.data_ptr(), B * H * W, C, slope, gain,
+                                        _stream()), "bias_act")
     return y
 
 
 def bias_act_bwd(gy, y, want_gbias, slope=0.2, gain=2 ** 0.5):
     lib = _lib.load()
     gy, y = nhwc(gy), nhwc(y)
+    _same_dtype(gy, y, "bias_act_bwd")
     B, C, H, W = y.shape
     npix = B * H * W
-    gx = empty_nhwc(B, C, H, W, y.device)
+    gx = empty_nhwc(B, C, H, W, y.device, y.dtype)
     gbias = partial = None
     if want_gbias:
         gbias = torch.empty((C,), device=y.device, dtype=torch.float32)
         partial = torch.empty((lib.gif_colsum_partial_floats(npix, C),), device=y.device, dtype=torch.float32)
-    _lib.check(lib.gif_bias_act_bwd_f32(gy.data_ptr(), y.data_ptr(), gx.data_ptr(), _p(gbias), _p(partial), npix, C, slope,
-                                        gain, _stream()), "bias_act_bwd")
+    _lib.check(_fn("bias_act_bwd", y.dtype)(gy.data_ptr(), y.data_ptr(), gx.data_ptr(), _p(gbias), _p(partial), npix, C, slope,
+                                            gain, _stream()), "bias_act_bwd")
     return gx, gbias
 
 
 def colsum(x):
-    """[B,C,H,W] (NHWC) -> [C] sum over B,H,W."""
+    """[B,C,H,W] (NHWC) -> [C] sum over B,H,W (fp32)."""
     lib = _lib.load()
     x = nhwc(x)
     B, C, H, W = x.shape
     npix = B * H * W
     out = torch.empty((C,), device=x.device, dtype=torch.float32)
     partial = torch.empty((lib.gif_colsum_partial_floats(npix, C),), device=x.device, dtype=torch.float32)
-    _lib.check(lib.gif_colsum_f32(x.data_ptr(), out.data_ptr(), partial.data_ptr(), npix, C, _stream()), "colsum")
+    _lib.check(_fn("colsum", x.dtype)(x.data_ptr(), out.data_ptr(), partial.data_ptr(), npix, C, _stream()), "colsum")
     return out
 
 
 def mul_reduce(a, b, scale=None, want_scaled=False):
-    """out[b,c] = sum_hw a*b ; optionally scaled = scale[b,c]*a."""
+    """out[b,c] = sum_hw a*b (fp32) ; optionally scaled = scale[b,c]*a (activation dtype)."""
     lib = _lib.load()
     a, b = nhwc(a), nhwc(b)
+    _same_dtype(a, b, "mul_reduce")
     B, C, H, W = a.shape
     assert b.shape == a.shape
     nchunk = lib.gif_mul_reduce_chunks(H * W)
     out = torch.empty((B, C), device=a.device, dtype=torch.float32)
     partial = torch.empty((B * nchunk * C,), device=a.device, dtype=torch.float32)
-    scaled = empty_nhwc(B, C, H, W, a.device) if want_scaled else None
+    scaled = empty_nhwc(B, C, H, W, a.device, a.dtype) if want_scaled else None
     if scale is not None:
         scale = scale.contiguous()
-        assert scale.shape == (B, C)
-    _lib.check(lib.gif_mul_reduce_f32(a.data_ptr(), b.data_ptr(), _p(scale), _p(scaled), out.data_ptr(), partial.data_ptr(),
-                                      B, H * W, C, _stream()), "mul_reduce")
+        assert scale.shape == (B, C) and scale.dtype == torch.float32
+    _lib.check(_fn("mul_reduce", a.dtype)(a.data_ptr(), b.data_ptr(), _p(scale), _p(scaled), out.data_ptr(), partial.data_ptr(),
+                                          B, H * W, C, _stream()), "mul_reduce")
     return out, scaled
 
 
@@ -332,6 +413,8 @@ def bilinear_down(x, S, backward_to=None):
     """Forward: x [B,C,R,R] -> [B,C,S,S].  backward_to=R: x is the gradient of a level, returns the gradient [B,C,R,R]."""
     lib = _lib.load()
     x = nhwc(x)
+    if x.dtype != torch.float32:
+        raise _lib.GifHipError("bilinear_down is fp32 only (the condition pyramid is built in fp32 and cast per level)")
     B, C = x.shape[:2]
     if backward_to is None:
         R = x.shape[2]
@@ -348,18 +431,22 @@ def act_inv_mul_reduce(g, y, residual, bias, slope, gain):
     """out[b,c] = sum_hw g * (act^-1(y) - residual - bias[c])  (see gif_hip.h)."""
     lib = _lib.load()
     g, y = nhwc(g), nhwc(y)
+    _same_dtype(g, y, "act_inv_mul_reduce")
     B, C, H, W = y.shape
     nchunk = lib.gif_mul_reduce_chunks(H * W)
     out = torch.empty((B, C), device=y.device, dtype=torch.float32)
     partial = torch.empty((B * nchunk * C,), device=y.device, dtype=torch.float32)
-    _lib.check(lib.gif_act_inv_mul_reduce_f32(g.data_ptr(), y.data_ptr(), _p(residual), _p(bias), out.data_ptr(),
-                                              partial.data_ptr(), B, H * W, C, slope, gain, _stream()), "act_inv_mul_reduce")
+    _lib.check(_fn("act_inv_mul_reduce", y.dtype)(g.data_ptr(), y.data_ptr(), _p(residual), _p(bias), out.data_ptr(),
+                                                  partial.data_ptr(), B, H * W, C, slope, gain, _stream()),
+               "act_inv_mul_reduce")
     return out
 
 
 def mbstd_fwd(x, G, Cy):
     lib = _lib.load()
     x = nhwc(x)
+    if x.dtype != torch.float32:
+        raise _lib.GifHipError("minibatch stddev is fp32 only (functional.minibatch_stddev casts the 4x4 tensor)")
     B, C, H, W = x.shape
     y = empty_nhwc(B, Cy, H, W, x.device)
     stat = torch.empty((B // G,), device=x.device, dtype=torch.float32)

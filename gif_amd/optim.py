@@ -77,9 +77,10 @@ class FlatAdam(torch.optim.Adam):
 
     # ---- step ----------------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def step(self, closure=None, ema_decay=None):
+    def step(self, closure=None, ema_decay=None, inv_grad_scale=None, found_inf=None):
         """One Adam update of every parameter in the bucket; ema_decay (with ema_params given) also runs
-        ema = ema*decay + (1-decay)*param in the same launch."""
+        ema = ema*decay + (1-decay)*param in the same launch.  inv_grad_scale / found_inf: optional fp32 DEVICE scalars of a
+        loss scaler — gradients are multiplied by the first, the update is skipped on device when the second is non-zero."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -100,12 +101,14 @@ class FlatAdam(torch.optim.Adam):
             _lib.check(lib.gif_adam_ema_step_f32(table.data_ptr(), n, self.bucket.flat.data_ptr(), self._m.data_ptr(),
                                                  self._v.data_ptr(), float(g["lr"]), float(b1), float(b2), float(g["eps"]),
                                                  1.0 - b1 ** t, 1.0 - b2 ** t, float(ema_decay or 0.0), 1 if has_ema else 0,
+                                                 None if inv_grad_scale is None else inv_grad_scale.data_ptr(),
+                                                 None if found_inf is None else found_inf.data_ptr(),
                                                  torch.cuda.current_stream().cuda_stream), "adam_ema_step")
         # the kernel wrote through raw pointers: tell autograd the tensors changed (saved-tensor checks, caches keyed on it)
         torch.autograd.graph.increment_version(self.bucket.params)
         if has_ema:
             torch.autograd.graph.increment_version(self._ema)
-            if self._ema_rest:
+            if self._ema_rest and found_inf is None:
                 e, p = [a for a, _ in self._ema_rest], [b for _, b in self._ema_rest]
                 torch._foreach_mul_(e, ema_decay)
                 torch._foreach_add_(e, p, alpha=1 - ema_decay)

@@ -129,6 +129,34 @@ class FlatGradBucket:
                 self.flat.div_(div)
 
 
+class DeviceLossScaler:
+    """Dynamic loss scaling for the f16-activation path, entirely on the device (no host sync per step): the loss is
+    multiplied by `scale` before backward(); after the gradient exchange update() looks for non-finite values in the flat
+    bucket, and FlatAdam.step(inv_grad_scale=, found_inf=) un-scales the gradients inside the Adam kernel or skips the update.
+    An overflow halves the scale; `growth_interval` consecutive clean steps double it (torch.cuda.amp.GradScaler's policy)."""
+
+    def __init__(self, device, init_scale=2.0 ** 12, growth_interval=1000, max_scale=2.0 ** 20):
+        self.scale = torch.tensor(float(init_scale), device=device)
+        self.inv_scale = torch.tensor(1.0 / float(init_scale), device=device)
+        self.found_inf = torch.zeros((), device=device)
+        self._good = torch.zeros((), device=device)
+        self.growth_interval, self.max_scale = float(growth_interval), float(max_scale)
+        self.skipped = torch.zeros((), device=device)  # number of skipped steps (read it after a synchronize)
+
+    @torch.no_grad()
+    def update(self, flat):
+        """Call once per optimiser step BEFORE the Adam launch, with the (already exchanged) gradient bucket."""
+        bad = (~torch.isfinite(flat).all()).to(torch.float32)
+        self.found_inf.copy_(bad)
+        self.inv_scale.copy_(1.0 / self.scale)  # the scale the gradients in `flat` were produced with
+        self.skipped.add_(bad)
+        good = (self._good + 1.0) * (1.0 - bad)
+        grow = (good >= self.growth_interval).to(torch.float32)
+        self._good.copy_(good * (1.0 - grow))
+        new_scale = torch.where(bad > 0, self.scale * 0.5, torch.where(grow > 0, self.scale * 2.0, self.scale))
+        self.scale.copy_(new_scale.clamp(1.0, self.max_scale))
+
+
 def _g_param_active(generator, step):
     """Predicate: does this generator parameter receive a gradient at resolution `step`?  Blocks / ToRGB layers above
     `step` are never executed (Generator.forward breaks at i == step, stg2_generator.py:205-206)."""
@@ -153,8 +181,16 @@ class GifTrainer:
 
     def __init__(self, generator, discriminator, g_running, step=6, alpha=1.0, r1_every=16, gen_reg_type='None',
                  embedding_reg_weight=0.0, lr=0.002, fused_adam=None, process_group=None,
-                 reuse_generator_forward=False, overlap_comm=None, sync_initial_state=True):
+                 reuse_generator_forward=False, overlap_comm=None, sync_initial_state=True, act_dtype=None,
+                 loss_scale=2.0 ** 12):
         self.G, self.D, self.G_ema = generator, discriminator, g_running
+        # act_dtype=torch.float16: BASELINE config 5 — f16 activations in G and D (fp32 master weights, demodulation,
+        # accumulation, optimiser), dynamic loss scaling on the device.  None keeps whatever the modules are set to.
+        if act_dtype is not None:
+            for m in (generator, discriminator, g_running):
+                m.set_activation_dtype(act_dtype)
+        self.f16 = getattr(generator, "act_dtype", torch.float32) == torch.float16 or \
+            getattr(discriminator, "act_dtype", torch.float32) == torch.float16
         self.res_step, self.alpha, self.r1_every = step, alpha, r1_every
         self.gen_reg_type = gen_reg_type.upper()
         self.embedding_reg_weight = embedding_reg_weight
@@ -174,6 +210,12 @@ class GifTrainer:
         else:
             self.g_optim = torch.optim.Adam(generator.parameters(), lr=lr * g_ratio, betas=(0.0, 0.99 ** g_ratio))
             self.d_optim = torch.optim.Adam(discriminator.parameters(), lr=lr * d_ratio, betas=(0.0, 0.99 ** d_ratio))
+        self.g_scaler = self.d_scaler = None
+        if self.f16:
+            if not hip_adam:
+                raise losses.ops._lib.GifHipError("f16 activations need the HIP optimiser (loss scaling is fused into FlatAdam)")
+            dev = next(generator.parameters()).device
+            self.g_scaler, self.d_scaler = DeviceLossScaler(dev, loss_scale), DeviceLossScaler(dev, loss_scale)
         self.pl_reg = losses.PathLengthRegularizor() if self.gen_reg_type == 'PATH_LEN_REG' else None
         # Optional (off by default, NOT used by bench.py): the reference runs the generator twice per iteration on
         # identical inputs and identical weights (train.py:157 and :197 — G only changes at :243).  With this flag the
@@ -188,11 +230,18 @@ class GifTrainer:
         requires_grad(self.D, True)
 
     # ---- optimiser updates -------------------------------------------------------------------------------------
+    def _d_optim_step(self):
+        if self.d_scaler is not None:
+            self.d_scaler.update(self.d_bucket.flat)
+            self.d_optim.step(inv_grad_scale=self.d_scaler.inv_scale, found_inf=self.d_scaler.found_inf)
+        else:
+            self.d_optim.step()
+
     def _finish_d_update(self):
         if self._d_update_pending:
             self._d_update_pending = False
             self.d_bucket.wait()
-            self.d_optim.step()
+            self._d_optim_step()
 
     def flush(self):
         """Complete a deferred discriminator update (overlap_comm)."""
@@ -200,7 +249,11 @@ class GifTrainer:
 
     def _g_update(self):
         self.g_bucket.all_reduce_mean()
-        if isinstance(self.g_optim, FlatAdam):
+        if self.g_scaler is not None:
+            self.g_scaler.update(self.g_bucket.flat)
+            self.g_optim.step(ema_decay=self.g_running_decay, inv_grad_scale=self.g_scaler.inv_scale,
+                              found_inf=self.g_scaler.found_inf)
+        elif isinstance(self.g_optim, FlatAdam):
             self.g_optim.step(ema_decay=self.g_running_decay)  # Adam + generic_utils.accumulate in one launch
         else:
             self.g_optim.step()
@@ -220,20 +273,24 @@ class GifTrainer:
         real_scores, _ = D([real_image], condition=cond, step=self.res_step, alpha=self.alpha)
         real_loss = F.softplus(-real_scores).mean()
         if r1_step:
-            real_loss = real_loss + losses.grad_penalty_loss([real_image], real_scores, step=None).mean()
+            # f16: the inner gradient (d scores / d image) is taken on scores pre-multiplied by a constant so that the
+            # activation gradients of the first backward stay inside the f16 range; the result is divided back
+            real_loss = real_loss + losses.grad_penalty_loss([real_image], real_scores, step=None,
+                                                             grad_scale=(2.0 ** 10 if self.f16 else 1.0)).mean()
         if fake is None:
             with torch.no_grad():  # the reference detaches the fake image right after the forward (train.py:160)
                 fake = G(cond, None, step=self.res_step, alpha=self.alpha, input_indices=input_indices)[0]
         fake_scores, _ = D([fake.detach()], condition=cond, step=self.res_step, alpha=self.alpha)
         fake_loss = F.softplus(fake_scores).mean()
-        (real_loss + fake_loss).backward()
+        d_loss = real_loss + fake_loss
+        (d_loss if self.d_scaler is None else d_loss * self.d_scaler.scale).backward()
         if self.overlap_comm:
             self.d_bucket.all_reduce_mean(async_op=True)
             self._d_update_pending = True  # completed right before D is used again
         else:
             self.d_bucket.all_reduce_mean()
-            self.d_optim.step()
-        return (real_loss + fake_loss).detach()
+            self._d_optim_step()
+        return d_loss.detach()
 
     def g_step(self, cond, input_indices, fake=None):
         """train.py:189-252"""
@@ -260,7 +317,7 @@ class GifTrainer:
             loss = loss + 1e-8 * 8 * losses.grad_penalty_loss([cond], torch.pow(fake[-1], 2), step=None).mean()
         if self.embedding_reg_weight:
             loss = loss + self.embedding_reg_weight * losses.l2_reg(G.z_to_w)
-        loss.backward()
+        (loss if self.g_scaler is None else loss * self.g_scaler.scale).backward()
         self._g_update()
         requires_grad(G, False)
         return loss.detach()

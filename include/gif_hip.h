@@ -263,9 +263,41 @@ int gif_resize_bwd_f32(const float* gy, float* gx, int64_t planes, int Hi, int W
  *   2 Winograd GEMM fwd+dgrad                3 Winograd wgrad GEMM
  *     (2, 3: ALGORITHMIC direct-convolution FLOPs; the kernels execute 16/36 of them)
  *   4 Winograd input / gradient transforms (HBM bytes: tensor read once + transformed planes written once)
+ *   5 direct conv on the register-staged kernel (Cin < 32), 6 f16 conv fwd / dgrad, 7 f16 weight gradient
  * ---------------------------------------------------------------------------------------------- */
 int gif_prof_enable(int on);
 int gif_prof_read(int family, double* ms, double* flops, int64_t* launches);
+
+/* ------------------------------------------------------------------------------------------------
+ * f16-activation variants (BASELINE.json configs[4]: "fp16 activations with fp32 demodulation"; no counterpart in the
+ * reference, which is fp32 only).  Activations, residuals and packed weights are IEEE half in HBM (void* here: C has no half
+ * type); everything else keeps the fp32 contract of the function it mirrors: master weights, per-sample modulation /
+ * demodulation scales, biases, FIR taps, all reductions, the weight-gradient workspace and dW are fp32, MFMA accumulates in
+ * fp32 (v_mfma_f32_32x32x16_f16), epilogues run in fp32 and stores saturate at +-65504.  Channel counts must be multiples
+ * of 8 (one 16-byte LDS-DMA chunk = 8 halfs).  The Winograd path is fp32 only.
+ * ---------------------------------------------------------------------------------------------- */
+int gif_conv2d_pack_dims_f16(int cout, int cin, int* RP, int* CP);
+int gif_pack_weight_f16(const float* w, void* wp, int R, int C, int KH, int KW, int RP, int CP, int64_t sr, int64_t sc,
+                        int64_t sky, int64_t skx, float scale, gif_stream_t stream);
+int gif_conv2d_fwd_f16(const void* big, const void* wp, void* small, const gif_conv_geom* g, const gif_conv_epilogue* e,
+                       gif_stream_t stream);
+int gif_conv2d_bwd_data_f16(const void* small, const void* wp, void* big, const gif_conv_geom* g,
+                            const gif_conv_epilogue* e, gif_stream_t stream);
+int gif_conv2d_wgrad_dims_f16(int Cs, int Cb, int* RP, int* CP);
+int gif_conv2d_wgrad_splits_f16(const gif_conv_geom* g);
+int gif_conv2d_wgrad_f16(const void* small, const void* big, float* ws, const float* small_scale, const float* big_scale,
+                         const gif_conv_geom* g, int nsplit, gif_stream_t stream);
+int gif_upfirdn2d_f16(const void* x, const float* k, void* y, int B, int Hi, int Wi, int C, int Ho, int Wo, int up, int down,
+                      int padx0, int pady0, int KH, int KW, int flip, const gif_conv_epilogue* e, gif_stream_t stream);
+int gif_bias_act_f16(const void* x, const float* bias, const void* residual, void* y, int64_t npix, int C, float slope,
+                     float gain, gif_stream_t stream);
+int gif_bias_act_bwd_f16(const void* gy, const void* y, void* gx, float* gbias, float* partial, int64_t npix, int C,
+                         float slope, float gain, gif_stream_t stream);
+int gif_colsum_f16(const void* x, float* out, float* partial, int64_t npix, int C, gif_stream_t stream);
+int gif_mul_reduce_f16(const void* a, const void* b, const float* scale, void* scaled, float* out, float* partial, int B,
+                       int64_t HW, int C, gif_stream_t stream);
+int gif_act_inv_mul_reduce_f16(const void* g, const void* y, const void* residual, const float* bias, float* out,
+                               float* partial, int B, int64_t HW, int C, float slope, float gain, gif_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused Adam (+ EMA generator) over the flat gradient bucket — replaces torch.optim.Adam.step() (train.py:173, :243;
@@ -275,6 +307,8 @@ int gif_prof_read(int family, double* ms, double* flops, int64_t* launches);
  *   m += (g - m)*(1 - beta1);  v = v*beta2 + (1 - beta2)*g*g;  p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
  *   ema = ema*ema_decay + (1 - ema_decay)*p      (has_ema != 0)
  * bias_correction1/2 = 1 - beta^step are computed by the caller (host, double).
+ * Loss scaling (f16 activation path): inv_grad_scale / found_inf are optional DEVICE scalars — every gradient is multiplied
+ * by *inv_grad_scale, and when *found_inf != 0 the launch changes nothing (an overflowed step is skipped without a host sync).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct gif_adam_chunk {
     float* param;        /* first element of this chunk in the parameter tensor */
@@ -286,7 +320,8 @@ typedef struct gif_adam_chunk {
 int gif_adam_chunk_floats(void);
 int gif_adam_ema_step_f32(const gif_adam_chunk* chunks, int nchunks, const float* grad_flat, float* exp_avg_flat,
                           float* exp_avg_sq_flat, float lr, float beta1, float beta2, float eps, double bias_correction1,
-                          double bias_correction2, float ema_decay, int has_ema, gif_stream_t stream);
+                          double bias_correction2, float ema_decay, int has_ema, const float* inv_grad_scale,
+                          const float* found_inf, gif_stream_t stream);
 
 #ifdef __cplusplus
 }

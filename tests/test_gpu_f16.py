@@ -1,0 +1,264 @@
+"""-m gpu: the f16-activation path (BASELINE.json configs[4]: "fp16 activations with fp32 demodulation").
+
+Kernel level: every f16 entry point against an fp32 ATen-CPU computation on the SAME f16-rounded operands (activations and
+packed weights are rounded to half exactly as the kernels see them; accumulation is fp32 on both sides), so the only
+differences are the final rounding of the output to half (2^-11 relative), the f16 product x*s of the modulated forms and
+the accumulation order: tolerance 2e-3 of the tensor max (fp32 outputs such as dW: 5e-4).
+Model level: G / D with f16 activations against the fp32 CPU oracle on identical fp32 weights — STATED TOLERANCE: generator
+image L_inf <= 3e-2 (images are O(1); measured values are printed), D scores 3e-2 relative; one full training iteration with
+the device-side loss scaler."""
+import contextlib
+import io
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_util import assert_close, rel_err
+
+pytestmark = pytest.mark.gpu
+
+H16 = torch.float16
+TOL = 2e-3
+
+
+def pad8(c):
+    return (c + 7) // 8 * 8
+
+
+def dev16(x, requires_grad=False):
+    """CPU NCHW fp32 tensor -> device f16, channels zero-padded to a multiple of 8, NHWC memory."""
+    c = x.shape[1]
+    if pad8(c) != c:
+        x = F.pad(x, (0, 0, 0, 0, 0, pad8(c) - c))
+    return x.detach().cuda().to(H16).contiguous(memory_format=torch.channels_last).requires_grad_(requires_grad)
+
+
+def r16(x):
+    """round to half and back: the value the f16 kernels actually read"""
+    return x.to(H16).float()
+
+
+def host(y, c=None):
+    y = y.detach().float()
+    if c is not None:
+        y = y[:, :c]
+    return y.cpu().contiguous()
+
+
+F16_CONV_CASES = [
+    # (B, Cin, Cout, K, stride, pad, H)
+    (2, 128, 128, 3, 1, 1, 32),   # G/D 3x3 same
+    (3, 512, 512, 3, 1, 1, 8),    # 512-ch layers, batch not a tile multiple
+    (2, 6, 12, 3, 1, 1, 16),      # noise conv 1 (6 -> 8 in, 12 -> 16 out)
+    (2, 12, 24, 3, 1, 1, 16),     # noise conv 2
+    (2, 24, 256, 3, 1, 1, 16),    # noise conv 3
+    (2, 9, 128, 1, 1, 0, 32),     # D first layer (9 -> 16 padded)
+    (2, 128, 3, 1, 1, 0, 32),     # ToRGB-shaped 1x1 (3 -> 8 padded)
+    (2, 128, 256, 3, 2, 0, 33),   # D conv2: stride 2 on the blurred (H+1) map
+    (2, 128, 256, 1, 2, 0, 31),   # D skip: 1x1 stride 2
+    (1, 513, 512, 3, 1, 1, 4),    # final_conv (513 -> 520 padded)
+    (5, 64, 160, 3, 1, 1, 7),     # ragged everything
+    (8, 128, 128, 3, 1, 1, 64),   # enough rows for the 128x128-tile path with bulk/tail split
+]
+
+
+def _case(case, seed=0):
+    B, Ci, Co, K, s, p, H = case
+    g = torch.Generator().manual_seed(seed)
+    x = r16(torch.randn(B, Ci, H, H, generator=g))
+    w = torch.randn(Co, Ci, K, K, generator=g) / (Ci * K * K) ** 0.5
+    return x, w
+
+
+@pytest.mark.parametrize("case", F16_CONV_CASES)
+def test_f16_conv_fwd_dgrad_wgrad(case):
+    from gif_amd import ops
+    B, Ci, Co, K, s, p, H = case
+    x, w = _case(case)
+    spec = ops.ConvSpec(K, K, s, p)
+    wq = r16(w)  # the packed operand is the half-rounded weight
+    ref = F.conv2d(x, wq, stride=s, padding=p)
+    got = ops.conv_fwd(dev16(x), w.cuda(), spec)
+    assert got.dtype == H16 and got.shape[1] == pad8(Co)
+    assert_close(host(got, Co), ref, TOL, f"f16 conv_fwd {case}")
+    if pad8(Co) != Co:
+        assert (host(got)[:, Co:] == 0).all(), "padded output channels must be zero"
+    Hs = ref.shape[2]
+    gy = r16(torch.randn(B, Co, Hs, Hs, generator=torch.Generator().manual_seed(1)))
+    refd = F.conv_transpose2d(gy, wq, stride=s, padding=p, output_padding=H - ((Hs - 1) * s + K - 2 * p))
+    gotd = ops.conv_bwd_data(dev16(gy), w.cuda(), spec, (H, H))
+    assert_close(host(gotd, Ci), refd, TOL, f"f16 conv_bwd_data {case}")
+    wl = wq.clone().requires_grad_(True)
+    (refw,) = torch.autograd.grad(F.conv2d(x, wl, stride=s, padding=p), wl, gy)
+    gotw = ops.conv_wgrad(dev16(gy), dev16(x), spec, Co, Ci)
+    assert gotw.dtype == torch.float32
+    assert_close(gotw, refw, 5e-4, f"f16 conv_wgrad {case}")
+
+
+def test_f16_conv_scales_epilogue_and_modulated_wgrad():
+    from gif_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B, Ci, Co, H = 3, 128, 256, 16
+    x, w = r16(torch.randn(B, Ci, H, H, generator=g)), torch.randn(Co, Ci, 3, 3, generator=g) / 34
+    s, d = torch.rand(B, Ci, generator=g) + 0.5, torch.rand(B, Co, generator=g) + 0.5
+    res, bias = r16(torch.randn(B, Co, H, H, generator=g)), torch.randn(Co, generator=g)
+    wq = r16(w)
+    xs = r16(x * r16(s)[:, :, None, None])  # the kernel multiplies in f16: half(x) * half(s) rounded to half
+    ref = F.conv2d(xs, wq, padding=1) * d[:, :, None, None]
+    got = ops.conv_fwd(dev16(x), w.cuda(), ops.ConvSpec(3, 3, 1, 1), in_scale=s.cuda(), out_scale=d.cuda())
+    assert_close(host(got), ref, TOL, "f16 scaled conv")
+    ref2 = 2 ** 0.5 * F.leaky_relu(ref + res + bias[None, :, None, None], 0.2)
+    got2 = ops.conv_fwd(dev16(x), w.cuda(), ops.ConvSpec(3, 3, 1, 1), in_scale=s.cuda(), out_scale=d.cuda(),
+                        bias=bias.cuda(), residual=dev16(res), act=True)
+    assert_close(host(got2), ref2, TOL, "f16 fused epilogue")
+    # transposed stride-2 with scales: the generator's up-sampling branch
+    wt = torch.randn(Ci, Co, 3, 3, generator=g) / 34
+    ref3 = F.conv_transpose2d(xs, r16(wt), stride=2) * d[:, :, None, None]
+    got3 = ops.conv_bwd_data(dev16(x), wt.cuda(), ops.ConvSpec(3, 3, 2, 0), (2 * H + 1, 2 * H + 1), in_scale=s.cuda(),
+                             out_scale=d.cuda())
+    assert_close(host(got3), ref3, TOL, "f16 modulated transposed conv")
+    # modulated weight gradient: dW = sum (gy * d) (x) (x * s), scales applied in f16 on the operands
+    gy = r16(torch.randn(B, Co, H, H, generator=g))
+    gyd = r16(gy * r16(d)[:, :, None, None])
+    wl = wq.clone().requires_grad_(True)
+    (refw,) = torch.autograd.grad(F.conv2d(xs, wl, padding=1), wl, gyd)
+    gotw = ops.conv_wgrad(dev16(gy), dev16(x), ops.ConvSpec(3, 3, 1, 1), Co, Ci, small_scale=d.cuda(), big_scale=s.cuda())
+    assert_close(gotw, refw, 1e-3, "f16 modulated wgrad")
+    # 4x4 maps (16 pixels per sample): the 16-pixel-stage variant of the scale table
+    x4 = r16(torch.randn(4, 64, 4, 4, generator=g))
+    gy4 = r16(torch.randn(4, 64, 4, 4, generator=g))
+    s4, d4 = torch.rand(4, 64, generator=g) + 0.5, torch.rand(4, 64, generator=g) + 0.5
+    wl = torch.zeros(64, 64, 3, 3, requires_grad=True)
+    (refw4,) = torch.autograd.grad(F.conv2d(r16(x4 * r16(s4)[:, :, None, None]), wl, padding=1), wl,
+                                   r16(gy4 * r16(d4)[:, :, None, None]))
+    gotw4 = ops.conv_wgrad(dev16(gy4), dev16(x4), ops.ConvSpec(3, 3, 1, 1), 64, 64, small_scale=d4.cuda(), big_scale=s4.cuda())
+    assert_close(gotw4, refw4, 1e-3, "f16 modulated wgrad at 4x4")
+
+
+def test_f16_elementwise_kernels():
+    from gif_amd import ops
+    from oracle import stylegan2_ref as R
+    g = torch.Generator().manual_seed(4)
+    x = r16(torch.randn(3, 24, 20, 20, generator=g))
+    k = R.make_kernel([1, 3, 3, 1])
+    for up, down, pad in [(1, 1, (2, 1)), (1, 1, (1, 1)), (2, 1, (2, 1)), (1, 2, (1, 1)), (1, 2, (2, 2))]:
+        ref = R.upfirdn2d(x, k * (up * up), up=up, down=down, pad=pad)
+        got = ops.upfirdn2d(dev16(x), (k * (up * up)).cuda(), up, down, pad[0], tuple(ref.shape[2:]))
+        assert_close(host(got), ref, TOL, f"f16 upfirdn2d up={up} down={down} pad={pad}")
+    big = r16(torch.randn(2, 64, 129, 129, generator=g))  # the sliding-window blur variant
+    ref = R.upfirdn2d(big, k, pad=(1, 1))
+    assert_close(host(ops.upfirdn2d(dev16(big), k.cuda(), 1, 1, 1, tuple(ref.shape[2:]))), ref, TOL, "f16 blur rows")
+    bias, res = torch.randn(24, generator=g), r16(torch.randn(3, 24, 20, 20, generator=g))
+    ref = 2 ** 0.5 * F.leaky_relu(x + res + bias[None, :, None, None], 0.2)
+    y = ops.bias_act(dev16(x), bias.cuda(), dev16(res))
+    assert_close(host(y), ref, TOL, "f16 bias_act")
+    gy = r16(torch.randn(3, 24, 20, 20, generator=g))
+    yh = host(y)
+    mask = torch.where(yh > 0, torch.tensor(1.0), torch.tensor(0.2)) * 2 ** 0.5
+    gx, gb = ops.bias_act_bwd(dev16(gy), y, True)
+    assert gb.dtype == torch.float32
+    assert_close(host(gx), gy * mask, TOL, "f16 bias_act_bwd gx")
+    assert_close(gb, (gy * mask).sum(dim=(0, 2, 3)), 5e-4, "f16 bias_act_bwd gbias (fp32 sum of the UNROUNDED products)")
+    assert_close(ops.colsum(dev16(x)), x.sum(dim=(0, 2, 3)), 5e-4, "f16 colsum")
+    s = torch.rand(3, 24, generator=g) + 0.5
+    out, scaled = ops.mul_reduce(dev16(x), dev16(res), scale=s.cuda(), want_scaled=True)
+    assert out.dtype == torch.float32 and scaled.dtype == H16
+    assert_close(out, (x * res).sum(dim=(2, 3)), 5e-4, "f16 mul_reduce")
+    assert_close(host(scaled), x * s[:, :, None, None], TOL, "f16 mul_reduce scaled output")
+
+
+def _build(res, vocab=16):
+    from gif_amd.discriminator import Discriminator
+    from gif_amd.generator import StyledGenerator
+    with contextlib.redirect_stdout(io.StringIO()):
+        g = StyledGenerator(embedding_vocab_size=vocab, rendered_flame_ascondition=True, normal_maps_as_cond=True)
+        d = Discriminator(size=res, num_color_chnls=9)
+    return g, d
+
+
+@pytest.mark.parametrize("res,step,batch", [(32, 3, 4), (256, 6, 2)])
+def test_f16_generator_and_discriminator_vs_fp32_oracle(res, step, batch):
+    """Stated tolerance of the f16 path: generator image L_inf <= 3e-2 against the fp32 CPU oracle on identical fp32 weights
+    (the fp32 path holds 1e-3); D scores within 3e-2 of their magnitude scale."""
+    from oracle import stylegan2_ref as R
+    torch.manual_seed(0)
+    g, d = _build(res)
+    sd = R.seeded_state_dict(g.state_dict(), 21)
+    sdd = R.seeded_state_dict(d.state_dict(), 22)
+    g.load_state_dict(sd, strict=True)
+    d.load_state_dict(sdd, strict=True)
+    gen = torch.Generator().manual_seed(5)
+    cond = torch.rand(batch, 6, res, res, generator=gen) * 2 - 1
+    idx = torch.randint(0, 16, (batch,), generator=gen)
+    with torch.no_grad():
+        ref = R.generator_forward(sd, cond, step, idx)
+        sref = R.discriminator_forward(sdd, ref, cond, res)
+        g, d = g.cuda().set_activation_dtype(H16), d.cuda().set_activation_dtype(H16)
+        got = g(cond.cuda(), None, step=step, alpha=1, input_indices=idx.cuda())[0]
+        assert got.dtype == torch.float32 and got.shape == ref.shape
+        linf = (got.cpu() - ref).abs().max().item()
+        print(f"f16 generator at {res}x{res}: L_inf vs fp32 oracle {linf:.3e} (image max {ref.abs().max().item():.2f})")
+        assert linf <= 3e-2, linf
+        sgot = d(ref.cuda(), condition=cond.cuda())[0]
+        e = ((sgot.cpu() - sref).abs().max() / (sref.abs().max() + 1.0)).item()
+        print(f"f16 discriminator at {res}x{res}: score error {e:.3e}")
+        assert e <= 3e-2, e
+
+
+def test_f16_gradients_and_training_iteration():
+    """Parameter gradients of a G+D loss with f16 activations against the fp32 HIP path (same weights), and two trainer
+    iterations (the second an R1 iteration) with the device-side loss scaler: finite losses close to the fp32 trainer's,
+    parameters move, no step skipped."""
+    import copy
+    from gif_amd.train_step import GifTrainer
+    torch.manual_seed(0)
+    g32, d32 = _build(32)
+    g32, d32 = g32.cuda(), d32.cuda()
+    g16, d16 = copy.deepcopy(g32).set_activation_dtype(H16), copy.deepcopy(d32).set_activation_dtype(H16)
+    gen = torch.Generator(device="cuda").manual_seed(6)
+    cond = torch.rand(4, 6, 32, 32, device="cuda", generator=gen) * 2 - 1
+    idx = torch.randint(0, 16, (4,), device="cuda", generator=gen)
+    grads = {}
+    for name, (g, d) in (("f32", (g32, d32)), ("f16", (g16, d16))):
+        for p in list(g.parameters()) + list(d.parameters()):
+            p.requires_grad_(True)
+            p.grad = None
+        fake = g(cond, None, step=3, alpha=1, input_indices=idx)
+        loss = F.softplus(-d(fake, condition=cond)[0]).mean()
+        (loss * 256.0).backward()
+        grads[name] = {k: p.grad / 256.0 for k, p in list(g.named_parameters()) + [("D." + k, p) for k, p in d.named_parameters()]
+                       if p.grad is not None}
+    worst = 0.0
+    for k, ref in grads["f32"].items():
+        if ref.abs().max().item() == 0:
+            continue
+        e = rel_err(grads["f16"][k], ref)
+        worst = max(worst, e)
+        assert e <= 5e-2, f"f16 gradient of {k}: rel err {e:.3e}"
+    print(f"worst f16-vs-fp32 parameter-gradient error: {worst:.3e}")
+    # trainer
+    res = {}
+    for name, dt in (("f32", None), ("f16", H16)):
+        torch.manual_seed(1)
+        G, D = _build(32)
+        G_ema, _ = _build(32)
+        G_ema.load_state_dict(G.state_dict())
+        tr = GifTrainer(G.cuda(), D.cuda(), G_ema.cuda(), step=3, r1_every=2, act_dtype=dt)
+        gen = torch.Generator(device="cuda").manual_seed(7)
+        w0 = G.generator.progression[2].st_cv2.conv.weight.detach().clone()
+        out = []
+        for i in range(2):
+            real = torch.rand(4, 3, 32, 32, device="cuda", generator=gen) * 2 - 1
+            c = torch.rand(4, 6, 32, 32, device="cuda", generator=gen) * 2 - 1
+            ii = torch.randint(0, 16, (4,), device="cuda", generator=gen)
+            out.append([t.item() for t in tr.step(i, real, c, ii)])
+        torch.cuda.synchronize()
+        res[name] = out
+        assert all(math.isfinite(v) for pair in out for v in pair)
+        assert (G.generator.progression[2].st_cv2.conv.weight - w0).abs().max().item() > 0
+        if dt is not None:
+            assert tr.g_scaler.skipped.item() == 0 and tr.d_scaler.skipped.item() == 0, "no overflow expected at scale 2^12"
+    for a, b in zip(res["f32"][0], res["f16"][0]):  # first iteration: identical weights, only the activation dtype differs
+        assert abs(a - b) <= 3e-2 * max(1.0, abs(a)), (res["f32"], res["f16"])
