@@ -361,11 +361,19 @@ def _modconv_composite(x, w, s, d, spec, transposed, out_hw, wscale, residual=No
 
 def _recorded_backward(inputs, needs, gy, build):
     """Gradients of build(*inputs) w.r.t. the inputs flagged in `needs`, contracted with gy, WITH history (create_graph):
-    the forward is re-run through differentiable Functions inside the backward pass."""
+    the forward is re-run through differentiable Functions inside the backward pass.
+
+    The inputs are graph-connected to each other (the demodulation d is a function of the modulation s, s of the style w,
+    ...).  torch.autograd.grad(y, [s, d]) would therefore return the TOTAL derivative w.r.t. s, including the path through
+    d — which the outer graph then adds a second time when it propagates the returned d-gradient back to s.  Each input is
+    replaced by an identity view first: the views are distinct graph nodes with no edges between each other, so every
+    returned gradient is the PARTIAL derivative (what a Function's backward must return), while still being connected to
+    the original tensors for the next differentiation."""
     with torch.enable_grad():
-        y = build()
+        proxies = [None if t is None else t.view_as(t) for t in inputs]
+        y = build(*proxies)
         idx = [i for i, (t, n) in enumerate(zip(inputs, needs)) if n and t is not None and t.requires_grad]
-        grads = torch.autograd.grad(y, [inputs[i] for i in idx], gy, create_graph=True, allow_unused=True)
+        grads = torch.autograd.grad(y, [proxies[i] for i in idx], gy, create_graph=True, allow_unused=True)
     out = [None] * len(inputs)
     for i, g in zip(idx, grads):
         out[i] = g
@@ -403,7 +411,7 @@ class ModConvFn(Function):
         if torch.is_grad_enabled():  # create_graph=True: the gradients must carry history
             gx, gw, gs, gd = _recorded_backward(
                 (x, w, s, d), ctx.needs_input_grad[:4], gy,
-                lambda: _modconv_composite(x, w, s, d, spec, tr, ctx.out_hw, ws))
+                lambda x_, w_, s_, d_: _modconv_composite(x_, w_, s_, d_, spec, tr, ctx.out_hw, ws))
             return gx, gw, gs, gd, None, None, None, None
         x, s, gy = ops.nhwc(x), s.contiguous(), ops.nhwc(gy)
         d = None if d is None else d.contiguous()
@@ -460,7 +468,7 @@ class ModConvActFn(Function):
         if torch.is_grad_enabled():  # create_graph=True: the gradients must carry history
             gx, gw, gs, gd, gr, gb = _recorded_backward(
                 (x, w, s, d, residual, bias), ctx.needs_input_grad[:6], gy,
-                lambda: _modconv_composite(x, w, s, d, spec, False, None, ws, residual, bias, (slope, gain)))
+                lambda x_, w_, s_, d_, r_, b_: _modconv_composite(x_, w_, s_, d_, spec, False, None, ws, r_, b_, (slope, gain)))
             return gx, gw, gs, gd, gr, gb, None, None, None, None
         x, s, d = ops.nhwc(x), s.contiguous(), d.contiguous()
         residual = None if residual is None else ops.nhwc(residual)

@@ -114,7 +114,13 @@ class EqualConv2d(nn.Module):
 
 
 class EqualLinear(nn.Module):
-    """Reference :193-235.  512x512 / 8192x512 GEMMs on [B,.] vectors: library GEMM through torch."""
+    """Reference :193-235 — y = [sqrt(2) *] lrelu(x @ (W * scale)^T + bias * lr_mul).
+
+    Runs on the fp32 MFMA implicit-GEMM kernels as a 1x1 convolution over a [rows, in_dim, 1, 1] "image": the equalised-lr
+    weight scale is folded into the weight packing (cached per parameter version), bias and leaky ReLU into the conv
+    epilogue, i.e. ONE launch per layer in the forward pass — the mapping network (8 layers), every modulation linear and
+    the discriminator head all go through it.  Backward = the any-order conv Functions (R1 differentiates the head twice,
+    the StyleGAN2-form path-length regulariser the mapping network).  No CPU path."""
 
     def __init__(self, in_dim, out_dim, bias=True, bias_init=0, lr_mul=1, activation=None, scale_weight=1.0,
                  apply_sqrt2_fac_in_eq_lin=False):
@@ -127,14 +133,28 @@ class EqualLinear(nn.Module):
         self.apply_sqrt2_fac_in_eq_lin = apply_sqrt2_fac_in_eq_lin
 
     def forward(self, input):
+        out_dim, in_dim = self.weight.shape
+        lead = input.shape[:-1]
+        x = input.reshape(-1, in_dim)
+        if x.dtype != torch.float32:
+            x = x.float()
+        kp = pad4(in_dim)
+        if kp != in_dim:
+            x = F.pad(x, (0, kp - in_dim))
+        x = x.reshape(x.shape[0], kp, 1, 1)
+        w = self.weight.view(out_dim, in_dim, 1, 1)
+        bias = None if self.bias is None else _pad_vec(self.bias * self.lr_mul, pad4(out_dim))
         if self.activation:
-            out = F.linear(input, self.weight * self.scale)
-            out = F.leaky_relu(out + self.bias * self.lr_mul, negative_slope=0.2)
-            if self.apply_sqrt2_fac_in_eq_lin:
-                out = out * 1.41421356237
+            gain = 1.41421356237 if self.apply_sqrt2_fac_in_eq_lin else 1.0
+            out = GF.conv2d_bias_act(x, w, bias, 1, 0, self.scale, 0.2, gain)
+        elif bias is not None:
+            out = GF.conv2d_bias_act(x, w, bias, 1, 0, self.scale, 1.0, 1.0)  # slope 1 / gain 1: bias only, no activation
         else:
-            out = F.linear(input, self.weight * self.scale, bias=self.bias * self.lr_mul)
-        return out
+            out = GF.conv2d(x, w, 1, 0, wscale=self.scale)
+        out = out.reshape(out.shape[0], -1)
+        if out.shape[1] != out_dim:
+            out = out[:, :out_dim]
+        return out.reshape(*lead, out_dim)
 
     def __repr__(self):
         return f'{self.__class__.__name__}({self.weight.shape[1]}, {self.weight.shape[0]})'
@@ -188,7 +208,13 @@ class ModulatedConv2d(nn.Module):
         d = None
         if self.demodulate:
             wsq = self.weight[0].pow(2).sum(dim=(2, 3))  # [Cout, Cin]
-            d = torch.rsqrt((self.scale ** 2) * (s.pow(2) @ wsq.t()) + self.eps)
+            # sum_ci s^2 * wsq as a 1x1 convolution on the MFMA kernel (like EqualLinear): d = rsqrt(scale^2 * (s^2 @ wsq^T) + eps)
+            cin = s.shape[1]
+            s2 = s.pow(2)
+            if pad4(cin) != cin:
+                s2 = F.pad(s2, (0, pad4(cin) - cin))
+            acc = GF.conv2d(s2.reshape(s.shape[0], -1, 1, 1), wsq.view(wsq.shape[0], cin, 1, 1), 1, 0, wscale=self.scale ** 2)
+            d = torch.rsqrt(acc.reshape(s.shape[0], -1)[:, :wsq.shape[0]] + self.eps)
         return s, d
 
     def _padded_scales(self, style, in_act, dtype=torch.float32):

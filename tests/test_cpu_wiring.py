@@ -1,0 +1,257 @@
+"""CPU tier: the autograd WIRING of gif_amd (functional.py Functions, layers, generator, discriminator, losses, GifTrainer)
+against the oracle, with every HIP launch replaced by its ATen contract (tests/cpu_ops.py).  Catches, without a GPU, what a
+kernel test cannot: a backward that calls the wrong op / operand / scale, a gradient that silently loses its history under
+create_graph (round-1 advisor finding), the data-parallel trainer's synchronisation.  The kernels behind the same entry points
+are checked against the same oracle in the -m gpu tier."""
+import contextlib
+import io
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import cpu_ops
+from gpu_util import assert_close, assert_grads_close
+from oracle import stylegan2_ref as R
+
+
+@pytest.fixture
+def cpu(monkeypatch):
+    cpu_ops.install(monkeypatch)
+
+
+def _build_g(vocab=16):
+    from gif_amd.generator import StyledGenerator
+    with contextlib.redirect_stdout(io.StringIO()):
+        return StyledGenerator(embedding_vocab_size=vocab, rendered_flame_ascondition=True, normal_maps_as_cond=True)
+
+
+def _build_d(size):
+    from gif_amd.discriminator import Discriminator
+    return Discriminator(size=size, num_color_chnls=9)
+
+
+def _leaves(sd):
+    return {k: (v.clone().requires_grad_(True) if (not k.endswith('kernel') and 'embd_weight' not in k) else v.clone())
+            for k, v in sd.items()}
+
+
+def _seeded(model, seed):
+    sd = R.seeded_state_dict(model.state_dict(), seed)
+    model.load_state_dict(sd, strict=True)
+    for p in model.parameters():
+        p.requires_grad_(True)
+    return sd
+
+
+def test_generator_and_discriminator_first_order_vs_oracle(cpu):
+    torch.manual_seed(0)
+    g, d = _build_g(), _build_d(16)
+    gsd, dsd = _seeded(g, 1), _seeded(d, 101)
+    gen = torch.Generator().manual_seed(201)  # a draw without activation sign flips (see gpu_util.assert_grads_close)
+    cond = torch.rand(4, 6, 16, 16, generator=gen) * 2 - 1
+    idx = torch.tensor([1, 5, 9, 13])
+    gl, dl = _leaves(gsd), _leaves(dsd)
+    fake_r = R.generator_forward(gl, cond, 2, idx)
+    loss_r = F.softplus(-R.discriminator_forward(dl, fake_r, cond, 16)).mean()
+    fake = g(cond, None, step=2, alpha=1, input_indices=idx)
+    assert_close(fake[0], fake_r, 1e-5, "G forward")
+    loss = F.softplus(-d(fake, condition=cond)[0]).mean()
+    assert abs(loss.item() - loss_r.item()) < 1e-5
+    gk = [k for k, v in gl.items() if v.requires_grad]
+    ref = torch.autograd.grad(loss_r, [gl[k] for k in gk], allow_unused=True)
+    named = dict(g.named_parameters())
+    got = torch.autograd.grad(loss, [named[k] for k in gk], allow_unused=True)
+    assert_grads_close(got, ref, gk, tight=1e-4, max_outlier_frac=0.0, what="G grads through D")
+
+
+def test_r1_double_backward_vs_oracle(cpu):
+    from gif_amd import losses
+    torch.manual_seed(0)
+    d = _build_d(16)
+    dsd = _seeded(d, 4)
+    gen = torch.Generator().manual_seed(5)
+    img = torch.rand(4, 3, 16, 16, generator=gen) * 2 - 1
+    cond = torch.rand(4, 6, 16, 16, generator=gen) * 2 - 1
+    dl = _leaves(dsd)
+    ir = img.clone().requires_grad_(True)
+    sr = R.discriminator_forward(dl, ir, cond, 16)
+    pen_r = R.grad_penalty_loss([ir], sr)
+    keys = [k for k, v in dl.items() if v.requires_grad]
+    ref = torch.autograd.grad(F.softplus(-sr).mean() + pen_r.mean(), [dl[k] for k in keys])
+    ih = img.clone().requires_grad_(True)
+    sh, _ = d([ih], condition=cond)
+    pen = losses.grad_penalty_loss([ih], sh, step=None)
+    assert_close(pen, pen_r.detach(), 1e-4, "R1 penalty")
+    named = dict(d.named_parameters())
+    got = torch.autograd.grad(F.softplus(-sh).mean() + pen.mean(), [named[k] for k in keys])
+    assert_grads_close(got, ref, keys, tight=1e-4, what="D grads through the R1 double backward")
+
+
+def test_generator_recorded_backward_path_length_and_direct_grad(cpu, monkeypatch):
+    """The generator's fused ops switch to a recorded (any-order) backward under create_graph: StyleGAN2-form path-length
+    penalty and DIRECT_GRAD_REG (train.py:203-215), values AND parameter gradients vs the oracle's autograd."""
+    from gif_amd import losses
+    torch.manual_seed(0)
+    g = _build_g()
+    gsd = _seeded(g, 6)
+    gen = torch.Generator().manual_seed(7)
+    B = 2
+    cond = torch.rand(B, 6, 16, 16, generator=gen) * 2 - 1
+    style = torch.randn(B, 512, generator=gen)
+    noise = torch.randn(B, 3, 16, 16, generator=gen)
+    gl = _leaves(gsd)
+    z = style.clone().requires_grad_(True)
+    fake_r = R.generator_forward(gl, cond, 2, z)
+    (pg_r,) = torch.autograd.grad((fake_r * noise / np.sqrt(16 * 16)).sum(), z, create_graph=True)
+    len_r = torch.sqrt(pg_r.pow(2).sum(1))
+    mean_r = 0.01 * len_r.mean().detach()
+    pen_r = (len_r - mean_r).pow(2).mean()
+    keys = [k for k, v in gl.items() if v.requires_grad and not any(f".{i}." in k for i in (3, 4, 5, 6, 7, 8))]
+    ref = torch.autograd.grad(pen_r, [gl[k] for k in keys], allow_unused=True)
+    draws = [style, noise]
+
+    def replay(*a, **k):
+        t = draws.pop(0)
+        return t.clone().requires_grad_(k.get("requires_grad", False))
+
+    monkeypatch.setattr(torch, "randn", replay)
+    reg = losses.PathLengthRegularizor(reference_semantics=False)
+    pen = reg.path_length_reg(g, step=2, alpha=1.0, input_indices=torch.zeros(B, dtype=torch.long), cond=cond)
+    monkeypatch.undo()
+    cpu_ops.install(monkeypatch)
+    assert pen.requires_grad
+    assert abs(pen.item() - pen_r.item()) < 2e-2 * abs(pen_r.item()), (pen.item(), pen_r.item())
+    named = dict(g.named_parameters())
+    got = torch.autograd.grad(pen, [named[k] for k in keys], allow_unused=True)
+    assert sum(1 for b in ref if b is not None and b.abs().max() > 0) > 40
+    assert_grads_close(got, ref, keys, tight=2e-4, what="d PL penalty / d parameters (recorded backward of G)")
+    # DIRECT_GRAD_REG
+    gl = _leaves(gsd)
+    idx = torch.tensor([3, 11])
+    c_r = cond.clone().requires_grad_(True)
+    pen_r = R.grad_penalty_loss([c_r], R.generator_forward(gl, c_r, 2, idx).pow(2)).mean()
+    ref = torch.autograd.grad(pen_r, [gl[k] for k in keys], allow_unused=True)
+    c_h = cond.clone().requires_grad_(True)
+    fake = g(c_h, None, step=2, alpha=1, input_indices=idx)
+    pen = losses.grad_penalty_loss([c_h], torch.pow(fake[-1], 2), step=None).mean()
+    assert abs(pen.item() - pen_r.item()) < 2e-2 * abs(pen_r.item())
+    got = torch.autograd.grad(pen, [named[k] for k in keys], allow_unused=True)
+    assert_grads_close(got, ref, keys, tight=2e-4, what="d direct-grad penalty / d parameters")
+
+
+def test_trainer_trajectory_vs_oracle_trainer_on_cpu(cpu):
+    """GifTrainer (torch Adam on CPU) vs oracle/train_ref.py: two iterations incl. an R1 one — losses, weights, EMA."""
+    from gif_amd.train_step import GifTrainer
+    from oracle.train_ref import RefTrainer
+    torch.manual_seed(0)
+    G, G_ema, D = _build_g(), _build_g(), _build_d(16)
+    g_sd = R.seeded_state_dict(G.state_dict(), 61)
+    d_sd = R.seeded_state_dict(D.state_dict(), 62)
+    G.load_state_dict(g_sd)
+    G_ema.load_state_dict(g_sd)
+    D.load_state_dict(d_sd)
+    ref = RefTrainer(g_sd, d_sd, res_step=2, size=16, r1_every=2)
+    tr = GifTrainer(G, D, G_ema, step=2, r1_every=2, fused_adam=False)
+    gen = torch.Generator().manual_seed(63)
+    for i in range(2):
+        real = torch.rand(4, 3, 16, 16, generator=gen) * 2 - 1
+        cond = torch.rand(4, 6, 16, 16, generator=gen) * 2 - 1
+        idx = torch.randint(0, 16, (4,), generator=gen)
+        d_ref, g_ref = ref.step(i, real, cond, idx)
+        d_got, g_got = tr.step(i, real, cond, idx)
+        assert abs(d_got.item() - d_ref.item()) < 1e-3 * max(1.0, abs(d_ref.item())), (i, d_got.item(), d_ref.item())
+        assert abs(g_got.item() - g_ref.item()) < 1e-3 * max(1.0, abs(g_ref.item())), (i, g_got.item(), g_ref.item())
+    # parameters above the current resolution never receive a gradient: like in the reference, Adam holds no state for them
+    dead = G.generator.progression[5].st_cv1.conv.weight
+    assert dead.grad is None and len(tr.g_optim.state.get(dead, {})) == 0
+
+
+# ---- the REAL trainer in two data-parallel processes (gloo, CPU) -------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _dp_worker(rank, world, port, q):
+    try:
+        import copy
+        import hashlib
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.set_num_threads(2)
+        cpu_ops.install()
+        from gif_amd.train_step import GifTrainer
+        torch.manual_seed(1000 + rank)  # different initial weights and embedding buffers per rank
+        G, G_ema, D = _build_g(), _build_g(), _build_d(16)
+        G_ema.load_state_dict(G.state_dict())
+        w_before = G.generator.progression[1].st_cv2.conv.weight.detach().clone()
+        tr = GifTrainer(G, D, G_ema, step=2, r1_every=2, fused_adam=False)  # broadcasts rank 0's state
+        w_synced = G.generator.progression[1].st_cv2.conv.weight.detach().clone()
+        emb = G.image_embedding.embd_weight.detach().clone()
+        gen = torch.Generator().manual_seed(9)  # the GLOBAL batch of 8, identical in both processes
+        real = torch.rand(2, 8, 3, 16, 16, generator=gen) * 2 - 1
+        cond = torch.rand(2, 8, 6, 16, 16, generator=gen) * 2 - 1
+        idx = torch.randint(0, 16, (2, 8), generator=gen)
+        sl = slice(rank * 4, rank * 4 + 4)
+        halves = []
+        for h in range(world):  # the two halves' D gradients WITHOUT data parallelism, on copies of the synced models
+            G2, D2 = copy.deepcopy(G), copy.deepcopy(D)
+            hs = slice(h * 4, h * 4 + 4)
+            rs, _ = D2([real[0, hs]], condition=cond[0, hs])
+            with torch.no_grad():
+                fk = G2(cond[0, hs], None, step=2, alpha=1.0, input_indices=idx[0, hs])[0]
+            fs, _ = D2([fk], condition=cond[0, hs])
+            gs = torch.autograd.grad(F.softplus(-rs).mean() + F.softplus(fs).mean(), list(D2.parameters()))
+            halves.append(torch.cat([g.reshape(-1) for g in gs]))
+        mean_halves = (halves[0] + halves[1]) / 2
+        assert tr.overlap_comm
+        tr.d_step(0, real[0, sl], cond[0, sl], idx[0, sl])
+        tr.d_bucket.wait()
+        exchanged = torch.cat([p.grad.reshape(-1) for p in D.parameters()]).clone()
+        tr.g_step(cond[0, sl], idx[0, sl])
+        l1 = tr.step(1, real[1, sl], cond[1, sl], idx[1, sl])  # R1 iteration
+        tr.flush()
+        err = ((exchanged - mean_halves).abs().max() / mean_halves.abs().max()).item()
+
+        def digest(m):
+            return hashlib.sha1(torch.cat([p.detach().reshape(-1) for p in m.parameters()]).numpy().tobytes()).hexdigest()
+
+        q.put((rank, "ok", hashlib.sha1(w_before.numpy().tobytes()).hexdigest(), hashlib.sha1(w_synced.numpy().tobytes()).hexdigest(),
+               hashlib.sha1(emb.numpy().tobytes()).hexdigest(), err, digest(G), digest(D), digest(G_ema), [t.item() for t in l1]))
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put((rank, "error", traceback.format_exc()))
+        raise
+
+
+def test_real_trainer_two_gloo_processes_on_cpu():
+    """GifTrainer itself (not a stand-in model) in two gloo processes: construction-time broadcast from different per-rank
+    seeds, exchanged D gradients == mean of the halves' single-process gradients, replicas bit-identical after two iterations."""
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=900) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+    for r in res:
+        assert r[1] == "ok", r[2]
+    (_, _, b0, s0, e0, err0, g0, d0, m0, l0), (_, _, b1, s1, e1, err1, g1, d1, m1, l1) = res
+    assert b0 != b1, "ranks started from different weights"
+    assert s0 == s1 == b0, "construction broadcast rank 0's parameters"
+    assert e0 == e1, "construction broadcast rank 0's embedding BUFFER"
+    assert err0 < 1e-5 and err1 < 1e-5, (err0, err1)
+    assert g0 == g1 and d0 == d1 and m0 == m1, "replicas bit-identical after 2 iterations"
+    assert all(np.isfinite(l0)) and all(np.isfinite(l1))
