@@ -547,7 +547,8 @@ struct TileCfg {
 template <typename T>
 inline TileCfg pick_cfg(int cout, int cin) {
     TileCfg c;
-    c.BN = cout <= 32 ? 32 : 128;
+    // f16 also has a 128x64 tile: the 64-channel layers of the 512^2 / 1024^2 blocks would waste half of a 128-wide N tile
+    c.BN = cout <= 32 ? 32 : ((sizeof(T) == 2 && cout <= 64) ? 64 : 128);
     c.BK = sizeof(T) == 2 ? 64 : (cin < 32 ? 8 : 32);
     c.BM = c.BN == 32 ? 256 : 128;
     return c;
@@ -665,6 +666,9 @@ int launch(GatherParams& p, hipStream_t s) {
         if (rc != 0) gif::set_error("conv (f16): launch configuration does not fit (rc=%d)", rc);
         return rc == 0 ? 0 : GIF_ENOSUP;
     };
+    if constexpr (F16) {
+        if (c.BN == 64) return fail_f16(launch_glds<T, 128, 64, 2, 2>(p, s));
+    }
     if (c.BN == 128 && (F16 || c.BK == 32)) {
         // low-resolution layers (4x4 .. 16x16 at batch 32): a 128x128 grid would leave most CUs idle behind a
         // 144-step K loop; 64x64 tiles give 4x the workgroups (and 32 KB of LDS: 4 per CU) at a quarter of the latency
