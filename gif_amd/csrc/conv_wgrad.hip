@@ -691,6 +691,104 @@ int gif_conv2d_wgrad_f16(const void* small, const void* big, float* ws, const fl
     return gif::check_launch("conv2d_wgrad_f16");
 }
 
+int gif_conv2d_wgrad_dims(int Cs, int Cb, int* RP, int* CP) {
+    GIF_REQUIRE(Cs > 0 && Cb > 0 && RP && CP, "wgrad_dims: bad arguments");
+    wgrad_dims(Cs, Cb, RP, CP);
+    return 0;
+}
+
+int gif_conv2d_wgrad_splits(const gif_conv_geom* g) {
+    if (!g || g->B <= 0) return 1;
+    if (small_wgrad_ok(g, false)) return 256;  // one 16-wave workgroup per CU (conv_wgrad_small_mfma); scaled calls never
+                                               // reach that kernel and simply use 256 splits of the generic one
+    int RP, CP;
+    wgrad_dims(g->Cs, g->Cb, &RP, &CP);
+    // (scaled launches of the same geometry use 128-row tiles: they simply get half the splits they could use)
+    long Ntot = (long)g->B * g->Hs * g->Ws;
+    long tiles = (long)(RP / tile_rows(g->Cs, g->Cb, false, Ntot)) * (CP / tile_of(g->Cb)) * g->KH * g->KW;
+    // 2 workgroups fit per CU (64 KB LDS each) => 512 concurrent slots on 256 CUs: fill k full rounds of 512
+    // and never spill a few blocks into an extra, almost empty round (floor, not ceil)
+    long want = tiles >= 1024 ? 1 : 1024 / tiles;
+    long max_by_work = (Ntot + 4 * BKP_MAX - 1) / (4 * BKP_MAX);  // >= 4 stages per split
+    long bytes_per_split = (long)g->KH * g->KW * RP * CP * 4;
+    long max_by_mem = (128L << 20) / bytes_per_split;
+    long n = want;
+    if (n > max_by_work) n = max_by_work;
+    if (n > max_by_mem) n = max_by_mem;
+    if (n < 1) n = 1;
+    return (int)n;
+}
+
+int gif_conv2d_wgrad_f32(const float* small, const float* big, float* ws, const float* small_scale,
+                         const float* big_scale, const gif_conv_geom* g, int nsplit, gif_stream_t stream) {
+    GIF_REQUIRE(g && small && big && ws && nsplit >= 1, "conv2d_wgrad: bad arguments");
+    GIF_REQUIRE(g->Cb % 4 == 0 && g->Cs % 4 == 0, "conv2d_wgrad: channels must be multiples of 4");
+    GIF_REQUIRE(g->KH >= 1 && g->KH <= 3 && g->KW >= 1 && g->KW <= 3 && (g->stride == 1 || g->stride == 2),
+                "conv2d_wgrad: unsupported kernel/stride");
+    GIF_REQUIRE((long)g->B * g->Hs * g->Ws * g->Cs < (1L << 31) && (long)g->B * g->Hb * g->Wb * g->Cb < (1L << 31),
+                "conv2d_wgrad: tensors of >= 2^31 elements are not supported (32-bit offsets)");
+    WgradParams p{};
+    p.sm = small; p.bg = big; p.ws = ws; p.ss = small_scale; p.bs = big_scale;
+    p.B = g->B; p.Hs = g->Hs; p.Ws = g->Ws; p.Cs = g->Cs; p.Hb = g->Hb; p.Wb = g->Wb; p.Cb = g->Cb;
+    p.KW = g->KW; p.stride = g->stride; p.pad = g->pad; p.T = g->KH * g->KW;
+    wgrad_dims(g->Cs, g->Cb, &p.RP, &p.CP);
+    p.Ntot = (long)g->B * g->Hs * g->Ws;
+    long chunk = (p.Ntot + nsplit - 1) / nsplit;
+    p.chunk = (chunk + BKP_MAX - 1) / BKP_MAX * BKP_MAX;
+    if (p.chunk < BKP_MAX) p.chunk = BKP_MAX;
+    const int bp = tile_of(g->Cs), bq = tile_of(g->Cb);
+    const bool big_tile = wgrad_big_tile(g->Cs, g->Cb, small_scale || big_scale, p.Ntot) && !getenv("GIF_CONV_VARIANT");
+    p.tiles_q = p.CP / bq;
+    p.tiles_pq = (p.RP / (big_tile ? 256 : bp)) * p.tiles_q;
+    dim3 grid((unsigned)(p.tiles_pq * p.T * nsplit));
+    hipStream_t s = gif::as_stream(stream);
+    p.zero = gif::zero_page16();
+    GIF_REQUIRE(p.zero, "conv2d_wgrad: zero page lookup failed");
+    double flops = 2.0 * p.Ntot * (double)g->Cs * g->Cb * p.T;
+    if (small_wgrad_ok(g, small_scale || big_scale)) {
+        gif::ProfScope prof(1, flops, s, (int)p.Ntot, g->Cs, g->Cb, p.T * 10 + g->stride);
+        SmallWgradParams q{};
+        q.sm = small; q.bg = big; q.ws = ws;
+        q.B = g->B; q.H = g->Hs; q.W = g->Ws; q.Cs = g->Cs; q.Cb = g->Cb; q.RP = p.RP; q.CP = p.CP;
+        q.Ntot = p.Ntot;
+        long ch = (p.Ntot + nsplit - 1) / nsplit;
+        q.chunk = (ch + 63) / 64 * 64;
+        const size_t lds = (size_t)8 * 18 * 256 * sizeof(float);
+        static gif::LdsAttr attr;
+        attr.ensure(reinterpret_cast<const void*>(conv_wgrad_small_mfma), lds);
+        hipLaunchKernelGGL(conv_wgrad_small_mfma, dim3((unsigned)nsplit), dim3(1024), lds, s, q);
+        return gif::check_launch("conv2d_wgrad(small)");
+    }
+    {
+        gif::ProfScope prof(1, flops, s, (int)p.Ntot, g->Cs, g->Cb, p.T * 10 + g->stride + (small_scale || big_scale ? 100 : 0));
+        const char* env = getenv("GIF_CONV_VARIANT");
+        const int variant = env ? atoi(env) : 0;
+        const bool glds = !small_scale && !big_scale && variant != 1;
+#define GIF_WGRAD_LAUNCH(BP_, BQ_, WP_, WQ_, TH_)                                                                  \
+    if (glds) wgrad_launch<float, BP_, BQ_, WP_, WQ_, true, 32>(grid, TH_, s, p);                                        \
+    else wgrad_launch<float, BP_, BQ_, WP_, WQ_, false, 32>(grid, TH_, s, p)
+        const long HWs = (long)g->Hs * g->Ws;
+        p.stab_nb = (int)((p.chunk + HWs - 1) / HWs + 1);
+        if (p.stab_nb > g->B) p.stab_nb = g->B;
+        const bool tab = (small_scale || big_scale) && variant != 1 && HWs % 16 == 0 &&
+                         (size_t)p.stab_nb * 256 * sizeof(float) <= 64 * 1024;
+        if (big_tile) {
+            wgrad_launch<float, 256, 128, 2, 2, true, 16>(grid, 256, s, p);
+        } else if (bp == 128 && bq == 128 && tab) {
+            // modulated wgrad (x*s, dy*d): LDS-DMA operands + scale table
+            wgrad_launch<float, 128, 128, 2, 2, true, 16, true>(grid, 256, s, p);
+        } else if (bp == 128 && bq == 128 && glds && variant != 7) {
+            // 16-pixel stages: 32 KB of LDS per workgroup => 4 workgroups (16 waves) per CU; +6 % over 32-pixel stages
+            wgrad_launch<float, 128, 128, 2, 2, true, 16>(grid, 256, s, p);
+        } else if (bp == 128 && bq == 128) { GIF_WGRAD_LAUNCH(128, 128, 2, 2, 256); }
+        else if (bp == 128 && bq == 32) { GIF_WGRAD_LAUNCH(128, 32, 4, 1, 256); }
+        else if (bp == 32 && bq == 128) { GIF_WGRAD_LAUNCH(32, 128, 1, 4, 256); }
+        else { GIF_WGRAD_LAUNCH(32, 32, 1, 1, 64); }
+#undef GIF_WGRAD_LAUNCH
+    }
+    return gif::check_launch("conv2d_wgrad");
+}
+
 int gif_unpack_wgrad_f32(const float* ws, float* dw, int nsplit, int R, int C, int KH, int KW, int RP, int CP,
                          int64_t sr, int64_t sc, int64_t sky, int64_t skx, float scale, gif_stream_t stream) {
     GIF_REQUIRE(ws && dw && nsplit >= 1 && R > 0 && C > 0 && RP >= R && CP >= C, "unpack_wgrad: bad arguments");
