@@ -175,9 +175,11 @@ class GifTrainer:
 
     Multi-GPU (one process per GPU, torch.distributed initialised by the caller): construction broadcasts rank 0's
     G / D / G_ema parameters and buffers to every rank; each optimiser step all-reduces one flat bucket.  With
-    overlap_comm (default when a process group of size > 1 exists) the discriminator's all-reduce + Adam update are
-    deferred to the point where D is next needed (the D forward of the G step), so the exchange runs under the
-    generator forward; flush() completes anything pending (call it before reading D's weights, e.g. to checkpoint)."""
+    overlap_comm (default when a process group of size > 1 exists) each network's all-reduce + Adam update are deferred to
+    the point where that network is next needed — D's until the D forward of the G step (the exchange runs under the
+    generator forward), G's until the generator forward of the next iteration (under the D forward on the real images) —
+    so neither exchange sits on the critical path; flush() completes anything pending (call it before reading weights or
+    the EMA generator, e.g. to checkpoint)."""
 
     def __init__(self, generator, discriminator, g_running, step=6, alpha=1.0, r1_every=16, gen_reg_type='None',
                  embedding_reg_weight=0.0, lr=0.002, fused_adam=None, process_group=None,
@@ -224,6 +226,7 @@ class GifTrainer:
         self.reuse_generator_forward = reuse_generator_forward
         self.overlap_comm = _dist_on(process_group) if overlap_comm is None else overlap_comm
         self._d_update_pending = False
+        self._g_update_pending = False
         self.g_running_decay = 0.5 ** (32 / (10 * 1000))
         self.G_ema.train(False)
         requires_grad(self.G, False)  # train.py:68
@@ -244,11 +247,25 @@ class GifTrainer:
             self._d_optim_step()
 
     def flush(self):
-        """Complete a deferred discriminator update (overlap_comm)."""
+        """Complete the deferred updates (overlap_comm)."""
         self._finish_d_update()
+        self._finish_g_update()
+
+    def _finish_g_update(self):
+        if self._g_update_pending:
+            self._g_update_pending = False
+            self.g_bucket.wait()
+            self._g_optim_step()
 
     def _g_update(self):
+        if self.overlap_comm:
+            self.g_bucket.all_reduce_mean(async_op=True)
+            self._g_update_pending = True  # completed right before G is used again
+            return
         self.g_bucket.all_reduce_mean()
+        self._g_optim_step()
+
+    def _g_optim_step(self):
         if self.g_scaler is not None:
             self.g_scaler.update(self.g_bucket.flat)
             self.g_optim.step(ema_decay=self.g_running_decay, inv_grad_scale=self.g_scaler.inv_scale,
@@ -278,6 +295,7 @@ class GifTrainer:
             real_loss = real_loss + losses.grad_penalty_loss([real_image], real_scores, step=None,
                                                              grad_scale=(2.0 ** 10 if self.f16 else 1.0)).mean()
         if fake is None:
+            self._finish_g_update()  # G's exchange of the previous iteration ran under the D forward above
             with torch.no_grad():  # the reference detaches the fake image right after the forward (train.py:160)
                 fake = G(cond, None, step=self.res_step, alpha=self.alpha, input_indices=input_indices)[0]
         fake_scores, _ = D([fake.detach()], condition=cond, step=self.res_step, alpha=self.alpha)
@@ -295,6 +313,7 @@ class GifTrainer:
     def g_step(self, cond, input_indices, fake=None):
         """train.py:189-252"""
         G, D = self.G, self.D
+        self._finish_g_update()
         requires_grad(G, True)
         requires_grad(D, False)
         self.g_bucket.zero()
@@ -324,6 +343,7 @@ class GifTrainer:
 
     def step(self, i, real_image, cond, input_indices):
         if self.reuse_generator_forward:
+            self._finish_g_update()
             requires_grad(self.G, True)
             fake = self.G(cond, None, step=self.res_step, alpha=self.alpha, input_indices=input_indices)
             d_loss = self.d_step(i, real_image, cond, input_indices, fake=fake[0])
