@@ -270,8 +270,12 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU path)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("GIF_FORCE_DIST") == "1"  # (forced: RCCL code paths on a 1-GPU box, tests)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
 
     from gif_amd import ops
@@ -313,7 +317,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -333,7 +337,7 @@ def main():
     ops.prof_enable(False)
 
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = t.item()
 
@@ -372,7 +376,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.res, res_step, args.cpu_batch, args.cpu_threads, args.cpu_timeout)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -82,6 +82,9 @@ PROTOTYPES = {
     "gif_colsum_f16": (c_int, [P, P, P, c_i64, c_int, P]),
     "gif_mul_reduce_f16": (c_int, [P, P, P, P, P, P, c_int, c_i64, c_int, P]),
     "gif_act_inv_mul_reduce_f16": (c_int, [P, P, P, P, P, P, c_int, c_i64, c_int, c_float, c_float, P]),
+    "gif_linear_nt_f32": (c_int, [P, P, P, P] + [c_int] * 7 + [c_float, c_int, c_float, c_float, P]),
+    "gif_linear_nn_f32": (c_int, [P, P, P] + [c_int] * 7 + [c_float, P]),
+    "gif_linear_tn_f32": (c_int, [P, P, P] + [c_int] * 6 + [c_float, P]),
     "gif_adam_chunk_floats": (c_int, []),
     "gif_adam_ema_step_f32": (c_int, [P, c_int, P, P, P, c_float, c_float, c_float, c_float, ctypes.c_double, ctypes.c_double,
                                       c_float, c_int, P, P, P]),

@@ -1,0 +1,194 @@
+// Skinny fp32 GEMMs for the linear layers of the G/D step (EqualLinear, stylegan2_common_layers.py:193-235: the 8-layer
+// mapping network, every modulation linear, the demodulation contraction and the discriminator head), gfx950.
+//
+// These are [rows x 512..8192] x [512..8192 x 512] products with rows = batch (4..64): a few MFLOP each, pure latency.
+// On the implicit-GEMM conv kernels (a 1x1 conv over a [rows, K, 1, 1] image) one launch costs 16 K-steps of
+// DMA -> barrier -> MFMA on 8 workgroups = 20 us (240 us for the 8192-wide head).  Here every operand goes straight from
+// global memory (L2 resident: the activations are <= 256 KB, a weight matrix 1 MB) into v_mfma_f32_32x32x2_f32 operands,
+// all loads of a wave are issued before its first MFMA, and the reduction axis is split over the waves of a workgroup
+// (fixed-order LDS reduction, deterministic).  Three access patterns, closed under differentiation:
+//   NT  C[m][n] = act(scale * sum_k A[m][k] * B[n][k] + bias[n])      forward            (A, B k-contiguous: 16-byte loads)
+//   NN  C[m][k] = scale * sum_n A[m][n] * B[n][k]                      data gradient      (B rows read 128 B per half wave)
+//   TN  C[n][k] = scale * sum_m A[m][n] * B[m][k]                      weight gradient    (both operands coalesced dwords)
+// MFMA operand convention (lane l: i = l & 31, h = l >> 5): A[i][kk], B[kk][i] with kk = 2*step + h; any K permutation
+// applied to BOTH operands is legal, which is what lets a lane consume a float4 (k = 8c + 4h + t, t = 0..3) as 4 steps.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct SkinnyParams {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;
+    int M, N, K;        // NT: C[M][N], reduce K.  NN: C[M][K], reduce N.  TN: C[N][K], reduce M.
+    int lda, ldb, ldc;  // row strides in floats
+    int cpad;           // NT / NN: columns [valid, cpad) of C are written as zero (channel padding of the caller)
+    float scale;
+    int act;
+    float slope, gain;
+};
+
+constexpr int SK_WAVES = 16;  // waves per workgroup = ways the reduction axis is split
+
+// fixed-order reduction of the SK_WAVES accumulator tiles through LDS + epilogue; C/D map of the 32x32 MFMA:
+// col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+__device__ __forceinline__ void reduce_store(const SkinnyParams& p, f32x16 acc, float (*red)[16][64], int wave, int lane, int row0,
+                                             int col0, int rows_valid, int cols_valid, int cols_pad, bool epilogue) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+    __syncthreads();
+    const int li = lane & 31, lh = lane >> 5;
+    const int r = wave;  // SK_WAVES == 16 accumulator registers: wave w finishes register w
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < SK_WAVES; ++w) s += red[w][r][lane];
+    const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lh, col = col0 + li;
+    if (row < rows_valid && col < cols_pad) {
+        float v = 0.f;
+        if (col < cols_valid) {
+            v = s * p.scale;
+            if (epilogue) {
+                if (p.bias) v += p.bias[col];
+                if (p.act) v = (v > 0.f ? v : v * p.slope) * p.gain;
+            }
+        }
+        p.C[(size_t)row * p.ldc + col] = v;
+    }
+}
+
+__global__ void __launch_bounds__(64 * SK_WAVES) skinny_nt_kernel(const SkinnyParams p) {
+    __shared__ float red[SK_WAVES][16][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+    const bool a_ok = m0 + li < p.M, b_ok = n0 + li < p.N;
+    const float* ap = p.A + (size_t)(a_ok ? m0 + li : 0) * p.lda + 4 * lh;
+    const float* bp = p.B + (size_t)(b_ok ? n0 + li : 0) * p.ldb + 4 * lh;
+    const int nchunks = (p.K + 7) / 8;  // chunk c: k = 8c .. 8c+7, this lane half takes 8c + 4h .. +3
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    constexpr int U = 4;  // chunks in flight per wave iteration
+    for (int c0 = wave * U; c0 < nchunks; c0 += SK_WAVES * U) {
+        f32x4 av[U], bv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = 8 * (c0 + u) + 4 * lh;
+            const bool ok = k < p.K;  // K % 4 == 0: a float4 is inside or outside as a whole
+            av[u] = (ok && a_ok) ? *reinterpret_cast<const f32x4*>(ap + 8 * (c0 + u)) : (f32x4)(0.f);
+            bv[u] = (ok && b_ok) ? *reinterpret_cast<const f32x4*>(bp + 8 * (c0 + u)) : (f32x4)(0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][t], bv[u][t], acc, 0, 0, 0);
+    }
+    reduce_store(p, acc, red, wave, lane, m0, n0, p.M, p.N, p.cpad, true);
+}
+
+__global__ void __launch_bounds__(64 * SK_WAVES) skinny_nn_kernel(const SkinnyParams p) {
+    __shared__ float red[SK_WAVES][16][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int k0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+    const bool a_ok = m0 + li < p.M, b_ok = k0 + li < p.K;
+    const float* ap = p.A + (size_t)(a_ok ? m0 + li : 0) * p.lda + 4 * lh;  // A[m][n]: float4 along n
+    const float* bp = p.B + (b_ok ? k0 + li : 0);                           // B[n][k0 + li]: one dword per n
+    const int nchunks = (p.N + 7) / 8;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    constexpr int U = 4;
+    for (int c0 = wave * U; c0 < nchunks; c0 += SK_WAVES * U) {
+        f32x4 av[U];
+        float bv[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int n = 8 * (c0 + u) + 4 * lh;
+            av[u] = (n < p.N && a_ok) ? *reinterpret_cast<const f32x4*>(ap + 8 * (c0 + u)) : (f32x4)(0.f);  // in-row: lda >= pad4(N)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bv[u][t] = (n + t < p.N && b_ok) ? bp[(size_t)(n + t) * p.ldb] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][t], bv[u][t], acc, 0, 0, 0);
+    }
+    reduce_store(p, acc, red, wave, lane, m0, k0, p.M, p.K, p.cpad, false);
+}
+
+// one wave = one 32x32 tile of C[N][K]; the reduction axis (rows m) is short, no split
+__global__ void __launch_bounds__(256) skinny_tn_kernel(const SkinnyParams p) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int tiles_k = (p.K + 31) / 32;
+    const int tile = blockIdx.x * 4 + wave;
+    const int tn = tile / tiles_k, tk = tile - tn * tiles_k;
+    const int n0 = tn * 32, k0 = tk * 32;
+    if (n0 >= p.N) return;
+    const bool a_ok = n0 + li < p.N, b_ok = k0 + li < p.K;
+    const float* ap = p.A + (a_ok ? n0 + li : 0);  // A[m][n0 + li]
+    const float* bp = p.B + (b_ok ? k0 + li : 0);  // B[m][k0 + li]
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    constexpr int U = 8;
+    for (int m0 = 0; m0 < p.M; m0 += 2 * U) {
+        float av[U], bv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int m = m0 + 2 * u + lh;
+            av[u] = (m < p.M && a_ok) ? ap[(size_t)m * p.lda] : 0.f;
+            bv[u] = (m < p.M && b_ok) ? bp[(size_t)m * p.ldb] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = n0 + (r & 3) + 8 * (r >> 2) + 4 * lh, col = k0 + li;
+        if (row < p.N && col < p.K) p.C[(size_t)row * p.ldc + col] = acc[r] * p.scale;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int gif_linear_nt_f32(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                      int cpad, float scale, int act, float slope, float gain, gif_stream_t stream) {
+    GIF_REQUIRE(A && B && C && M >= 0 && N > 0 && K > 0, "linear_nt: bad arguments");
+    GIF_REQUIRE(K % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0,
+                "linear_nt: K and the row strides must be multiples of 4 floats, operands 16-byte aligned (K=%d lda=%d ldb=%d)", K, lda, ldb);
+    GIF_REQUIRE(cpad >= N && ldc >= cpad, "linear_nt: cpad %d / ldc %d too small for N=%d", cpad, ldc, N);
+    if (M == 0) return 0;
+    SkinnyParams p{A, B, C, bias, M, N, K, lda, ldb, ldc, cpad, scale, act, slope, gain};
+    skinny_nt_kernel<<<dim3(gif::cdiv(cpad, 32), gif::cdiv(M, 32)), 64 * SK_WAVES, 0, gif::as_stream(stream)>>>(p);
+    return gif::check_launch("linear_nt");
+}
+
+int gif_linear_nn_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int cpad,
+                      float scale, gif_stream_t stream) {
+    GIF_REQUIRE(A && B && C && M >= 0 && N > 0 && K > 0, "linear_nn: bad arguments");
+    GIF_REQUIRE(lda % 4 == 0 && lda >= (N + 3) / 4 * 4 && ((uintptr_t)A & 15) == 0,
+                "linear_nn: lda must be a multiple of 4 floats covering N rounded up to 4, A 16-byte aligned (N=%d lda=%d)", N, lda);
+    GIF_REQUIRE(cpad >= K && ldc >= cpad, "linear_nn: cpad %d / ldc %d too small for K=%d", cpad, ldc, K);
+    if (M == 0) return 0;
+    SkinnyParams p{A, B, C, nullptr, M, N, K, lda, ldb, ldc, cpad, scale, 0, 1.f, 1.f};
+    skinny_nn_kernel<<<dim3(gif::cdiv(cpad, 32), gif::cdiv(M, 32)), 64 * SK_WAVES, 0, gif::as_stream(stream)>>>(p);
+    return gif::check_launch("linear_nn");
+}
+
+int gif_linear_tn_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, float scale,
+                      gif_stream_t stream) {
+    GIF_REQUIRE(A && B && C && M >= 0 && N > 0 && K > 0 && ldc >= K, "linear_tn: bad arguments");
+    SkinnyParams p{A, B, C, nullptr, M, N, K, lda, ldb, ldc, K, scale, 0, 1.f, 1.f};
+    const int tiles = gif::cdiv(N, 32) * gif::cdiv(K, 32);
+    skinny_tn_kernel<<<gif::cdiv(tiles, 4), 256, 0, gif::as_stream(stream)>>>(p);
+    return gif::check_launch("linear_tn");
+}
+}

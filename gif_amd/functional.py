@@ -133,6 +133,101 @@ def conv_transpose2d(x, w, stride, pad, out_hw, wscale=1.0):
 
 
 # --------------------------------------------------------------------------------------------------------
+# linear layers (EqualLinear, stylegan2_common_layers.py:193-235) on the skinny-GEMM kernels (csrc/linear.hip).
+# Three products, closed under differentiation like Conv2dFn / WgradFn (R1 differentiates the discriminator head twice, the
+# path-length regulariser the mapping network):  nt: a @ b^T   nn: a @ b   tn: a^T @ b.   Column padding is explicit: an
+# operand may carry zero columns beyond the logical width, outputs are produced with the requested padded width.
+# --------------------------------------------------------------------------------------------------------
+class LinearNtFn(Function):
+    """y [M, n_pad] = scale * a[:, :K] @ b[N, K]^T  (columns N..n_pad zero)."""
+
+    @staticmethod
+    def forward(ctx, a, b, scale, n_pad):
+        ctx.scale = scale
+        ctx.save_for_backward(a, b)
+        return ops.linear_nt(a, b, None, scale, n_pad=n_pad)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        N, K = b.shape
+        ga = LinearNnFn.apply(g, b, ctx.scale, a.shape[1]) if ctx.needs_input_grad[0] else None
+        gb = LinearTnFn.apply(g, a, ctx.scale, N, K) if ctx.needs_input_grad[1] else None
+        return ga, gb, None, None
+
+
+class LinearNnFn(Function):
+    """y [M, k_pad] = scale * a[:, :N] @ b[N, K]  (columns K..k_pad zero)."""
+
+    @staticmethod
+    def forward(ctx, a, b, scale, k_pad):
+        ctx.scale = scale
+        ctx.save_for_backward(a, b)
+        return ops.linear_nn(a, b, scale, k_pad=k_pad)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        N, K = b.shape
+        ga = LinearNtFn.apply(g, b, ctx.scale, a.shape[1]) if ctx.needs_input_grad[0] else None
+        gb = LinearTnFn.apply(a, g, ctx.scale, N, K) if ctx.needs_input_grad[1] else None
+        return ga, gb, None, None
+
+
+class LinearTnFn(Function):
+    """y [N, K] = scale * a[:, :N]^T @ b[:, :K]."""
+
+    @staticmethod
+    def forward(ctx, a, b, scale, N, K):
+        ctx.scale = scale
+        ctx.save_for_backward(a, b)
+        return ops.linear_tn(a, b, scale, n_valid=N, k_valid=K)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        ga = LinearNtFn.apply(b, g, ctx.scale, a.shape[1]) if ctx.needs_input_grad[0] else None
+        gb = LinearNnFn.apply(a, g, ctx.scale, b.shape[1]) if ctx.needs_input_grad[1] else None
+        return ga, gb, None, None, None
+
+
+class LinearBiasActFn(Function):
+    """y [M, n_pad] = gain * lrelu(scale * x @ w^T + bias)  (act) or scale * x @ w^T + bias: one launch, bias and activation in
+    the GEMM epilogue; backward composed of BiasActBwdFn + LinearNnFn + LinearTnFn (any order)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, scale, act, slope, gain, n_pad):
+        y = ops.linear_nt(x, w, bias, scale, act=act, slope=slope, gain=gain, n_pad=n_pad)
+        ctx.cfg = (scale, act, slope, gain, bias is not None)
+        ctx.save_for_backward(x, w, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        scale, act, slope, gain, has_bias = ctx.cfg
+        N, K = w.shape
+        want_b = has_bias and ctx.needs_input_grad[2]
+        M, n_pad = y.shape
+        if act:
+            gpre, gb = BiasActBwdFn.apply(gy.reshape(M, n_pad, 1, 1), y.reshape(M, n_pad, 1, 1), want_b, slope, gain)
+        else:
+            gpre, gb = BiasActBwdFn.apply(gy.reshape(M, n_pad, 1, 1), y.reshape(M, n_pad, 1, 1), want_b, 1.0, 1.0)
+        gpre = gpre.reshape(M, n_pad)
+        gx = LinearNnFn.apply(gpre, w, scale, x.shape[1]) if ctx.needs_input_grad[0] else None
+        gw = LinearTnFn.apply(gpre, x, scale, N, K) if ctx.needs_input_grad[1] else None
+        return gx, gw, (gb if want_b else None), None, None, None, None, None
+
+
+def linear_bias_act(x, w, bias=None, scale=1.0, act=False, slope=0.2, gain=1.0, n_pad=None):
+    """x [M, K'] (K' >= K = w.shape[1], K % 4 == 0), w [N, K], bias [n_pad] or None -> [M, n_pad]."""
+    n_pad = w.shape[0] if n_pad is None else n_pad
+    if bias is None and not act:
+        return LinearNtFn.apply(x, w, scale, n_pad)
+    return LinearBiasActFn.apply(x, w, bias, scale, bool(act), slope, gain, n_pad)
+
+
+# --------------------------------------------------------------------------------------------------------
 # fused bias + leaky ReLU (FusedLeakyReLU, stylegan2_common_layers.py:22-39)
 # --------------------------------------------------------------------------------------------------------
 class BiasActFn(Function):

@@ -20,6 +20,7 @@ from .ops import cpad, pad4
 
 # A/B benchmarking switch only (GIF_HIP_LINEAR=0): EqualLinear through torch's library GEMM instead of the HIP conv kernels
 _HIP_LINEAR = os.environ.get("GIF_HIP_LINEAR", "1") != "0"
+_SKINNY_MAX_ROWS = int(os.environ.get("GIF_SKINNY_MAX_ROWS", "512"))  # above: the implicit-GEMM conv kernels take over
 
 
 def _pad_vec(v, n):
@@ -121,11 +122,11 @@ class EqualConv2d(nn.Module):
 class EqualLinear(nn.Module):
     """Reference :193-235 — y = [sqrt(2) *] lrelu(x @ (W * scale)^T + bias * lr_mul).
 
-    Runs on the fp32 MFMA implicit-GEMM kernels as a 1x1 convolution over a [rows, in_dim, 1, 1] "image": the equalised-lr
-    weight scale is folded into the weight packing (cached per parameter version), bias and leaky ReLU into the conv
-    epilogue, i.e. ONE launch per layer in the forward pass — the mapping network (8 layers), every modulation linear and
-    the discriminator head all go through it.  Backward = the any-order conv Functions (R1 differentiates the head twice,
-    the StyleGAN2-form path-length regulariser the mapping network).  No CPU path."""
+    Batch-sized inputs (the mapping network's 8 layers, every modulation linear, the discriminator head) run on the fp32
+    skinny-GEMM kernels of csrc/linear.hip: ONE launch per layer forward with the equalised-lr scale, bias and leaky ReLU
+    in the epilogue; inputs with many rows fall through to the implicit-GEMM conv kernels (a 1x1 convolution).  Backward =
+    any-order Functions in both cases (R1 differentiates the head twice, the StyleGAN2-form path-length regulariser the
+    mapping network).  No CPU path."""
 
     def __init__(self, in_dim, out_dim, bias=True, bias_init=0, lr_mul=1, activation=None, scale_weight=1.0,
                  apply_sqrt2_fac_in_eq_lin=False):
@@ -148,20 +149,27 @@ class EqualLinear(nn.Module):
         x = input.reshape(-1, in_dim)
         if x.dtype != torch.float32:
             x = x.float()
-        kp = pad4(in_dim)
-        if kp != in_dim:
-            x = F.pad(x, (0, kp - in_dim))
-        x = x.reshape(x.shape[0], kp, 1, 1)
-        w = self.weight.view(out_dim, in_dim, 1, 1)
-        bias = None if self.bias is None else _pad_vec(self.bias * self.lr_mul, pad4(out_dim))
-        if self.activation:
-            gain = 1.41421356237 if self.apply_sqrt2_fac_in_eq_lin else 1.0
-            out = GF.conv2d_bias_act(x, w, bias, 1, 0, self.scale, 0.2, gain)
-        elif bias is not None:
-            out = GF.conv2d_bias_act(x, w, bias, 1, 0, self.scale, 1.0, 1.0)  # slope 1 / gain 1: bias only, no activation
+        np_ = pad4(out_dim)
+        bias = None if self.bias is None else _pad_vec(self.bias * self.lr_mul, np_)
+        gain = (1.41421356237 if self.apply_sqrt2_fac_in_eq_lin else 1.0) if self.activation else 1.0
+        if in_dim % 4 == 0 and x.shape[0] <= _SKINNY_MAX_ROWS and np_ <= 1024:
+            # batch-sized row counts: the skinny-GEMM kernels (csrc/linear.hip), one launch, epilogue fused
+            out = GF.linear_bias_act(x, self.weight, bias, self.scale, bool(self.activation), 0.2, gain, np_)
         else:
-            out = GF.conv2d(x, w, 1, 0, wscale=self.scale)
-        out = out.reshape(out.shape[0], -1)
+            # many rows (e.g. the mean style over the whole code book) or an odd width: a 1x1 convolution over a
+            # [rows, in_dim, 1, 1] image on the implicit-GEMM kernels (weight scale folded into the cached packing)
+            kp = pad4(in_dim)
+            if kp != in_dim:
+                x = F.pad(x, (0, kp - in_dim))
+            x = x.reshape(x.shape[0], kp, 1, 1)
+            w = self.weight.view(out_dim, in_dim, 1, 1)
+            if self.activation:
+                out = GF.conv2d_bias_act(x, w, bias, 1, 0, self.scale, 0.2, gain)
+            elif bias is not None:
+                out = GF.conv2d_bias_act(x, w, bias, 1, 0, self.scale, 1.0, 1.0)  # slope 1 / gain 1: bias only
+            else:
+                out = GF.conv2d(x, w, 1, 0, wscale=self.scale)
+            out = out.reshape(out.shape[0], -1)
         if out.shape[1] != out_dim:
             out = out[:, :out_dim]
         return out.reshape(*lead, out_dim)
@@ -220,13 +228,17 @@ class ModulatedConv2d(nn.Module):
             wsq = self.weight[0].pow(2).sum(dim=(2, 3))  # [Cout, Cin]
             if not _HIP_LINEAR:
                 return s, torch.rsqrt((self.scale ** 2) * (s.pow(2) @ wsq.t()) + self.eps)
-            # sum_ci s^2 * wsq as a 1x1 convolution on the MFMA kernel (like EqualLinear): d = rsqrt(scale^2 * (s^2 @ wsq^T) + eps)
-            cin = s.shape[1]
+            # sum_ci s^2 * wsq on the MFMA kernels (like EqualLinear): d = rsqrt(scale^2 * (s^2 @ wsq^T) + eps)
+            cin, cout = s.shape[1], wsq.shape[0]
             s2 = s.pow(2)
-            if pad4(cin) != cin:
-                s2 = F.pad(s2, (0, pad4(cin) - cin))
-            acc = GF.conv2d(s2.reshape(s.shape[0], -1, 1, 1), wsq.view(wsq.shape[0], cin, 1, 1), 1, 0, wscale=self.scale ** 2)
-            d = torch.rsqrt(acc.reshape(s.shape[0], -1)[:, :wsq.shape[0]] + self.eps)
+            if cin % 4 == 0 and s.shape[0] <= _SKINNY_MAX_ROWS:
+                acc = GF.linear_bias_act(s2, wsq, None, self.scale ** 2, n_pad=cout)
+            else:
+                if pad4(cin) != cin:
+                    s2 = F.pad(s2, (0, pad4(cin) - cin))
+                acc = GF.conv2d(s2.reshape(s.shape[0], -1, 1, 1), wsq.view(cout, cin, 1, 1), 1, 0, wscale=self.scale ** 2)
+                acc = acc.reshape(s.shape[0], -1)[:, :cout]
+            d = torch.rsqrt(acc + self.eps)
         return s, d
 
     def _padded_scales(self, style, in_act, dtype=torch.float32):

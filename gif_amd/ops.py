@@ -555,6 +555,59 @@ for _name in ("pack_weight", "conv3x3_winograd", "conv_fwd", "conv_bwd_data", "c
 del _name
 
 
+def _mat(t, what):
+    if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2:
+        raise _lib.GifHipError(f"{what}: need a 2-D fp32 device tensor (no CPU fallback), got {tuple(t.shape)} {t.dtype} on {t.device}")
+    return t if t.stride(1) == 1 and t.stride(0) >= t.shape[1] and t.data_ptr() % 16 == 0 and t.stride(0) % 4 == 0 else t.contiguous()
+
+
+def linear_nt(a, b, bias=None, scale=1.0, act=False, slope=0.2, gain=1.0, n_pad=None):
+    """[M, n_pad] = act(scale * a[M,K] @ b[N,K]^T + bias[n_pad]); columns N..n_pad are zero.  K % 4 == 0."""
+    lib = _lib.load()
+    a, b = _mat(a, "linear_nt"), _mat(b, "linear_nt")
+    M, K = a.shape
+    N = b.shape[0]
+    assert b.shape[1] == K
+    n_pad = N if n_pad is None else n_pad
+    c = torch.empty((M, n_pad), device=a.device, dtype=torch.float32)
+    _lib.check(lib.gif_linear_nt_f32(a.data_ptr(), b.data_ptr(), _p(bias), c.data_ptr(), M, N, K, a.stride(0), b.stride(0), n_pad,
+                                     n_pad, float(scale), 1 if act else 0, float(slope), float(gain), _stream()), "linear_nt")
+    return c
+
+
+def linear_nn(a, b, scale=1.0, n_valid=None, k_pad=None):
+    """[M, k_pad] = scale * a[M, :n_valid] @ b[n_valid, K]; columns K..k_pad are zero."""
+    lib = _lib.load()
+    a, b = _mat(a, "linear_nn"), _mat(b, "linear_nn")
+    M = a.shape[0]
+    N, K = b.shape
+    assert a.shape[1] >= N
+    k_pad = K if k_pad is None else k_pad
+    c = torch.empty((M, k_pad), device=a.device, dtype=torch.float32)
+    _lib.check(lib.gif_linear_nn_f32(a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, a.stride(0), b.stride(0), k_pad, k_pad,
+                                     float(scale), _stream()), "linear_nn")
+    return c
+
+
+def linear_tn(a, b, scale=1.0, n_valid=None, k_valid=None):
+    """[n_valid, k_valid] = scale * a[M, :n_valid]^T @ b[M, :k_valid]."""
+    lib = _lib.load()
+    a, b = _mat(a, "linear_tn"), _mat(b, "linear_tn")
+    M = a.shape[0]
+    assert b.shape[0] == M
+    N = a.shape[1] if n_valid is None else n_valid
+    K = b.shape[1] if k_valid is None else k_valid
+    c = torch.empty((N, K), device=a.device, dtype=torch.float32)
+    _lib.check(lib.gif_linear_tn_f32(a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, a.stride(0), b.stride(0), K, float(scale),
+                                     _stream()), "linear_tn")
+    return c
+
+
+for _name in ("linear_nt", "linear_nn", "linear_tn"):
+    globals()[_name] = _device_guard(globals()[_name])
+del _name
+
+
 def prof_enable(on: bool):
     _lib.load().gif_prof_enable(1 if on else 0)
 

@@ -10,6 +10,8 @@ Semantics that change with DataParallel -> per-rank replicas: param
 from rank 0 ONCE, at construction (DataParallel re-broadcasts them on every forward); minibatch-stddev groups are
 formed inside the per-rank batch.
 """
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn.functional as F
@@ -32,7 +34,11 @@ def accumulate(model1, model2, decay=0.999):  # my_utils/generic_utils.py:63-76 
 
 
 def _dist_on(group=None):
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    """A process group with more than one rank exists.  GIF_FORCE_DIST=1 also takes the collective code paths in a group of
+    ONE rank (tests: the RCCL calls — broadcast, asynchronous AVG all-reduce, waits — are exercised on a single-GPU box)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or os.environ.get("GIF_FORCE_DIST") == "1"
 
 
 @torch.no_grad()

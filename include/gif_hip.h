@@ -300,6 +300,22 @@ int gif_act_inv_mul_reduce_f16(const void* g, const void* y, const void* residua
                                float* partial, int B, int64_t HW, int C, float slope, float gain, gif_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Skinny fp32 GEMMs of the linear layers — replace F.linear and its autograd in EqualLinear.forward
+ * (stylegan2_common_layers.py:218-232: mapping network, modulation linears, discriminator head) when the row count is the
+ * batch size.  Row-major operands with explicit row strides (floats); deterministic (fixed-order reduction).
+ *   gif_linear_nt_f32: C[M][0:N] = act(scale * A[M][K] . B[N][K]^T + bias[N]), columns [N, cpad) written as zero
+ *   gif_linear_nn_f32: C[M][0:K] = scale * A[M][N] . B[N][K]                  , columns [K, cpad) written as zero   (d/dx)
+ *   gif_linear_tn_f32: C[N][K]   = scale * A[M][N]^T . B[M][K]                                                      (d/dW)
+ * act: 0 identity, 1 gain * leaky_relu(., slope).  NT needs K, lda, ldb multiples of 4 and 16-byte aligned A, B.
+ * ---------------------------------------------------------------------------------------------- */
+int gif_linear_nt_f32(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int lda, int ldb,
+                      int ldc, int cpad, float scale, int act, float slope, float gain, gif_stream_t stream);
+int gif_linear_nn_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int cpad,
+                      float scale, gif_stream_t stream);
+int gif_linear_tn_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, float scale,
+                      gif_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Fused Adam (+ EMA generator) over the flat gradient bucket — replaces torch.optim.Adam.step() (train.py:173, :243;
  * Adam(lr, betas=(0, 0.99**r)): no weight decay, no amsgrad) and generic_utils.accumulate (my_utils/generic_utils.py:63-76)
  * by one launch.  grad / exp_avg / exp_avg_sq are flat buffers sharing one offset table; parameters (and the EMA copies,

@@ -156,7 +156,31 @@ def sqnorm_per_sample(g):
     return g.reshape(g.shape[0], -1).pow(2).sum(dim=1)
 
 
-OPS = dict(nhwc=nhwc, conv_fwd=conv_fwd, conv_bwd_data=conv_bwd_data, conv_wgrad=conv_wgrad, upfirdn2d=upfirdn2d,
+def linear_nt(a, b, bias=None, scale=1.0, act=False, slope=0.2, gain=1.0, n_pad=None):
+    N, K = b.shape
+    n_pad = N if n_pad is None else n_pad
+    y = F.pad(scale * (a[:, :K] @ b.t()), (0, n_pad - N))
+    valid = torch.arange(n_pad) < N
+    if bias is not None:
+        y = y + bias[None, :] * valid
+    if act:
+        y = gain * F.leaky_relu(y, slope)
+    return y * valid  # padding columns are written as zero
+
+
+def linear_nn(a, b, scale=1.0, n_valid=None, k_pad=None):
+    N, K = b.shape
+    k_pad = K if k_pad is None else k_pad
+    return F.pad(scale * (a[:, :N] @ b), (0, k_pad - K))
+
+
+def linear_tn(a, b, scale=1.0, n_valid=None, k_valid=None):
+    N = a.shape[1] if n_valid is None else n_valid
+    K = b.shape[1] if k_valid is None else k_valid
+    return scale * (a[:, :N].t() @ b[:, :K])
+
+
+OPS = dict(linear_nt=linear_nt, linear_nn=linear_nn, linear_tn=linear_tn, nhwc=nhwc, conv_fwd=conv_fwd, conv_bwd_data=conv_bwd_data, conv_wgrad=conv_wgrad, upfirdn2d=upfirdn2d,
            bias_act=bias_act, bias_act_bwd=bias_act_bwd, colsum=colsum, mul_reduce=mul_reduce,
            act_inv_mul_reduce=act_inv_mul_reduce, bilinear_down=bilinear_down, mbstd_fwd=mbstd_fwd, mbstd_bwd=mbstd_bwd,
            sqnorm_per_sample=sqnorm_per_sample)

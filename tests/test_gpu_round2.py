@@ -153,6 +153,38 @@ def test_raw_functions_refuse_a_double_backward():
 # ------------------------------------------------------------------------------------------------------------------------
 # a6: EqualLinear / mapping network on the HIP kernels
 # ------------------------------------------------------------------------------------------------------------------------
+def test_skinny_gemm_kernels_vs_torch():
+    """csrc/linear.hip: the three products (nt / nn / tn) with ragged row counts, column padding, strided operands, the fused
+    bias + leaky-ReLU epilogue; fp32 MFMA accumulates in a fixed order, so the results are also run-to-run identical."""
+    from gif_amd import ops
+    g = torch.Generator().manual_seed(21)
+    for M, N, K in [(32, 512, 512), (4, 512, 8192), (1, 1, 512), (33, 96, 64), (100, 40, 24), (64, 516, 128), (7, 5, 8)]:
+        a = torch.randn(M, K + 4, generator=g)[:, :K]            # row stride K + 4: operands with padding columns
+        b = torch.randn(N, K, generator=g)
+        bias = torch.randn((N + 3) // 4 * 4, generator=g)
+        n_pad = (N + 3) // 4 * 4
+        ad = torch.cat([a, torch.zeros(M, 4)], 1).cuda()          # [M, K + 4] on the device, the kernels read K columns
+        bd = b.cuda()
+        ref = 0.37 * (a @ b.t())
+        got = ops.linear_nt(ad, bd, None, 0.37, n_pad=n_pad)
+        assert got.shape == (M, n_pad)
+        assert_close(got[:, :N], ref, 2e-5, f"linear_nt {M}x{N}x{K}")
+        assert (got[:, N:] == 0).all(), "padding columns must be zero"
+        assert torch.equal(got, ops.linear_nt(ad, bd, None, 0.37, n_pad=n_pad)), "deterministic"
+        refa = 2 ** 0.5 * F.leaky_relu(ref + bias[None, :N], 0.2)
+        gota = ops.linear_nt(ad, bd, bias.cuda(), 0.37, act=True, slope=0.2, gain=2 ** 0.5, n_pad=n_pad)
+        assert_close(gota[:, :N], refa, 2e-5, f"linear_nt + bias + lrelu {M}x{N}x{K}")
+        gy = torch.randn(M, n_pad, generator=g)
+        gy[:, N:] = 0
+        k_pad = (K + 3) // 4 * 4 + 4
+        gotx = ops.linear_nn(gy.cuda(), bd, 0.37, k_pad=k_pad)
+        assert_close(gotx[:, :K], 0.37 * (gy[:, :N] @ b), 2e-5, f"linear_nn {M}x{N}x{K}")
+        assert (gotx[:, K:] == 0).all()
+        gotw = ops.linear_tn(gy.cuda(), ad, 0.37, n_valid=N, k_valid=K)
+        assert gotw.shape == (N, K)
+        assert_close(gotw, 0.37 * (gy[:, :N].t() @ a), 2e-5, f"linear_tn {M}x{N}x{K}")
+
+
 def test_equal_linear_on_hip_kernels_vs_oracle():
     """EqualLinear (mapping network, modulation linears, discriminator head) runs as a 1x1 convolution on the MFMA kernels:
     forward, first-order gradients and a double backward against the oracle's torch restatement, incl. lr_mul, the optional
@@ -164,14 +196,16 @@ def test_equal_linear_on_hip_kernels_vs_oracle():
              dict(in_dim=512, out_dim=128, bias_init=1),                                      # modulation linear
              dict(in_dim=8192, out_dim=512, activation='fused_lrelu'),                        # D head, first linear
              dict(in_dim=512, out_dim=1),                                                     # D head, score
-             dict(in_dim=671, out_dim=96, activation='fused_lrelu', apply_sqrt2_fac_in_eq_lin=True),
-             dict(in_dim=64, out_dim=40, bias=False)]
+             dict(in_dim=671, out_dim=96, activation='fused_lrelu', apply_sqrt2_fac_in_eq_lin=True),  # odd width: conv path
+             dict(in_dim=64, out_dim=40, bias=False),
+             dict(in_dim=512, out_dim=512, lr_mul=0.01, activation='fused_lrelu', rows=700)]       # many rows: conv path
     for kw in cases:
+        rows = kw.pop("rows", None)
         m = L.EqualLinear(**kw).cuda()
         if m.bias is not None:
             with torch.no_grad():
                 m.bias.add_(torch.randn_like(m.bias))
-        lead = (3, 5) if kw["in_dim"] == 64 else (7,)
+        lead = (3, 5) if kw["in_dim"] == 64 else ((rows,) if rows else (7,))
         x = torch.randn(*lead, kw["in_dim"])
         xr = x.clone().requires_grad_(True)
         wr = m.weight.detach().cpu().clone().requires_grad_(True)
@@ -424,3 +458,24 @@ def test_real_trainer_two_processes_one_gpu():
     assert err0 < 1e-5 and err1 < 1e-5, (err0, err1)
     assert g0 == g1 and d0 == d1 and m0 == m1, "replicas bit-identical after 2 iterations"
     assert all(np.isfinite(l0)) and all(np.isfinite(l1))
+
+
+def test_bench_rccl_code_path_on_one_gpu():
+    """bench.py through torch.distributed.run with ONE rank and GIF_FORCE_DIST=1: the exact RCCL calls of the multi-GPU run
+    (init with device_id, construction-time broadcast of every parameter and buffer, asynchronous AVG all-reduce of both
+    gradient buckets + waits, barrier, MAX all-reduce of the time) execute on the single GPU of this box and the JSON contract
+    line comes out.  The 8-GPU run itself belongs to the driver."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GIF_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--res", "64", "--batch", "8", "--vocab", "64", "--r1-every", "2", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "weak"
+    assert "roofline" in d and d["config"]["parallelism"] == "dp1"
