@@ -565,9 +565,9 @@ def linear_nt(a, b, bias=None, scale=1.0, act=False, slope=0.2, gain=1.0, n_pad=
     """[M, n_pad] = act(scale * a[M,K] @ b[N,K]^T + bias[n_pad]); columns N..n_pad are zero.  K % 4 == 0."""
     lib = _lib.load()
     a, b = _mat(a, "linear_nt"), _mat(b, "linear_nt")
-    M, K = a.shape
-    N = b.shape[0]
-    assert b.shape[1] == K
+    M = a.shape[0]
+    N, K = b.shape
+    assert a.shape[1] >= K, (a.shape, b.shape)  # `a` may carry padding columns beyond K
     n_pad = N if n_pad is None else n_pad
     c = torch.empty((M, n_pad), device=a.device, dtype=torch.float32)
     _lib.check(lib.gif_linear_nt_f32(a.data_ptr(), b.data_ptr(), _p(bias), c.data_ptr(), M, N, K, a.stride(0), b.stride(0), n_pad,
