@@ -150,7 +150,8 @@ class EqualLinear(nn.Module):
         if x.dtype != torch.float32:
             x = x.float()
         np_ = pad4(out_dim)
-        bias = None if self.bias is None else _pad_vec(self.bias * self.lr_mul, np_)
+        # (lr_mul == 1 for every modulation linear: no multiply launch)
+        bias = None if self.bias is None else _pad_vec(self.bias if self.lr_mul == 1 else self.bias * self.lr_mul, np_)
         gain = (1.41421356237 if self.apply_sqrt2_fac_in_eq_lin else 1.0) if self.activation else 1.0
         if in_dim % 4 == 0 and x.shape[0] <= _SKINNY_MAX_ROWS and np_ <= 1024:
             # batch-sized row counts: the skinny-GEMM kernels (csrc/linear.hip), one launch, epilogue fused
