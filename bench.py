@@ -142,6 +142,7 @@ def cpu_baseline(res, step_idx, batch, threads, timeout_s):
                 "sample": f"cpu baseline did not finish within {timeout_s}s ({type(e).__name__})"}
 
 
+BF16X3_EXECUTED = 6.0  # bf16 MFMA FLOPs the bf16x3 kernels execute per algorithmic fp32 FLOP
 WINOGRAD_EXECUTED = 16.0 / 36.0  # MFMA FLOPs a Winograd F(2x2,3x3)/F(3x3,2x2) GEMM executes per algorithmic FLOP
 
 # family id -> (description, executed MFMA fraction of the algorithmic FLOPs, key in profiles/pmc_traffic.json)
@@ -157,10 +158,16 @@ FAMILIES = {
     6: ("conv_gather_mfma_glds<f16> (f16 fwd / dgrad / stride-2 / transposed conv, v_mfma_f32_32x32x16_f16)", 1.0,
         "conv_gather_mfma_glds_f16"),
     7: ("conv_wgrad_mfma<f16> (f16 weight gradient, fp32 accumulation)", 1.0, "conv_wgrad_mfma_f16"),
+    8: ("conv_gather_mfma_glds<float, bf16x3> (fp32 direct fwd / dgrad / stride-2 / transposed conv on the bf16 matrix cores: exact "
+        "3-way bf16 split of both operands, 6 v_mfma_f32_32x32x16_bf16 products per fp32 product, fp32 accumulation)", BF16X3_EXECUTED,
+        "conv_gather_mfma_glds_x3"),
+    9: ("conv_wgrad_mfma<float, bf16x3> (fp32 weight gradient on the bf16 matrix cores, same split)", BF16X3_EXECUTED,
+        "conv_wgrad_mfma_x3"),
 }
 FAMILY_KEYS = {0: "roofline_conv_direct", 1: "roofline_wgrad_direct", 2: "roofline_conv_winograd", 3: "roofline_wgrad_winograd",
-               5: "roofline_conv_direct_small_cin", 6: "roofline_conv_f16", 7: "roofline_wgrad_f16"}
-FAMILY_PEAK = {6: PEAK_F16_MFMA_TFLOPS, 7: PEAK_F16_MFMA_TFLOPS}
+               5: "roofline_conv_direct_small_cin", 6: "roofline_conv_f16", 7: "roofline_wgrad_f16",
+               8: "roofline_conv_direct_bf16x3", 9: "roofline_wgrad_direct_bf16x3"}
+FAMILY_PEAK = {6: PEAK_F16_MFMA_TFLOPS, 7: PEAK_F16_MFMA_TFLOPS, 8: PEAK_F16_MFMA_TFLOPS, 9: PEAK_F16_MFMA_TFLOPS}
 
 
 def load_pmc():
@@ -195,7 +202,8 @@ def roofline_objects(ops, steps, wall_s):
         if exec_frac != 1.0:
             o["algorithmic_achieved"] = alg
             o["algorithmic_frac"] = alg / peak
-            o["note"] = "achieved = executed MFMA FLOP/s (16/36 of the algorithmic direct-convolution FLOPs)"
+            o["note"] = ("achieved = executed bf16 MFMA FLOP/s (6x the algorithmic fp32 FLOPs), priced at the 2.5 PFLOP/s bf16 peak"
+                         if exec_frac > 1 else "achieved = executed MFMA FLOP/s (16/36 of the algorithmic direct-convolution FLOPs)")
         fam_pmc = (pmc or {}).get("families", {}).get(pmc_key)
         if fam_pmc:
             o["traffic"] = fam_pmc["hbm_bytes_per_launch"]

@@ -28,6 +28,8 @@ GP, EP = ctypes.POINTER(ConvGeom), ctypes.POINTER(ConvEpilogue)
 PROTOTYPES = {
     "gif_last_error": (ctypes.c_char_p, []),
     "gif_abi_version": (c_int, []),
+    "gif_set_fp32_mfma_mode": (c_int, [c_int]),
+    "gif_get_fp32_mfma_mode": (c_int, []),
     "gif_rasterize_workspace_bytes": (c_i64, [c_int, c_int, c_int]),
     "gif_rasterize_f32": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P]),
     "gif_rasterize_colors_f32": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P, P]),
@@ -41,6 +43,10 @@ PROTOTYPES = {
     "gif_pack_weight_f32": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_float, P]),
     "gif_conv2d_fwd_f32": (c_int, [P, P, P, GP, EP, P]),
     "gif_conv2d_bwd_data_f32": (c_int, [P, P, P, GP, EP, P]),
+    "gif_conv2d_fwd_f32x3": (c_int, [P, P, P, GP, EP, P]),
+    "gif_conv2d_bwd_data_f32x3": (c_int, [P, P, P, GP, EP, P]),
+    "gif_conv2d_x3_eligible": (c_int, [c_int, c_int]),
+    "gif_pack_weight_f32x3": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_float, P]),
     "gif_conv2d_wgrad_dims": (c_int, [c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "gif_conv2d_wgrad_splits": (c_int, [GP]),
     "gif_conv2d_wgrad_f32": (c_int, [P, P, P, P, P, GP, c_int, P]),

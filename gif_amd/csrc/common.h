@@ -43,11 +43,15 @@ struct LdsAttr {
     void ensure(const void* kernel, size_t bytes);
 };
 
+// ---- fp32 contraction mode (runtime.hip; gif_set_fp32_mfma_mode / GIF_FP32_MFMA) ----
+int fp32_mfma_mode();
+
 // ---- kernel profiling (runtime.hip): HIP events around launches, grouped in families ----
 // 0 direct conv fwd/dgrad on the LDS-DMA kernel (Cin >= 32; flops), 1 direct wgrad (flops), 2 Winograd GEMM fwd/dgrad
 // (ALGORITHMIC direct-conv flops; the kernel executes 16/36 of them), 3 Winograd wgrad GEMM (same convention),
-// 4 Winograd transforms (HBM bytes), 5 direct conv fwd/dgrad on the register-staged kernel (Cin < 32; flops)
-#define GIF_PROF_FAMILIES 8
+// 4 Winograd transforms (HBM bytes), 5 direct conv fwd/dgrad on the register-staged kernel (Cin < 32; flops),
+// 6 / 7 f16 conv / wgrad, 8 / 9 bf16x3 conv fwd/dgrad / wgrad (algorithmic flops; the bf16 pipe executes 6x)
+#define GIF_PROF_FAMILIES 10
 struct ProfScope {
     int family;
     hipStream_t stream;
@@ -85,6 +89,28 @@ __device__ __forceinline__ void store4(f16* p, float4 v) {
     f16x4_t h;
     h[0] = (f16)sat_f16(v.x); h[1] = (f16)sat_f16(v.y); h[2] = (f16)sat_f16(v.z); h[3] = (f16)sat_f16(v.w);
     *reinterpret_cast<f16x4_t*>(p) = h;
+}
+
+// ---- bf16x3: three-way split of fp32 operands for the bf16 matrix cores -------------------------------------------
+// a = hi + mid + lo with hi = bf16(a), mid = bf16(a - hi), lo = bf16(a - hi - mid), every conversion round-to-nearest-even
+// (v_cvt_pk_bf16_f32).  Both subtractions are exact in fp32 (a rounding residual always fits), |mid| <= 2^-8 |a|,
+// |lo| <= 2^-16 |a|, and hi + mid + lo reproduces a to 2^-24 |a| or better (exactly, whenever the last residual has <= 8
+// significant bits).  bf16 has fp32's exponent range, so there is no scaling and no overflow / underflow caveat.
+// 8 consecutive-k floats of a lane (two 16-byte LDS fragments) -> one operand of v_mfma_f32_32x32x16_bf16 per term.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+// one pair of floats -> the packed {a1, a0} dword of each term (9 VALU: 3 cvt_pk, 2 shl, 2 and, 2 packed subtracts)
+__device__ __forceinline__ void split_pair(const float a0, const float a1, unsigned& hi, unsigned& mid, unsigned& lo) {
+    const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a0, a1}, bf16x2_t));
+    const float r0 = a0 - __uint_as_float(h << 16), r1 = a1 - __uint_as_float(h & 0xffff0000u);
+    const unsigned m = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{r0, r1}, bf16x2_t));
+    const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+    hi = h;
+    mid = m;
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{s0, s1}, bf16x2_t));
 }
 
 }  // namespace gif

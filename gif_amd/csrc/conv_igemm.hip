@@ -59,6 +59,7 @@ struct GatherParams {
     int stab_nb, stab_stride;  // LDS table of per-sample input scales (LDS-DMA kernel): samples per tile, row stride
     const void* zero;          // 16 zero bytes in HBM: source of the LDS-DMA lanes that fall outside the tensor
     int m_begin;               // first GEMM row of this launch (a launch may cover only rows [m_begin, M))
+    int x3;                    // fp32 only: wp is the pre-split bf16x3 packing, run the bf16 matrix-core kernels
 };
 
 // XCD-aware, bijective block remap (cdna guide T1): consecutive logical tiles share an XCD's L2.
@@ -73,12 +74,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // Epilogue shared by both kernels.  The accumulator tile is transposed through LDS (the staging buffers are free by
 // then) so that global I/O is row-wise float4: residual / out_scale / bias loads and the output store are 16 B per lane
 // and fully coalesced along the channel axis.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5).
-template <int BM, int BN, int LD, int MT, int NT, typename T = float>
+template <int BM, int BN, int LD, int MT, int NT, typename T = float, int THREADS = 256>
 __device__ __forceinline__ void conv_epilogue(const GatherParams& p, f32x16 (&acc)[MT][NT], float* smem, int m0, int n0,
                                               int wm0, int wn0, int tid, int li, int lh, int HWp) {
     const T* const res = static_cast<const T*>(p.residual);
     T* const yout = static_cast<T*>(p.y);
-    constexpr int THREADS = 256;
     constexpr int LDC = BN + 4;
     // the tile goes through LDS in EPI_CHUNKS row chunks so that it fits into the staging buffers' footprint
     constexpr int STAGE_FLOATS = 2 * (BM + BN) * LD;
@@ -322,25 +322,40 @@ __global__ void __launch_bounds__(256) conv_gather_mfma(const GatherParams p) {
 //            one ds_read_b128 = 8 halfs = the whole operand of one MFMA (lane half h supplies k = 16*kk + 8*h .. +7),
 //            fp32 accumulators, fp32 epilogue (demodulation, bias, residual, lrelu), saturating f16 store.  The per-sample
 //            modulation table is f16 (x * s is what the f16 MFMA consumes anyway); demodulation stays fp32 in the epilogue.
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool SCALE, int BK>
+// X3   : fp32 data, bf16 matrix cores ("bf16x3", see common.h split_pair).  A: the same fp32 rows are staged by the same
+//        DMA; the 16-byte fragments of two consecutive k-groups (8 floats per lane) are split exactly into three bf16x8
+//        vectors after the LDS read (and after the fp32 modulation multiply).  B: the weights arrive PRE-SPLIT
+//        (gif_pack_weight_f32x3: [tap][3 terms][RP][CP] bf16), three [BN][32] bf16 tiles of 64-byte rows per stage whose
+//        16-byte chunks are XOR-swizzled with (row >> 2) & 3, so a B operand is one ds_read_b128 and costs no VALU.
+//        Six v_mfma_f32_32x32x16_bf16 per tile pair and 16 k-values.  On this chip VALU work does NOT hide under the MFMAs
+//        of the same SIMD (measured: time ~ MFMA + VALU), so the split work per MFMA is what bounds the kernel.
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool SCALE, int BK, bool X3 = false>
 __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, const int nwg) {
     constexpr bool F16 = sizeof(T) == 2;
+    static_assert(!X3 || !F16, "the split path is an fp32 mode");
     constexpr int EPC = 16 / sizeof(T);  // elements per 16-byte chunk
     constexpr int LD = BK;             // unpadded LDS row (elements)
     constexpr int CH = BK / EPC;       // 16-byte chunks per row
     constexpr int RB = 256 / (BK * (int)sizeof(T));  // rows per 256-byte LDS bank row (2 for 128-byte rows)
-    constexpr int RPP = 256 / CH;      // rows filled by one pass of the 256 lanes
+    constexpr int THREADS = 64 * WAVES_M * WAVES_N;
+    constexpr int NWAVES = WAVES_M * WAVES_N;
+    constexpr int RPP = THREADS / CH;  // rows filled by one pass of the workgroup's lanes
     constexpr int RPW = 64 / CH;       // rows filled by one wave instruction (1 KiB)
-    constexpr int KG = CH / 2;         // k-groups per step: two chunks (lane halves h = 0 / 1) each
+    constexpr int KG = X3 ? CH / 4 : CH / 2;  // k-groups per step: two chunks (lane halves h = 0 / 1) each; X3: four
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int MT = WM / 32, NT = WN / 32;
     constexpr int A_IT = BM / RPP, B_IT = (BN + RPP - 1) / RPP;
-    static_assert(WAVES_M * WAVES_N == 4 && BM % RPP == 0 && (BN % RPP == 0 || BN < RPP), "tile config");
+    static_assert((NWAVES == 4 || NWAVES == 8) && BM % RPP == 0 && (X3 || BN % RPP == 0 || BN < RPP), "tile config");
     static_assert(BK * sizeof(T) == 128, "only 128-byte rows are validated (a 64-byte-row variant measured 8-10 % slower)");
+    // X3: pre-split weight tiles, [2][3][BN][32] bf16 in 1-KiB DMA blocks of 16 rows
+    constexpr int B3_BLK = 3 * BN / 16;                      // blocks per stage
+    constexpr int B3_IT = (B3_BLK + NWAVES - 1) / NWAVES;    // blocks per wave and stage
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     T* As = reinterpret_cast<T*>(smem);  // [2][BM][LD]
     T* Bs = As + 2 * BM * LD;            // [2][BN][LD]
+    unsigned short* const B3 = reinterpret_cast<unsigned short*>(Bs);  // X3: [2][3][BN][32] bf16
+    const unsigned short* const pw3 = static_cast<const unsigned short*>(p.wp);
     const T* const px = static_cast<const T*>(p.x);
     const T* const pw = static_cast<const T*>(p.wp);
     const T* const pzero = static_cast<const T*>(p.zero);
@@ -379,11 +394,11 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
     // samples this tile touches are parked in an LDS table and multiplied into the A fragments after the operand read
     // ("weight modulation" applied on the activation side; algebraically identical).  Filled BEFORE the first DMA so no
     // ordinary global load is outstanding while DMAs are in flight (hipcc would drain them with vmcnt(0)).
-    T* Stab = As + 2 * (BM + BN) * LD;  // [stab_nb][stab_stride], tail of each row zeroed
+    T* Stab = X3 ? reinterpret_cast<T*>(B3 + 2 * 3 * BN * 32) : As + 2 * (BM + BN) * LD;  // [stab_nb][stab_stride], row tails zeroed
     int s_row[MT];
     if (SCALE) {
         const int b_first = m0 / HWp;
-        for (int e = tid; e < p.stab_nb * p.stab_stride; e += 256) {
+        for (int e = tid; e < p.stab_nb * p.stab_stride; e += THREADS) {
             int bl = e / p.stab_stride, c = e - bl * p.stab_stride;
             int b = b_first + bl;
             Stab[e] = (T)((c < p.Ci && b < p.B) ? p.in_scale[(size_t)b * p.Ci + c] : 0.f);
@@ -399,6 +414,17 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
     const int nsteps = p.ntaps * (p.CP / BK);
     int ld_a = 0, ld_b = 0, ld_kc = 0;
     int cmp_kc = 0;  // K-chunk of the step being computed (for the scale lookup)
+    // X3 weight DMA: block = wave + it * NWAVES covers rows (block % (BN/16)) * 16 + lane/4 of term block / (BN/16); this
+    // lane's physical chunk lane%4 holds the logical chunk (lane%4) ^ ((lane/16)%4)  [(row>>2)&3 of a 16-aligned block]
+    int b3_off[B3_IT];
+    if constexpr (X3) {
+#pragma unroll
+        for (int it = 0; it < B3_IT; ++it) {
+            const int blk = wave + it * NWAVES;
+            const int term = blk / (BN / 16), r = (blk % (BN / 16)) * 16 + (lane >> 2);
+            b3_off[it] = (term * p.RP + n0 + r) * p.CP + (((lane & 3) ^ ((lane >> 4) & 3)) << 3);
+        }
+    }
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -417,12 +443,22 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
             const T* g = ok ? px + (a_base[it] + tap_off) : pzero;
             __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Ad + it * RPP * LD), 16, 0, 0);
         }
-        const T* wt = pw + ((size_t)widx * p.RP + n0 + t_row) * p.CP + kc + src_c4;
-        if (BN % RPP == 0 || wave * RPW < BN) {  // wave-uniform: waves beyond the B tile issue nothing
+        if constexpr (X3) {
+            const unsigned short* wt = pw3 + (size_t)widx * 3 * p.RP * p.CP + kc;
 #pragma unroll
-            for (int it = 0; it < B_IT; ++it)
-                __builtin_amdgcn_global_load_lds((gptr_t)(b_lane_ok ? wt + (size_t)it * RPP * p.CP : pzero),
-                                                 (lptr_t)(Bd + it * RPP * LD), 16, 0, 0);
+            for (int it = 0; it < B3_IT; ++it) {
+                const int blk = wave + it * NWAVES;  // wave-uniform
+                if (B3_BLK % NWAVES == 0 || blk < B3_BLK)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(wt + b3_off[it]), (lptr_t)(B3 + (buf * B3_BLK + blk) * 512), 16, 0, 0);
+            }
+        } else {
+            const T* wt = pw + ((size_t)widx * p.RP + n0 + t_row) * p.CP + kc + src_c4;
+            if (BN % RPP == 0 || wave * RPW < BN) {  // wave-uniform: waves beyond the B tile issue nothing
+#pragma unroll
+                for (int it = 0; it < B_IT; ++it)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(b_lane_ok ? wt + (size_t)it * RPP * p.CP : pzero),
+                                                     (lptr_t)(Bd + it * RPP * LD), 16, 0, 0);
+            }
         }
         ld_kc += BK;
         if (ld_kc >= p.CP) {
@@ -443,6 +479,111 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
     // operand fragments of one k-group: register double buffer, read one group ahead of its MFMAs (16 bytes per fragment:
     // 4 floats or 8 halfs)
     typedef typename std::conditional<F16, gif::f16x8_t, f32x4>::type frag_t;
+    auto next_kc = [&](int kc) { return (kc + BK >= p.CP) ? 0 : kc + BK; };
+    int cur = 0;
+    if constexpr (X3) {
+        // ---- bf16x3 schedule.  A k-group is 16 k-values: two 16-byte fragments per 32-row tile and lane.  Software
+        // pipeline, per group: [LDS reads of the NEXT group's fp32 fragments] then the 6*MT*NT bf16 MFMAs of THIS group's
+        // split operands with the split of the next group's fragments (44 VALU per fragment pair) interleaved between
+        // them — the matrix pipe and the VALU are separate, and the in-order wave only overlaps them when the instruction
+        // stream alternates (sched_group_barrier pins the pattern).
+        gif::u32x4_t sa[2][3][MT], sb[2][3][NT];  // [slot][hi, mid, lo][tile]: 8 packed bf16 each
+        f32x4 ra[MT][2], rs[MT][2];              // raw A fragments (and modulation scales) of the group being split
+        const int b3_sw = (li >> 2) & 3;         // (row >> 2) & 3 of every weight row this lane reads
+        // LDS reads of group q of stage `buf`: raw fp32 A fragments (split later, piecewise) and the pre-split B operands
+        auto read_raw = [&](int buf, int q, int kc, int slot) __attribute__((always_inline)) {
+            const T* Ab = As + buf * BM * LD + (wm0 + li) * LD;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                // lane half h supplies k = 16 q + 8 h + 0..7 of the group (the MFMA's own operand layout, which is also the
+                // order of the pre-split weights): fp32 chunks 4 q + 2 h and 4 q + 2 h + 1 of the 128-byte row
+                const int lc = q * 4 + lh * 2 + u;
+                const int c = (lc ^ fsw) * EPC;
+#pragma unroll
+                for (int i = 0; i < MT; ++i) ra[i][u] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LD + c);
+                if (SCALE) {
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+                        rs[i][u] = *reinterpret_cast<const f32x4*>(Stab + s_row[i] - lh * EPC + kc + lc * EPC);
+                }
+            }
+            const unsigned short* Bb = B3 + buf * 3 * BN * 32 + (wn0 + li) * 32 + (((q * 2 + lh) ^ b3_sw) << 3);
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    sb[slot][t][j] = *reinterpret_cast<const gif::u32x4_t*>(Bb + (t * BN + j * 32) * 32);
+        };
+        // piece k of the split of one group: one pair of floats -> one packed dword of each term (11 VALU, +2 modulated)
+        constexpr int NP = MT * 4;
+        auto split_piece = [&](int slot, int k) __attribute__((always_inline)) {
+            const int f = k / 4, e = k % 4;  // A tile, dword of the packed operand
+            float a0 = ra[f][e / 2][(e % 2) * 2], a1 = ra[f][e / 2][(e % 2) * 2 + 1];
+            if (SCALE) { a0 *= rs[f][e / 2][(e % 2) * 2]; a1 *= rs[f][e / 2][(e % 2) * 2 + 1]; }
+            unsigned h, m, l;
+            gif::split_pair(a0, a1, h, m, l);
+            sa[slot][0][f][e] = h; sa[slot][1][f][e] = m; sa[slot][2][f][e] = l;
+        };
+        // The 6*MT*NT MFMAs of the group in `slot` (smallest terms first; lo*mid, mid*lo, lo*lo <= 2^-23 of the product are
+        // not formed; term-major: consecutive MFMAs write different accumulators), with the split of the next group
+        // (-> slot `nslot`, or nothing if nslot < 0) placed piecewise between them.  sched_barrier(0) after every MFMA and
+        // every piece: the compiler keeps exactly this interleave (sched_group_barrier's VALU class also matches MFMAs).
+        constexpr int LEAD = 2;  // MFMAs ahead of the first piece: they cover the LDS latency of the raw reads
+        auto group = [&](int slot, int nslot) __attribute__((always_inline)) {
+            constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+            int n = 0, piece = 0;
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gif::bf16x8_t, sa[slot][TA[t]][i]),
+                                                                            __builtin_bit_cast(gif::bf16x8_t, sb[slot][TB[t]][j]),
+                                                                            acc[i][j], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        ++n;
+                        if (nslot >= 0 && n >= LEAD && piece < NP) {
+                            split_piece(nslot, piece++);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+            if (nslot >= 0) {
+#pragma unroll
+                for (; piece < NP; ++piece) split_piece(nslot, piece);
+            }
+        };
+        static_assert(KG == 2, "bf16x3: 32 floats per K chunk");
+        issue(0);
+        __syncthreads();
+        read_raw(0, 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) split_piece(0, k);
+        for (int step = 0; step + 1 < nsteps; ++step) {
+            issue(cur ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g + 1 < KG; ++g) {
+                read_raw(cur, g + 1, cmp_kc, (g + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+                group(g & 1, (g + 1) & 1);
+            }
+            __syncthreads();
+            cmp_kc = next_kc(cmp_kc);
+            cur ^= 1;
+            read_raw(cur, 0, cmp_kc, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            group((KG - 1) & 1, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < KG; ++g) {
+            if (g + 1 < KG) {
+                read_raw(cur, g + 1, cmp_kc, (g + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            group(g & 1, g + 1 < KG ? (g + 1) & 1 : -1);
+        }
+    } else {
     frag_t av[2][MT], bv[2][NT];
     auto frag_read = [&](int buf, int kk, int slot, int kc) __attribute__((always_inline)) {
         const T* Ab = As + buf * BM * LD + (wm0 + li) * LD;
@@ -479,7 +620,6 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
             __builtin_amdgcn_sched_group_barrier(0x008, 4 * MT * NT, 0);
         }
     };
-    auto next_kc = [&](int kc) { return (kc + BK >= p.CP) ? 0 : kc + BK; };
 
     // Schedule of one step (KG k-groups g0..g{KG-1} of the current buffer):
     //   DMA(step+1) | g0 | ... | g{KG-2} | vmcnt(0)+barrier | read g0 of step+1 | g{KG-1}
@@ -487,7 +627,6 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
     // when it arrives, and the first operand read of the next step runs under the MFMAs of the last group.
     issue(0);
     __syncthreads();  // the workgroup release waits for the outstanding LDS-DMA (vmcnt(0)) of every wave
-    int cur = 0;
     frag_read(0, 0, 0, 0);
     for (int step = 0; step + 1 < nsteps; ++step) {
         issue(cur ^ 1);  // DMA of step+1 runs under the MFMAs of this step
@@ -513,12 +652,13 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
         if (g + 1 < KG) frag_read(cur, g + 1, (g + 1) & 1, cmp_kc);
         mfma_group(g & 1);
     }
-    conv_epilogue<BM, BN, 32, MT, NT, T>(p, acc, smem, m0, n0, wm0, wn0, tid, li, lh, HWp);
+    }
+    conv_epilogue<BM, BN, 32, MT, NT, T, THREADS>(p, acc, smem, m0, n0, wm0, wn0, tid, li, lh, HWp);
 }
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool SCALE, int BK>
-__global__ void __launch_bounds__(256) conv_gather_mfma_glds(const GatherParams p) {
-    glds_body<T, BM, BN, WAVES_M, WAVES_N, SCALE, BK>(p, (int)blockIdx.x, (int)gridDim.x);
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool SCALE, int BK, bool X3 = false>
+__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_gather_mfma_glds(const GatherParams p) {
+    glds_body<T, BM, BN, WAVES_M, WAVES_N, SCALE, BK, X3>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Up to 4 independent problems (the output-parity phases of a small transposed convolution) in ONE launch: each phase
@@ -529,13 +669,13 @@ struct MultiParams {
     int nph;
 };
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool SCALE, int BK>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool SCALE, int BK, bool X3 = false>
 __global__ void __launch_bounds__(256) conv_gather_mfma_glds_multi(const MultiParams mp) {
     const int b = (int)blockIdx.x;
     int k = 0;
     while (k + 1 < mp.nph && b >= mp.wg_end[k]) ++k;  // wave-uniform
     const int begin = k ? mp.wg_end[k - 1] : 0;
-    glds_body<T, BM, BN, WAVES_M, WAVES_N, SCALE, BK>(mp.ph[k], b - begin, mp.wg_end[k] - begin);
+    glds_body<T, BM, BN, WAVES_M, WAVES_N, SCALE, BK, X3>(mp.ph[k], b - begin, mp.wg_end[k] - begin);
 }
 
 struct TileCfg {
@@ -582,28 +722,34 @@ inline size_t scale_table(GatherParams& p) {
     return (size_t)nb * p.stab_stride * sizeof(T);
 }
 
-template <typename T, int BM, int BN, int WMv, int WNv, bool SCALE>
+// LDS bytes of the double-buffered operand tiles: 128-byte rows; X3: the weight tile is three 64-byte-row bf16 tiles
+template <int BM, int BN, bool X3>
+constexpr size_t stage_bytes() { return X3 ? (size_t)2 * BM * 128 + (size_t)2 * 3 * BN * 64 : (size_t)2 * (BM + BN) * 128; }
+
+template <typename T, int BM, int BN, int WMv, int WNv, bool SCALE, bool X3 = false>
 int launch_glds_impl(GatherParams& p, hipStream_t s) {
     constexpr int BK = 128 / sizeof(T);  // 128-byte LDS rows
     static gif::LdsAttr attr;
     p.tiles_m = gif::cdiv(p.M - p.m_begin, BM);
     p.tiles_n = p.RP / BN;
-    size_t lds = (size_t)2 * (BM + BN) * 128;
+    size_t lds = stage_bytes<BM, BN, X3>();
     p.stab_nb = 0;
     p.stab_stride = 0;
     if (SCALE) lds += scale_table<T, BM>(p);
+    static const int lds_pad = getenv("GIF_LDS_PAD") ? atoi(getenv("GIF_LDS_PAD")) : 0;  // occupancy experiments
+    if (lds + lds_pad <= 160 * 1024) lds += lds_pad;
     if (lds > 160 * 1024) return -100;  // fp32 caller falls back to the register-staged kernel
-    auto kern = conv_gather_mfma_glds<T, BM, BN, WMv, WNv, SCALE, BK>;
+    auto kern = conv_gather_mfma_glds<T, BM, BN, WMv, WNv, SCALE, BK, X3>;
     attr.ensure(reinterpret_cast<const void*>(kern), lds);
     // passed as a kernel argument: a GOT load inside the K loop costs a scalar memory round trip + s_waitcnt per stage
     p.zero = gif::zero_page16();
     if (!p.zero) return -101;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(256), lds, s, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(64 * WMv * WNv), lds, s, p);
     return 0;
 }
 
 // all phases in one launch (64x64 tiles); returns -100 if the configuration does not fit
-template <typename T, bool SCALE>
+template <typename T, bool SCALE, bool X3 = false>
 int launch_glds_multi(GatherParams* ph, int nph, hipStream_t s) {
     constexpr int BM = 64, BN = 64, BK = 128 / sizeof(T);
     static gif::LdsAttr attr;
@@ -616,7 +762,7 @@ int launch_glds_multi(GatherParams* ph, int nph, hipStream_t s) {
         GatherParams& p = ph[i];
         p.tiles_m = gif::cdiv(p.M - p.m_begin, BM);
         p.tiles_n = p.RP / BN;
-        size_t lds = (size_t)2 * (BM + BN) * 128;
+        size_t lds = stage_bytes<BM, BN, X3>();
         p.stab_nb = 0;
         p.stab_stride = 0;
         if (SCALE) lds += scale_table<T, BM>(p);
@@ -628,7 +774,7 @@ int launch_glds_multi(GatherParams* ph, int nph, hipStream_t s) {
     }
     mp.nph = nph;
     if (lds_max > 160 * 1024) return -100;
-    auto kern = conv_gather_mfma_glds_multi<T, BM, BN, 2, 2, SCALE, BK>;
+    auto kern = conv_gather_mfma_glds_multi<T, BM, BN, 2, 2, SCALE, BK, X3>;
     attr.ensure(reinterpret_cast<const void*>(kern), lds_max);
     hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), lds_max, s, mp);
     return 0;
@@ -636,8 +782,21 @@ int launch_glds_multi(GatherParams* ph, int nph, hipStream_t s) {
 
 template <typename T, int BM, int BN, int WMv, int WNv>
 int launch_glds(GatherParams& p, hipStream_t s) {
+    if constexpr (sizeof(T) == 4) {
+        if (p.x3)
+            return p.in_scale ? launch_glds_impl<T, BM, BN, WMv, WNv, true, true>(p, s)
+                              : launch_glds_impl<T, BM, BN, WMv, WNv, false, true>(p, s);
+    }
     return p.in_scale ? launch_glds_impl<T, BM, BN, WMv, WNv, true>(p, s)
                       : launch_glds_impl<T, BM, BN, WMv, WNv, false>(p, s);
+}
+
+template <typename T>
+int launch_multi(GatherParams* ph, int nph, bool scale, hipStream_t s) {
+    if constexpr (sizeof(T) == 4) {
+        if (ph[0].x3) return scale ? launch_glds_multi<T, true, true>(ph, nph, s) : launch_glds_multi<T, false, true>(ph, nph, s);
+    }
+    return scale ? launch_glds_multi<T, true>(ph, nph, s) : launch_glds_multi<T, false>(ph, nph, s);
 }
 
 // GIF_CONV_VARIANT=1 forces the register-staged kernel everywhere (A/B benchmarking only)
@@ -661,11 +820,16 @@ int launch(GatherParams& p, hipStream_t s) {
     TileCfg c = pick_cfg<T>(p.Co, p.Ci);
     // LDS-DMA path: every layer whose K chunk is a 128-byte row (rows are 16-byte aligned in HBM: Ci % 4 == 0 for fp32,
     // Ci % 8 == 0 for f16)
-    const bool glds = F16 || (c.BK == 32 && conv_variant() != 1);
+    const bool only_glds = F16 || p.x3;  // no register-staged fallback for these operand formats
+    const bool glds = only_glds || (c.BK == 32 && conv_variant() != 1);
     auto fail_f16 = [&](int rc) {
-        if (rc != 0) gif::set_error("conv (f16): launch configuration does not fit (rc=%d)", rc);
+        if (rc != 0) gif::set_error("conv (%s): launch configuration does not fit (rc=%d)", F16 ? "f16" : "bf16x3", rc);
         return rc == 0 ? 0 : GIF_ENOSUP;
     };
+    if (p.x3 && c.BK != 32) {
+        gif::set_error("conv (bf16x3): needs >= 32 input channels (gif_conv2d_x3_eligible)");
+        return GIF_ENOSUP;
+    }
     if constexpr (F16) {
         if (c.BN == 64) return fail_f16(launch_glds<T, 128, 64, 2, 2>(p, s));
     }
@@ -674,6 +838,31 @@ int launch(GatherParams& p, hipStream_t s) {
         // 144-step K loop; 64x64 tiles give 4x the workgroups (and 32 KB of LDS: 4 per CU) at a quarter of the latency
         const long tiles128 = (long)gif::cdiv(p.M, 128) * (p.RP / 128);
         if (glds && tiles128 < 384 && launch_glds<T, 64, 64, 2, 2>(p, s) == 0) return 0;
+        if constexpr (!F16) {
+            // bf16x3: the pre-split weight tile (48 KB) + the fp32 activation tile (32 KB) fill half a CU's LDS exactly, and a
+            // modulated conv's scale table no longer fits beside them.  Big layers run 256x128 tiles on 8 waves instead: one
+            // workgroup per CU (112 KB + table), still two waves per SIMD, a quarter less operand traffic per MFMA.
+            static const int big_off = getenv("GIF_X3_BIG") ? atoi(getenv("GIF_X3_BIG")) == 0 : 0;
+            const long tn = p.RP / 128, tiles256 = (long)gif::cdiv(p.M, 256) * tn;
+            if (p.x3 && !big_off && tiles256 >= 512) {
+                const long slots = 256, full = tiles256 / slots, rem = tiles256 % slots;
+                if (rem > 0 && rem * 2 <= slots && slots % tn == 0) {  // nearly empty last round: remainder rows on 64x64 tiles
+                    const int M = p.M;
+                    const int m_bulk = (int)(full * slots / tn) * 256;
+                    p.M = m_bulk;
+                    if (launch_glds<T, 256, 128, 4, 2>(p, s) == 0) {
+                        p.M = M;
+                        p.m_begin = m_bulk;
+                        int rc = launch_glds<T, 64, 64, 2, 2>(p, s);
+                        p.m_begin = 0;
+                        return rc;
+                    }
+                    p.M = M;
+                } else if (launch_glds<T, 256, 128, 4, 2>(p, s) == 0) {
+                    return 0;
+                }
+            }
+        }
         if (glds && conv_variant() != 3) {
             // Tile quantisation: 512 workgroups of this kernel are resident (2 per CU), so T tiles cost ceil(T / 512) rounds.
             // The odd-sized phase grids of the transposed convolutions (129^2, 65^2, 33^2 pixels) give e.g. 4161 or 1092
@@ -698,13 +887,12 @@ int launch(GatherParams& p, hipStream_t s) {
         if (glds) {
             int rc = launch_glds<T, 128, 128, 2, 2>(p, s);
             if (rc == 0) return 0;
-            if constexpr (F16) return fail_f16(rc);
+            if (only_glds) return fail_f16(rc);
         }
         if constexpr (!F16) return launch_simple<128, 128, 32, 2, 2>(p, s);
     }
-    if constexpr (F16) {
-        return fail_f16(launch_glds<T, 256, 32, 4, 1>(p, s));
-    } else {
+    if (only_glds) return fail_f16(launch_glds<T, 256, 32, 4, 1>(p, s));
+    if constexpr (!F16) {
         if (c.BN == 128 && c.BK == 8) return launch_simple<128, 128, 8, 2, 2>(p, s);
         if (c.BN == 32 && c.BK == 32) {
             if (glds && launch_glds<T, 256, 32, 4, 1>(p, s) == 0) return 0;
@@ -712,6 +900,7 @@ int launch(GatherParams& p, hipStream_t s) {
         }
         return launch_simple<256, 32, 8, 4, 1>(p, s);
     }
+    return GIF_ENOSUP;
 }
 
 int check_geom(const gif_conv_geom* g, const char* who) {
@@ -756,13 +945,13 @@ int check_channels(const gif_conv_geom* g, const char* who) {
 
 template <typename T>
 int conv2d_fwd_impl(const void* big, const void* wp, void* small, const gif_conv_geom* g, const gif_conv_epilogue* e,
-                    gif_stream_t stream, const char* who) {
+                    gif_stream_t stream, const char* who, bool x3 = false) {
     if (int rc = check_geom(g, who)) return rc;
     if (int rc = check_channels<T>(g, who)) return rc;
     if (g->B == 0) return 0;
     GIF_REQUIRE(big && wp && small, "%s: null pointer", who);
     GatherParams p{};
-    p.x = big; p.wp = wp; p.y = small;
+    p.x = big; p.wp = wp; p.y = small; p.x3 = x3 ? 1 : 0;
     fill_epilogue(p, e);
     p.B = g->B; p.Hi = g->Hb; p.Wi = g->Wb; p.Ci = g->Cb;
     p.Ho = g->Hs; p.Wo = g->Ws; p.Co = g->Cs;
@@ -773,7 +962,7 @@ int conv2d_fwd_impl(const void* big, const void* wp, void* small, const gif_conv
     pack_dims<T>(p.Co, p.Ci, &p.RP, &p.CP);
     p.M = p.B * p.Hp * p.Wp;
     double flops = 2.0 * p.M * (double)p.Co * p.Ci * p.ntaps;
-    const int fam = sizeof(T) == 2 ? 6 : (p.Ci >= 32 ? 0 : 5);
+    const int fam = sizeof(T) == 2 ? 6 : x3 ? 8 : (p.Ci >= 32 ? 0 : 5);
     gif::ProfScope prof(fam, flops, gif::as_stream(stream), p.M, p.Co, p.Ci, p.ntaps * 10 + g->stride);
     if (int rc = launch<T>(p, gif::as_stream(stream))) return rc;
     return gif::check_launch(who);
@@ -781,14 +970,14 @@ int conv2d_fwd_impl(const void* big, const void* wp, void* small, const gif_conv
 
 template <typename T>
 int conv2d_bwd_data_impl(const void* small, const void* wp, void* big, const gif_conv_geom* g, const gif_conv_epilogue* e,
-                         gif_stream_t stream, const char* who) {
+                         gif_stream_t stream, const char* who, bool x3 = false) {
     if (int rc = check_geom(g, who)) return rc;
     if (int rc = check_channels<T>(g, who)) return rc;
     if (g->B == 0) return 0;
     GIF_REQUIRE(small && wp && big, "%s: null pointer", who);
     hipStream_t s = gif::as_stream(stream);
     GatherParams base{};
-    base.x = small; base.wp = wp; base.y = big;
+    base.x = small; base.wp = wp; base.y = big; base.x3 = x3 ? 1 : 0;
     fill_epilogue(base, e);
     base.B = g->B; base.Hi = g->Hs; base.Wi = g->Ws; base.Ci = g->Cs;
     base.Ho = g->Hb; base.Wo = g->Wb; base.Co = g->Cb;
@@ -825,7 +1014,7 @@ int conv2d_bwd_data_impl(const void* small, const void* wp, void* big, const gif
     // algorithmic FLOPs of a transposed conv: every small-side pixel scatters through every tap
     double flops = 2.0 * g->B * (double)g->Hs * g->Ws * g->KH * g->KW * (double)g->Cs * g->Cb;
     {
-        const int fam = sizeof(T) == 2 ? 6 : (base.Ci >= 32 ? 0 : 5);
+        const int fam = sizeof(T) == 2 ? 6 : x3 ? 8 : (base.Ci >= 32 ? 0 : 5);
         gif::ProfScope prof(fam, flops, s, g->B * g->Hb * g->Wb, base.Co, base.Ci, -(g->KH * g->KW * 10 + g->stride));
         // small transposed convs: every phase alone would sit on the 64x64-tile path with a partly filled chip
         bool merged = false;
@@ -837,7 +1026,7 @@ int conv2d_bwd_data_impl(const void* small, const void* wp, void* big, const gif
                             (long)ph[i].B * ph[i].Hi * ph[i].Wi * ph[i].Ci < (1L << 31) &&
                             (long)ph[i].B * ph[i].Ho * ph[i].Wo * ph[i].Co < (1L << 31);
             if (small_all)
-                merged = (base.in_scale ? launch_glds_multi<T, true>(ph, nph, s) : launch_glds_multi<T, false>(ph, nph, s)) == 0;
+                merged = launch_multi<T>(ph, nph, base.in_scale != nullptr, s) == 0;
         }
         if (!merged)
             for (int i = 0; i < nph; ++i)
@@ -870,6 +1059,18 @@ int gif_conv2d_fwd_f32(const float* big, const float* wp, float* small, const gi
 int gif_conv2d_bwd_data_f32(const float* small, const float* wp, float* big, const gif_conv_geom* g,
                             const gif_conv_epilogue* e, gif_stream_t stream) {
     return conv2d_bwd_data_impl<float>(small, wp, big, g, e, stream, "conv2d_bwd_data");
+}
+
+int gif_conv2d_x3_eligible(int cout, int cin) { return cout > 0 && cin >= 32 && cin % 4 == 0 ? 1 : 0; }
+
+int gif_conv2d_fwd_f32x3(const float* big, const void* wp3, float* small, const gif_conv_geom* g, const gif_conv_epilogue* e,
+                         gif_stream_t stream) {
+    return conv2d_fwd_impl<float>(big, wp3, small, g, e, stream, "conv2d_fwd_f32x3", true);
+}
+
+int gif_conv2d_bwd_data_f32x3(const float* small, const void* wp3, float* big, const gif_conv_geom* g,
+                              const gif_conv_epilogue* e, gif_stream_t stream) {
+    return conv2d_bwd_data_impl<float>(small, wp3, big, g, e, stream, "conv2d_bwd_data_f32x3", true);
 }
 
 int gif_conv2d_fwd_f16(const void* big, const void* wp, void* small, const gif_conv_geom* g, const gif_conv_epilogue* e,

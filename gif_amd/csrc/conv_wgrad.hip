@@ -379,6 +379,28 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
     wp[idx] = (T)v;
 }
 
+// bf16x3 packing: wp3[t][term][r][c] (bf16 bits) = term-th part of the exact three-way split of scale * w
+__global__ void pack_weight_x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp3, int R, int C, int KH,
+                                      int KW, int RP, int CP, long sr, long sc, long sky, long skx, float scale) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)KH * KW * RP * CP;
+    if (idx >= total) return;
+    int c = (int)(idx % CP);
+    long rest = idx / CP;
+    int r = (int)(rest % RP);
+    int t = (int)(rest / RP);
+    int ky = t / KW, kx = t - ky * KW;
+    float v = 0.f;
+    if (r < R && c < C) v = scale * w[r * sr + c * sc + ky * sky + kx * skx];
+    unsigned h, m, l;
+    gif::split_pair(v, 0.f, h, m, l);
+    const size_t plane = (size_t)RP * CP;
+    unsigned short* o = wp3 + (size_t)t * 3 * plane + (size_t)r * CP + c;
+    o[0] = (unsigned short)(h & 0xffffu);
+    o[plane] = (unsigned short)(m & 0xffffu);
+    o[2 * plane] = (unsigned short)(l & 0xffffu);
+}
+
 __global__ void unpack_wgrad_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit, int R, int C,
                                     int KH, int KW, int RP, int CP, long sr, long sc, long sky, long skx,
                                     float scale) {
@@ -594,6 +616,15 @@ int gif_pack_weight_f32(const float* w, float* wp, int R, int C, int KH, int KW,
 }
 
 /* fp32 master weights -> f16 packed operand of the f16 convolution kernels (same [tap][RP][CP] layout) */
+int gif_pack_weight_f32x3(const float* w, void* wp3, int R, int C, int KH, int KW, int RP, int CP, int64_t sr, int64_t sc,
+                          int64_t sky, int64_t skx, float scale, gif_stream_t stream) {
+    GIF_REQUIRE(w && wp3 && R > 0 && C > 0 && RP >= R && CP >= C && KH > 0 && KW > 0, "pack_weight_f32x3: bad arguments");
+    long total = (long)KH * KW * RP * CP;
+    pack_weight_x3_kernel<<<gif::cdiv(total, 256), 256, 0, gif::as_stream(stream)>>>(w, static_cast<unsigned short*>(wp3), R, C,
+                                                                                       KH, KW, RP, CP, sr, sc, sky, skx, scale);
+    return gif::check_launch("pack_weight_f32x3");
+}
+
 int gif_pack_weight_f16(const float* w, void* wp, int R, int C, int KH, int KW, int RP, int CP, int64_t sr, int64_t sc,
                         int64_t sky, int64_t skx, float scale, gif_stream_t stream) {
     GIF_REQUIRE(w && wp && R > 0 && C > 0 && RP >= R && CP >= C && KH > 0 && KW > 0, "pack_weight_f16: bad arguments");

@@ -1,7 +1,9 @@
 // Error reporting + event-based kernel timing for bench.py's roofline line.
 #include <stdarg.h>
 #include <stdlib.h>
+#include <string.h>
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -83,6 +85,19 @@ ProfScope::ProfScope(int fam, double flops, hipStream_t s, int d0, int d1, int d
     (void)hipEventRecord(e0, stream);
 }
 
+// -1 = not decided yet: the first query reads GIF_FP32_MFMA
+static std::atomic<int> g_fp32_mode{-1};
+
+int fp32_mfma_mode() {
+    int m = g_fp32_mode.load(std::memory_order_relaxed);
+    if (m >= 0) return m;
+    const char* e = getenv("GIF_FP32_MFMA");
+    m = GIF_FP32_MFMA_BF16X3;
+    if (e && (!strcmp(e, "native") || !strcmp(e, "0"))) m = GIF_FP32_MFMA_NATIVE;
+    g_fp32_mode.store(m, std::memory_order_relaxed);
+    return m;
+}
+
 ProfScope::~ProfScope() {
     if (e1) (void)hipEventRecord(e1, stream);
 }
@@ -93,6 +108,17 @@ extern "C" {
 
 const char* gif_last_error(void) { return gif::g_err; }
 int gif_abi_version(void) { return 1; }
+
+int gif_set_fp32_mfma_mode(int mode) {
+    if (mode != GIF_FP32_MFMA_NATIVE && mode != GIF_FP32_MFMA_BF16X3) {
+        gif::set_error("set_fp32_mfma_mode: unknown mode %d", mode);
+        return GIF_EINVAL;
+    }
+    gif::g_fp32_mode.store(mode, std::memory_order_relaxed);
+    return 0;
+}
+
+int gif_get_fp32_mfma_mode(void) { return gif::fp32_mfma_mode(); }
 
 int gif_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(gif::g_prof_mu);

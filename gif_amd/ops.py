@@ -139,8 +139,14 @@ def _cached_weight_op(w, tag, build):
     return out
 
 
-def pack_weight(w: torch.Tensor, rows_are_out: bool, cout_act: int, cin_act: int, scale: float = 1.0, dtype=torch.float32):
-    """Pack a canonical forward-conv weight view w[O,I,KH,KW] (any strides) into [T][RP][CP] of `dtype` (fp32 or f16).
+def x3_conv(dtype, cin_act: int) -> bool:
+    """fp32 conv fwd/dgrad with `cin_act` contraction channels runs on the bf16x3 kernels (mode + eligibility)."""
+    return dtype == torch.float32 and cin_act >= 32 and get_fp32_mfma_mode() == "bf16x3"
+
+
+def pack_weight(w: torch.Tensor, rows_are_out: bool, cout_act: int, cin_act: int, scale: float = 1.0, dtype=torch.float32, x3=False):
+    """Pack a canonical forward-conv weight view w[O,I,KH,KW] (any strides) into [T][RP][CP] of `dtype` (fp32 or f16), or
+    (x3=True) into the pre-split bf16x3 operand [T][3][RP][CP] (bf16) of the gif_conv2d_*_f32x3 entry points.
 
     rows_are_out=True : rows = O, cols = I (operand of gif_conv2d_fwd)
     rows_are_out=False: rows = I, cols = O (operand of gif_conv2d_bwd_data)
@@ -157,12 +163,17 @@ def pack_weight(w: torch.Tensor, rows_are_out: bool, cout_act: int, cin_act: int
         RP, CP = ctypes.c_int(), ctypes.c_int()
         dims = lib.gif_conv2d_pack_dims_f16 if f16 else lib.gif_conv2d_pack_dims
         _lib.check(dims(cout_act, cin_act, ctypes.byref(RP), ctypes.byref(CP)), "pack_dims")
-        wp = torch.empty((KH * KW, RP.value, CP.value), device=w.device, dtype=dtype)
-        _lib.check(_fn("pack_weight", dtype)(w.data_ptr(), wp.data_ptr(), R, C, KH, KW, RP.value, CP.value, sr, sc, sky, skx,
-                                             float(scale), _stream()), "pack_weight")
+        if x3:
+            wp = torch.empty((KH * KW, 3, RP.value, CP.value), device=w.device, dtype=torch.bfloat16)
+            fn = lib.gif_pack_weight_f32x3
+        else:
+            wp = torch.empty((KH * KW, RP.value, CP.value), device=w.device, dtype=dtype)
+            fn = _fn("pack_weight", dtype)
+        _lib.check(fn(w.data_ptr(), wp.data_ptr(), R, C, KH, KW, RP.value, CP.value, sr, sc, sky, skx, float(scale), _stream()),
+                   "pack_weight")
         return wp
 
-    return _cached_weight_op(w, ("pack", rows_are_out, cout_act, cin_act, float(scale), dtype), build)
+    return _cached_weight_op(w, ("pack", rows_are_out, cout_act, cin_act, float(scale), dtype, bool(x3)), build)
 
 
 # Winograd F(2x2,3x3) dispatch for stride-1 / pad-1 3x3 convs (conv_winograd.hip).  GIF_WINOGRAD=0 forces the direct
@@ -240,12 +251,13 @@ def conv_fwd(big, w, spec: ConvSpec, wscale=1.0, keep_v=False, **epi):
         return conv3x3_winograd(big, w, True, Cs, wscale, keep_v=keep_v, **epi)
     if keep_v:
         return conv_fwd(big, w, spec, wscale, **epi), None
-    wp = pack_weight(w, True, Cs, Cb, wscale, dt)
+    x3 = x3_conv(dt, Cb)
+    wp = pack_weight(w, True, Cs, Cb, wscale, dt, x3=x3)
     out = empty_nhwc(B, Cs, Hs, Ws, big.device, dt)
     g = _geom(B, Hb, Wb, Cb, Hs, Ws, Cs, spec)
     e = _epilogue(**epi)
-    _lib.check(_fn("conv2d_fwd", dt)(big.data_ptr(), wp.data_ptr(), out.data_ptr(), ctypes.byref(g), ctypes.byref(e),
-                                     _stream()), "conv2d_fwd")
+    fn = _lib.load().gif_conv2d_fwd_f32x3 if x3 else _fn("conv2d_fwd", dt)
+    _lib.check(fn(big.data_ptr(), wp.data_ptr(), out.data_ptr(), ctypes.byref(g), ctypes.byref(e), _stream()), "conv2d_fwd")
     return out
 
 
@@ -260,12 +272,13 @@ def conv_bwd_data(small, w, spec: ConvSpec, big_hw, wscale=1.0, **epi):
     _epi_check(small, epi)
     if (Hb, Wb) == (Hs, Ws) and winograd_eligible(spec, B, Hs, Ws, Cs, Cb, dtype=dt):
         return conv3x3_winograd(small, w, False, Cb, wscale, **epi)
-    wp = pack_weight(w, False, Cb, Cs, wscale, dt)
+    x3 = x3_conv(dt, Cs)
+    wp = pack_weight(w, False, Cb, Cs, wscale, dt, x3=x3)
     out = empty_nhwc(B, Cb, Hb, Wb, small.device, dt)
     g = _geom(B, Hb, Wb, Cb, Hs, Ws, Cs, spec)
     e = _epilogue(**epi)
-    _lib.check(_fn("conv2d_bwd_data", dt)(small.data_ptr(), wp.data_ptr(), out.data_ptr(), ctypes.byref(g),
-                                          ctypes.byref(e), _stream()), "conv2d_bwd_data")
+    fn = _lib.load().gif_conv2d_bwd_data_f32x3 if x3 else _fn("conv2d_bwd_data", dt)
+    _lib.check(fn(small.data_ptr(), wp.data_ptr(), out.data_ptr(), ctypes.byref(g), ctypes.byref(e), _stream()), "conv2d_bwd_data")
     return out
 
 
@@ -606,6 +619,29 @@ def linear_tn(a, b, scale=1.0, n_valid=None, k_valid=None):
 for _name in ("linear_nt", "linear_nn", "linear_tn"):
     globals()[_name] = _device_guard(globals()[_name])
 del _name
+
+
+FP32_MFMA_MODES = {"native": 0, "bf16x3": 1}
+
+
+def set_fp32_mfma_mode(mode):
+    """How fp32 convolution contractions reach the matrix cores (process-wide, see include/gif_hip.h): "native" fp32 MFMA
+    or "bf16x3" (exact three-way bf16 split of every fp32 operand, six bf16 MFMA products, fp32 accumulation).  Tensors
+    are fp32 in HBM either way."""
+    global _fp32_mode_cache
+    _lib.check(_lib.load().gif_set_fp32_mfma_mode(FP32_MFMA_MODES[mode] if isinstance(mode, str) else int(mode)), "set_fp32_mfma_mode")
+    _fp32_mode_cache = None
+
+
+_fp32_mode_cache = None
+
+
+def get_fp32_mfma_mode() -> str:
+    global _fp32_mode_cache
+    if _fp32_mode_cache is None:
+        m = _lib.load().gif_get_fp32_mfma_mode()
+        _fp32_mode_cache = {v: k for k, v in FP32_MFMA_MODES.items()}[m]
+    return _fp32_mode_cache
 
 
 def prof_enable(on: bool):

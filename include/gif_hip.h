@@ -30,6 +30,29 @@ typedef void* gif_stream_t;
 const char* gif_last_error(void);
 int gif_abi_version(void);
 
+/* How the fp32 convolution contractions reach the matrix cores (process-wide; fp32 tensors in, fp32 tensors out either way):
+ *   NATIVE : v_mfma_f32_32x32x2_f32 on the fp32 operands (157 TFLOP/s peak).
+ *   BF16X3 : every fp32 operand element a is split into three bf16 terms a = hi + mid + lo (round-to-nearest at each level,
+ *            8 + 8 + 8 mantissa bits, fp32's exponent range; the sum reproduces a to <= 2^-24 |a|), and a*b is accumulated in
+ *            fp32 from the six products hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi on v_mfma_f32_32x32x16_bf16 (2.5 PFLOP/s
+ *            peak => 417 TFLOP/s of fp32-equivalent work).  Each bf16*bf16 product is exact in fp32; the three dropped cross
+ *            terms are <= 2^-23 |a*b| (typically 2^-25: below one fp32 product rounding).  Measured error against an fp64
+ *            convolution: equal to or below the native fp32 MFMA path (tools/probes/x3_probe.py).
+ *            Default: the GIF_FP32_MFMA environment variable ("native" / "bf16x3"), else BF16X3. */
+#define GIF_FP32_MFMA_NATIVE 0
+#define GIF_FP32_MFMA_BF16X3 1
+int gif_set_fp32_mfma_mode(int mode);
+int gif_get_fp32_mfma_mode(void);
+/* The bf16x3 entry points (fp32 activations in and out, exactly like their _f32 namesakes; stylegan2_common_layers.py:330-345).
+ * The mode above is only the default a host should honour; the kernels are selected by the entry point.
+ * Weights are pre-split once per optimiser step: gif_pack_weight_f32x3 writes wp3[tap][3][RP][CP] bf16 (hi, mid, lo planes;
+ * RP/CP from gif_conv2d_pack_dims; 6 bytes per padded element).  Activations are split inside the kernels after the LDS
+ * read.  Layers with fewer than 32 input channels stay on the native kernels (gif_conv2d_x3_eligible() == 0). */
+int gif_conv2d_x3_eligible(int cout, int cin);
+int gif_pack_weight_f32x3(const float* w, void* wp3, int R, int C, int KH, int KW, int RP, int CP, int64_t sr, int64_t sc,
+                          int64_t sky, int64_t skx, float scale, gif_stream_t stream);
+/* gif_conv2d_fwd_f32x3 / gif_conv2d_bwd_data_f32x3: declared next to their _f32 namesakes below */
+
 /* ------------------------------------------------------------------------------------------------
  * Mesh rasteriser — replaces standard_rasterize_cuda.standard_rasterize / standard_rasterize_colors
  * (standard_rasterize_cuda.cpp:26-40, :59-75; kernels standard_rasterize_cuda_kernel.cu:111-233).
@@ -124,6 +147,10 @@ int gif_conv2d_fwd_f32(const float* big, const float* wp, float* small, const gi
                        const gif_conv_epilogue* e, gif_stream_t stream);
 int gif_conv2d_bwd_data_f32(const float* small, const float* wp, float* big, const gif_conv_geom* g,
                             const gif_conv_epilogue* e, gif_stream_t stream);
+int gif_conv2d_fwd_f32x3(const float* big, const void* wp3, float* small, const gif_conv_geom* g, const gif_conv_epilogue* e,
+                         gif_stream_t stream);
+int gif_conv2d_bwd_data_f32x3(const float* small, const void* wp3, float* big, const gif_conv_geom* g,
+                              const gif_conv_epilogue* e, gif_stream_t stream);
 /* Partial weight gradients: ws[nsplit][KH*KW][RP][CP] with rows = small-side channels (o), cols = big-side
  * channels (i); (RP,CP) = gif_conv2d_wgrad_dims(Cs, Cb).  nsplit from gif_conv2d_wgrad_splits().
  * small_scale [B,Cs] / big_scale [B,Cb] (or NULL) are applied to the operands on load. */

@@ -382,6 +382,7 @@ def test_training_trajectory_vs_oracle_trainer():
             agree += int((diff <= 0.05 * lr).sum())
             total += diff.numel()
             assert diff.max().item() <= 4.2 * lr, (k, diff.max().item())  # at most two sign flips of lr-sized steps
+        print(f"trajectory agreement: {agree / total:.4f} ({total} weights)")
         assert agree / total > 0.985, (agree, total)  # (0.992 observed: 0.8 % of the ~21 M trained weights have |grad| ~ rounding)
     decay = 0.5 ** (32 / 10000)
     w_ema = G_ema.state_dict()["generator.progression.2.st_cv2.conv.weight"].cpu()

@@ -1,0 +1,67 @@
+"""bf16x3 vs native fp32 MFMA on the direct conv kernels: error against an fp64 ATen convolution and time per launch.
+Usage (GPU): python tools/probes/x3_probe.py [--batch 32]"""
+import argparse
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from gif_amd import ops  # noqa: E402
+from tools.kernel_bench import timeit  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=32)
+    a = ap.parse_args()
+    B = a.batch
+    dev = "cuda"
+    torch.manual_seed(0)
+    ops.WINOGRAD = False  # the direct kernels are what is being compared
+    # accuracy: small enough for an fp64 reference
+    print("# error vs fp64 (max |diff| / max |ref|), batch 4")
+    for ci, co, k, s, p, h in ((128, 128, 3, 1, 1, 192), (128, 256, 3, 2, 0, 257), (128, 128, 3, 1, 1, 32), (512, 512, 3, 1, 1, 16), (128, 256, 3, 2, 0, 33), (256, 128, 1, 1, 0, 32)):
+        spec = ops.ConvSpec(k, k, s, p)
+        x = torch.randn(4, ci, h, h, device=dev).contiguous(memory_format=torch.channels_last)
+        w = torch.randn(co, ci, k, k, device=dev) / (ci * k * k) ** 0.5
+        sc = torch.rand(4, ci, device=dev) + 0.5
+        ref = F.conv2d(x.double() * sc.double()[:, :, None, None], w.double(), stride=s, padding=p)
+        hs, ws_ = spec.small_hw(h, h)
+        gy = torch.randn(4, co, hs, ws_, device=dev).contiguous(memory_format=torch.channels_last)
+        refd = F.conv_transpose2d(gy.double(), w.double(), stride=s, padding=p,
+                                  output_padding=(h - ((hs - 1) * s + k - 2 * p), h - ((ws_ - 1) * s + k - 2 * p)))
+        for mode in ("native", "bf16x3"):
+            ops.set_fp32_mfma_mode(mode)
+            y = ops.conv_fwd(x, w, spec, in_scale=sc)[:, :co]
+            gx = ops.conv_bwd_data(gy, w, spec, (h, h))[:, :ci]
+            e_f = float((y.double() - ref).abs().max() / ref.abs().max())
+            e_d = float((gx.double() - refd).abs().max() / refd.abs().max())
+            print(f"{ci:4d}->{co:4d} k{k} s{s} @{h:3d} {mode:7s}: fwd {e_f:.2e}  dgrad {e_d:.2e}")
+    print(f"# time per launch, batch {B}")
+    shapes = [("128->128 @256", 128, 128, 3, 1, 1, 256), ("256->256 @128", 256, 256, 3, 1, 1, 128),
+              ("512->512 @64", 512, 512, 3, 1, 1, 64), ("512->512 @32", 512, 512, 3, 1, 1, 32),
+              ("512->512 @16", 512, 512, 3, 1, 1, 16), ("512->512 @8", 512, 512, 3, 1, 1, 8),
+              ("128->256 s2 @257", 128, 256, 3, 2, 0, 257), ("256->512 s2 @129", 256, 512, 3, 2, 0, 129),
+              ("128->256 1x1 @128", 128, 256, 1, 1, 0, 128), ("128->3 1x1 @256", 128, 3, 1, 1, 0, 256)]
+    for name, ci, co, k, s, p, h in shapes:
+        spec = ops.ConvSpec(k, k, s, p)
+        x = torch.randn(B, ci, h, h, device=dev).contiguous(memory_format=torch.channels_last)
+        w = torch.randn(co, ci, k, k, device=dev)
+        sc = torch.rand(B, ci, device=dev) + 0.5
+        hs, ws_ = spec.small_hw(h, h)
+        gy = torch.randn(B, ops.pad4(co), hs, ws_, device=dev).contiguous(memory_format=torch.channels_last)
+        fl = 2.0 * B * hs * ws_ * co * ci * k * k
+        line = f"{name:20s}"
+        for mode in ("native", "bf16x3"):
+            ops.set_fp32_mfma_mode(mode)
+            t_f = timeit(lambda: ops.conv_fwd(x, w, spec))
+            t_m = timeit(lambda: ops.conv_fwd(x, w, spec, in_scale=sc))
+            t_d = timeit(lambda: ops.conv_bwd_data(gy, w, spec, (h, h)))
+            line += f" | {mode}: fwd {fl / t_f / 1e9:6.1f} mod {fl / t_m / 1e9:6.1f} dgrad {fl / t_d / 1e9:6.1f} TF"
+        print(line)
+
+
+if __name__ == "__main__":
+    main()
