@@ -55,9 +55,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // 8 consecutive K (= pixels) of ONE channel per lane, i.e. a transposed operand, which is gathered with eight 16-bit LDS reads
 // per fragment (lane = channel: the 32 lanes of a half wave read 64 contiguous bytes of one pixel row, conflict free).
 // Accumulators and the partial-sum workspace stay fp32.
-template <typename T, int BP, int BQ, int WAVES_P, int WAVES_Q, bool GLDS, int BKP, bool TAB = false>
+// X3 (T = float, GLDS): fp32 tiles, bf16 matrix cores ("bf16x3", common.h split_pair): like the f16 path every lane gathers 8
+// consecutive pixels of its channel per operand tile (eight ds_read_b32, conflict free), then splits the 8 floats into the
+// three bf16x8 terms; six v_mfma_f32_32x32x16_bf16 per tile pair and 16 pixels.  Both operands are activations, so neither can
+// be pre-split; the split (36 VALU per fragment) overlaps with the MFMAs of the other resident waves.
+template <typename T, int BP, int BQ, int WAVES_P, int WAVES_Q, bool GLDS, int BKP, bool TAB = false, bool X3 = false>
 __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const WgradParams p) {
     constexpr bool F16 = sizeof(T) == 2;
+    static_assert(!X3 || (!F16 && GLDS && BKP % 16 == 0), "bf16x3: fp32 tiles through the LDS-DMA path, 16-pixel K steps");
     constexpr int EPC = 16 / sizeof(T);  // elements per 16-byte chunk
     constexpr int THREADS = 64 * WAVES_P * WAVES_Q;
     constexpr int WPt = BP / WAVES_P, WQt = BQ / WAVES_Q;
@@ -225,7 +230,64 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     auto compute = [&](int buf) __attribute__((always_inline)) {
-        if constexpr (F16) {
+        if constexpr (X3) {
+            float psv[MT], qsv[NT];
+            if (TAB) {
+                const float* row = Stab + tab_row * (BP + BQ);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) psv[i] = row[wp0 + i * 32 + li];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) qsv[j] = row[BP + wq0 + j * 32 + li];
+                tab_rem += BKP;
+                if (tab_rem >= (int)HWs) { tab_rem -= (int)HWs; ++tab_row; }
+            }
+#pragma unroll
+            for (int ks = 0; ks < BKP / 16; ++ks) {
+                const int k0 = 16 * ks + 8 * lh;  // this lane half's 8 pixels of the K step
+                float a[MT][8], b[NT][8];
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) a[i][e] = Ps[buf][k0 + e][wp0 + i * 32 + li];
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) b[j][e] = Qs[buf][k0 + e][wq0 + j * 32 + li];
+                gif::u32x4_t sa[3][MT], sb[3][NT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x0 = a[i][2 * e], x1 = a[i][2 * e + 1];
+                        if (TAB) { x0 *= psv[i]; x1 *= psv[i]; }
+                        unsigned h, m, l;
+                        gif::split_pair(x0, x1, h, m, l);
+                        sa[0][i][e] = h; sa[1][i][e] = m; sa[2][i][e] = l;
+                    }
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x0 = b[j][2 * e], x1 = b[j][2 * e + 1];
+                        if (TAB) { x0 *= qsv[j]; x1 *= qsv[j]; }
+                        unsigned h, m, l;
+                        gif::split_pair(x0, x1, h, m, l);
+                        sb[0][j][e] = h; sb[1][j][e] = m; sb[2][j][e] = l;
+                    }
+                // smallest terms first; mid*lo, lo*mid, lo*lo (<= 2^-23 of the product) are not formed
+                constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gif::bf16x8_t, sa[TA[t6]][i]),
+                                                                                __builtin_bit_cast(gif::bf16x8_t, sb[TB[t6]][j]),
+                                                                                acc[i][j], 0, 0, 0);
+            }
+            return;
+        } else if constexpr (F16) {
             float psv[MT], qsv[NT];
             if (TAB) {
                 const float* row = Stab + tab_row * (BP + BQ);
@@ -336,11 +398,11 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const 
         }
 }
 
-template <typename T, int BP, int BQ, int WP_, int WQ_, bool GLDS, int BKP, bool TAB = false>
+template <typename T, int BP, int BQ, int WP_, int WQ_, bool GLDS, int BKP, bool TAB = false, bool X3 = false>
 void wgrad_launch(dim3 grid, int threads, hipStream_t s, const WgradParams& p) {
     static gif::LdsAttr attr;
     const size_t lds = (size_t)2 * BKP * (BP + BQ) * sizeof(T) + (size_t)(TAB ? p.stab_nb * (BP + BQ) : 0) * sizeof(float);
-    auto kern = conv_wgrad_mfma<T, BP, BQ, WP_, WQ_, GLDS, BKP, TAB>;
+    auto kern = conv_wgrad_mfma<T, BP, BQ, WP_, WQ_, GLDS, BKP, TAB, X3>;
     attr.ensure(reinterpret_cast<const void*>(kern), lds);
     hipLaunchKernelGGL(kern, grid, dim3(threads), lds, s, p);
 }
@@ -750,8 +812,8 @@ int gif_conv2d_wgrad_splits(const gif_conv_geom* g) {
     return (int)n;
 }
 
-int gif_conv2d_wgrad_f32(const float* small, const float* big, float* ws, const float* small_scale,
-                         const float* big_scale, const gif_conv_geom* g, int nsplit, gif_stream_t stream) {
+static int conv2d_wgrad_f32_impl(const float* small, const float* big, float* ws, const float* small_scale,
+                                 const float* big_scale, const gif_conv_geom* g, int nsplit, gif_stream_t stream, bool x3) {
     GIF_REQUIRE(g && small && big && ws && nsplit >= 1, "conv2d_wgrad: bad arguments");
     GIF_REQUIRE(g->Cb % 4 == 0 && g->Cs % 4 == 0, "conv2d_wgrad: channels must be multiples of 4");
     GIF_REQUIRE(g->KH >= 1 && g->KH <= 3 && g->KW >= 1 && g->KW <= 3 && (g->stride == 1 || g->stride == 2),
@@ -768,7 +830,14 @@ int gif_conv2d_wgrad_f32(const float* small, const float* big, float* ws, const 
     p.chunk = (chunk + BKP_MAX - 1) / BKP_MAX * BKP_MAX;
     if (p.chunk < BKP_MAX) p.chunk = BKP_MAX;
     const int bp = tile_of(g->Cs), bq = tile_of(g->Cb);
-    const bool big_tile = wgrad_big_tile(g->Cs, g->Cb, small_scale || big_scale, p.Ntot) && !getenv("GIF_CONV_VARIANT");
+    // bf16x3: 128x128 tiles only (the 256x128 tile's 128 accumulator registers leave no room for the split operands); layers
+    // with a <= 32-channel side stay on the native kernels (same operands, same workspace)
+    const long HWs = (long)g->Hs * g->Ws;
+    p.stab_nb = (int)((p.chunk + HWs - 1) / HWs + 1);
+    if (p.stab_nb > g->B) p.stab_nb = g->B;
+    const bool tab_fits = HWs % 16 == 0 && (size_t)p.stab_nb * 256 * sizeof(float) <= 64 * 1024;
+    x3 = x3 && tile_of(g->Cs) == 128 && tile_of(g->Cb) == 128 && (!(small_scale || big_scale) || tab_fits);
+    const bool big_tile = !x3 && wgrad_big_tile(g->Cs, g->Cb, small_scale || big_scale, p.Ntot) && !getenv("GIF_CONV_VARIANT");
     p.tiles_q = p.CP / bq;
     p.tiles_pq = (p.RP / (big_tile ? 256 : bp)) * p.tiles_q;
     dim3 grid((unsigned)(p.tiles_pq * p.T * nsplit));
@@ -791,19 +860,19 @@ int gif_conv2d_wgrad_f32(const float* small, const float* big, float* ws, const 
         return gif::check_launch("conv2d_wgrad(small)");
     }
     {
-        gif::ProfScope prof(1, flops, s, (int)p.Ntot, g->Cs, g->Cb, p.T * 10 + g->stride + (small_scale || big_scale ? 100 : 0));
+        gif::ProfScope prof(x3 ? 9 : 1, flops, s, (int)p.Ntot, g->Cs, g->Cb, p.T * 10 + g->stride + (small_scale || big_scale ? 100 : 0));
         const char* env = getenv("GIF_CONV_VARIANT");
         const int variant = env ? atoi(env) : 0;
         const bool glds = !small_scale && !big_scale && variant != 1;
 #define GIF_WGRAD_LAUNCH(BP_, BQ_, WP_, WQ_, TH_)                                                                  \
     if (glds) wgrad_launch<float, BP_, BQ_, WP_, WQ_, true, 32>(grid, TH_, s, p);                                        \
     else wgrad_launch<float, BP_, BQ_, WP_, WQ_, false, 32>(grid, TH_, s, p)
-        const long HWs = (long)g->Hs * g->Ws;
-        p.stab_nb = (int)((p.chunk + HWs - 1) / HWs + 1);
-        if (p.stab_nb > g->B) p.stab_nb = g->B;
-        const bool tab = (small_scale || big_scale) && variant != 1 && HWs % 16 == 0 &&
-                         (size_t)p.stab_nb * 256 * sizeof(float) <= 64 * 1024;
-        if (big_tile) {
+        const bool tab = (small_scale || big_scale) && (variant != 1 || x3) && tab_fits;
+        if (x3 && tab) {
+            wgrad_launch<float, 128, 128, 2, 2, true, 16, true, true>(grid, 256, s, p);
+        } else if (x3) {
+            wgrad_launch<float, 128, 128, 2, 2, true, 16, false, true>(grid, 256, s, p);
+        } else if (big_tile) {
             wgrad_launch<float, 256, 128, 2, 2, true, 16>(grid, 256, s, p);
         } else if (bp == 128 && bq == 128 && tab) {
             // modulated wgrad (x*s, dy*d): LDS-DMA operands + scale table
@@ -818,6 +887,16 @@ int gif_conv2d_wgrad_f32(const float* small, const float* big, float* ws, const 
 #undef GIF_WGRAD_LAUNCH
     }
     return gif::check_launch("conv2d_wgrad");
+}
+
+int gif_conv2d_wgrad_f32(const float* small, const float* big, float* ws, const float* small_scale,
+                         const float* big_scale, const gif_conv_geom* g, int nsplit, gif_stream_t stream) {
+    return conv2d_wgrad_f32_impl(small, big, ws, small_scale, big_scale, g, nsplit, stream, false);
+}
+
+int gif_conv2d_wgrad_f32x3(const float* small, const float* big, float* ws, const float* small_scale,
+                           const float* big_scale, const gif_conv_geom* g, int nsplit, gif_stream_t stream) {
+    return conv2d_wgrad_f32_impl(small, big, ws, small_scale, big_scale, g, nsplit, stream, true);
 }
 
 int gif_unpack_wgrad_f32(const float* ws, float* dw, int nsplit, int R, int C, int KH, int KW, int RP, int CP,
@@ -848,9 +927,9 @@ int gif_conv3x3_winograd_wgrad_splits(int B, int H, int W, int Cs, int Cb) {
     return (int)n;
 }
 
-int gif_conv3x3_winograd_wgrad_f32(const float* x, const float* gy, float* V, float* Mg, float* ws,
-                                   const float* small_scale, const float* big_scale, int B, int H, int W, int Cs, int Cb,
-                                   int nsplit, gif_stream_t stream) {
+static int conv3x3_winograd_wgrad_impl(const float* x, const float* gy, float* V, float* Mg, float* ws,
+                                       const float* small_scale, const float* big_scale, int B, int H, int W, int Cs, int Cb,
+                                       int nsplit, gif_stream_t stream, bool x3) {
     GIF_REQUIRE(gy && V && Mg && ws && nsplit >= 1, "winograd_wgrad: bad arguments");  // x == NULL: V is already filled
     GIF_REQUIRE(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "winograd_wgrad: bad dims (H, W must be even)");
     GIF_REQUIRE(Cs > 0 && Cb > 0 && Cs % 4 == 0 && Cb % 4 == 0, "winograd_wgrad: channels must be multiples of 4");
@@ -869,7 +948,7 @@ int gif_conv3x3_winograd_wgrad_f32(const float* x, const float* gy, float* V, fl
             if (int rc = gif::winograd_input_transform(x, big_scale, V, B, H, W, Cb, s)) return rc;
         if (int rc = gif::winograd_gy_transform(gy, small_scale, Mg, B, H, W, Cs, s)) return rc;
     }
-    gif::ProfScope prof(3, flops, s, (int)((long)B * H * W), Cs, Cb, 1091 + (small_scale || big_scale ? 100 : 0));
+    gif::ProfScope prof(3, flops, s, (int)((long)B * H * W), Cs, Cb, 1091 + (small_scale || big_scale ? 100 : 0) + (x3 ? 1000 : 0));
     WgradParams p{};
     p.sm = Mg; p.bg = V; p.ws = ws; p.ss = nullptr; p.bs = nullptr;
     // one "image" of 1 x ntiles pixels per plane, 1x1 taps
@@ -883,18 +962,32 @@ int gif_conv3x3_winograd_wgrad_f32(const float* x, const float* gy, float* V, fl
     p.chunk = (chunk + BKP_MAX - 1) / BKP_MAX * BKP_MAX;
     if (p.chunk < BKP_MAX) p.chunk = BKP_MAX;
     const int bp = tile_of(CsP), bq = tile_of(CbP);
-    const bool big = wgrad_big_tile(CsP, CbP, false, ntiles);
+    x3 = x3 && bp == 128 && bq == 128;
+    const bool big = !x3 && wgrad_big_tile(CsP, CbP, false, ntiles);
     p.tiles_q = p.CP / bq;
     p.tiles_pq = (p.RP / (big ? 256 : bp)) * p.tiles_q;
     dim3 grid((unsigned)(p.tiles_pq * p.T * nsplit));
     p.zero = gif::zero_page16();
     GIF_REQUIRE(p.zero, "winograd_wgrad: zero page lookup failed");
-    if (big) wgrad_launch<float, 256, 128, 2, 2, true, 16>(grid, 256, s, p);
+    if (x3) wgrad_launch<float, 128, 128, 2, 2, true, 16, false, true>(grid, 256, s, p);
+    else if (big) wgrad_launch<float, 256, 128, 2, 2, true, 16>(grid, 256, s, p);
     else if (bp == 128 && bq == 128) wgrad_launch<float, 128, 128, 2, 2, true, 16>(grid, 256, s, p);
     else if (bp == 128 && bq == 32) wgrad_launch<float, 128, 32, 4, 1, true, 32>(grid, 256, s, p);
     else if (bp == 32 && bq == 128) wgrad_launch<float, 32, 128, 1, 4, true, 32>(grid, 256, s, p);
     else wgrad_launch<float, 32, 32, 1, 1, true, 32>(grid, 64, s, p);
     return gif::check_launch("conv3x3_winograd_wgrad");
+}
+
+int gif_conv3x3_winograd_wgrad_f32(const float* x, const float* gy, float* V, float* Mg, float* ws,
+                                   const float* small_scale, const float* big_scale, int B, int H, int W, int Cs, int Cb,
+                                   int nsplit, gif_stream_t stream) {
+    return conv3x3_winograd_wgrad_impl(x, gy, V, Mg, ws, small_scale, big_scale, B, H, W, Cs, Cb, nsplit, stream, false);
+}
+
+int gif_conv3x3_winograd_wgrad_f32x3(const float* x, const float* gy, float* V, float* Mg, float* ws,
+                                     const float* small_scale, const float* big_scale, int B, int H, int W, int Cs, int Cb,
+                                     int nsplit, gif_stream_t stream) {
+    return conv3x3_winograd_wgrad_impl(x, gy, V, Mg, ws, small_scale, big_scale, B, H, W, Cs, Cb, nsplit, stream, true);
 }
 
 int gif_winograd_unpack_wgrad_f32(const float* ws, float* dw, int nsplit, int R, int C, int RP, int CP, int64_t sr,

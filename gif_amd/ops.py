@@ -306,7 +306,8 @@ def conv3x3_winograd_wgrad(small, big, O, I, wscale=1.0, small_scale=None, big_s
     V = big_v if big_v is not None else torch.empty((nv,), device=dev, dtype=torch.float32)
     Mg = torch.empty((lib.gif_winograd_workspace_floats(B, H, W, Cs),), device=dev, dtype=torch.float32)
     ws = torch.empty((nsplit, 16, RP.value, CP.value), device=dev, dtype=torch.float32)
-    _lib.check(lib.gif_conv3x3_winograd_wgrad_f32(None if big_v is not None else big.data_ptr(), small.data_ptr(), V.data_ptr(), Mg.data_ptr(), ws.data_ptr(),
+    fn = lib.gif_conv3x3_winograd_wgrad_f32x3 if get_fp32_mfma_mode() == "bf16x3" else lib.gif_conv3x3_winograd_wgrad_f32
+    _lib.check(fn(None if big_v is not None else big.data_ptr(), small.data_ptr(), V.data_ptr(), Mg.data_ptr(), ws.data_ptr(),
                                                   _p(small_scale), _p(big_scale), B, H, W, Cs, Cb, nsplit, _stream()),
                "conv3x3_winograd_wgrad")
     dw = torch.empty((O, I, 3, 3), device=dev, dtype=torch.float32)
@@ -338,8 +339,9 @@ def conv_wgrad(small, big, spec: ConvSpec, O, I, wscale=1.0, small_scale=None, b
     nsplit = splits(ctypes.byref(g))
     T = spec.KH * spec.KW
     ws = torch.empty((nsplit, T, RP.value, CP.value), device=small.device, dtype=torch.float32)
-    _lib.check(_fn("conv2d_wgrad", dt)(small.data_ptr(), big.data_ptr(), ws.data_ptr(), _p(small_scale), _p(big_scale),
-                                       ctypes.byref(g), nsplit, _stream()), "conv2d_wgrad")
+    fn = lib.gif_conv2d_wgrad_f32x3 if (not f16 and get_fp32_mfma_mode() == "bf16x3") else _fn("conv2d_wgrad", dt)
+    _lib.check(fn(small.data_ptr(), big.data_ptr(), ws.data_ptr(), _p(small_scale), _p(big_scale), ctypes.byref(g), nsplit, _stream()),
+               "conv2d_wgrad")
     dw = torch.empty((O, I, spec.KH, spec.KW), device=small.device, dtype=torch.float32)
     so, si, sky, skx = dw.stride()
     _lib.check(lib.gif_unpack_wgrad_f32(ws.data_ptr(), dw.data_ptr(), nsplit, O, I, spec.KH, spec.KW, RP.value, CP.value,

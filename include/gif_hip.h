@@ -158,6 +158,9 @@ int gif_conv2d_wgrad_dims(int Cs, int Cb, int* RP, int* CP);
 int gif_conv2d_wgrad_splits(const gif_conv_geom* g);
 int gif_conv2d_wgrad_f32(const float* small, const float* big, float* ws, const float* small_scale,
                          const float* big_scale, const gif_conv_geom* g, int nsplit, gif_stream_t stream);
+/* same contract (operands, workspace, splits) on the bf16x3 kernels; layers with a <= 32-channel side run the native kernel */
+int gif_conv2d_wgrad_f32x3(const float* small, const float* big, float* ws, const float* small_scale,
+                           const float* big_scale, const gif_conv_geom* g, int nsplit, gif_stream_t stream);
 /* dw[r*sr + c*sc + ky*sky + kx*skx] = scale * sum_s ws[s][t][r][c]   (inverse of gif_pack_weight_f32) */
 int gif_unpack_wgrad_f32(const float* ws, float* dw, int nsplit, int R, int C, int KH, int KW, int RP, int CP,
                          int64_t sr, int64_t sc, int64_t sky, int64_t skx, float scale, gif_stream_t stream);
@@ -193,6 +196,10 @@ int gif_conv3x3_winograd_wgrad_splits(int B, int H, int W, int Cs, int Cb);
 int gif_conv3x3_winograd_wgrad_f32(const float* x, const float* gy, float* V, float* Mg, float* ws,
                                    const float* small_scale, const float* big_scale, int B, int H, int W, int Cs,
                                    int Cb, int nsplit, gif_stream_t stream);
+/* same contract with the 16 plane GEMMs on the bf16x3 kernel (the transforms stay fp32) */
+int gif_conv3x3_winograd_wgrad_f32x3(const float* x, const float* gy, float* V, float* Mg, float* ws,
+                                     const float* small_scale, const float* big_scale, int B, int H, int W, int Cs,
+                                     int Cb, int nsplit, gif_stream_t stream);
 int gif_winograd_unpack_wgrad_f32(const float* ws, float* dw, int nsplit, int R, int C, int RP, int CP, int64_t sr,
                                   int64_t sc, int64_t sky, int64_t skx, float scale, gif_stream_t stream);
 

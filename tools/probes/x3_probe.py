@@ -32,13 +32,23 @@ def main():
         gy = torch.randn(4, co, hs, ws_, device=dev).contiguous(memory_format=torch.channels_last)
         refd = F.conv_transpose2d(gy.double(), w.double(), stride=s, padding=p,
                                   output_padding=(h - ((hs - 1) * s + k - 2 * p), h - ((ws_ - 1) * s + k - 2 * p)))
+        wd = w.double().requires_grad_(True)
+        sd = torch.rand(4, co, device=dev) + 0.5
+        (refw,) = torch.autograd.grad(F.conv2d(x.double() * sc.double()[:, :, None, None], wd, stride=s, padding=p),
+                                      wd, gy.double() * sd.double()[:, :, None, None])
         for mode in ("native", "bf16x3"):
             ops.set_fp32_mfma_mode(mode)
             y = ops.conv_fwd(x, w, spec, in_scale=sc)[:, :co]
             gx = ops.conv_bwd_data(gy, w, spec, (h, h))[:, :ci]
             e_f = float((y.double() - ref).abs().max() / ref.abs().max())
             e_d = float((gx.double() - refd).abs().max() / refd.abs().max())
-            print(f"{ci:4d}->{co:4d} k{k} s{s} @{h:3d} {mode:7s}: fwd {e_f:.2e}  dgrad {e_d:.2e}")
+            line = f"{ci:4d}->{co:4d} k{k} s{s} @{h:3d} {mode:7s}: fwd {e_f:.2e}  dgrad {e_d:.2e}"
+            for wino in (False, True):
+                ops.WINOGRAD = wino
+                gw = ops.conv_wgrad(gy, x, spec, co, ci, small_scale=sd, big_scale=sc)
+                line += f"  wgrad{'(wino)' if wino else ''} {float((gw.double() - refw).abs().max() / refw.abs().max()):.2e}"
+            ops.WINOGRAD = False
+            print(line)
     print(f"# time per launch, batch {B}")
     shapes = [("128->128 @256", 128, 128, 3, 1, 1, 256), ("256->256 @128", 256, 256, 3, 1, 1, 128),
               ("512->512 @64", 512, 512, 3, 1, 1, 64), ("512->512 @32", 512, 512, 3, 1, 1, 32),
@@ -59,7 +69,14 @@ def main():
             t_f = timeit(lambda: ops.conv_fwd(x, w, spec))
             t_m = timeit(lambda: ops.conv_fwd(x, w, spec, in_scale=sc))
             t_d = timeit(lambda: ops.conv_bwd_data(gy, w, spec, (h, h)))
-            line += f" | {mode}: fwd {fl / t_f / 1e9:6.1f} mod {fl / t_m / 1e9:6.1f} dgrad {fl / t_d / 1e9:6.1f} TF"
+            t_w = timeit(lambda: ops.conv_wgrad(gy, x, spec, co, ci))
+            sd = torch.rand(B, ops.pad4(co), device=dev) + 0.5
+            t_wm = timeit(lambda: ops.conv_wgrad(gy, x, spec, co, ci, small_scale=sd, big_scale=sc))
+            ops.WINOGRAD = True
+            t_ww = timeit(lambda: ops.conv_wgrad(gy, x, spec, co, ci))
+            ops.WINOGRAD = False
+            line += (f" | {mode}: fwd {fl / t_f / 1e9:6.1f} mod {fl / t_m / 1e9:6.1f} dgrad {fl / t_d / 1e9:6.1f} wgrad {fl / t_w / 1e9:6.1f} "
+                     f"wmod {fl / t_wm / 1e9:6.1f} wwino {fl / t_ww / 1e9:6.1f}")
         print(line)
 
 
