@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--dtype", type=str, default="f32", choices=["f32", "f16"],
                     help="activation dtype: f32 = the reference's (headline); f16 = BASELINE configs[4] (f16 activations, fp32 "
                          "weights / demodulation / accumulation, loss scaling) — use with --res 1024 --batch 8")
+    ap.add_argument("--fp32-mfma", type=str, default=None, choices=["native", "bf16x3"],
+                    help="fp32 contraction mode of the conv kernels (default: GIF_FP32_MFMA, else bf16x3 — fp32 tensors, every fp32 "
+                         "operand split exactly into 3 bf16 terms, 6 bf16 MFMA products, fp32 accumulation)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4, help="CPU baseline batch (BASELINE.md §3: 4; 32 does not fit)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = calibrate: fastest of {all host cores, 64, 32, 16}")
@@ -236,7 +239,7 @@ def roofline_objects(ops, steps, wall_s):
         "mfma_kernel_ms_per_step": mfma_ms / steps,
         "frac_while_mfma_kernels_run": executed_peak_s / (mfma_ms * 1e-3) if mfma_ms else None,
         "note": "MFMA FLOPs actually executed (direct kernels: all; Winograd GEMMs: 16/36 of the algorithmic count), each priced "
-                "at the dense peak of the MFMA type it ran on (fp32 157.3 TF, f16 2500 TF): time at peak / wall time of the "
+                "at the dense peak of the MFMA type it ran on (fp32 157.3 TF, f16 / bf16 2500 TF; bf16x3: 6 executed per algorithmic): time at peak / wall time of the "
                 "timed region"}
     return out
 
@@ -287,6 +290,8 @@ def main():
         dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
 
     from gif_amd import ops
+    if args.fp32_mfma:
+        ops.set_fp32_mfma_mode(args.fp32_mfma)
     from gif_amd.discriminator import Discriminator
     from gif_amd.generator import StyledGenerator
     from gif_amd.train_step import GifTrainer, flops_per_image
@@ -355,10 +360,15 @@ def main():
         fl_img = flops_per_image(args.res, args.r1_every)
         step_tflops = value * fl_img / 1e12 / world
         f16 = args.dtype == "f16"
+        fp32_mode = ops.get_fp32_mfma_mode()
         peak = PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS
         workload = (f"GIF run-29 G+D training iteration, {args.res}x{args.res}, batch {B}/GPU, R1 every {args.r1_every}th step, "
                     + ("f16 activations / f16 MFMA with fp32 accumulation, fp32 weights + demodulation, dynamic loss scaling "
-                       "(BASELINE configs[4])" if f16 else "fp32 MFMA (BASELINE configs[1]/[3] shape)"))
+                       "(BASELINE configs[4])" if f16 else
+                       "fp32 tensors and fp32 accumulation; contractions on "
+                       + ("the bf16 matrix cores via the exact 3-way bf16 split (bf16x3: 6 products per fp32 product, error vs fp64 <= "
+                          "the native fp32 MFMA path); Winograd fwd/dgrad GEMMs and the < 32-channel layers on native fp32 MFMA"
+                          if fp32_mode == "bf16x3" else "native fp32 MFMA") + " (BASELINE configs[1]/[3] shape)"))
         if args.render_cond:
             workload += "; condition rasterised from a posed mesh inside the timed region (configs[2])"
         if args.gen_reg.upper() != "NONE":
@@ -369,12 +379,15 @@ def main():
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": workload, "global_batch": world * B, "resolution": args.res, "parallelism": f"dp{world}",
+                       "fp32_mfma": None if f16 else fp32_mode,
                        "algorithmic_tflop_per_image": fl_img / 1e12,
                        "peak_hbm_allocated_gb": torch.cuda.max_memory_allocated() / 2 ** 30},
             "step_mfma_roofline": {"achieved": step_tflops, "peak": peak, "unit": "TFLOP/s",
                                    "frac": step_tflops / peak,
-                                   "note": "whole step, ALGORITHMIC direct-convolution FLOPs (Winograd executes fewer: see "
-                                           "executed_mfma_frac_wall) incl. HBM-bound kernels, optimiser, host; per GPU"},
+                                   "note": "whole step, ALGORITHMIC direct-convolution FLOPs (Winograd executes fewer, bf16x3 six "
+                                           "times more on a 16x faster pipe: see executed_mfma_frac_wall) incl. HBM-bound kernels, "
+                                           "optimiser, host; per GPU.  peak = the fp32-input MFMA peak: a reference for the fp32 "
+                                           "workload, not the ceiling of the bf16x3 kernels (2500 / 6 = 417 fp32-equivalent TFLOP/s)"},
         }
         if not args.no_prof:
             out.update(roofline_objects(ops, args.steps, dt))

@@ -1,0 +1,124 @@
+"""-m gpu: the two fp32 contraction modes of the conv kernels (include/gif_hip.h: GIF_FP32_MFMA_NATIVE / _BF16X3).
+
+bf16x3 is the default, so every other -m gpu test already runs it against the CPU oracle at the fp32 tolerances.  Here:
+  * both modes against an fp64 convolution on the SAME inputs: the bf16x3 error must not exceed the native fp32-MFMA error
+    (beyond measurement noise) on every tile configuration of the split kernels — 256x128 / 8 waves with a 64x64 remainder
+    launch, 128x128, 64x64, the merged transposed-conv phases, 256x32 (thin outputs), modulated and plain, all three passes;
+  * the native kernels stay covered: the conv cases of test_gpu_kernels.py re-run with the mode switched to native;
+  * the mode API itself."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import test_gpu_kernels as K
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _restore_mode():
+    from gif_amd import ops
+    before = ops.get_fp32_mfma_mode()
+    wino = ops.WINOGRAD
+    yield
+    ops.set_fp32_mfma_mode(before)
+    ops.WINOGRAD = wino
+
+
+def test_mode_api():
+    from gif_amd import _lib, ops
+    lib = _lib.load()
+    assert ops.get_fp32_mfma_mode() in ("native", "bf16x3")
+    ops.set_fp32_mfma_mode("native")
+    assert lib.gif_get_fp32_mfma_mode() == 0 and ops.get_fp32_mfma_mode() == "native"
+    ops.set_fp32_mfma_mode("bf16x3")
+    assert lib.gif_get_fp32_mfma_mode() == 1 and ops.get_fp32_mfma_mode() == "bf16x3"
+    assert lib.gif_set_fp32_mfma_mode(7) != 0 and b"unknown mode" in lib.gif_last_error()
+    assert lib.gif_conv2d_x3_eligible(128, 128) == 1 and lib.gif_conv2d_x3_eligible(128, 24) == 0
+
+
+# (B, Cin, Cout, K, stride, pad, H): what each case exercises on the bf16x3 side
+X3_CASES = [
+    (4, 128, 128, 3, 1, 1, 192),   # 256x128 tiles + 64x64 remainder launch (576 tiles = 2 rounds + 64)
+    (4, 128, 256, 3, 2, 0, 257),   # stride 2 fwd; transposed dgrad in 4 phases (odd phase grids)
+    (4, 256, 256, 3, 1, 1, 64),    # 128x128 tiles (256 <= tiles256 < 512)
+    (4, 512, 512, 3, 1, 1, 16),    # 64x64 tiles
+    (2, 128, 256, 3, 2, 0, 33),    # small transposed conv: the four phases merged into one launch
+    (4, 128, 24, 3, 1, 1, 64),     # thin output: 256x32 tiles (fwd); dgrad has 24 contraction channels => native kernel
+    (2, 256, 128, 1, 1, 0, 32),    # 1x1
+    (3, 160, 96, 3, 1, 1, 20),     # ragged channel counts (padded K chunk, padded N tile)
+]
+
+
+@pytest.mark.parametrize("case", X3_CASES)
+def test_bf16x3_not_less_accurate_than_native_fp32_mfma(case):
+    from gif_amd import ops
+    B, ci, co, k, s, p, h = case
+    torch.manual_seed(sum(case))
+    dev = "cuda"
+    ops.WINOGRAD = False  # the direct kernels are the ones with two modes (the Winograd plane GEMMs are covered through wgrad)
+    spec = ops.ConvSpec(k, k, s, p)
+    x = torch.randn(B, ci, h, h, device=dev).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(co, ci, k, k, device=dev) / (ci * k * k) ** 0.5
+    sc, sd = torch.rand(B, ci, device=dev) + 0.5, torch.rand(B, ops.pad4(co), device=dev) + 0.5
+    hs, ws_ = spec.small_hw(h, h)
+    gy = torch.randn(B, ops.pad4(co), hs, ws_, device=dev).contiguous(memory_format=torch.channels_last)
+    gy[:, co:] = 0
+    xd, wd, gyd = x.double(), w.double().requires_grad_(True), gy[:, :co].double()
+    ref_f = F.conv2d(xd * sc.double()[:, :, None, None], wd, stride=s, padding=p)
+    op = (h - ((hs - 1) * s + k - 2 * p), h - ((ws_ - 1) * s + k - 2 * p))
+    ref_d = F.conv_transpose2d(gyd * sd[:, :co].double()[:, :, None, None], wd, stride=s, padding=p, output_padding=op)
+    (ref_w,) = torch.autograd.grad(ref_f, wd, gyd * sd[:, :co].double()[:, :, None, None])
+    ref_f, ref_d = ref_f.detach(), ref_d.detach()
+
+    def err(got, ref):
+        return float((got.double() - ref).abs().max() / ref.abs().max())
+
+    errs = {}
+    for mode in ("native", "bf16x3"):
+        ops.set_fp32_mfma_mode(mode)
+        e_f = err(ops.conv_fwd(x, w, spec, in_scale=sc)[:, :co], ref_f)
+        e_d = err(ops.conv_bwd_data(gy, w, spec, (h, h), in_scale=sd)[:, :ci], ref_d)
+        e_w = err(ops.conv_wgrad(gy, x, spec, co, ci, small_scale=sd, big_scale=sc), ref_w)
+        errs[mode] = (e_f, e_d, e_w)
+    for name, en, ex in zip(("fwd", "dgrad", "wgrad"), errs["native"], errs["bf16x3"]):
+        assert en < 1e-5 and ex < 1e-5, (case, name, en, ex)                    # both are fp32-grade results
+        assert ex <= 1.3 * en + 2e-7, (case, name, "bf16x3", ex, "native", en)  # and the split costs no accuracy
+
+
+def test_bf16x3_winograd_plane_gemms_vs_fp64():
+    """The 16 plane GEMMs of the Winograd weight gradient run on the same bf16x3 kernel (planes mode)."""
+    from gif_amd import ops
+    torch.manual_seed(5)
+    B, C, H = 4, 128, 64
+    x = torch.randn(B, C, H, H, device="cuda").contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(B, C, H, H, device="cuda").contiguous(memory_format=torch.channels_last)
+    wd = torch.zeros(C, C, 3, 3, device="cuda", dtype=torch.float64, requires_grad=True)
+    (ref,) = torch.autograd.grad(F.conv2d(x.double(), wd, padding=1), wd, gy.double())
+    spec = ops.ConvSpec(3, 3, 1, 1)
+    out = {}
+    for mode in ("native", "bf16x3"):
+        ops.set_fp32_mfma_mode(mode)
+        n0 = ops.prof_winograd_calls()
+        gw = ops.conv_wgrad(gy, x, spec, C, C)
+        assert ops.prof_winograd_calls() == n0 + 1, "the Winograd weight-gradient path must have run"
+        out[mode] = float((gw.double() - ref).abs().max() / ref.abs().max())
+    assert out["native"] < 1e-5 and out["bf16x3"] <= 1.3 * out["native"] + 2e-7, out
+
+
+@pytest.mark.parametrize("case", K.CONV_CASES)
+def test_native_mode_conv_cases_vs_oracle(case):
+    """The native fp32-MFMA kernels against the CPU oracle (the default mode of the other tests is bf16x3)."""
+    from gif_amd import ops
+    ops.set_fp32_mfma_mode("native")
+    K.test_conv_fwd(case)
+    K.test_conv_bwd_data(case)
+    K.test_conv_wgrad(case)
+
+
+def test_native_mode_epilogues_and_scaled_wgrad_vs_oracle():
+    from gif_amd import ops
+    ops.set_fp32_mfma_mode("native")
+    K.test_conv_scales_and_epilogue()
+    K.test_conv_wgrad_with_scales()
+    K.test_conv_launch_split_on_tile_quantisation()
