@@ -145,8 +145,8 @@ def cpu_baseline(res, step_idx, batch, threads, timeout_s):
                 "sample": f"cpu baseline did not finish within {timeout_s}s ({type(e).__name__})"}
 
 
-BF16X3_EXECUTED = 6.0  # bf16 MFMA FLOPs the bf16x3 kernels execute per algorithmic fp32 FLOP
-WINOGRAD_EXECUTED = 16.0 / 36.0  # MFMA FLOPs a Winograd F(2x2,3x3)/F(3x3,2x2) GEMM executes per algorithmic FLOP
+WINOGRAD_EXECUTED = 16.0 / 36.0
+BF16X3_EXECUTED = 6.0  # bf16 MFMA FLOPs the bf16x3 kernels execute per algorithmic fp32 FLOP  # MFMA FLOPs a Winograd F(2x2,3x3)/F(3x3,2x2) GEMM executes per algorithmic FLOP
 
 # family id -> (description, executed MFMA fraction of the algorithmic FLOPs, key in profiles/pmc_traffic.json)
 FAMILIES = {
@@ -166,11 +166,17 @@ FAMILIES = {
         "conv_gather_mfma_glds_x3"),
     9: ("conv_wgrad_mfma<float, bf16x3> (fp32 weight gradient on the bf16 matrix cores, same split)", BF16X3_EXECUTED,
         "conv_wgrad_mfma_x3"),
+    10: ("wino_gemm_x3 (Winograd F(2x2,3x3) fwd / dgrad GEMM on the bf16 matrix cores: bf16x3 split of V in the kernel, pre-split "
+         "U, fused output transform and epilogue)", BF16X3_EXECUTED * WINOGRAD_EXECUTED, "wino_gemm_x3"),
+    11: ("conv_wgrad_mfma<float, bf16x3> in planes mode (Winograd F(3x3,2x2) weight-gradient GEMMs on the bf16 matrix cores)",
+         BF16X3_EXECUTED * WINOGRAD_EXECUTED, "conv_wgrad_mfma_x3"),
 }
 FAMILY_KEYS = {0: "roofline_conv_direct", 1: "roofline_wgrad_direct", 2: "roofline_conv_winograd", 3: "roofline_wgrad_winograd",
                5: "roofline_conv_direct_small_cin", 6: "roofline_conv_f16", 7: "roofline_wgrad_f16",
-               8: "roofline_conv_direct_bf16x3", 9: "roofline_wgrad_direct_bf16x3"}
-FAMILY_PEAK = {6: PEAK_F16_MFMA_TFLOPS, 7: PEAK_F16_MFMA_TFLOPS, 8: PEAK_F16_MFMA_TFLOPS, 9: PEAK_F16_MFMA_TFLOPS}
+               8: "roofline_conv_direct_bf16x3", 9: "roofline_wgrad_direct_bf16x3", 10: "roofline_conv_winograd_bf16x3",
+               11: "roofline_wgrad_winograd_bf16x3"}
+FAMILY_PEAK = {6: PEAK_F16_MFMA_TFLOPS, 7: PEAK_F16_MFMA_TFLOPS, 8: PEAK_F16_MFMA_TFLOPS, 9: PEAK_F16_MFMA_TFLOPS,
+               10: PEAK_F16_MFMA_TFLOPS, 11: PEAK_F16_MFMA_TFLOPS}
 
 
 def load_pmc():
@@ -205,8 +211,9 @@ def roofline_objects(ops, steps, wall_s):
         if exec_frac != 1.0:
             o["algorithmic_achieved"] = alg
             o["algorithmic_frac"] = alg / peak
-            o["note"] = ("achieved = executed bf16 MFMA FLOP/s (6x the algorithmic fp32 FLOPs), priced at the 2.5 PFLOP/s bf16 peak"
-                         if exec_frac > 1 else "achieved = executed MFMA FLOP/s (16/36 of the algorithmic direct-convolution FLOPs)")
+            o["note"] = (f"achieved = executed bf16 MFMA FLOP/s ({exec_frac:.3g}x the algorithmic fp32 direct-convolution FLOPs: 6 bf16 "
+                         "products per fp32 product" + (", 16/36 of the products with Winograd" if exec_frac != 6 else "")
+                         + "), priced at the 2.5 PFLOP/s bf16 peak" if exec_frac > 1 else "achieved = executed MFMA FLOP/s (16/36 of the algorithmic direct-convolution FLOPs)")
         fam_pmc = (pmc or {}).get("families", {}).get(pmc_key)
         if fam_pmc:
             o["traffic"] = fam_pmc["hbm_bytes_per_launch"]
@@ -336,7 +343,7 @@ def main():
 
     data = [batch() for _ in range(min(args.steps, 4))]  # synthetic batches resident in HBM before the timed region
     if not args.no_prof:
-        for fam in range(8):
+        for fam in range(12):
             ops.prof_read(fam)
         ops.prof_enable(True)
     sync()

@@ -53,9 +53,12 @@ PROTOTYPES = {
     "gif_conv2d_wgrad_f32x3": (c_int, [P, P, P, P, P, GP, c_int, P]),
     "gif_unpack_wgrad_f32": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_float, P]),
     "gif_winograd_pack_dims": (c_int, [c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "gif_winograd_pack_dims_x3": (c_int, [c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "gif_winograd_workspace_floats": (c_i64, [c_int, c_int, c_int, c_int]),
     "gif_winograd_weight_f32": (c_int, [P, P, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_int, c_float, P]),
+    "gif_winograd_weight_f32x3": (c_int, [P, P, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_int, c_float, P]),
     "gif_conv3x3_winograd_f32": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, EP, P]),
+    "gif_conv3x3_winograd_f32x3": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, EP, P]),
     "gif_conv3x3_winograd_wgrad_splits": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "gif_conv3x3_winograd_wgrad_f32": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "gif_conv3x3_winograd_wgrad_f32x3": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),

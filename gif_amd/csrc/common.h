@@ -50,8 +50,9 @@ int fp32_mfma_mode();
 // 0 direct conv fwd/dgrad on the LDS-DMA kernel (Cin >= 32; flops), 1 direct wgrad (flops), 2 Winograd GEMM fwd/dgrad
 // (ALGORITHMIC direct-conv flops; the kernel executes 16/36 of them), 3 Winograd wgrad GEMM (same convention),
 // 4 Winograd transforms (HBM bytes), 5 direct conv fwd/dgrad on the register-staged kernel (Cin < 32; flops),
-// 6 / 7 f16 conv / wgrad, 8 / 9 bf16x3 conv fwd/dgrad / wgrad (algorithmic flops; the bf16 pipe executes 6x)
-#define GIF_PROF_FAMILIES 10
+// 6 / 7 f16 conv / wgrad, 8 / 9 bf16x3 conv fwd/dgrad / wgrad (algorithmic flops; the bf16 pipe executes 6x),
+// 10 / 11 bf16x3 Winograd GEMM fwd/dgrad / Winograd wgrad plane GEMMs (algorithmic flops; execute 6 * 16/36 of them)
+#define GIF_PROF_FAMILIES 12
 struct ProfScope {
     int family;
     hipStream_t stream;

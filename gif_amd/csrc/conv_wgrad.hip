@@ -948,7 +948,8 @@ static int conv3x3_winograd_wgrad_impl(const float* x, const float* gy, float* V
             if (int rc = gif::winograd_input_transform(x, big_scale, V, B, H, W, Cb, s)) return rc;
         if (int rc = gif::winograd_gy_transform(gy, small_scale, Mg, B, H, W, Cs, s)) return rc;
     }
-    gif::ProfScope prof(3, flops, s, (int)((long)B * H * W), Cs, Cb, 1091 + (small_scale || big_scale ? 100 : 0) + (x3 ? 1000 : 0));
+    x3 = x3 && tile_of(CsP) == 128 && tile_of(CbP) == 128;
+    gif::ProfScope prof(x3 ? 11 : 3, flops, s, (int)((long)B * H * W), Cs, Cb, 1091 + (small_scale || big_scale ? 100 : 0));
     WgradParams p{};
     p.sm = Mg; p.bg = V; p.ws = ws; p.ss = nullptr; p.bs = nullptr;
     // one "image" of 1 x ntiles pixels per plane, 1x1 taps
@@ -962,7 +963,6 @@ static int conv3x3_winograd_wgrad_impl(const float* x, const float* gy, float* V
     p.chunk = (chunk + BKP_MAX - 1) / BKP_MAX * BKP_MAX;
     if (p.chunk < BKP_MAX) p.chunk = BKP_MAX;
     const int bp = tile_of(CsP), bq = tile_of(CbP);
-    x3 = x3 && bp == 128 && bq == 128;
     const bool big = !x3 && wgrad_big_tile(CsP, CbP, false, ntiles);
     p.tiles_q = p.CP / bq;
     p.tiles_pq = (p.RP / (big ? 256 : bp)) * p.tiles_q;

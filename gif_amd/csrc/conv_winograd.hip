@@ -400,6 +400,264 @@ __global__ void __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) wino_gemm_mfma(cons
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ bf16x3 GEMM + output transform
+// The same 16 position GEMMs with the fp32 operands on the bf16 matrix cores (common.h split_pair): V stays fp32 in HBM and LDS
+// and is split after the LDS read; U arrives PRE-SPLIT (wino_weight_transform_x3: U3 [16][3 terms][RP][CP] bf16) in three
+// [128][32] bf16 tiles of 64-byte rows per stage (16-byte chunks XOR-swizzled with (row >> 2) & 3, as in conv_igemm.hip), so a
+// weight operand is one ds_read_b128.  512 threads = 8 waves as 4 (M) x 2 (N); wave tile 32 tiles x 64 couts (ONE V fragment
+// to split per 12 MFMAs); block 128 x 128; BK = 32 = two 16-k groups; 3-stage ring (120 KB) => one workgroup per CU, two waves
+// per SIMD.  Registers: 4 x 2 output accumulators (128) + ONE position accumulator set (32): the fold into the 2x2 outputs runs
+// at the end of each position, un-overlapped inside the wave (the SIMD's other wave keeps the matrix pipe busy).
+// Per group: the V fragments of the NEXT group are read first and split piecewise between this group's MFMAs; the weight
+// operands are reloaded term by term as soon as the last MFMA that uses a term has issued (lo after 2, mid after 6, hi after 12).
+__global__ void __launch_bounds__(512, 1) wino_gemm_x3(const WinoParams p) {
+    constexpr int THREADS = 512, BN = 128, PROWS = THREADS / 8;
+    constexpr int LD = WBK, CH = WBK / 4, RB = 64 / WBK, RPW = 64 / CH;
+    constexpr int NT = 2;
+    constexpr int A_IT = WBM / PROWS;          // 2
+    constexpr int B3_BLK = 3 * BN / 16;        // 24 one-KiB blocks (16 rows x 64 B) per stage
+    constexpr int B3_IT = B3_BLK / 8;          // 3 per wave
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                                                                     // [NSTAGE][WBM][LD] fp32
+    unsigned short* B3 = reinterpret_cast<unsigned short*>(smem + WNSTAGE * WBM * LD);   // [NSTAGE][3][BN][32] bf16
+    const unsigned short* const U3 = reinterpret_cast<const unsigned short*>(p.U);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 64;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
+    const int m0 = tm * WBM, n0 = tn * BN;
+    const int t_row = tid / CH;
+    const int src_c4 = ((tid % CH) ^ ((t_row / RB) % CH)) * 4;
+    const int fsw = (li / RB) % CH;
+    const int b3_sw = (li >> 2) & 3;
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+
+    const unsigned a_off = (unsigned)(m0 + t_row) * (unsigned)p.CP + (unsigned)src_c4;
+    const size_t pass_stride = (size_t)PROWS * p.CP;
+    const size_t planeV = (size_t)p.ntiles_pad * p.CP, planeU = (size_t)p.RP * p.CP;  // planeU: one TERM plane of one position
+    unsigned b3_off[B3_IT];
+#pragma unroll
+    for (int it = 0; it < B3_IT; ++it) {
+        const int blk = wave + it * 8;
+        const int term = blk / (BN / 16), r = (blk % (BN / 16)) * 16 + (lane >> 2);
+        b3_off[it] = (unsigned)((size_t)term * planeU + (size_t)(n0 + r) * p.CP + (((lane & 3) ^ ((lane >> 4) & 3)) << 3));
+    }
+    const int kchunks = p.CP / WBK;
+    const int nsteps = 16 * kchunks;
+    const float* vptr = p.V;
+    const unsigned short* uptr = U3;
+    int ld_kc = 0;
+
+    auto issue = [&](int buf) __attribute__((always_inline)) {
+        float* Ad = As + buf * WBM * LD + wave * RPW * LD;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it)
+            __builtin_amdgcn_global_load_lds((gptr_t)((vptr + it * pass_stride) + a_off), (lptr_t)(Ad + it * PROWS * LD), 16, 0, 0);
+#pragma unroll
+        for (int it = 0; it < B3_IT; ++it)
+            __builtin_amdgcn_global_load_lds((gptr_t)(uptr + b3_off[it]), (lptr_t)(B3 + (buf * B3_BLK + wave + it * 8) * 512), 16, 0, 0);
+        vptr += WBK;
+        uptr += WBK;
+        ld_kc += WBK;
+        if (ld_kc >= p.CP) {  // next position: same rows of the next plane (U3: skip the three term planes)
+            ld_kc = 0;
+            vptr += planeV - p.CP;
+            uptr += 3 * planeU - p.CP;
+        }
+    };
+
+    f32x16 acc[NT];
+    f32x16 yo[4][NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc[j][r] = 0.f;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) yo[o][j][r] = 0.f;
+        }
+
+    gif::u32x4_t sa[2][3];   // [slot][hi, mid, lo] of the V fragment
+    gif::u32x4_t sb[3][NT];  // [hi, mid, lo][cout tile]
+    f32x4 ra[2];             // raw V fragments of the group being split
+
+    auto read_a = [&](int buf, int q) __attribute__((always_inline)) {
+        const float* Ab = As + buf * WBM * LD + (wm0 + li) * LD;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) ra[u] = *reinterpret_cast<const f32x4*>(Ab + (((q * 4 + lh * 2 + u) ^ fsw) << 2));
+    };
+    auto read_b = [&](int buf, int q, int t) __attribute__((always_inline)) {
+        const unsigned short* Bb = B3 + (buf * 3 + t) * BN * 32 + (wn0 + li) * 32 + (((q * 2 + lh) ^ b3_sw) << 3);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) sb[t][j] = *reinterpret_cast<const gif::u32x4_t*>(Bb + j * 32 * 32);
+    };
+    auto split_piece = [&](int slot, int e) __attribute__((always_inline)) {
+        unsigned h, m, l;
+        gif::split_pair(ra[e / 2][(e % 2) * 2], ra[e / 2][(e % 2) * 2 + 1], h, m, l);
+        sa[slot][0][e] = h; sa[slot][1][e] = m; sa[slot][2][e] = l;
+    };
+    auto mma = [&](int slot, int ta, int tb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gif::bf16x8_t, sa[slot][ta]),
+                                                             __builtin_bit_cast(gif::bf16x8_t, sb[tb][j]), acc[j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // one 16-k group: MFMAs of (slot) + operand preparation of the next group (V fragments of (rbuf, nq) -> slot ^ 1, weights)
+    auto group = [&](int slot, int rbuf, int nq) __attribute__((always_inline)) {
+        read_a(rbuf, nq);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(slot, 0, 2);  // hi * lo
+        read_b(rbuf, nq, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(slot, 1, 1);  // mid * mid
+        split_piece(slot ^ 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(slot, 0, 1);  // hi * mid
+        read_b(rbuf, nq, 1);
+        split_piece(slot ^ 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(slot, 2, 0);  // lo * hi
+        split_piece(slot ^ 1, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(slot, 1, 0);  // mid * hi
+        split_piece(slot ^ 1, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(slot, 0, 0);  // hi * hi
+        read_b(rbuf, nq, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto fold = [&](int pos) __attribute__((always_inline)) {
+        const int xi = pos >> 2, nu = pos & 3;
+        float cf[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) cf[o] = wino_coef(o >> 1, xi) * wino_coef(o & 1, nu);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+#pragma unroll
+            for (int o = 0; o < 4; ++o) yo[o][j] += cf[o] * acc[j];
+            acc[j] = (f32x16)(0.f);
+        }
+    };
+
+    constexpr int NI = A_IT + B3_IT;
+    static_assert(NI == 5, "the s_waitcnt immediates below encode vmcnt(NI)");
+    issue(0);
+    issue(1);  // nsteps >= 16
+    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    read_a(0, 0);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) read_b(0, 0, t);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split_piece(0, e);
+
+    int cur = 0, kc_in_pos = 0, pos = 0;
+    for (int step = 0; step < nsteps; ++step) {
+        if (step + 2 < nsteps) issue(cur >= 1 ? cur - 1 : 2);  // (cur + 2) % 3: last read before the previous stage's barrier
+        __builtin_amdgcn_sched_barrier(0);
+        group(0, cur, 1);
+        // stage step+1 must have landed before its operands are read (this stage's are all in registers by now)
+        if (step + 2 < nsteps) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        cur = cur == 2 ? 0 : cur + 1;
+        group(1, cur, 0);  // (after the last stage this prepares operands nobody uses: the reads stay inside the ring)
+        if (++kc_in_pos == kchunks) {
+            fold(pos);
+            kc_in_pos = 0;
+            ++pos;
+        }
+    }
+
+    // ---- epilogue: for each output position (a,b): transpose through LDS, then coalesced float4 rows
+    constexpr int LDC = BN + 4;
+    float* Cs = smem;  // [WBM][LDC]
+    constexpr int C4_ROW = BN / 4, EROWS = THREADS / C4_ROW, E_IT = WBM / EROWS;
+    const int e_row0 = tid / C4_ROW, e_c = (tid % C4_ROW) * 4;
+    const int n = n0 + e_c;
+    f32x4 bias4 = (f32x4)(0.f);
+    if (p.bias && n < p.Co) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = wm0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                Cs[row * LDC + wn0 + j * 32 + li] = yo[o][j][r];
+            }
+        __syncthreads();
+        if (n < p.Co) {
+            const int oa = o >> 1, ob = o & 1;
+#pragma unroll 4
+            for (int it = 0; it < E_IT; ++it) {
+                const int row = e_row0 + it * EROWS;
+                const int m = m0 + row;
+                if (m >= p.ntiles) break;
+                int tx = m % p.TW;
+                int t2 = m / p.TW;
+                int ty = t2 % p.TH, b = t2 / p.TH;
+                size_t off = (((size_t)b * p.H + 2 * ty + oa) * p.W + 2 * tx + ob) * p.Co + n;
+                f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * LDC + e_c);
+                if (p.out_scale) v *= *reinterpret_cast<const f32x4*>(p.out_scale + (size_t)b * p.Co + n);
+                if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + off);
+                v += bias4;
+                if (p.act) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (v[e] > 0.f ? v[e] : v[e] * p.slope) * p.gain;
+                }
+                *reinterpret_cast<f32x4*>(p.y + off) = v;
+            }
+        }
+    }
+}
+
+// U3 = the three bf16 terms of G g G^T: [16][3][RP][CP]
+__global__ void wino_weight_transform_x3(const float* __restrict__ w, unsigned short* __restrict__ U3, int R, int C, int RP, int CP,
+                                         long sr, long sc, long sky, long skx, int flip, float scale) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)RP * CP) return;
+    int c = (int)(idx % CP), r = (int)(idx / CP);
+    float g[3][3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            int sy = flip ? 2 - ky : ky, sx = flip ? 2 - kx : kx;
+            g[ky][kx] = (r < R && c < C) ? scale * w[r * sr + c * sc + sy * sky + sx * skx] : 0.f;
+        }
+    float u[4][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        u[0][j] = g[0][j];
+        u[1][j] = 0.5f * (g[0][j] + g[1][j] + g[2][j]);
+        u[2][j] = 0.5f * (g[0][j] - g[1][j] + g[2][j]);
+        u[3][j] = g[2][j];
+    }
+    const size_t plane = (size_t)RP * CP;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float v4[4] = {u[i][0], 0.5f * (u[i][0] + u[i][1] + u[i][2]), 0.5f * (u[i][0] - u[i][1] + u[i][2]), u[i][2]};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned h, m, l;
+            gif::split_pair(v4[q], 0.f, h, m, l);
+            unsigned short* o = U3 + (size_t)(i * 4 + q) * 3 * plane + idx;
+            o[0] = (unsigned short)(h & 0xffffu);
+            o[plane] = (unsigned short)(m & 0xffffu);
+            o[2 * plane] = (unsigned short)(l & 0xffffu);
+        }
+    }
+}
+
 }  // namespace
 
 namespace gif {
@@ -513,5 +771,58 @@ int gif_conv3x3_winograd_f32(const float* x, const float* U, float* y, float* V,
     if (wide) hipLaunchKernelGGL(wino_gemm_mfma<4>, grid, dim3(512), lds, s, p);
     else hipLaunchKernelGGL(wino_gemm_mfma<2>, grid, dim3(256), lds, s, p);
     return gif::check_launch("conv3x3_winograd");
+}
+// ---- bf16x3 variants: same contract; U3 = [16][3][RP][CP] bf16 from gif_winograd_weight_f32x3, RP a multiple of 128
+int gif_winograd_pack_dims_x3(int cout, int cin, int* RP, int* CP) {
+    GIF_REQUIRE(cout > 0 && cin > 0 && RP && CP, "winograd_pack_dims_x3: bad arguments");
+    *RP = (cout + 127) / 128 * 128;
+    *CP = (cin + WBK - 1) / WBK * WBK;
+    return 0;
+}
+
+int gif_winograd_weight_f32x3(const float* w, void* U3, int R, int C, int RP, int CP, int64_t sr, int64_t sc, int64_t sky,
+                              int64_t skx, int flip, float scale, gif_stream_t stream) {
+    GIF_REQUIRE(w && U3 && R > 0 && C > 0 && RP >= R && CP >= C && RP % 128 == 0, "winograd_weight_f32x3: bad arguments");
+    long total = (long)RP * CP;
+    wino_weight_transform_x3<<<gif::cdiv(total, 256), 256, 0, gif::as_stream(stream)>>>(w, static_cast<unsigned short*>(U3), R, C, RP,
+                                                                                         CP, sr, sc, sky, skx, flip, scale);
+    return gif::check_launch("winograd_weight_f32x3");
+}
+
+int gif_conv3x3_winograd_f32x3(const float* x, const void* U3, float* y, float* V, int B, int H, int W, int C, int Co,
+                               const gif_conv_epilogue* e, gif_stream_t stream) {
+    GIF_REQUIRE(x && U3 && y && V && B >= 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "winograd_x3: bad dims (H, W must be even)");
+    GIF_REQUIRE(C > 0 && Co > 0 && C % 4 == 0 && Co % 4 == 0, "winograd_x3: channels must be multiples of 4");
+    if (B == 0) return 0;
+    const long ntiles = (long)B * (H / 2) * (W / 2);
+    WinoParams p{};
+    gif_winograd_pack_dims_x3(Co, C, &p.RP, &p.CP);
+    const long ntiles_pad = (ntiles + WBM - 1) / WBM * WBM;
+    GIF_REQUIRE(ntiles_pad * p.CP < (1L << 31) && (long)B * H * W * Co < (1L << 31) && (long)B * H * W * C < (1L << 31) &&
+                    3L * p.RP * p.CP < (1L << 31),
+                "winograd_x3: tensor too large for 32-bit offsets");
+    hipStream_t s = gif::as_stream(stream);
+    double flops = 2.0 * B * H * W * 9.0 * C * Co;  // ALGORITHMIC (direct-convolution) FLOPs
+    {
+        gif::ProfScope prof_t(4, 4.0 * ((double)B * H * W * C + 16.0 * ntiles_pad * p.CP), s, (int)((long)B * H * W), C, 0, 1);
+        if (int rc = gif::winograd_input_transform(x, e ? e->in_scale : nullptr, V, B, H, W, C, s)) return rc;
+    }
+    gif::ProfScope prof(10, flops, s, (int)((long)B * H * W), Co, C, 2091);
+    p.V = V; p.U = static_cast<const float*>(U3); p.y = y;
+    p.out_scale = e ? e->out_scale : nullptr;
+    p.bias = e ? e->bias : nullptr;
+    p.residual = e ? static_cast<const float*>(e->residual) : nullptr;
+    p.act = e ? e->act : 0;
+    p.slope = e ? e->slope : 0.f;
+    p.gain = e ? e->gain : 1.f;
+    p.B = B; p.H = H; p.W = W; p.Co = Co;
+    p.ntiles = (int)ntiles; p.ntiles_pad = (int)ntiles_pad; p.TH = H / 2; p.TW = W / 2;
+    p.tiles_m = (int)(ntiles_pad / WBM);
+    p.tiles_n = p.RP / 128;
+    const size_t lds = (size_t)WNSTAGE * (WBM * WBK * sizeof(float) + 3 * 128 * 64);
+    static gif::LdsAttr attr;
+    attr.ensure(reinterpret_cast<const void*>(wino_gemm_x3), lds);
+    hipLaunchKernelGGL(wino_gemm_x3, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), lds, s, p);
+    return gif::check_launch("conv3x3_winograd_f32x3");
 }
 }

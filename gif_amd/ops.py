@@ -181,6 +181,7 @@ def pack_weight(w: torch.Tensor, rows_are_out: bool, cout_act: int, cin_act: int
 WINOGRAD = os.environ.get("GIF_WINOGRAD", "1") != "0"
 WINOGRAD_MIN_TILES = int(os.environ.get("GIF_WINOGRAD_MIN_TILES", "8192"))
 WINOGRAD_WGRAD = os.environ.get("GIF_WINOGRAD_WGRAD", "1") != "0"
+WINOGRAD_X3 = os.environ.get("GIF_WINO_X3", "1") != "0"  # bf16x3 mode: Winograd fwd/dgrad GEMMs on the bf16x3 kernel too
 WINOGRAD_WGRAD_MIN_TILES = int(os.environ.get("GIF_WINOGRAD_WGRAD_MIN_TILES", "2048"))  # split-K fills the chip earlier
 _winograd_calls = 0
 
@@ -212,20 +213,30 @@ def conv3x3_winograd(x, w, rows_are_out: bool, cout_act: int, wscale=1.0, keep_v
     R, Cc, sr, sc = (O, I, so, si) if rows_are_out else (I, O, si, so)
     assert R <= cout_act and Cc <= C, (R, cout_act, Cc, C)
 
+    # bf16x3: the GEMM's 128-wide N tile wants full tiles; other channel counts stay on the native GEMM (GIF_WINO_X3=0: A/B)
+    x3 = WINOGRAD_X3 and get_fp32_mfma_mode() == "bf16x3" and cout_act % 128 == 0
+
     def build():
         RP, CP = ctypes.c_int(), ctypes.c_int()
-        _lib.check(lib.gif_winograd_pack_dims(cout_act, C, ctypes.byref(RP), ctypes.byref(CP)), "winograd_pack_dims")
-        U = torch.empty((16, RP.value, CP.value), device=x.device, dtype=torch.float32)
-        _lib.check(lib.gif_winograd_weight_f32(w.data_ptr(), U.data_ptr(), R, Cc, RP.value, CP.value, sr, sc, sky, skx,
-                                               0 if rows_are_out else 1, float(wscale), _stream()), "winograd_weight")
+        dims = lib.gif_winograd_pack_dims_x3 if x3 else lib.gif_winograd_pack_dims
+        _lib.check(dims(cout_act, C, ctypes.byref(RP), ctypes.byref(CP)), "winograd_pack_dims")
+        if x3:
+            U = torch.empty((16, 3, RP.value, CP.value), device=x.device, dtype=torch.bfloat16)
+            fn = lib.gif_winograd_weight_f32x3
+        else:
+            U = torch.empty((16, RP.value, CP.value), device=x.device, dtype=torch.float32)
+            fn = lib.gif_winograd_weight_f32
+        _lib.check(fn(w.data_ptr(), U.data_ptr(), R, Cc, RP.value, CP.value, sr, sc, sky, skx, 0 if rows_are_out else 1, float(wscale),
+                      _stream()), "winograd_weight")
         return U
 
-    U = _cached_weight_op(w, ("wino", rows_are_out, cout_act, C, float(wscale)), build)
+    U = _cached_weight_op(w, ("wino", rows_are_out, cout_act, C, float(wscale), x3), build)
     V = torch.empty((lib.gif_winograd_workspace_floats(B, H, W, C),), device=x.device, dtype=torch.float32)
     out = empty_nhwc(B, cout_act, H, W, x.device)
     e = _epilogue(**epi)
-    _lib.check(lib.gif_conv3x3_winograd_f32(x.data_ptr(), U.data_ptr(), out.data_ptr(), V.data_ptr(), B, H, W, C, cout_act,
-                                            ctypes.byref(e), _stream()), "conv3x3_winograd")
+    fn = lib.gif_conv3x3_winograd_f32x3 if x3 else lib.gif_conv3x3_winograd_f32
+    _lib.check(fn(x.data_ptr(), U.data_ptr(), out.data_ptr(), V.data_ptr(), B, H, W, C, cout_act, ctypes.byref(e), _stream()),
+               "conv3x3_winograd")
     return (out, V) if keep_v else out
 
 

@@ -185,6 +185,13 @@ int gif_winograd_weight_f32(const float* w, float* U, int R, int C, int RP, int 
                             int64_t sky, int64_t skx, int flip, float scale, gif_stream_t stream);
 int gif_conv3x3_winograd_f32(const float* x, const float* U, float* y, float* V, int B, int H, int W, int C,
                              int Co, const gif_conv_epilogue* e, gif_stream_t stream);
+/* bf16x3 variants of the forward / data-gradient path (same contract; the transforms stay fp32): U3 is the transformed weight
+ * split into its three bf16 terms, [16][3][RP][CP] with (RP, CP) = gif_winograd_pack_dims_x3 (RP a multiple of 128). */
+int gif_winograd_pack_dims_x3(int cout, int cin, int* RP, int* CP);
+int gif_winograd_weight_f32x3(const float* w, void* U3, int R, int C, int RP, int CP, int64_t sr, int64_t sc, int64_t sky,
+                              int64_t skx, int flip, float scale, gif_stream_t stream);
+int gif_conv3x3_winograd_f32x3(const float* x, const void* U3, float* y, float* V, int B, int H, int W, int C, int Co,
+                               const gif_conv_epilogue* e, gif_stream_t stream);
 /* Weight gradient of the same convolution via Winograd F(3x3,2x2) (replaces autograd's wgrad of the F.conv2d calls
  * above): x [B,H,W,Cb] = conv input, gy [B,H,W,Cs] = output gradient, optional per-sample scales as in
  * gif_conv2d_wgrad_f32.  V / Mg = scratch of gif_winograd_workspace_floats(B,H,W,Cb / Cs) floats; ws = per-split partial

@@ -106,6 +106,37 @@ def test_bf16x3_winograd_plane_gemms_vs_fp64():
     assert out["native"] < 1e-5 and out["bf16x3"] <= 1.3 * out["native"] + 2e-7, out
 
 
+@pytest.mark.parametrize("case", [(4, 128, 128, 64), (2, 256, 512, 32), (3, 512, 256, 16), (2, 128, 192, 32)])
+def test_bf16x3_winograd_fwd_dgrad_vs_fp64(case, monkeypatch):
+    """wino_gemm_x3 (pre-split U3, 128-wide N tile, fused output transform + epilogue) against fp64, next to the native Winograd
+    GEMM; 192 output channels are not a multiple of the 128-wide tile and must fall back to the native GEMM in both modes."""
+    from gif_amd import ops
+    monkeypatch.setattr(ops, "WINOGRAD_MIN_TILES", 1)
+    B, ci, co, h = case
+    torch.manual_seed(sum(case))
+    spec = ops.ConvSpec(3, 3, 1, 1)
+    x = torch.randn(B, ci, h, h, device="cuda").contiguous(memory_format=torch.channels_last)
+    w = torch.randn(co, ci, 3, 3, device="cuda") / (ci * 9) ** 0.5
+    sc, sd = torch.rand(B, ci, device="cuda") + 0.5, torch.rand(B, co, device="cuda") + 0.5
+    bias = torch.randn(co, device="cuda")
+    res = torch.randn(B, co, h, h, device="cuda").contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(B, co, h, h, device="cuda").contiguous(memory_format=torch.channels_last)
+    z = F.conv2d(x.double() * sc.double()[:, :, None, None], w.double(), padding=1) * sd.double()[:, :, None, None]
+    ref_f = 2 ** 0.5 * F.leaky_relu(z + res.double() + bias.double()[None, :, None, None], 0.2)
+    ref_d = F.conv_transpose2d(gy.double() * sd.double()[:, :, None, None], w.double(), padding=1) * sc.double()[:, :, None, None]
+    out = {}
+    for mode in ("native", "bf16x3"):
+        ops.set_fp32_mfma_mode(mode)
+        n0 = ops.prof_winograd_calls()
+        y = ops.conv_fwd(x, w, spec, in_scale=sc, out_scale=sd, bias=bias, residual=res, act=True, slope=0.2, gain=2 ** 0.5)
+        gx = ops.conv_bwd_data(gy, w, spec, (h, h), in_scale=sd, out_scale=sc)
+        assert ops.prof_winograd_calls() == n0 + 2, "both passes must have taken the Winograd path"
+        out[mode] = (float((y.double() - ref_f).abs().max() / ref_f.abs().max()),
+                     float((gx.double() - ref_d).abs().max() / ref_d.abs().max()))
+    for en, ex in zip(out["native"], out["bf16x3"]):
+        assert en < 1e-5 and ex <= 1.3 * en + 2e-7, (case, out)
+
+
 @pytest.mark.parametrize("case", K.CONV_CASES)
 def test_native_mode_conv_cases_vs_oracle(case):
     """The native fp32-MFMA kernels against the CPU oracle (the default mode of the other tests is bf16x3)."""
@@ -122,3 +153,5 @@ def test_native_mode_epilogues_and_scaled_wgrad_vs_oracle():
     K.test_conv_scales_and_epilogue()
     K.test_conv_wgrad_with_scales()
     K.test_conv_launch_split_on_tile_quantisation()
+    for case in K.WINO_CASES[:3]:
+        K.test_winograd_conv_fwd_and_bwd_data(case)

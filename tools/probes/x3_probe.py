@@ -21,6 +21,9 @@ def main():
     torch.manual_seed(0)
     ops.WINOGRAD = False  # the direct kernels are what is being compared
     # accuracy: small enough for an fp64 reference
+    def err(a, b):
+        return float((a.double() - b).abs().max() / b.abs().max())
+
     print("# error vs fp64 (max |diff| / max |ref|), batch 4")
     for ci, co, k, s, p, h in ((128, 128, 3, 1, 1, 192), (128, 256, 3, 2, 0, 257), (128, 128, 3, 1, 1, 32), (512, 512, 3, 1, 1, 16), (128, 256, 3, 2, 0, 33), (256, 128, 1, 1, 0, 32)):
         spec = ops.ConvSpec(k, k, s, p)
@@ -47,6 +50,13 @@ def main():
                 ops.WINOGRAD = wino
                 gw = ops.conv_wgrad(gy, x, spec, co, ci, small_scale=sd, big_scale=sc)
                 line += f"  wgrad{'(wino)' if wino else ''} {float((gw.double() - refw).abs().max() / refw.abs().max()):.2e}"
+            if (k, s, p) == (3, 1, 1) and h % 2 == 0:
+                ops.WINOGRAD, mt = True, ops.WINOGRAD_MIN_TILES
+                ops.WINOGRAD_MIN_TILES = 1
+                yw = ops.conv_fwd(x, w, spec, in_scale=sc)[:, :co]
+                gxw = ops.conv_bwd_data(gy, w, spec, (h, h))[:, :ci]
+                ops.WINOGRAD_MIN_TILES = mt
+                line += f"  wino fwd {err(yw, ref):.2e} dgrad {err(gxw, refd):.2e}"
             ops.WINOGRAD = False
             print(line)
     print(f"# time per launch, batch {B}")
@@ -74,9 +84,11 @@ def main():
             t_wm = timeit(lambda: ops.conv_wgrad(gy, x, spec, co, ci, small_scale=sd, big_scale=sc))
             ops.WINOGRAD = True
             t_ww = timeit(lambda: ops.conv_wgrad(gy, x, spec, co, ci))
+            t_wf = timeit(lambda: ops.conv_fwd(x, w, spec, in_scale=sc))
+            t_wd = timeit(lambda: ops.conv_bwd_data(gy, w, spec, (h, h)))
             ops.WINOGRAD = False
             line += (f" | {mode}: fwd {fl / t_f / 1e9:6.1f} mod {fl / t_m / 1e9:6.1f} dgrad {fl / t_d / 1e9:6.1f} wgrad {fl / t_w / 1e9:6.1f} "
-                     f"wmod {fl / t_wm / 1e9:6.1f} wwino {fl / t_ww / 1e9:6.1f}")
+                     f"wmod {fl / t_wm / 1e9:6.1f} wwino {fl / t_ww / 1e9:6.1f} wino-fwd {fl / t_wf / 1e9:6.1f} wino-dgrad {fl / t_wd / 1e9:6.1f}")
         print(line)
 
 
