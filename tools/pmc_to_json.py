@@ -20,7 +20,12 @@ import json
 import re
 import sys
 
-FAMILY_OF = [  # (regex on the kernel name, family key used by bench.py)
+FAMILY_OF = [  # (regex on the kernel name, family key used by bench.py); first match wins
+    (r"conv_gather_mfma_glds(_multi)?<_Float16", "conv_gather_mfma_glds_f16"),
+    (r"conv_wgrad_mfma<_Float16", "conv_wgrad_mfma_f16"),
+    (r"conv_gather_mfma_glds(_multi)?<float,.*, true>$", "conv_gather_mfma_glds_x3"),  # last template argument X3 = true
+    (r"conv_wgrad_mfma<float,.*, true>$", "conv_wgrad_mfma_x3"),
+    (r"wino_gemm_x3", "wino_gemm_x3"),
     (r"conv_gather_mfma_glds", "conv_gather_mfma_glds"),
     (r"conv_gather_mfma<", "conv_gather_mfma"),
     (r"wino_gemm_mfma", "wino_gemm_mfma"),

@@ -1,12 +1,14 @@
 // Microbenchmark for the bf16x3 conv kernel (gfx950): what does each ingredient of the K loop cost next to the bf16 MFMAs?
 // One iteration = one 16-k group of a 64x64 wave tile: 24 x v_mfma_f32_32x32x16_bf16 on 4 accumulators, plus optionally
-//   NREAD ds_read_b128 (operand fragments), NPIECE split pieces (11 VALU each: the fp32 -> 3 x bf16 split of one float pair),
+//   NREAD ds_read_b128 (operand fragments), NPIECE split pieces (9 VALU each: the fp32 -> 3 x bf16 split of one float pair),
 //   NDMA global_load_lds_dwordx4 (L2-resident source), a workgroup barrier every second iteration.
 // 4 waves per workgroup, 80 KB of LDS => 2 workgroups per CU, like the real kernel.
 // Build: hipcc -O3 --offload-arch=gfx950 -o x3_mfma_probe tools/probes/x3_mfma_probe.hip ; run: ./x3_mfma_probe
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -15,14 +17,15 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split_pair(const float a0, const float a1, unsigned& hi, unsigned& mid, unsigned& lo) {
-    const unsigned u0 = __float_as_uint(a0), u1 = __float_as_uint(a1);
-    hi = __builtin_amdgcn_perm(u1, u0, 0x07060302);
-    const float r0 = a0 - __uint_as_float(u0 & 0xffff0000u), r1 = a1 - __uint_as_float(u1 & 0xffff0000u);
-    const unsigned w0 = __float_as_uint(r0), w1 = __float_as_uint(r1);
-    mid = __builtin_amdgcn_perm(w1, w0, 0x07060302);
-    const float s0 = r0 - __uint_as_float(w0 & 0xffff0000u), s1 = r1 - __uint_as_float(w1 & 0xffff0000u);
-    lo = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302);
+    const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a0, a1}, bf16x2));
+    const float r0 = a0 - __uint_as_float(h << 16), r1 = a1 - __uint_as_float(h & 0xffff0000u);
+    const unsigned m = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r0, r1}, bf16x2));
+    const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+    hi = h; mid = m;
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{s0, s1}, bf16x2));
 }
 
 template <int NREAD, int NPIECE, int NDMA, bool BARRIER, bool INTERLEAVE, int WGS>
@@ -44,14 +47,15 @@ __global__ void __launch_bounds__(256, WGS) probe(const float* __restrict__ src,
     f32x4 raw[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) raw[r] = f32x4{1.f + lane, 2.f, 3.f, 4.f};
-    for (int it = 0; it < iters; ++it) {
-        const int slot = it & 1;
+    // one group with compile-time operand slots (a runtime slot index would turn into v_cndmask chains)
+    auto group = [&](auto slot_c, int it) __attribute__((always_inline)) {
+        constexpr int slot = decltype(slot_c)::value;
 #pragma unroll
         for (int d = 0; d < NDMA; ++d)
-            __builtin_amdgcn_global_load_lds((gptr_t)(g + d * 256), (lptr_t)(smem + ((it & 1) * 8192) + wave * 2048 + d * 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(g + d * 256), (lptr_t)(smem + (slot * 8192) + wave * 2048 + d * 256), 16, 0, 0);
 #pragma unroll
         for (int r = 0; r < NREAD; ++r)
-            raw[r] = *reinterpret_cast<const f32x4*>(smem + (((it + 1) & 1) * 8192) + ((wave * 2048 + r * 256 + lane * 4) & 8191));
+            raw[r] = *reinterpret_cast<const f32x4*>(smem + ((slot ^ 1) * 8192) + ((wave * 2048 + r * 256 + lane * 4) & 8191));
         __builtin_amdgcn_sched_barrier(0);
         int piece = 0;
 #pragma unroll
@@ -79,7 +83,11 @@ __global__ void __launch_bounds__(256, WGS) probe(const float* __restrict__ src,
                 op[slot ^ 1][(f * 3) % 6][e] = h; op[slot ^ 1][(f * 3 + 1) % 6][e] = mm; op[slot ^ 1][(f * 3 + 2) % 6][e] = l;
             }
         }
-        if (BARRIER && (it & 1)) __syncthreads();
+    };
+    for (int it = 0; it < iters; it += 2) {
+        group(std::integral_constant<int, 0>{}, it);
+        group(std::integral_constant<int, 1>{}, it);
+        if (BARRIER) __syncthreads();
     }
     float s = 0.f;
 #pragma unroll
@@ -124,9 +132,9 @@ int main() {
     run<0, 0, 0, false, false, 2>(src, out, "MFMA only, 2 WG/CU");
     run<0, 0, 0, false, false, 1>(src, out, "MFMA only, 1 WG/CU");
     run<10, 0, 0, false, false, 2>(src, out, "+ 10 ds_read_b128");
-    run<10, 8, 0, false, false, 2>(src, out, "+ 10 reads + 8 pieces (88 VALU) after the MFMAs");
+    run<10, 8, 0, false, false, 2>(src, out, "+ 10 reads + 8 pieces (72 VALU) after the MFMAs");
     run<10, 8, 0, false, true, 2>(src, out, "+ 10 reads + 8 pieces interleaved");
-    run<16, 16, 0, false, false, 2>(src, out, "+ 16 reads + 16 pieces (176 VALU) after the MFMAs");
+    run<16, 16, 0, false, false, 2>(src, out, "+ 16 reads + 16 pieces (144 VALU) after the MFMAs");
     run<16, 16, 0, false, true, 2>(src, out, "+ 16 reads + 16 pieces interleaved");
     run<10, 8, 5, false, true, 2>(src, out, "+ 10 reads + 8 pieces interleaved + 5 DMA");
     run<10, 8, 5, true, true, 2>(src, out, "+ 10 reads + 8 pieces interleaved + 5 DMA + barrier");
