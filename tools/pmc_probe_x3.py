@@ -1,0 +1,24 @@
+"""Launches the bf16x3 kernels once (after a warm-up) on the benchmark's big layer shapes so that `rocprofv3 --pmc ...` can
+attribute counters to them.  Usage (on the GPU box):
+    rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES ... --output-format csv -d out -- python tools/pmc_probe_x3.py"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gif_amd import ops  # noqa: E402
+
+B = int(os.environ.get("PROBE_BATCH", "32"))
+ops.set_fp32_mfma_mode("bf16x3")
+spec = ops.ConvSpec(3, 3, 1, 1)
+for C, H in ((128, 256), (512, 64)):
+    x = torch.randn(B, C, H, H, device="cuda").contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(B, C, H, H, device="cuda").contiguous(memory_format=torch.channels_last)
+    w = torch.randn(C, C, 3, 3, device="cuda")
+    for _ in range(2):
+        for wino in (False, True):
+            ops.WINOGRAD = wino
+            ops.conv_fwd(x, w, spec)
+            ops.conv_wgrad(gy, x, spec, C, C)
+torch.cuda.synchronize()
