@@ -114,4 +114,21 @@ __device__ __forceinline__ void split_pair(const float a0, const float a1, unsig
     lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{s0, s1}, bf16x2_t));
 }
 
+// Same split for two floats that do NOT sit in an aligned register pair (operands gathered by scalar LDS reads: the weight
+// gradient's eight ds_read_b32 per fragment).  The packed subtract of split_pair wants 64-bit aligned pairs and hipcc pays for
+// it with one v_mov per element behind a full lgkmcnt(0) wait; the empty asm statements keep the two subtractions scalar.
+__device__ __forceinline__ void split_pair_scalar(const float a0, const float a1, unsigned& hi, unsigned& mid, unsigned& lo) {
+    const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a0, a1}, bf16x2_t));
+    float r0 = a0 - __uint_as_float(h << 16);
+    asm volatile("" : "+v"(r0));
+    float r1 = a1 - __uint_as_float(h & 0xffff0000u);
+    const unsigned m = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{r0, r1}, bf16x2_t));
+    float s0 = r0 - __uint_as_float(m << 16);
+    asm volatile("" : "+v"(s0));
+    float s1 = r1 - __uint_as_float(m & 0xffff0000u);
+    hi = h;
+    mid = m;
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{s0, s1}, bf16x2_t));
+}
+
 }  // namespace gif

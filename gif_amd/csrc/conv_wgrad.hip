@@ -367,7 +367,104 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const 
         }
     };
 
-    if (n_begin < n_end) {
+    if constexpr (X3 && BKP == 32) {
+        // ---- bf16x3, software-pipelined (two 16-pixel groups per stage; same schedule as conv_gather_mfma_glds' X3 path):
+        //   DMA(stage+1) | MFMAs(g0) + read & split g1 | barrier | MFMAs(g1) + read & split g0 of stage+1
+        // The split of the NEXT group (16 pieces of 9 VALU, +2 with per-sample scales) sits piecewise between the 24 MFMAs of
+        // the current one; sched_barrier(0) pins the interleave.
+        gif::u32x4_t sa[2][3][MT], sb[2][3][NT];  // [slot][hi, mid, lo][tile]
+        float ra[MT][8], rb[NT][8];               // raw fragments of the group being split
+        float psv[MT], qsv[NT];                   // per-sample scales of the stage being split (TAB)
+        auto scales = [&]() __attribute__((always_inline)) {
+            if (TAB) {
+                const float* row = Stab + tab_row * (BP + BQ);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) psv[i] = row[wp0 + i * 32 + li];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) qsv[j] = row[BP + wq0 + j * 32 + li];
+                tab_rem += BKP;
+                if (tab_rem >= (int)HWs) { tab_rem -= (int)HWs; ++tab_row; }
+            }
+        };
+        auto read_raw = [&](int buf, int ks) __attribute__((always_inline)) {
+            const int k0 = 16 * ks + 8 * lh;  // this lane half's 8 pixels of the group
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ra[i][e] = Ps[buf][k0 + e][wp0 + i * 32 + li];
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) rb[j][e] = Qs[buf][k0 + e][wq0 + j * 32 + li];
+        };
+        constexpr int NPC = (MT + NT) * 4;
+        auto split_piece = [&](int slot, int k) __attribute__((always_inline)) {
+            const int f = k / 4, e = k % 4;
+            unsigned h, m, l;
+            if (f < MT) {
+                float x0 = ra[f][2 * e], x1 = ra[f][2 * e + 1];
+                if (TAB) { x0 *= psv[f]; x1 *= psv[f]; }
+                gif::split_pair_scalar(x0, x1, h, m, l);
+                sa[slot][0][f][e] = h; sa[slot][1][f][e] = m; sa[slot][2][f][e] = l;
+            } else {
+                float x0 = rb[f - MT][2 * e], x1 = rb[f - MT][2 * e + 1];
+                if (TAB) { x0 *= qsv[f - MT]; x1 *= qsv[f - MT]; }
+                gif::split_pair_scalar(x0, x1, h, m, l);
+                sb[slot][0][f - MT][e] = h; sb[slot][1][f - MT][e] = m; sb[slot][2][f - MT][e] = l;
+            }
+        };
+        constexpr int LEAD = 6;  // MFMAs ahead of the first piece: they cover the latency of the 32 ds_read_b32 (issued as 20 ds_read2)
+        auto group = [&](int slot, int nslot) __attribute__((always_inline)) {
+            constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+            int n = 0, piece = 0;
+#pragma unroll
+            for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gif::bf16x8_t, sa[slot][TA[t6]][i]),
+                                                                            __builtin_bit_cast(gif::bf16x8_t, sb[slot][TB[t6]][j]),
+                                                                            acc[i][j], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        ++n;
+                        if (nslot >= 0 && n >= LEAD && piece < NPC) {
+                            split_piece(nslot, piece++);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+            if (nslot >= 0) {
+#pragma unroll
+                for (; piece < NPC; ++piece) split_piece(nslot, piece);
+            }
+        };
+        if (n_begin < n_end) {
+            load_global(0);
+            __syncthreads();
+            scales();
+            read_raw(0, 0);
+#pragma unroll
+            for (int k = 0; k < NPC; ++k) split_piece(0, k);
+            int cur = 0;
+            for (int n0 = n_begin; n0 + BKP < n_end; n0 += BKP) {
+                load_global(cur ^ 1);  // stage n0 + BKP: its buffer was last read before the previous stage's barrier
+                __builtin_amdgcn_sched_barrier(0);
+                read_raw(cur, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                group(0, 1);
+                __syncthreads();
+                cur ^= 1;
+                scales();
+                read_raw(cur, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                group(1, 0);
+            }
+            read_raw(cur, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            group(0, 1);
+            group(1, -1);
+        }
+    } else if (n_begin < n_end) {
         load_global(0);
         store_lds(0);
         __syncthreads();
@@ -868,8 +965,13 @@ static int conv2d_wgrad_f32_impl(const float* small, const float* big, float* ws
     if (glds) wgrad_launch<float, BP_, BQ_, WP_, WQ_, true, 32>(grid, TH_, s, p);                                        \
     else wgrad_launch<float, BP_, BQ_, WP_, WQ_, false, 32>(grid, TH_, s, p)
         const bool tab = (small_scale || big_scale) && (variant != 1 || x3) && tab_fits;
-        if (x3 && tab) {
+        static const int x3_simple = getenv("GIF_X3_WGRAD_SIMPLE") ? atoi(getenv("GIF_X3_WGRAD_SIMPLE")) : 0;  // A/B: 16-pixel stages, no pipeline
+        if (x3 && tab && HWs % 32 == 0 && !x3_simple) {
+            wgrad_launch<float, 128, 128, 2, 2, true, 32, true, true>(grid, 256, s, p);
+        } else if (x3 && tab) {
             wgrad_launch<float, 128, 128, 2, 2, true, 16, true, true>(grid, 256, s, p);
+        } else if (x3 && !x3_simple) {
+            wgrad_launch<float, 128, 128, 2, 2, true, 32, false, true>(grid, 256, s, p);
         } else if (x3) {
             wgrad_launch<float, 128, 128, 2, 2, true, 16, false, true>(grid, 256, s, p);
         } else if (big_tile) {
@@ -969,7 +1071,9 @@ static int conv3x3_winograd_wgrad_impl(const float* x, const float* gy, float* V
     dim3 grid((unsigned)(p.tiles_pq * p.T * nsplit));
     p.zero = gif::zero_page16();
     GIF_REQUIRE(p.zero, "winograd_wgrad: zero page lookup failed");
-    if (x3) wgrad_launch<float, 128, 128, 2, 2, true, 16, false, true>(grid, 256, s, p);
+    static const int x3_simple = getenv("GIF_X3_WGRAD_SIMPLE") ? atoi(getenv("GIF_X3_WGRAD_SIMPLE")) : 0;
+    if (x3 && !x3_simple) wgrad_launch<float, 128, 128, 2, 2, true, 32, false, true>(grid, 256, s, p);
+    else if (x3) wgrad_launch<float, 128, 128, 2, 2, true, 16, false, true>(grid, 256, s, p);
     else if (big) wgrad_launch<float, 256, 128, 2, 2, true, 16>(grid, 256, s, p);
     else if (bp == 128 && bq == 128) wgrad_launch<float, 128, 128, 2, 2, true, 16>(grid, 256, s, p);
     else if (bp == 128 && bq == 32) wgrad_launch<float, 128, 32, 4, 1, true, 32>(grid, 256, s, p);

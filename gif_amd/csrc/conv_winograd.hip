@@ -411,6 +411,8 @@ __global__ void __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) wino_gemm_mfma(cons
 // at the end of each position, un-overlapped inside the wave (the SIMD's other wave keeps the matrix pipe busy).
 // Per group: the V fragments of the NEXT group are read first and split piecewise between this group's MFMAs; the weight
 // operands are reloaded term by term as soon as the last MFMA that uses a term has issued (lo after 2, mid after 6, hi after 12).
+// DBG (ablation builds only, GIF_WINO_DBG; results are wrong): 1 = no fold, 2 = no split of V, 4 = no weight-operand reloads
+template <int DBG = 0>
 __global__ void __launch_bounds__(512, 1) wino_gemm_x3(const WinoParams p) {
     constexpr int THREADS = 512, BN = 128, PROWS = THREADS / 8;
     constexpr int LD = WBK, CH = WBK / 4, RB = 64 / WBK, RPW = 64 / CH;
@@ -514,23 +516,23 @@ __global__ void __launch_bounds__(512, 1) wino_gemm_x3(const WinoParams p) {
         read_a(rbuf, nq);
         __builtin_amdgcn_sched_barrier(0);
         mma(slot, 0, 2);  // hi * lo
-        read_b(rbuf, nq, 2);
+        if (!(DBG & 4)) read_b(rbuf, nq, 2);
         __builtin_amdgcn_sched_barrier(0);
         mma(slot, 1, 1);  // mid * mid
-        split_piece(slot ^ 1, 0);
+        if (!(DBG & 2)) split_piece(slot ^ 1, 0);
         __builtin_amdgcn_sched_barrier(0);
         mma(slot, 0, 1);  // hi * mid
-        read_b(rbuf, nq, 1);
-        split_piece(slot ^ 1, 1);
+        if (!(DBG & 4)) read_b(rbuf, nq, 1);
+        if (!(DBG & 2)) split_piece(slot ^ 1, 1);
         __builtin_amdgcn_sched_barrier(0);
         mma(slot, 2, 0);  // lo * hi
-        split_piece(slot ^ 1, 2);
+        if (!(DBG & 2)) split_piece(slot ^ 1, 2);
         __builtin_amdgcn_sched_barrier(0);
         mma(slot, 1, 0);  // mid * hi
-        split_piece(slot ^ 1, 3);
+        if (!(DBG & 2)) split_piece(slot ^ 1, 3);
         __builtin_amdgcn_sched_barrier(0);
         mma(slot, 0, 0);  // hi * hi
-        read_b(rbuf, nq, 0);
+        if (!(DBG & 4)) read_b(rbuf, nq, 0);
         __builtin_amdgcn_sched_barrier(0);
     };
     auto fold = [&](int pos) __attribute__((always_inline)) {
@@ -570,11 +572,12 @@ __global__ void __launch_bounds__(512, 1) wino_gemm_x3(const WinoParams p) {
         cur = cur == 2 ? 0 : cur + 1;
         group(1, cur, 0);  // (after the last stage this prepares operands nobody uses: the reads stay inside the ring)
         if (++kc_in_pos == kchunks) {
-            fold(pos);
+            if (!(DBG & 1)) fold(pos);
             kc_in_pos = 0;
             ++pos;
         }
     }
+    if (DBG & 1) fold(5);
 
     // ---- epilogue: for each output position (a,b): transpose through LDS, then coalesced float4 rows
     constexpr int LDC = BN + 4;
@@ -820,9 +823,20 @@ int gif_conv3x3_winograd_f32x3(const float* x, const void* U3, float* y, float* 
     p.tiles_m = (int)(ntiles_pad / WBM);
     p.tiles_n = p.RP / 128;
     const size_t lds = (size_t)WNSTAGE * (WBM * WBK * sizeof(float) + 3 * 128 * 64);
-    static gif::LdsAttr attr;
-    attr.ensure(reinterpret_cast<const void*>(wino_gemm_x3), lds);
-    hipLaunchKernelGGL(wino_gemm_x3, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), lds, s, p);
+    static const int dbg = getenv("GIF_WINO_DBG") ? atoi(getenv("GIF_WINO_DBG")) : 0;
+    const dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
+#define GIF_WINO_X3_LAUNCH(D)                                                      \
+    {                                                                              \
+        static gif::LdsAttr attr;                                                  \
+        attr.ensure(reinterpret_cast<const void*>(wino_gemm_x3<D>), lds);          \
+        hipLaunchKernelGGL(wino_gemm_x3<D>, grid, dim3(512), lds, s, p);           \
+    }
+    if (dbg == 1) GIF_WINO_X3_LAUNCH(1)
+    else if (dbg == 2) GIF_WINO_X3_LAUNCH(2)
+    else if (dbg == 4) GIF_WINO_X3_LAUNCH(4)
+    else if (dbg == 7) GIF_WINO_X3_LAUNCH(7)
+    else GIF_WINO_X3_LAUNCH(0)
+#undef GIF_WINO_X3_LAUNCH
     return gif::check_launch("conv3x3_winograd_f32x3");
 }
 }
