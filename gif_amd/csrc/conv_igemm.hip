@@ -521,7 +521,7 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
             float a0 = ra[f][e / 2][(e % 2) * 2], a1 = ra[f][e / 2][(e % 2) * 2 + 1];
             if (SCALE) { a0 *= rs[f][e / 2][(e % 2) * 2]; a1 *= rs[f][e / 2][(e % 2) * 2 + 1]; }
             unsigned h, m, l;
-            gif::split_pair(a0, a1, h, m, l);
+            gif::split_pair_scalar(a0, a1, h, m, l);
             sa[slot][0][f][e] = h; sa[slot][1][f][e] = m; sa[slot][2][f][e] = l;
         };
         // The 6*MT*NT MFMAs of the group in `slot` (smallest terms first; lo*mid, mid*lo, lo*lo <= 2^-23 of the product are

@@ -500,7 +500,7 @@ __global__ void __launch_bounds__(512, 1) wino_gemm_x3(const WinoParams p) {
     };
     auto split_piece = [&](int slot, int e) __attribute__((always_inline)) {
         unsigned h, m, l;
-        gif::split_pair(ra[e / 2][(e % 2) * 2], ra[e / 2][(e % 2) * 2 + 1], h, m, l);
+        gif::split_pair_scalar(ra[e / 2][(e % 2) * 2], ra[e / 2][(e % 2) * 2 + 1], h, m, l);
         sa[slot][0][e] = h; sa[slot][1][e] = m; sa[slot][2][e] = l;
     };
     auto mma = [&](int slot, int ta, int tb) __attribute__((always_inline)) {
@@ -540,12 +540,16 @@ __global__ void __launch_bounds__(512, 1) wino_gemm_x3(const WinoParams p) {
         float cf[4];
 #pragma unroll
         for (int o = 0; o < 4; ++o) cf[o] = wino_coef(o >> 1, xi) * wino_coef(o & 1, nu);
+        // 36 of the 64 (position, output) coefficients are non-zero: skip the others (wave-uniform branches)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
+        for (int o = 0; o < 4; ++o) {
+            if (cf[o] != 0.f) {
 #pragma unroll
-            for (int o = 0; o < 4; ++o) yo[o][j] += cf[o] * acc[j];
-            acc[j] = (f32x16)(0.f);
+                for (int j = 0; j < NT; ++j) yo[o][j] += cf[o] * acc[j];
+            }
         }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = (f32x16)(0.f);
     };
 
     constexpr int NI = A_IT + B3_IT;
