@@ -89,28 +89,40 @@ class FlatGradBucket:
         self.attach()
 
     def attach(self):
-        """(Re-)alias every active p.grad to its bucket view; a gradient that lives elsewhere is moved in first."""
+        """(Re-)alias every active p.grad to its bucket view; gradients that live elsewhere are moved in first — all of them
+        in ONE multi-tensor copy (after zero() that is every gradient of the backward pass: autograd hands a fresh tensor to a
+        parameter whose .grad is None, where it would otherwise launch one accumulation add per parameter into the view)."""
+        dst, src = [], []
         for p, v in zip(self.params, self.views):
             g = p.grad
             if g is None or g.data_ptr() != v.data_ptr():
                 if g is not None:
-                    v.copy_(g)
+                    dst.append(v)
+                    src.append(g.detach())
                 p.grad = v
+        if dst:
+            with torch.no_grad():
+                torch._foreach_copy_(dst, src)
         for p in self.inactive:
             p.grad = None
 
     def zero(self):
+        """Zero the bucket and hand the parameters over to autograd with .grad = None; attach() (called by the exchange and by
+        the optimiser) gathers what the backward pass produced."""
         self.wait()
         self.flat.zero_()
-        self.attach()
+        for p in self.params:
+            p.grad = None
+        for p in self.inactive:
+            p.grad = None
 
     def all_reduce_mean(self, async_op=False):
         """Average the bucket over the process group.  async_op=True only ENQUEUES the collective (it runs on the
         backend's own stream behind the work already queued on the current stream) — call wait() before the bucket is
         read; everything launched in between overlaps with the exchange."""
+        self.attach()  # gather the backward pass's gradients (also without a process group: the bucket is what the optimiser reads)
         if not _dist_on(self.group):
             return
-        self.attach()  # a detached p.grad would leave its gradient out of the exchange
         ws = dist.get_world_size(self.group)
         if dist.get_backend(self.group) == "nccl":  # RCCL: the mean is taken inside the collective, no separate pass
             work = dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op)

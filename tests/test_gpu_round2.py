@@ -270,7 +270,7 @@ def test_flat_adam_matches_torch_adam_and_accumulate(betas):
             if k == 3:
                 continue
             gsrc = torch.randn_like(pa) * (10.0 ** (k % 3 - 1))
-            pa.grad.copy_(gsrc)
+            pa.grad = gsrc.clone()  # what autograd hands to a parameter whose .grad is None after bucket.zero()
             pb.grad = gsrc.clone()
         opt_a.step(ema_decay=decay)
         opt_b.step()
@@ -413,6 +413,7 @@ def _dp_worker(rank, world, port, q):
                 fk = G2(cond[0, hs], None, step=3, alpha=1.0, input_indices=idx[0, hs])[0]
             fs, _ = D2([fk], condition=cond[0, hs], step=3, alpha=1.0)
             (Fn.softplus(-rs).mean() + Fn.softplus(fs).mean()).backward()
+            t2.d_bucket.attach()  # gather the gradients autograd produced into the bucket
             halves.append(t2.d_bucket.flat.clone())
         mean_halves = (halves[0] + halves[1]) / 2
         # the data-parallel step: D half with the exchange deferred (overlap), then inspect the bucket
