@@ -528,7 +528,7 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
         // not formed; term-major: consecutive MFMAs write different accumulators), with the split of the next group
         // (-> slot `nslot`, or nothing if nslot < 0) placed piecewise between them.  sched_barrier(0) after every MFMA and
         // every piece: the compiler keeps exactly this interleave (sched_group_barrier's VALU class also matches MFMAs).
-        constexpr int LEAD = 2;  // MFMAs ahead of the first piece: they cover the LDS latency of the raw reads
+        constexpr int LEAD = 6;  // MFMAs ahead of the first piece: they cover the LDS latency of the raw reads
         auto group = [&](int slot, int nslot) __attribute__((always_inline)) {
             constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
             int n = 0, piece = 0;
