@@ -818,6 +818,7 @@ int launch(GatherParams& p, hipStream_t s) {
         return GIF_ENOSUP;
     }
     TileCfg c = pick_cfg<T>(p.Co, p.Ci);
+    if (p.x3) c.BK = 32;
     // LDS-DMA path: every layer whose K chunk is a 128-byte row (rows are 16-byte aligned in HBM: Ci % 4 == 0 for fp32,
     // Ci % 8 == 0 for f16)
     const bool only_glds = F16 || p.x3;  // no register-staged fallback for these operand formats
@@ -826,8 +827,8 @@ int launch(GatherParams& p, hipStream_t s) {
         if (rc != 0) gif::set_error("conv (%s): launch configuration does not fit (rc=%d)", F16 ? "f16" : "bf16x3", rc);
         return rc == 0 ? 0 : GIF_ENOSUP;
     };
-    if (p.x3 && c.BK != 32) {
-        gif::set_error("conv (bf16x3): needs >= 32 input channels (gif_conv2d_x3_eligible)");
+    if (p.x3 && p.Ci < 24) {
+        gif::set_error("conv (bf16x3): needs >= 24 input channels (gif_conv2d_x3_eligible)");
         return GIF_ENOSUP;
     }
     if constexpr (F16) {
@@ -930,8 +931,9 @@ void fill_epilogue(GatherParams& p, const gif_conv_epilogue* e) {
 
 
 template <typename T>
-void pack_dims(int cout, int cin, int* RP, int* CP) {
+void pack_dims(int cout, int cin, int* RP, int* CP, bool x3 = false) {
     TileCfg c = pick_cfg<T>(cout, cin);
+    if (x3) c.BK = 32;  // the bf16x3 kernels only have 32-float K chunks: 24..31 input channels are zero-padded to one chunk
     *RP = (cout + c.BN - 1) / c.BN * c.BN;
     *CP = (cin + c.BK - 1) / c.BK * c.BK;
 }
@@ -959,7 +961,7 @@ int conv2d_fwd_impl(const void* big, const void* wp, void* small, const gif_conv
     p.nky = g->KH; p.nkx = g->KW; p.ntaps = g->KH * g->KW;
     p.dy0 = -g->pad; p.ddy = 1; p.dx0 = -g->pad; p.ddx = 1;
     p.ky0 = 0; p.kx0 = 0; p.kstep = 1; p.KW = g->KW;
-    pack_dims<T>(p.Co, p.Ci, &p.RP, &p.CP);
+    pack_dims<T>(p.Co, p.Ci, &p.RP, &p.CP, x3);
     p.M = p.B * p.Hp * p.Wp;
     double flops = 2.0 * p.M * (double)p.Co * p.Ci * p.ntaps;
     const int fam = sizeof(T) == 2 ? 6 : x3 ? 8 : (p.Ci >= 32 ? 0 : 5);
@@ -981,7 +983,7 @@ int conv2d_bwd_data_impl(const void* small, const void* wp, void* big, const gif
     fill_epilogue(base, e);
     base.B = g->B; base.Hi = g->Hs; base.Wi = g->Ws; base.Ci = g->Cs;
     base.Ho = g->Hb; base.Wo = g->Wb; base.Co = g->Cb;
-    pack_dims<T>(base.Co, base.Ci, &base.RP, &base.CP);
+    pack_dims<T>(base.Co, base.Ci, &base.RP, &base.CP, x3);
     const int st = g->stride;
     auto pmod = [st](int a) { return ((a % st) + st) % st; };
     // Build the (up to 4) output-parity phases; phases with no tap (e.g. 1x1 stride 2) are zero-filled.
@@ -1019,7 +1021,8 @@ int conv2d_bwd_data_impl(const void* small, const void* wp, void* big, const gif
         // small transposed convs: every phase alone would sit on the 64x64-tile path with a partly filled chip
         bool merged = false;
         if (nph > 1 && conv_variant() == 0) {
-            const TileCfg c = pick_cfg<T>(base.Co, base.Ci);
+            TileCfg c = pick_cfg<T>(base.Co, base.Ci);
+            if (x3) c.BK = 32;
             bool small_all = c.BN == 128 && (sizeof(T) == 2 || c.BK == 32);
             for (int i = 0; i < nph && small_all; ++i)
                 small_all = (long)gif::cdiv(ph[i].M, 128) * (ph[i].RP / 128) < 384 &&
@@ -1061,7 +1064,14 @@ int gif_conv2d_bwd_data_f32(const float* small, const float* wp, float* big, con
     return conv2d_bwd_data_impl<float>(small, wp, big, g, e, stream, "conv2d_bwd_data");
 }
 
-int gif_conv2d_x3_eligible(int cout, int cin) { return cout > 0 && cin >= 32 && cin % 4 == 0 ? 1 : 0; }
+// >= 24 input channels: a 24-channel layer wastes a quarter of its one 32-float K chunk and still beats the native kernel
+int gif_conv2d_x3_eligible(int cout, int cin) { return cout > 0 && cin >= 24 && cin % 4 == 0 ? 1 : 0; }
+
+int gif_conv2d_pack_dims_x3(int cout, int cin, int* RP, int* CP) {
+    GIF_REQUIRE(cout > 0 && cin > 0 && RP && CP, "pack_dims_x3: bad arguments");
+    pack_dims<float>(cout, cin, RP, CP, true);
+    return 0;
+}
 
 int gif_conv2d_fwd_f32x3(const float* big, const void* wp3, float* small, const gif_conv_geom* g, const gif_conv_epilogue* e,
                          gif_stream_t stream) {

@@ -139,9 +139,12 @@ def _cached_weight_op(w, tag, build):
     return out
 
 
+X3_MIN_CIN = int(os.environ.get("GIF_X3_MIN_CIN", "24"))  # gif_conv2d_x3_eligible: >= 24 (one zero-padded 32-float K chunk)
+
+
 def x3_conv(dtype, cin_act: int) -> bool:
     """fp32 conv fwd/dgrad with `cin_act` contraction channels runs on the bf16x3 kernels (mode + eligibility)."""
-    return dtype == torch.float32 and cin_act >= 32 and get_fp32_mfma_mode() == "bf16x3"
+    return dtype == torch.float32 and cin_act >= X3_MIN_CIN and get_fp32_mfma_mode() == "bf16x3"
 
 
 def pack_weight(w: torch.Tensor, rows_are_out: bool, cout_act: int, cin_act: int, scale: float = 1.0, dtype=torch.float32, x3=False):
@@ -161,7 +164,7 @@ def pack_weight(w: torch.Tensor, rows_are_out: bool, cout_act: int, cin_act: int
 
     def build():
         RP, CP = ctypes.c_int(), ctypes.c_int()
-        dims = lib.gif_conv2d_pack_dims_f16 if f16 else lib.gif_conv2d_pack_dims
+        dims = lib.gif_conv2d_pack_dims_x3 if x3 else (lib.gif_conv2d_pack_dims_f16 if f16 else lib.gif_conv2d_pack_dims)
         _lib.check(dims(cout_act, cin_act, ctypes.byref(RP), ctypes.byref(CP)), "pack_dims")
         if x3:
             wp = torch.empty((KH * KW, 3, RP.value, CP.value), device=w.device, dtype=torch.bfloat16)

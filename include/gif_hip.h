@@ -46,9 +46,10 @@ int gif_get_fp32_mfma_mode(void);
 /* The bf16x3 entry points (fp32 activations in and out, exactly like their _f32 namesakes; stylegan2_common_layers.py:330-345).
  * The mode above is only the default a host should honour; the kernels are selected by the entry point.
  * Weights are pre-split once per optimiser step: gif_pack_weight_f32x3 writes wp3[tap][3][RP][CP] bf16 (hi, mid, lo planes;
- * RP/CP from gif_conv2d_pack_dims; 6 bytes per padded element).  Activations are split inside the kernels after the LDS
- * read.  Layers with fewer than 32 input channels stay on the native kernels (gif_conv2d_x3_eligible() == 0). */
+ * RP/CP from gif_conv2d_pack_dims_x3; 6 bytes per padded element).  Activations are split inside the kernels after the LDS
+ * read.  Layers with fewer than 24 input channels stay on the native kernels (gif_conv2d_x3_eligible() == 0). */
 int gif_conv2d_x3_eligible(int cout, int cin);
+int gif_conv2d_pack_dims_x3(int cout, int cin, int* RP, int* CP); /* like gif_conv2d_pack_dims; CP a multiple of 32 */
 int gif_pack_weight_f32x3(const float* w, void* wp3, int R, int C, int KH, int KW, int RP, int CP, int64_t sr, int64_t sc,
                           int64_t sky, int64_t skx, float scale, gif_stream_t stream);
 /* gif_conv2d_fwd_f32x3 / gif_conv2d_bwd_data_f32x3: declared next to their _f32 namesakes below */

@@ -34,7 +34,7 @@ def test_mode_api():
     ops.set_fp32_mfma_mode("bf16x3")
     assert lib.gif_get_fp32_mfma_mode() == 1 and ops.get_fp32_mfma_mode() == "bf16x3"
     assert lib.gif_set_fp32_mfma_mode(7) != 0 and b"unknown mode" in lib.gif_last_error()
-    assert lib.gif_conv2d_x3_eligible(128, 128) == 1 and lib.gif_conv2d_x3_eligible(128, 24) == 0
+    assert lib.gif_conv2d_x3_eligible(128, 128) == 1 and lib.gif_conv2d_x3_eligible(128, 24) == 1 and lib.gif_conv2d_x3_eligible(128, 12) == 0
 
 
 # (B, Cin, Cout, K, stride, pad, H): what each case exercises on the bf16x3 side
@@ -44,7 +44,8 @@ X3_CASES = [
     (4, 256, 256, 3, 1, 1, 64),    # 128x128 tiles (256 <= tiles256 < 512)
     (4, 512, 512, 3, 1, 1, 16),    # 64x64 tiles
     (2, 128, 256, 3, 2, 0, 33),    # small transposed conv: the four phases merged into one launch
-    (4, 128, 24, 3, 1, 1, 64),     # thin output: 256x32 tiles (fwd); dgrad has 24 contraction channels => native kernel
+    (4, 128, 24, 3, 1, 1, 64),     # thin output: 256x32 tiles (fwd); dgrad has 24 contraction channels: one zero-padded K chunk
+    (4, 24, 128, 3, 1, 1, 96),     # condition-noise conv 3: 24 input channels padded to the 32-float K chunk (fwd), thin dgrad
     (2, 256, 128, 1, 1, 0, 32),    # 1x1
     (3, 160, 96, 3, 1, 1, 20),     # ragged channel counts (padded K chunk, padded N tile)
 ]
