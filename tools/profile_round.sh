@@ -20,6 +20,7 @@ python tools/pmc_to_json.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE --commit $CO
 rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
 # 3. bench lines
 python bench.py --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err
+$B --steps 12 --warmup 3 --fp32-mfma native > $OUT/bench_native_fp32_mfma.json 2> /dev/null
 $B --steps 12 --warmup 3 --batch 16 > $OUT/bench_config2_batch16.json 2> /dev/null
 $B --steps 12 --warmup 3 --render-cond --gen-reg PATH_LEN_REG > $OUT/bench_config3_render_plreg.json 2> /dev/null
 $B --steps 12 --warmup 3 --dtype f16 > $OUT/bench_f16_256.json 2> /dev/null

@@ -4,7 +4,7 @@
 set -eu
 O=$1; C=$2
 cp $O/pmc_traffic.json profiles/pmc_traffic.json
-for f in default config2_batch16 config3_render_plreg f16_256 f16_1024; do cp $O/bench_$f.json profiles/r2_bench_$f.json; done
+for f in default native_fp32_mfma config2_batch16 config3_render_plreg f16_256 f16_1024; do cp $O/bench_$f.json profiles/r2_bench_$f.json; done
 v=$(python -c "import json;d=json.load(open('$O/stats_bench.json'));print(f\"{d['value']:.1f} images/s, {d['ms_per_step']:.1f} ms/step\")")
 { echo "# rocprofv3 --kernel-trace --stats, round 2 (commit $C, bf16x3 default): python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-prof"; echo
   echo "7 training iterations (5 timed + 2 warm-up) at 256x256, batch 32, fp32 tensors; summarised from the rocpd database by tools/rocpd_stats.py."
