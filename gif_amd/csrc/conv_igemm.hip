@@ -736,8 +736,6 @@ int launch_glds_impl(GatherParams& p, hipStream_t s) {
     p.stab_nb = 0;
     p.stab_stride = 0;
     if (SCALE) lds += scale_table<T, BM>(p);
-    static const int lds_pad = getenv("GIF_LDS_PAD") ? atoi(getenv("GIF_LDS_PAD")) : 0;  // occupancy experiments
-    if (lds + lds_pad <= 160 * 1024) lds += lds_pad;
     if (lds > 160 * 1024) return -100;  // fp32 caller falls back to the register-staged kernel
     auto kern = conv_gather_mfma_glds<T, BM, BN, WMv, WNv, SCALE, BK, X3>;
     attr.ensure(reinterpret_cast<const void*>(kern), lds);
