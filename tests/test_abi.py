@@ -48,6 +48,28 @@ def test_argument_validation_without_gpu():
     assert lib.gif_rasterize_f32(None, None, None, None, 2, 0, 4, 4, None, None) == 0
 
 
+def test_fp32_mfma_mode_api_without_gpu():
+    """include/gif_hip.h: process-wide numerics mode of the fp32 contractions; default bf16x3 unless GIF_FP32_MFMA says otherwise."""
+    import os
+    from gif_amd import ops
+    lib = _lib.load()
+    before = lib.gif_get_fp32_mfma_mode()
+    if os.environ.get("GIF_FP32_MFMA") in (None, "bf16x3"):
+        assert before in (0, 1)  # (an earlier test of this process may have switched it)
+    try:
+        assert lib.gif_set_fp32_mfma_mode(0) == 0 and lib.gif_get_fp32_mfma_mode() == 0
+        ops.set_fp32_mfma_mode("bf16x3")
+        assert ops.get_fp32_mfma_mode() == "bf16x3" and lib.gif_get_fp32_mfma_mode() == 1
+        assert lib.gif_set_fp32_mfma_mode(5) == -1 and b"unknown mode" in lib.gif_last_error()
+    finally:
+        lib.gif_set_fp32_mfma_mode(before)
+        ops._fp32_mode_cache = None
+    rp, cp = ctypes.c_int(), ctypes.c_int()
+    assert lib.gif_conv2d_pack_dims_x3(128, 24, ctypes.byref(rp), ctypes.byref(cp)) == 0 and (rp.value, cp.value) == (128, 32)
+    assert lib.gif_winograd_pack_dims_x3(192, 100, ctypes.byref(rp), ctypes.byref(cp)) == 0 and (rp.value, cp.value) == (256, 128)
+    assert lib.gif_conv2d_x3_eligible(64, 24) == 1 and lib.gif_conv2d_x3_eligible(64, 20) == 0
+
+
 def test_no_cpu_fallback():
     from gif_amd import functional as GF, ops
     with pytest.raises(_lib.GifHipError):
