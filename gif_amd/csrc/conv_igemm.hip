@@ -789,6 +789,24 @@ int launch_glds(GatherParams& p, hipStream_t s) {
                       : launch_glds_impl<T, BM, BN, WMv, WNv, false>(p, s);
 }
 
+// 256x128 tile of the bf16x3 path: 8 waves as 8 (M) x 1 (N) — wave tile 32 x 128: ONE activation fragment to split per 24 MFMAs
+// (the 4 x 2 layout splits two; GIF_X3_WAVES=42 selects it for A/B)
+template <typename T>
+int launch_big_x3(GatherParams& p, hipStream_t s) {
+    static const int layout = getenv("GIF_X3_WAVES") ? atoi(getenv("GIF_X3_WAVES")) : 81;
+    return layout == 42 ? launch_glds<T, 256, 128, 4, 2>(p, s) : launch_glds<T, 256, 128, 8, 1>(p, s);
+}
+
+// 128x128 tile: 2 x 2 waves of 64 x 64; bf16x3: 4 x 1 waves of 32 x 128 (one activation fragment to split per 24 MFMAs)
+template <typename T>
+int launch_128(GatherParams& p, hipStream_t s) {
+    if constexpr (sizeof(T) == 4) {
+        static const int layout = getenv("GIF_X3_WAVES") ? atoi(getenv("GIF_X3_WAVES")) : 81;
+        if (p.x3 && layout != 42) return launch_glds<T, 128, 128, 4, 1>(p, s);
+    }
+    return launch_glds<T, 128, 128, 2, 2>(p, s);
+}
+
 template <typename T>
 int launch_multi(GatherParams* ph, int nph, bool scale, hipStream_t s) {
     if constexpr (sizeof(T) == 4) {
@@ -849,7 +867,7 @@ int launch(GatherParams& p, hipStream_t s) {
                     const int M = p.M;
                     const int m_bulk = (int)(full * slots / tn) * 256;
                     p.M = m_bulk;
-                    if (launch_glds<T, 256, 128, 4, 2>(p, s) == 0) {
+                    if (launch_big_x3<T>(p, s) == 0) {
                         p.M = M;
                         p.m_begin = m_bulk;
                         int rc = launch_glds<T, 64, 64, 2, 2>(p, s);
@@ -857,7 +875,7 @@ int launch(GatherParams& p, hipStream_t s) {
                         return rc;
                     }
                     p.M = M;
-                } else if (launch_glds<T, 256, 128, 4, 2>(p, s) == 0) {
+                } else if (launch_big_x3<T>(p, s) == 0) {
                     return 0;
                 }
             }
@@ -873,7 +891,7 @@ int launch(GatherParams& p, hipStream_t s) {
                 const int M = p.M;
                 const int m_bulk = (int)(full * slots / tn) * 128;
                 p.M = m_bulk;
-                if (launch_glds<T, 128, 128, 2, 2>(p, s) == 0) {
+                if (launch_128<T>(p, s) == 0) {
                     p.M = M;
                     p.m_begin = m_bulk;
                     int rc = launch_glds<T, 64, 64, 2, 2>(p, s);
@@ -884,7 +902,7 @@ int launch(GatherParams& p, hipStream_t s) {
             }
         }
         if (glds) {
-            int rc = launch_glds<T, 128, 128, 2, 2>(p, s);
+            int rc = launch_128<T>(p, s);
             if (rc == 0) return 0;
             if (only_glds) return fail_f16(rc);
         }
