@@ -34,6 +34,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 // GEMM tile: 256 threads = 4 waves as 2 (M) x 2 (N); wave tile 64 tiles x 32 couts; block tile 128 x 64; BK = 32.
 constexpr int WBM = 128, WBN = 64, WBK = 32, WNSTAGE = 3;
+constexpr int WPAD = 256;  // row padding of the V / Mg planes: the bf16x3 GEMM walks them in 256-row blocks
 
 // ------------------------------------------------------------------------------------------------ input transform
 // one lane = one 4x4 input patch of one tile x 4 channels; B^T d B with B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1].
@@ -412,26 +413,28 @@ __global__ void __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) wino_gemm_mfma(cons
 // Per group: the V fragments of the NEXT group are read first and split piecewise between this group's MFMAs; the weight
 // operands are reloaded term by term as soon as the last MFMA that uses a term has issued (lo after 2, mid after 6, hi after 12).
 // DBG (ablation builds only, GIF_WINO_DBG; results are wrong): 1 = no fold, 2 = no split of V, 4 = no weight-operand reloads
-template <int DBG = 0>
+// Block BM x BN = 128 x 128 (4 x 2 waves; default) or 256 x 64 (8 x 1 waves: every V fragment is split by exactly one wave).
+template <int DBG = 0, int BM = 256, int BN = 64>
 __global__ void __launch_bounds__(512, 1) wino_gemm_x3(const WinoParams p) {
-    constexpr int THREADS = 512, BN = 128, PROWS = THREADS / 8;
+    constexpr int THREADS = 512, PROWS = THREADS / 8;
     constexpr int LD = WBK, CH = WBK / 4, RB = 64 / WBK, RPW = 64 / CH;
-    constexpr int NT = 2;
-    constexpr int A_IT = WBM / PROWS;          // 2
-    constexpr int B3_BLK = 3 * BN / 16;        // 24 one-KiB blocks (16 rows x 64 B) per stage
-    constexpr int B3_IT = B3_BLK / 8;          // 3 per wave
+    constexpr int NT = 2, WAVES_N = BN / 64;
+    static_assert(BM * BN == 128 * 128 && (8 / WAVES_N) * 32 == BM, "8 waves of 32 tiles x 64 couts");
+    constexpr int A_IT = BM / PROWS;                  // 4 / 2
+    constexpr int B3_BLK = 3 * BN / 16;               // 12 / 24 one-KiB blocks (16 rows x 64 B) per stage
+    constexpr int B3_IT = (B3_BLK + 7) / 8;           // 2 (waves 4-7: 1) / 3 per wave
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                                                                     // [NSTAGE][WBM][LD] fp32
-    unsigned short* B3 = reinterpret_cast<unsigned short*>(smem + WNSTAGE * WBM * LD);   // [NSTAGE][3][BN][32] bf16
+    float* As = smem;                                                                    // [NSTAGE][BM][LD] fp32
+    unsigned short* B3 = reinterpret_cast<unsigned short*>(smem + WNSTAGE * BM * LD);   // [NSTAGE][3][BN][32] bf16
     const unsigned short* const U3 = reinterpret_cast<const unsigned short*>(p.U);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
-    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 64;
+    const int wm0 = (wave / WAVES_N) * 32, wn0 = (wave % WAVES_N) * 64;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
-    const int m0 = tm * WBM, n0 = tn * BN;
+    const int m0 = tm * BM, n0 = tn * BN;
     const int t_row = tid / CH;
     const int src_c4 = ((tid % CH) ^ ((t_row / RB) % CH)) * 4;
     const int fsw = (li / RB) % CH;
@@ -456,13 +459,14 @@ __global__ void __launch_bounds__(512, 1) wino_gemm_x3(const WinoParams p) {
     int ld_kc = 0;
 
     auto issue = [&](int buf) __attribute__((always_inline)) {
-        float* Ad = As + buf * WBM * LD + wave * RPW * LD;
+        float* Ad = As + buf * BM * LD + wave * RPW * LD;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it)
             __builtin_amdgcn_global_load_lds((gptr_t)((vptr + it * pass_stride) + a_off), (lptr_t)(Ad + it * PROWS * LD), 16, 0, 0);
 #pragma unroll
         for (int it = 0; it < B3_IT; ++it)
-            __builtin_amdgcn_global_load_lds((gptr_t)(uptr + b3_off[it]), (lptr_t)(B3 + (buf * B3_BLK + wave + it * 8) * 512), 16, 0, 0);
+            if (B3_BLK % 8 == 0 || wave + it * 8 < B3_BLK)  // wave-uniform
+                __builtin_amdgcn_global_load_lds((gptr_t)(uptr + b3_off[it]), (lptr_t)(B3 + (buf * B3_BLK + wave + it * 8) * 512), 16, 0, 0);
         vptr += WBK;
         uptr += WBK;
         ld_kc += WBK;
@@ -489,7 +493,7 @@ __global__ void __launch_bounds__(512, 1) wino_gemm_x3(const WinoParams p) {
     f32x4 ra[2];             // raw V fragments of the group being split
 
     auto read_a = [&](int buf, int q) __attribute__((always_inline)) {
-        const float* Ab = As + buf * WBM * LD + (wm0 + li) * LD;
+        const float* Ab = As + buf * BM * LD + (wm0 + li) * LD;
 #pragma unroll
         for (int u = 0; u < 2; ++u) ra[u] = *reinterpret_cast<const f32x4*>(Ab + (((q * 4 + lh * 2 + u) ^ fsw) << 2));
     };
@@ -552,11 +556,16 @@ __global__ void __launch_bounds__(512, 1) wino_gemm_x3(const WinoParams p) {
         for (int j = 0; j < NT; ++j) acc[j] = (f32x16)(0.f);
     };
 
-    constexpr int NI = A_IT + B3_IT;
-    static_assert(NI == 5, "the s_waitcnt immediates below encode vmcnt(NI)");
+    // DMA instructions per stage and wave: 256x64: 4 + 2 (waves 0-3) / 4 + 1 (waves 4-7); 128x128: 2 + 3
+    static_assert((BM == 256 && A_IT == 4 && B3_BLK == 12) || (BM == 128 && A_IT == 2 && B3_BLK == 24), "the s_waitcnt immediates");
+    auto wait_newest_in_flight = [&]() __attribute__((always_inline)) {
+        if (BM == 128) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else if (wave < 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    };
     issue(0);
     issue(1);  // nsteps >= 16
-    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    wait_newest_in_flight();
     __builtin_amdgcn_s_barrier();
     read_a(0, 0);
 #pragma unroll
@@ -570,7 +579,7 @@ __global__ void __launch_bounds__(512, 1) wino_gemm_x3(const WinoParams p) {
         __builtin_amdgcn_sched_barrier(0);
         group(0, cur, 1);
         // stage step+1 must have landed before its operands are read (this stage's are all in registers by now)
-        if (step + 2 < nsteps) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        if (step + 2 < nsteps) wait_newest_in_flight();
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         cur = cur == 2 ? 0 : cur + 1;
@@ -585,8 +594,8 @@ __global__ void __launch_bounds__(512, 1) wino_gemm_x3(const WinoParams p) {
 
     // ---- epilogue: for each output position (a,b): transpose through LDS, then coalesced float4 rows
     constexpr int LDC = BN + 4;
-    float* Cs = smem;  // [WBM][LDC]
-    constexpr int C4_ROW = BN / 4, EROWS = THREADS / C4_ROW, E_IT = WBM / EROWS;
+    float* Cs = smem;  // [BM][LDC]
+    constexpr int C4_ROW = BN / 4, EROWS = THREADS / C4_ROW, E_IT = BM / EROWS;
     const int e_row0 = tid / C4_ROW, e_c = (tid % C4_ROW) * 4;
     const int n = n0 + e_c;
     f32x4 bias4 = (f32x4)(0.f);
@@ -670,7 +679,7 @@ __global__ void wino_weight_transform_x3(const float* __restrict__ w, unsigned s
 namespace gif {
 
 void winograd_padded_dims(long ntiles, int C, long* ntiles_pad, int* CP) {
-    *ntiles_pad = (ntiles + WBM - 1) / WBM * WBM;
+    *ntiles_pad = (ntiles + WPAD - 1) / WPAD * WPAD;
     *CP = (C + WBK - 1) / WBK * WBK;
 }
 
@@ -714,7 +723,7 @@ int gif_winograd_pack_dims(int cout, int cin, int* RP, int* CP) {
 int64_t gif_winograd_workspace_floats(int B, int H, int W, int C) {
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
     const int64_t ntiles = (int64_t)B * (H / 2) * (W / 2);
-    const int64_t ntiles_pad = (ntiles + WBM - 1) / WBM * WBM;
+    const int64_t ntiles_pad = (ntiles + WPAD - 1) / WPAD * WPAD;
     const int64_t CP = (C + WBK - 1) / WBK * WBK;
     return 16 * ntiles_pad * CP;
 }
@@ -738,7 +747,7 @@ int gif_conv3x3_winograd_f32(const float* x, const float* U, float* y, float* V,
     const long ntiles = (long)B * (H / 2) * (W / 2);
     WinoParams p{};
     gif_winograd_pack_dims(Co, C, &p.RP, &p.CP);
-    const long ntiles_pad = (ntiles + WBM - 1) / WBM * WBM;
+    const long ntiles_pad = (ntiles + WPAD - 1) / WPAD * WPAD;
     GIF_REQUIRE(ntiles_pad * p.CP < (1L << 31) && (long)B * H * W * Co < (1L << 31) && (long)B * H * W * C < (1L << 31),
                 "winograd: tensor too large for 32-bit offsets");
     hipStream_t s = gif::as_stream(stream);
@@ -804,7 +813,7 @@ int gif_conv3x3_winograd_f32x3(const float* x, const void* U3, float* y, float* 
     const long ntiles = (long)B * (H / 2) * (W / 2);
     WinoParams p{};
     gif_winograd_pack_dims_x3(Co, C, &p.RP, &p.CP);
-    const long ntiles_pad = (ntiles + WBM - 1) / WBM * WBM;
+    const long ntiles_pad = (ntiles + WPAD - 1) / WPAD * WPAD;
     GIF_REQUIRE(ntiles_pad * p.CP < (1L << 31) && (long)B * H * W * Co < (1L << 31) && (long)B * H * W * C < (1L << 31) &&
                     3L * p.RP * p.CP < (1L << 31),
                 "winograd_x3: tensor too large for 32-bit offsets");
@@ -824,22 +833,27 @@ int gif_conv3x3_winograd_f32x3(const float* x, const void* U3, float* y, float* 
     p.gain = e ? e->gain : 1.f;
     p.B = B; p.H = H; p.W = W; p.Co = Co;
     p.ntiles = (int)ntiles; p.ntiles_pad = (int)ntiles_pad; p.TH = H / 2; p.TW = W / 2;
-    p.tiles_m = (int)(ntiles_pad / WBM);
-    p.tiles_n = p.RP / 128;
-    const size_t lds = (size_t)WNSTAGE * (WBM * WBK * sizeof(float) + 3 * 128 * 64);
     static const int dbg = getenv("GIF_WINO_DBG") ? atoi(getenv("GIF_WINO_DBG")) : 0;
+    // 128 x 128 blocks (4 x 2 waves) by default; GIF_WINO_X3_TILE=256 selects 256 x 64 (8 x 1 waves: every V fragment split
+    // once instead of twice) — measured equal (2.998 / 2.141 / 1.790 ms vs 2.993 / 2.133 / 1.757 ms on the three big layers)
+    static const int sq = getenv("GIF_WINO_X3_TILE") ? atoi(getenv("GIF_WINO_X3_TILE")) != 256 : 1;
+    const int bm = sq ? 128 : 256, bn = sq ? 128 : 64;
+    p.tiles_m = (int)(ntiles_pad / bm);
+    p.tiles_n = p.RP / bn;
+    const size_t lds = (size_t)WNSTAGE * ((size_t)bm * WBK * sizeof(float) + 3 * (size_t)bn * 64);
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
-#define GIF_WINO_X3_LAUNCH(D)                                                      \
-    {                                                                              \
-        static gif::LdsAttr attr;                                                  \
-        attr.ensure(reinterpret_cast<const void*>(wino_gemm_x3<D>), lds);          \
-        hipLaunchKernelGGL(wino_gemm_x3<D>, grid, dim3(512), lds, s, p);           \
+#define GIF_WINO_X3_LAUNCH(D, BM_, BN_)                                                        \
+    {                                                                                          \
+        static gif::LdsAttr attr;                                                              \
+        attr.ensure(reinterpret_cast<const void*>(wino_gemm_x3<D, BM_, BN_>), lds);            \
+        hipLaunchKernelGGL((wino_gemm_x3<D, BM_, BN_>), grid, dim3(512), lds, s, p);           \
     }
-    if (dbg == 1) GIF_WINO_X3_LAUNCH(1)
-    else if (dbg == 2) GIF_WINO_X3_LAUNCH(2)
-    else if (dbg == 4) GIF_WINO_X3_LAUNCH(4)
-    else if (dbg == 7) GIF_WINO_X3_LAUNCH(7)
-    else GIF_WINO_X3_LAUNCH(0)
+    if (!sq) GIF_WINO_X3_LAUNCH(0, 256, 64)
+    else if (dbg == 1) GIF_WINO_X3_LAUNCH(1, 128, 128)
+    else if (dbg == 2) GIF_WINO_X3_LAUNCH(2, 128, 128)
+    else if (dbg == 4) GIF_WINO_X3_LAUNCH(4, 128, 128)
+    else if (dbg == 7) GIF_WINO_X3_LAUNCH(7, 128, 128)
+    else GIF_WINO_X3_LAUNCH(0, 128, 128)
 #undef GIF_WINO_X3_LAUNCH
     return gif::check_launch("conv3x3_winograd_f32x3");
 }
