@@ -933,7 +933,10 @@ static int conv2d_wgrad_f32_impl(const float* small, const float* big, float* ws
     p.stab_nb = (int)((p.chunk + HWs - 1) / HWs + 1);
     if (p.stab_nb > g->B) p.stab_nb = g->B;
     const bool tab_fits = HWs % 16 == 0 && (size_t)p.stab_nb * 256 * sizeof(float) <= 64 * 1024;
-    x3 = x3 && tile_of(g->Cs) == 128 && tile_of(g->Cb) == 128 && (!(small_scale || big_scale) || tab_fits);
+    // bf16x3 tiles: 128x128, and 128x32 for the un-modulated layers with a thin big side (the 24-channel condition-noise maps)
+    static const int x3_thin_off = getenv("GIF_X3_WGRAD_THIN") ? atoi(getenv("GIF_X3_WGRAD_THIN")) == 0 : 0;
+    const bool x3_thin = x3 && !x3_thin_off && tile_of(g->Cs) == 128 && tile_of(g->Cb) == 32 && !small_scale && !big_scale;
+    x3 = x3 && tile_of(g->Cs) == 128 && (tile_of(g->Cb) == 128 || x3_thin) && (!(small_scale || big_scale) || tab_fits);
     const bool big_tile = !x3 && wgrad_big_tile(g->Cs, g->Cb, small_scale || big_scale, p.Ntot) && !getenv("GIF_CONV_VARIANT");
     p.tiles_q = p.CP / bq;
     p.tiles_pq = (p.RP / (big_tile ? 256 : bp)) * p.tiles_q;
@@ -966,7 +969,9 @@ static int conv2d_wgrad_f32_impl(const float* small, const float* big, float* ws
     else wgrad_launch<float, BP_, BQ_, WP_, WQ_, false, 32>(grid, TH_, s, p)
         const bool tab = (small_scale || big_scale) && (variant != 1 || x3) && tab_fits;
         static const int x3_simple = getenv("GIF_X3_WGRAD_SIMPLE") ? atoi(getenv("GIF_X3_WGRAD_SIMPLE")) : 0;  // A/B: 16-pixel stages, no pipeline
-        if (x3 && tab && HWs % 32 == 0 && !x3_simple) {
+        if (x3_thin) {
+            wgrad_launch<float, 128, 32, 4, 1, true, 32, false, true>(grid, 256, s, p);
+        } else if (x3 && tab && HWs % 32 == 0 && !x3_simple) {
             wgrad_launch<float, 128, 128, 2, 2, true, 32, true, true>(grid, 256, s, p);
         } else if (x3 && tab) {
             wgrad_launch<float, 128, 128, 2, 2, true, 16, true, true>(grid, 256, s, p);

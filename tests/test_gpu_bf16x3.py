@@ -107,6 +107,26 @@ def test_bf16x3_winograd_plane_gemms_vs_fp64():
     assert out["native"] < 1e-5 and out["bf16x3"] <= 1.3 * out["native"] + 2e-7, out
 
 
+@pytest.mark.parametrize("case", [(4, 24, 128, 3, 64), (2, 12, 256, 1, 40), (3, 24, 512, 3, 17)])
+def test_bf16x3_thin_weight_gradient_vs_fp64(case):
+    """Un-modulated weight gradients with a <= 32-channel big side (the 24-channel condition-noise maps, the 12-channel D input)
+    run the bf16x3 kernel on 128x32 tiles."""
+    from gif_amd import ops
+    B, ci, co, k, h = case
+    torch.manual_seed(sum(case))
+    spec = ops.ConvSpec(k, k, 1, k // 2)
+    x = torch.randn(B, ci, h, h, device="cuda").contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(B, co, h, h, device="cuda").contiguous(memory_format=torch.channels_last)
+    wd = torch.zeros(co, ci, k, k, device="cuda", dtype=torch.float64, requires_grad=True)
+    (ref,) = torch.autograd.grad(F.conv2d(x.double(), wd, padding=k // 2), wd, gy.double())
+    out = {}
+    for mode in ("native", "bf16x3"):
+        ops.set_fp32_mfma_mode(mode)
+        gw = ops.conv_wgrad(gy, x, spec, co, ci)
+        out[mode] = float((gw.double() - ref).abs().max() / ref.abs().max())
+    assert out["native"] < 1e-5 and out["bf16x3"] <= 1.3 * out["native"] + 2e-7, out
+
+
 @pytest.mark.parametrize("case", [(4, 128, 128, 64), (2, 256, 512, 32), (3, 512, 256, 16), (2, 128, 192, 32)])
 def test_bf16x3_winograd_fwd_dgrad_vs_fp64(case, monkeypatch):
     """wino_gemm_x3 (pre-split U3, 128-wide N tile, fused output transform + epilogue) against fp64, next to the native Winograd
