@@ -21,6 +21,9 @@
 //   * conv_gather_mfma (Cin < 32, BK = 8, and fallback): global -> VGPR -> LDS with a +4-float row pad (odd number of
 //     16-B slots => conflict-free ds_read_b128), double buffered, loads of step s+1 issued before the MFMAs of step s.
 // Both share conv_epilogue(): accumulators -> LDS -> coalesced float4 rows with out_scale / residual / bias / lrelu.
+// The LDS-DMA kernel has two more instantiations of the same staging / addressing / epilogue: T = f16 activations
+// (v_mfma_f32_32x32x16_f16) and X3 = fp32 tensors on the bf16 matrix cores ("bf16x3": exact three-way bf16 split of both operands,
+// six v_mfma_f32_32x32x16_bf16 products per fp32 product, fp32 accumulation — the default mode, see glds_body and DESIGN.md 3a).
 #include <stdlib.h>
 
 #include <type_traits>
