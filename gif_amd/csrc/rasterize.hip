@@ -2,14 +2,12 @@
 //
 // Replaces the reference's only native code,
 //   my_utils/standard_rasterize_cuda/standard_rasterize_cuda_kernel.cu:111-233 (+ host :237-320),
-// with a different, race-free formulation:
-//   1. init   : key[p] = (ordered_bits(depth_in[p]) << 32) | 0xFFFFFFFF
-//   2. faces  : one lane per (image, face); every covered pixel does ONE 64-bit atomicMin of
-//               (ordered_bits(zp) << 32) | face  — depth test and winner selection in a single atomic,
-//               so the reference's second launch (:252-269, a race work-around) is not needed and
-//               exact-depth ties deterministically go to the lowest face index;
-//   3. resolve: one lane per pixel re-evaluates the winning face at that pixel (same fp32 operation
-//               order => same bits) and writes depth / face index / barycentrics or colours.
+// with a different, race-free formulation built around the CU's LDS (160 KB): the image is cut into 64x64-pixel tiles whose
+// z-buffers live in LDS; depth test and winner selection are ONE 64-bit LDS atomic-min of (ordered_bits(zp) << 32) | face per
+// covered pixel, so the reference's second launch (:252-269, a race work-around) is not needed, no atomic ever reaches HBM,
+// and exact-depth ties deterministically go to the lowest face index.  See raster_setup / raster_tiles below.  (The
+// reference runs one thread per face over its whole bounding box, :111-167: one large triangle serialises a lane while
+// its 63 neighbours idle, and every pixel test is a global atomic.)
 // Arithmetic follows the reference operation by operation with FP contraction off, so results are
 // bit-identical to oracle/rasterize_ref.c.
 #include "common.h"
@@ -92,42 +90,46 @@ __device__ __forceinline__ void face_bbox(const Face<T>& f, int H, int W, int& x
     y_max = min((int)floor(fmax(f.y0, fmax(f.y1, f.y2))), H - 1);
 }
 
-__global__ void raster_init_keys(const float* __restrict__ depth, unsigned long long* __restrict__ key, long n) {
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) key[i] = ((unsigned long long)ordered_bits(depth[i]) << 32) | kNoFace;
-}
-
-__global__ void __launch_bounds__(256)
-raster_faces(const float* __restrict__ fv, unsigned long long* __restrict__ key, int B, int F, int H, int W) {
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)B * F) return;
-    int b = (int)(i / F);
-    uint32_t fidx = (uint32_t)(i - (long)b * F);
-    Face<float> f = load_face(fv + i * 9);
-    if (!front_facing(f)) return;
-    int x_min, x_max, y_min, y_max;
-    face_bbox(f, H, W, x_min, x_max, y_min, y_max);
-    BaryCtx<float> c = bary_setup(f);
-    unsigned long long* kb = key + (long)b * H * W;
-    for (int y = y_min; y <= y_max; ++y) {
-        for (int x = x_min; x <= x_max; ++x) {
-            float w[3];
-            bary_at(f, c, (float)x, (float)y, w);
-            if (inside(w)) {
-                float zp = persp_depth(f, w);
-                if (zp == zp) {  // NaN never wins (fminf in the reference's atomicMin, .cu:8-18)
-                    unsigned long long k = ((unsigned long long)ordered_bits(zp) << 32) | fidx;
-                    atomicMin(kb + (long)y * W + x, k);
-                }
-            }
-        }
+// ---------------------------------------------------------------------------------------------------------------------
+// Kernel 1, raster_setup: one lane per (image, face): front-facing test + clamped bounding box, packed into 4 x u16
+// (x_min, x_max, y_min, y_max; culled / empty => x_min = y_min = 0xFFFF, x_max = y_max = 0, which overlaps no tile).
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) raster_setup(const T* __restrict__ fv, uint2* __restrict__ box, long nfaces, int H, int W) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nfaces) return;
+    const Face<T> f = load_face(fv + i * 9);
+    uint2 b = make_uint2(0x0000FFFFu, 0x0000FFFFu);  // lo 16 bits = min, hi 16 bits = max
+    if (front_facing(f)) {
+        int x_min, x_max, y_min, y_max;
+        face_bbox(f, H, W, x_min, x_max, y_min, y_max);
+        if (x_min <= x_max && y_min <= y_max) b = make_uint2((unsigned)x_min | ((unsigned)x_max << 16), (unsigned)y_min | ((unsigned)y_max << 16));
     }
+    box[i] = b;
 }
 
-// ---- float64 variant (the reference dispatches AT_DISPATCH_FLOATING_TYPES, .cu:252,295).  A 64-bit depth and a face index
-// do not fit one 64-bit atomic, so the winner is found in two passes over the faces: (A) 64-bit atomicMin of the ordered depth
-// bits, (B) among the faces whose depth at the pixel EQUALS that minimum (recomputed: same arithmetic, same bits) a 32-bit
-// atomicMin of the face index — the same deterministic "lowest face index wins an exact tie" rule as the float path.
+// ---------------------------------------------------------------------------------------------------------------------
+// Kernel 2, raster_tiles: one 512-thread workgroup per (image, 64x64-pixel tile); the tile's z-buffer lives in LDS.
+//   seed   : key[p] = (ordered_bits(depth_in[p]) << 32) | 0xFFFFFFFF from the caller's depth buffer
+//   scan   : the workgroup streams the image's packed boxes (8 B per face, L2-resident) in chunks of 4096 faces and
+//            compacts the faces whose box overlaps the tile into an LDS list
+//   shade  : listed faces, box clipped to the tile: <= 16 px => the lane walks it; larger => the wave walks it together,
+//            8x8 pixels per step (face broadcast by shuffles).  Every covered pixel does ONE 64-bit LDS atomic-min of
+//            (ordered_bits(zp) << 32) | face.  Per-pixel arithmetic is identical in both classes and to the oracle.
+//   resolve: per pixel of the tile, re-evaluate the winner (same fp operation order => same bits), write depth / face
+//            index / barycentrics or colours; untouched pixels keep the caller's contents.
+// No global atomics, no key buffer in HBM, no second launch; a screen-filling triangle costs every tile 64 wave-steps.
+// float64 (the reference dispatches AT_DISPATCH_FLOATING_TYPES, .cu:252,295): a 64-bit depth and a face index do not fit
+// one 64-bit atomic, so scan + shade run twice: (PASS 0) atomic-min of the ordered depth bits, (PASS 1) among the faces
+// whose depth at the pixel EQUALS that minimum (recomputed: same arithmetic, same bits) a 32-bit atomic-min of the face
+// index — the same deterministic "lowest face index wins an exact tie" rule as the float path.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kTile = 64;          // pixels per tile edge
+constexpr int kTilePix = kTile * kTile;
+constexpr int kChunk = 4096;       // faces scanned per round (= capacity of the LDS candidate list)
+constexpr int kThreads = 512;
+constexpr int kSmallArea = 16;     // clipped boxes up to this many pixels are walked by their own lane
+
 __device__ __forceinline__ unsigned long long ordered_bits64(double d) {
     unsigned long long u = (unsigned long long)__double_as_longlong(d);
     return (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
@@ -136,142 +138,216 @@ __device__ __forceinline__ double from_ordered_bits64(unsigned long long u) {
     return __longlong_as_double((long long)((u & 0x8000000000000000ull) ? (u & 0x7FFFFFFFFFFFFFFFull) : ~u));
 }
 
-__global__ void raster_init_keys64(const double* __restrict__ depth, unsigned long long* __restrict__ zkey,
-                                   uint32_t* __restrict__ fkey, long n) {
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        zkey[i] = ordered_bits64(depth[i]);
-        fkey[i] = kNoFace;
+template <typename T>
+struct TileKeys;
+template <>
+struct TileKeys<float> {
+    unsigned long long* key;  // LDS [kTilePix]
+    __device__ __forceinline__ void hit(int p, float zp, uint32_t fidx, int) const {
+        atomicMin(key + p, ((unsigned long long)ordered_bits(zp) << 32) | fidx);
+    }
+};
+template <>
+struct TileKeys<double> {
+    unsigned long long* key;  // LDS [kTilePix] ordered depth bits
+    uint32_t* fkey;           // LDS [kTilePix]
+    __device__ __forceinline__ void hit(int p, double zp, uint32_t fidx, int pass) const {
+        const unsigned long long k = ordered_bits64(zp);
+        if (pass == 0) atomicMin(key + p, k);
+        else if (key[p] == k) atomicMin(fkey + p, fidx);
+    }
+};
+
+// one pixel (global x, y; tile origin tx0, ty0) of one face
+template <typename T>
+__device__ __forceinline__ void shade(const Face<T>& f, const BaryCtx<T>& c, int x, int y, int tx0, int ty0, uint32_t fidx,
+                                      const TileKeys<T>& keys, int pass) {
+    T w[3];
+    bary_at(f, c, (T)x, (T)y, w);
+    if (inside(w)) {
+        T zp = persp_depth(f, w);
+        if (zp == zp) keys.hit((y - ty0) * kTile + (x - tx0), zp, fidx, pass);  // NaN never wins (fminf in the reference's atomicMin, .cu:8-18)
     }
 }
 
-template <int PASS>
-__global__ void __launch_bounds__(256)
-raster_faces64(const double* __restrict__ fv, unsigned long long* __restrict__ zkey, uint32_t* __restrict__ fkey, int B, int F,
-               int H, int W) {
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)B * F) return;
-    int b = (int)(i / F);
-    uint32_t fidx = (uint32_t)(i - (long)b * F);
-    Face<double> f = load_face(fv + i * 9);
-    if (!front_facing(f)) return;
-    int x_min, x_max, y_min, y_max;
-    face_bbox(f, H, W, x_min, x_max, y_min, y_max);
-    BaryCtx<double> c = bary_setup(f);
-    const long base = (long)b * H * W;
-    for (int y = y_min; y <= y_max; ++y) {
-        for (int x = x_min; x <= x_max; ++x) {
-            double w[3];
-            bary_at(f, c, (double)x, (double)y, w);
-            if (inside(w)) {
-                double zp = persp_depth(f, w);
-                if (zp == zp) {
-                    const long p = base + (long)y * W + x;
-                    const unsigned long long k = ordered_bits64(zp);
-                    if (PASS == 0) atomicMin(zkey + p, k);
-                    else if (zkey[p] == k) atomicMin(fkey + p, fidx);
+template <typename T>
+__device__ __forceinline__ Face<T> shfl_face(const Face<T>& f, int src) {
+    Face<T> g;
+    g.x0 = __shfl(f.x0, src, 64); g.y0 = __shfl(f.y0, src, 64); g.z0 = __shfl(f.z0, src, 64);
+    g.x1 = __shfl(f.x1, src, 64); g.y1 = __shfl(f.y1, src, 64); g.z1 = __shfl(f.z1, src, 64);
+    g.x2 = __shfl(f.x2, src, 64); g.y2 = __shfl(f.y2, src, 64); g.z2 = __shfl(f.z2, src, 64);
+    return g;
+}
+
+template <typename T, bool COLORS>
+__global__ void __launch_bounds__(kThreads)
+raster_tiles(const T* __restrict__ fv, const T* __restrict__ fc, const uint2* __restrict__ box, T* __restrict__ depth,
+             int32_t* __restrict__ tri, T* __restrict__ out3, int F, int H, int W, int tiles_x, int tiles_y) {
+    constexpr bool F64 = sizeof(T) == 8;
+    __shared__ unsigned long long key[kTilePix];
+    __shared__ uint32_t fkey[F64 ? kTilePix : 1];
+    __shared__ uint32_t cand[kChunk];
+    __shared__ uint32_t ncand;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = blockIdx.x % (tiles_x * tiles_y), b = blockIdx.x / (tiles_x * tiles_y);
+    const int tx0 = (tile % tiles_x) * kTile, ty0 = (tile / tiles_x) * kTile;
+    const int tx1 = min(tx0 + kTile, W) - 1, ty1 = min(ty0 + kTile, H) - 1;
+    const long img = (long)b * H * W;
+    TileKeys<T> keys;
+    keys.key = key;
+    if constexpr (F64) keys.fkey = fkey;
+
+    // ---- seed the tile's keys from the caller's depth buffer
+    for (int p = tid; p < kTilePix; p += kThreads) {
+        const int x = tx0 + (p & (kTile - 1)), y = ty0 + (p >> 6);
+        const bool in = x <= tx1 && y <= ty1;
+        if constexpr (F64) {
+            key[p] = in ? ordered_bits64(depth[img + (long)y * W + x]) : 0ull;
+            fkey[p] = kNoFace;
+        } else {
+            key[p] = in ? (((unsigned long long)ordered_bits(depth[img + (long)y * W + x]) << 32) | kNoFace) : 0ull;
+        }
+    }
+    if (tid == 0) ncand = 0;
+    __syncthreads();
+
+    const uint2* bx = box + (long)b * F;
+    const T* fvb = fv + (long)b * F * 9;
+    const int lx = lane & 7, ly = lane >> 3;
+    for (int pass = 0; pass < (F64 ? 2 : 1); ++pass) {
+        for (int c0 = 0; c0 < F; c0 += kChunk) {
+            // ---- scan: compact the faces of this chunk whose box overlaps the tile
+#pragma unroll
+            for (int k = 0; k < kChunk / kThreads; ++k) {
+                const int fi = c0 + tid + k * kThreads;
+                if (fi < F) {
+                    const uint2 q = bx[fi];
+                    const int x_min = q.x & 0xFFFF, x_max = q.x >> 16, y_min = q.y & 0xFFFF, y_max = q.y >> 16;
+                    if (x_min <= tx1 && x_max >= tx0 && y_min <= ty1 && y_max >= ty0) cand[atomicAdd(&ncand, 1u)] = (uint32_t)fi;
                 }
             }
+            __syncthreads();
+            const int n = (int)ncand;
+            // ---- shade: one candidate per lane; every wave runs the same number of rounds
+            for (int j0 = wave * 64; j0 < n; j0 += kThreads) {
+                const int j = j0 + lane;
+                uint32_t fidx = 0;
+                Face<T> f{};
+                int x_min = 0, x_max = -1, y_min = 0, y_max = -1, area = 0;
+                if (j < n) {
+                    fidx = cand[j];
+                    f = load_face(fvb + (long)fidx * 9);
+                    const uint2 q = bx[fidx];
+                    x_min = max((int)(q.x & 0xFFFF), tx0); x_max = min((int)(q.x >> 16), tx1);
+                    y_min = max((int)(q.y & 0xFFFF), ty0); y_max = min((int)(q.y >> 16), ty1);
+                    area = (x_max - x_min + 1) * (y_max - y_min + 1);
+                }
+                if (area > 0 && area <= kSmallArea) {
+                    const BaryCtx<T> c = bary_setup(f);
+                    for (int y = y_min; y <= y_max; ++y)
+                        for (int x = x_min; x <= x_max; ++x) shade(f, c, x, y, tx0, ty0, fidx, keys, pass);
+                }
+                unsigned long long todo = __ballot(area > kSmallArea);
+                while (todo) {
+                    const int src = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                    const Face<T> g = shfl_face(f, src);
+                    const int gx0 = __shfl(x_min, src, 64), gx1 = __shfl(x_max, src, 64);
+                    const int gy0 = __shfl(y_min, src, 64), gy1 = __shfl(y_max, src, 64);
+                    const uint32_t gf = (uint32_t)__shfl((int)fidx, src, 64);
+                    const BaryCtx<T> c = bary_setup(g);
+                    for (int y0 = gy0; y0 <= gy1; y0 += 8)
+                        for (int x0 = gx0; x0 <= gx1; x0 += 8) {
+                            const int x = x0 + lx, y = y0 + ly;
+                            if (x <= gx1 && y <= gy1) shade(g, c, x, y, tx0, ty0, gf, keys, pass);
+                        }
+                }
+            }
+            __syncthreads();
+            if (tid == 0) ncand = 0;
+            __syncthreads();
+        }
+    }
+
+    // ---- resolve
+    for (int p = tid; p < kTilePix; p += kThreads) {
+        const int x = tx0 + (p & (kTile - 1)), y = ty0 + (p >> 6);
+        if (x > tx1 || y > ty1) continue;
+        const unsigned long long k = key[p];
+        uint32_t fidx;
+        if constexpr (F64) fidx = fkey[p];
+        else fidx = (uint32_t)(k & 0xFFFFFFFFu);
+        if (fidx == kNoFace) continue;  // pixel keeps the caller's depth / tri / payload
+        const long gp = img + (long)y * W + x;
+        const long fi = (long)b * F + fidx;
+        const Face<T> f = load_face(fv + fi * 9);
+        const BaryCtx<T> c = bary_setup(f);
+        T w[3];
+        bary_at(f, c, (T)x, (T)y, w);
+        if constexpr (F64) depth[gp] = from_ordered_bits64(k);
+        else depth[gp] = from_ordered_bits((uint32_t)(k >> 32));
+        tri[gp] = (int32_t)fidx;
+        if (COLORS) {
+            const T* cl = fc + fi * 9;  // [3 verts][3 channels], .cu:189-194
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) out3[gp * 3 + ch] = w[0] * cl[ch] + w[1] * cl[3 + ch] + w[2] * cl[6 + ch];
+        } else {
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) out3[gp * 3 + ch] = w[ch];
         }
     }
 }
 
-template <typename T, bool COLORS>
-__global__ void __launch_bounds__(256)
-raster_resolve(const T* __restrict__ fv, const T* __restrict__ fc, const unsigned long long* __restrict__ key,
-               const uint32_t* __restrict__ fkey, T* __restrict__ depth, int32_t* __restrict__ tri, T* __restrict__ out3, int B,
-               int F, int H, int W) {
-    long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    long hw = (long)H * W;
-    if (p >= (long)B * hw) return;
-    unsigned long long k = key[p];
-    uint32_t fidx = sizeof(T) == 4 ? (uint32_t)(k & 0xFFFFFFFFu) : fkey[p];
-    if (fidx == kNoFace) return;  // pixel keeps the caller's depth / tri / payload
-    int b = (int)(p / hw);
-    int rem = (int)(p - (long)b * hw);
-    int y = rem / W, x = rem - y * W;
-    long fi = (long)b * F + fidx;
-    Face<T> f = load_face(fv + fi * 9);
-    BaryCtx<T> c = bary_setup(f);
-    T w[3];
-    bary_at(f, c, (T)x, (T)y, w);
-    if (sizeof(T) == 4) depth[p] = (T)from_ordered_bits((uint32_t)(k >> 32));
-    else depth[p] = (T)from_ordered_bits64(k);
-    tri[p] = (int32_t)fidx;
-    if (COLORS) {
-        const T* cl = fc + fi * 9;  // [3 verts][3 channels], .cu:189-194
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) out3[p * 3 + ch] = w[0] * cl[ch] + w[1] * cl[3 + ch] + w[2] * cl[6 + ch];
-    } else {
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) out3[p * 3 + ch] = w[ch];
-    }
-}
-
-int run(const float* fv, const float* fc, float* depth, int32_t* tri, float* out3, int B, int F, int H, int W,
-        void* workspace, gif_stream_t stream) {
-    GIF_REQUIRE(B >= 0 && F >= 0 && H > 0 && W > 0, "rasterize: bad dims B=%d F=%d H=%d W=%d", B, F, H, W);
-    long npix = (long)B * H * W;
-    if (npix == 0 || F == 0) return 0;
-    GIF_REQUIRE(fv && depth && tri && out3 && workspace, "rasterize: null pointer");
-    GIF_REQUIRE(((uintptr_t)workspace & 7) == 0, "rasterize: workspace must be 8-byte aligned");
+template <typename T>
+int run(const T* fv, const T* fc, T* depth, int32_t* tri, T* out3, int B, int F, int H, int W, void* workspace,
+        gif_stream_t stream, const char* who) {
+    GIF_REQUIRE(B >= 0 && F >= 0 && H > 0 && W > 0, "%s: bad dims B=%d F=%d H=%d W=%d", who, B, F, H, W);
+    if ((long)B * H * W == 0 || F == 0) return 0;
+    GIF_REQUIRE(fv && depth && tri && out3 && workspace, "%s: null pointer", who);
+    GIF_REQUIRE(((uintptr_t)workspace & 7) == 0, "%s: workspace must be 8-byte aligned", who);
+    GIF_REQUIRE(H <= 65535 && W <= 65535, "%s: images larger than 65535 pixels per side are not supported (16-bit boxes)", who);
+    const int tiles_x = (W + kTile - 1) / kTile, tiles_y = (H + kTile - 1) / kTile;
+    GIF_REQUIRE((long)B * tiles_x * tiles_y < (1L << 31) && (long)B * F < (1L << 40), "%s: too many tiles / faces", who);
     hipStream_t s = gif::as_stream(stream);
-    auto* key = reinterpret_cast<unsigned long long*>(workspace);
-    raster_init_keys<<<gif::cdiv(npix, 256), 256, 0, s>>>(depth, key, npix);
-    raster_faces<<<gif::cdiv((long)B * F, 256), 256, 0, s>>>(fv, key, B, F, H, W);
-    if (fc)
-        raster_resolve<float, true><<<gif::cdiv(npix, 256), 256, 0, s>>>(fv, fc, key, nullptr, depth, tri, out3, B, F, H, W);
-    else
-        raster_resolve<float, false><<<gif::cdiv(npix, 256), 256, 0, s>>>(fv, nullptr, key, nullptr, depth, tri, out3, B, F, H, W);
-    return gif::check_launch("rasterize");
-}
-
-int run64(const double* fv, const double* fc, double* depth, int32_t* tri, double* out3, int B, int F, int H, int W,
-          void* workspace, gif_stream_t stream) {
-    GIF_REQUIRE(B >= 0 && F >= 0 && H > 0 && W > 0, "rasterize_f64: bad dims B=%d F=%d H=%d W=%d", B, F, H, W);
-    long npix = (long)B * H * W;
-    if (npix == 0 || F == 0) return 0;
-    GIF_REQUIRE(fv && depth && tri && out3 && workspace, "rasterize_f64: null pointer");
-    GIF_REQUIRE(((uintptr_t)workspace & 7) == 0, "rasterize_f64: workspace must be 8-byte aligned");
-    hipStream_t s = gif::as_stream(stream);
-    auto* zkey = reinterpret_cast<unsigned long long*>(workspace);
-    auto* fkey = reinterpret_cast<uint32_t*>(zkey + npix);
-    const int fb = gif::cdiv((long)B * F, 256), pb = gif::cdiv(npix, 256);
-    raster_init_keys64<<<pb, 256, 0, s>>>(depth, zkey, fkey, npix);
-    raster_faces64<0><<<fb, 256, 0, s>>>(fv, zkey, fkey, B, F, H, W);
-    raster_faces64<1><<<fb, 256, 0, s>>>(fv, zkey, fkey, B, F, H, W);
-    if (fc) raster_resolve<double, true><<<pb, 256, 0, s>>>(fv, fc, zkey, fkey, depth, tri, out3, B, F, H, W);
-    else raster_resolve<double, false><<<pb, 256, 0, s>>>(fv, nullptr, zkey, fkey, depth, tri, out3, B, F, H, W);
-    return gif::check_launch("rasterize_f64");
+    uint2* box = reinterpret_cast<uint2*>(workspace);
+    const long nfaces = (long)B * F;
+    raster_setup<T><<<gif::cdiv(nfaces, 256), 256, 0, s>>>(fv, box, nfaces, H, W);
+    const dim3 grid((unsigned)((long)B * tiles_x * tiles_y));
+    if (fc) raster_tiles<T, true><<<grid, kThreads, 0, s>>>(fv, fc, box, depth, tri, out3, F, H, W, tiles_x, tiles_y);
+    else raster_tiles<T, false><<<grid, kThreads, 0, s>>>(fv, nullptr, box, depth, tri, out3, F, H, W, tiles_x, tiles_y);
+    return gif::check_launch(who);
 }
 
 }  // namespace
 
 extern "C" {
 
-int64_t gif_rasterize_workspace_bytes(int B, int H, int W) { return (int64_t)B * H * W * 8; }
+// 8 bytes (one packed bounding box) per face; the z-buffer itself never leaves LDS
+int64_t gif_rasterize_workspace_bytes(int B, int F, int H, int W) {
+    (void)H; (void)W;
+    const int64_t n = (int64_t)B * F * 8;
+    return n > 8 ? n : 8;
+}
 
 int gif_rasterize_f32(const float* face_vertices, float* depth, int32_t* tri, float* bary, int B, int F, int H,
                       int W, void* workspace, gif_stream_t stream) {
-    return run(face_vertices, nullptr, depth, tri, bary, B, F, H, W, workspace, stream);
+    return run<float>(face_vertices, nullptr, depth, tri, bary, B, F, H, W, workspace, stream, "rasterize");
 }
 
 int gif_rasterize_colors_f32(const float* face_vertices, const float* face_colors, float* depth, int32_t* tri,
                              float* images, int B, int F, int H, int W, void* workspace, gif_stream_t stream) {
     GIF_REQUIRE(face_colors || (long)B * F == 0, "rasterize_colors: null face_colors");
-    return run(face_vertices, face_colors, depth, tri, images, B, F, H, W, workspace, stream);
+    return run<float>(face_vertices, face_colors, depth, tri, images, B, F, H, W, workspace, stream, "rasterize_colors");
 }
-
-int64_t gif_rasterize_workspace_bytes_f64(int B, int H, int W) { return (int64_t)B * H * W * 12; }
 
 int gif_rasterize_f64(const double* face_vertices, double* depth, int32_t* tri, double* bary, int B, int F, int H, int W,
                       void* workspace, gif_stream_t stream) {
-    return run64(face_vertices, nullptr, depth, tri, bary, B, F, H, W, workspace, stream);
+    return run<double>(face_vertices, nullptr, depth, tri, bary, B, F, H, W, workspace, stream, "rasterize_f64");
 }
 
 int gif_rasterize_colors_f64(const double* face_vertices, const double* face_colors, double* depth, int32_t* tri,
                              double* images, int B, int F, int H, int W, void* workspace, gif_stream_t stream) {
     GIF_REQUIRE(face_colors || (long)B * F == 0, "rasterize_colors_f64: null face_colors");
-    return run64(face_vertices, face_colors, depth, tri, images, B, F, H, W, workspace, stream);
+    return run<double>(face_vertices, face_colors, depth, tri, images, B, F, H, W, workspace, stream, "rasterize_colors_f64");
 }
 }

@@ -509,8 +509,7 @@ def rasterize(face_vertices, depth, tri, out3, h, w, face_colors=None):
     lib = _lib.load()
     B, F = face_vertices.shape[:2]
     f64 = face_vertices.dtype == torch.float64
-    ws_bytes = (lib.gif_rasterize_workspace_bytes_f64 if f64 else lib.gif_rasterize_workspace_bytes)(B, h, w)
-    ws = torch.empty((max(ws_bytes // 8, 1),), device=face_vertices.device, dtype=torch.int64)
+    ws = torch.empty((max(lib.gif_rasterize_workspace_bytes(B, F, h, w) // 8, 1),), device=face_vertices.device, dtype=torch.int64)
     plain, colors = (lib.gif_rasterize_f64, lib.gif_rasterize_colors_f64) if f64 else (lib.gif_rasterize_f32,
                                                                                         lib.gif_rasterize_colors_f32)
     if face_colors is None:

@@ -61,9 +61,12 @@ int gif_pack_weight_f32x3(const float* w, void* wp3, int R, int C, int KH, int K
  * bary / images [B,H,W,3]: caller-allocated, caller-initialised, updated IN PLACE exactly like the
  * reference (depth=min, tri=face index of the min, bary/colour of that face).  Exact-depth ties are
  * resolved deterministically to the lowest face index (the reference leaves them to a race).
- * `workspace` holds B*H*W uint64 keys (gif_rasterize_workspace_bytes).
+ * Two launches: per-face set-up (front-facing test + clamped bounding box, 8 bytes per face into `workspace`), then one
+ * workgroup per (image, 64x64-pixel tile) whose z-buffer stays in LDS from the seeding by the caller's depth buffer to the
+ * final write of depth / face / attributes (no global atomics, no key buffer in HBM).  H, W <= 65535.
+ * `workspace`: gif_rasterize_workspace_bytes(B, F, H, W) bytes, 8-byte aligned (float32 and float64 entry points alike).
  * ---------------------------------------------------------------------------------------------- */
-int64_t gif_rasterize_workspace_bytes(int B, int H, int W);
+int64_t gif_rasterize_workspace_bytes(int B, int F, int H, int W);
 int gif_rasterize_f32(const float* face_vertices, float* depth, int32_t* tri, float* bary, int B, int F,
                       int H, int W, void* workspace, gif_stream_t stream);
 int gif_rasterize_colors_f32(const float* face_vertices, const float* face_colors, float* depth,
@@ -71,12 +74,11 @@ int gif_rasterize_colors_f32(const float* face_vertices, const float* face_color
                              gif_stream_t stream);
 
 /* float64 variants: the reference dispatches both floating types (AT_DISPATCH_FLOATING_TYPES,
- * standard_rasterize_cuda_kernel.cu:252,295).  Same contract with double buffers; `workspace` holds
- * gif_rasterize_workspace_bytes_f64 bytes (a uint64 depth key + a uint32 face key per pixel).  NOTE: the reference's own
+ * standard_rasterize_cuda_kernel.cu:252,295).  Same contract with double buffers and the same workspace (the tile keeps a
+ * uint64 depth key + a uint32 face key per pixel in LDS and walks the faces twice).  NOTE: the reference's own
  * double path funnels the depth through fminf (.cu:19-29: the CAS loop of atomicMin(double*) calls fminf), i.e. it stores
  * FLOAT-rounded depths and then almost never finds `depth == zp`, so it leaves the face / barycentric buffers unwritten;
  * this implementation computes what that code intends: true double-precision minimum depth and its face. */
-int64_t gif_rasterize_workspace_bytes_f64(int B, int H, int W);
 int gif_rasterize_f64(const double* face_vertices, double* depth, int32_t* tri, double* bary, int B, int F,
                       int H, int W, void* workspace, gif_stream_t stream);
 int gif_rasterize_colors_f64(const double* face_vertices, const double* face_colors, double* depth,

@@ -32,7 +32,7 @@ def test_header_symbols_exported_and_bound():
 
 def test_argument_validation_without_gpu():
     lib = _lib.load()
-    assert lib.gif_rasterize_workspace_bytes(2, 16, 8) == 2 * 16 * 8 * 8
+    assert lib.gif_rasterize_workspace_bytes(2, 100, 16, 8) == 2 * 100 * 8  # one packed bounding box per face
     rp, cp = ctypes.c_int(), ctypes.c_int()
     assert lib.gif_conv2d_pack_dims(512, 512, ctypes.byref(rp), ctypes.byref(cp)) == 0
     assert (rp.value, cp.value) == (512, 512)
