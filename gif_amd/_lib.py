@@ -18,8 +18,12 @@ class ConvGeom(ctypes.Structure):
 
 
 class ConvEpilogue(ctypes.Structure):
+    # ABI 2: + the gradient-producer fusions (mask of the leaky ReLU the gradient flows into, modulation-gradient dot product,
+    # bias-gradient column sums; include/gif_hip.h)
     _fields_ = [("in_scale", P), ("out_scale", P), ("bias", P), ("residual", P),
-                ("act", ctypes.c_int32), ("slope", c_float), ("gain", c_float)]
+                ("act", ctypes.c_int32), ("slope", c_float), ("gain", c_float),
+                ("mask_src", P), ("mask_slope", c_float), ("mask_gain", c_float),
+                ("dot_src", P), ("dot", P), ("colsum", P), ("red_ws", P)]
 
 
 GP, EP = ctypes.POINTER(ConvGeom), ctypes.POINTER(ConvEpilogue)
@@ -38,6 +42,7 @@ PROTOTYPES = {
     "gif_vertex_normals_f32": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),
     "gif_texture_map_f32": (c_int, [P] * 9 + [c_int] * 6 + [P]),
     "gif_texture_map_bwd_f32": (c_int, [P] * 8 + [c_int] * 6 + [P]),
+    "gif_conv_epilogue_ws_floats": (c_i64, [c_i64, c_int]),
     "gif_conv2d_pack_dims": (c_int, [c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "gif_pack_weight_f32": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_float, P]),
     "gif_conv2d_fwd_f32": (c_int, [P, P, P, GP, EP, P]),

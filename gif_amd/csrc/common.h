@@ -61,6 +61,12 @@ struct ProfScope {
     ~ProfScope();
 };
 
+// ---- fixed-order reduction of per-tile partial sums (elementwise.hip): out[y][c] = sum_k partial[y][k][c], y < Y, k < nblk.
+// Long single-group reductions (Y == 1, nblk > 512) go through `tmp` (>= 64 * C floats) in two launches.
+int reduce_partials(const float* partial, float* out, int Y, int nblk, int C, float* tmp, hipStream_t s);
+// partial rows an epilogue reduction may need for `rows` output rows (conv tiles of >= 64 rows, FIR blocks <= 4096) + tmp
+inline int64_t epilogue_ws_rows(int64_t rows) { return 2 * (rows / 64 + 16) + 4096 + 64; }
+
 // ---- Winograd transforms (conv_winograd.hip), shared with the Winograd wgrad in conv_wgrad.hip ----
 // padded dims of a transformed operand [16][ntiles_pad][CP]
 void winograd_padded_dims(long ntiles, int C, long* ntiles_pad, int* CP);

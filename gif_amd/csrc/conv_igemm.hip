@@ -63,7 +63,21 @@ struct GatherParams {
     const void* zero;          // 16 zero bytes in HBM: source of the LDS-DMA lanes that fall outside the tensor
     int m_begin;               // first GEMM row of this launch (a launch may cover only rows [m_begin, M))
     int x3;                    // fp32 only: wp is the pre-split bf16x3 packing, run the bf16 matrix-core kernels
+    // gradient-producer fusions (gif_conv_epilogue ABI 2, see gif_hip.h): mask of the leaky ReLU this gradient flows into, and
+    // per-tile partial sums (row part_row0 + tile_m of part_cs / part_dot, [rows][Co]) of the stored values / of contraction * dot_src
+    const void* mask_src;
+    const void* dot_src;
+    float mask_slope, mask_gain;
+    float* part_cs;
+    float* part_dot;
+    int part_row0;
+    int no_split;              // keep the launch in ONE tile size (per-sample partial sums need uniform rows)
 };
+
+// partial-sum rows handed out to the launches of one op (bulk + remainder launches, transposed-conv phases), and the tile height
+// of the last launch (host side, per calling thread)
+thread_local int t_part_rows = 0;
+thread_local int t_last_bm = 0;
 
 // XCD-aware, bijective block remap (cdna guide T1): consecutive logical tiles share an XCD's L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -98,6 +112,9 @@ __device__ __forceinline__ void conv_epilogue(const GatherParams& p, f32x16 (&ac
     const int n = n0 + e_c;
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias && n < p.Co) bias4 = *reinterpret_cast<const float4*>(p.bias + n);
+    const T* const msk = static_cast<const T*>(p.mask_src);
+    const T* const dsrc = static_cast<const T*>(p.dot_src);
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), ds = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int c = 0; c < EPI_CHUNKS; ++c) {
         __syncthreads();  // staging buffers (c == 0) / previous chunk fully consumed
@@ -125,6 +142,11 @@ __device__ __forceinline__ void conv_epilogue(const GatherParams& p, f32x16 (&ac
                 int oy = rr / p.Wp, ox = rr - oy * p.Wp;
                 size_t o = (((size_t)b * p.Ho + (oy * p.os + p.ooy)) * p.Wo + (ox * p.os + p.oox)) * p.Co + n;
                 float4 v = *reinterpret_cast<const float4*>(Cs + row * LDC + e_c);
+                float4 xs = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (dsrc) {  // modulation gradient: sum_pixels contraction * x
+                    xs = gif::load4(dsrc + o);
+                    ds.x += v.x * xs.x; ds.y += v.y * xs.y; ds.z += v.z * xs.z; ds.w += v.w * xs.w;
+                }
                 if (p.out_scale) {
                     float4 d = *reinterpret_cast<const float4*>(p.out_scale + (size_t)b * p.Co + n);
                     v.x *= d.x; v.y *= d.y; v.z *= d.z; v.w *= d.w;
@@ -138,8 +160,33 @@ __device__ __forceinline__ void conv_epilogue(const GatherParams& p, f32x16 (&ac
                     v.x = (v.x > 0.f ? v.x : v.x * p.slope) * p.gain; v.y = (v.y > 0.f ? v.y : v.y * p.slope) * p.gain;
                     v.z = (v.z > 0.f ? v.z : v.z * p.slope) * p.gain; v.w = (v.w > 0.f ? v.w : v.w * p.slope) * p.gain;
                 }
+                if (msk) {  // backward of the leaky ReLU that produced the tensor this gradient belongs to
+                    if (msk != dsrc) xs = gif::load4(msk + o);
+                    v.x *= p.mask_gain * (xs.x > 0.f ? 1.f : p.mask_slope); v.y *= p.mask_gain * (xs.y > 0.f ? 1.f : p.mask_slope);
+                    v.z *= p.mask_gain * (xs.z > 0.f ? 1.f : p.mask_slope); v.w *= p.mask_gain * (xs.w > 0.f ? 1.f : p.mask_slope);
+                }
+                cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
                 gif::store4(yout + o, v);
             }
+        }
+    }
+    if (p.part_cs || p.part_dot) {  // workgroup-uniform: per-tile partial sums, fixed order
+        __syncthreads();
+        float4* red = reinterpret_cast<float4*>(smem);  // [2][THREADS]
+        red[tid] = cs;
+        red[THREADS + tid] = ds;
+        __syncthreads();
+        if (tid < C4_ROW && n < p.Co) {
+            float4 a = red[tid], b = red[THREADS + tid];
+#pragma unroll
+            for (int k = 1; k < EROWS; ++k) {
+                const float4 a2 = red[k * C4_ROW + tid], b2 = red[THREADS + k * C4_ROW + tid];
+                a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w;
+                b.x += b2.x; b.y += b2.y; b.z += b2.z; b.w += b2.w;
+            }
+            const size_t prow = (size_t)(p.part_row0 + (m0 - p.m_begin) / BM) * p.Co + n;
+            if (p.part_cs) *reinterpret_cast<float4*>(p.part_cs + prow) = a;
+            if (p.part_dot) *reinterpret_cast<float4*>(p.part_dot + prow) = b;
         }
     }
 }
@@ -704,6 +751,9 @@ int launch_kernel(K kern, GatherParams& p, int BM, int BN, int BK, hipStream_t s
     size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
     attr.ensure(reinterpret_cast<const void*>(kern), lds);
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
+    p.part_row0 = t_part_rows;
+    t_part_rows += p.tiles_m;
+    t_last_bm = BM;
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
     return 0;
 }
@@ -745,6 +795,9 @@ int launch_glds_impl(GatherParams& p, hipStream_t s) {
     // passed as a kernel argument: a GOT load inside the K loop costs a scalar memory round trip + s_waitcnt per stage
     p.zero = gif::zero_page16();
     if (!p.zero) return -101;
+    p.part_row0 = t_part_rows;
+    t_part_rows += p.tiles_m;
+    t_last_bm = BM;
     hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(64 * WMv * WNv), lds, s, p);
     return 0;
 }
@@ -758,7 +811,7 @@ int launch_glds_multi(GatherParams* ph, int nph, hipStream_t s) {
     if (!zero_page) return -101;
     MultiParams mp{};
     size_t lds_max = 0;
-    int total = 0;
+    int total = 0, rows = 0;
     for (int i = 0; i < nph; ++i) {
         GatherParams& p = ph[i];
         p.tiles_m = gif::cdiv(p.M - p.m_begin, BM);
@@ -770,11 +823,15 @@ int launch_glds_multi(GatherParams* ph, int nph, hipStream_t s) {
         if (lds > lds_max) lds_max = lds;
         p.zero = zero_page;
         total += p.tiles_m * p.tiles_n;
+        p.part_row0 = t_part_rows + rows;
+        rows += p.tiles_m;
         mp.ph[i] = p;
         mp.wg_end[i] = total;
     }
     mp.nph = nph;
     if (lds_max > 160 * 1024) return -100;
+    t_part_rows += rows;
+    t_last_bm = BM;
     auto kern = conv_gather_mfma_glds_multi<T, BM, BN, 2, 2, SCALE, BK, X3>;
     attr.ensure(reinterpret_cast<const void*>(kern), lds_max);
     hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), lds_max, s, mp);
@@ -857,6 +914,14 @@ int launch(GatherParams& p, hipStream_t s) {
         // low-resolution layers (4x4 .. 16x16 at batch 32): a 128x128 grid would leave most CUs idle behind a
         // 144-step K loop; 64x64 tiles give 4x the workgroups (and 32 KB of LDS: 4 per CU) at a quarter of the latency
         const long tiles128 = (long)gif::cdiv(p.M, 128) * (p.RP / 128);
+        if constexpr (!F16) {
+            // low-resolution bf16x3 layers with at least one workgroup per CU: 128x64 tiles, 4 waves stacked along M (wave tile
+            // 32x64: one activation fragment split per 12 MFMAs instead of per 6 on the 64x64 tile's 32x32 wave tiles) — 512->512 at
+            // 16^2 143 -> 165 TFLOP/s, modulated 127 -> 157, stride-2 512->512 at 33^2 142 -> 170 (profiles/r3_dispatch_ab.txt)
+            if (p.x3 && tiles128 < 384 && (long)gif::cdiv(p.M, 128) * (p.RP / 64) >= 256 &&
+                launch_glds<T, 128, 64, 4, 1>(p, s) == 0)
+                return 0;
+        }
         if (glds && tiles128 < 384 && launch_glds<T, 64, 64, 2, 2>(p, s) == 0) return 0;
         if constexpr (!F16) {
             // bf16x3: the pre-split weight tile (48 KB) + the fp32 activation tile (32 KB) fill half a CU's LDS exactly, and a
@@ -866,7 +931,7 @@ int launch(GatherParams& p, hipStream_t s) {
             const long tn = p.RP / 128, tiles256 = (long)gif::cdiv(p.M, 256) * tn;
             if (p.x3 && !big_off && tiles256 >= 512) {
                 const long slots = 256, full = tiles256 / slots, rem = tiles256 % slots;
-                if (rem > 0 && rem * 2 <= slots && slots % tn == 0) {  // nearly empty last round: remainder rows on 64x64 tiles
+                if (!p.no_split && rem > 0 && rem * 2 <= slots && slots % tn == 0) {  // nearly empty last round: remainder rows on 64x64 tiles
                     const int M = p.M;
                     const int m_bulk = (int)(full * slots / tn) * 256;
                     p.M = m_bulk;
@@ -890,7 +955,7 @@ int launch(GatherParams& p, hipStream_t s) {
             // on 128x128 tiles, the remaining rows on 64x64 tiles (4x the workgroups, a quarter of the latency each).
             const long slots = 512, tn = p.RP / 128;
             const long full = tiles128 / slots, rem = tiles128 % slots;
-            if (full >= 1 && rem > 0 && rem * 2 <= slots && slots % tn == 0) {
+            if (!p.no_split && full >= 1 && rem > 0 && rem * 2 <= slots && slots % tn == 0) {
                 const int M = p.M;
                 const int m_bulk = (int)(full * slots / tn) * 128;
                 p.M = m_bulk;
@@ -946,7 +1011,54 @@ void fill_epilogue(GatherParams& p, const gif_conv_epilogue* e) {
     p.act = e ? e->act : 0;
     p.slope = e ? e->slope : 0.f;
     p.gain = e ? e->gain : 1.f;
+    p.mask_src = e ? e->mask_src : nullptr;
+    p.mask_slope = e ? e->mask_slope : 1.f;
+    p.mask_gain = e ? e->mask_gain : 1.f;
+    p.dot_src = e ? e->dot_src : nullptr;
 }
+
+// Gradient-producer fusions of one op: validate, carve the partial-sum buffers out of red_ws (before the launches) and reduce
+// them in a fixed order (after).  out_rows = B * Ho * Wo of the op's output.
+struct FusedSums {
+    float* colsum = nullptr;
+    float* dot = nullptr;
+    float* part_cs = nullptr;
+    float* part_dot = nullptr;
+    float* tmp = nullptr;
+    long cap = 0;  // partial rows available per buffer
+
+    int begin(GatherParams& p, const gif_conv_epilogue* e, long out_rows, int Co, int B, long hw, bool single_phase, const char* who) {
+        t_part_rows = 0;
+        if (!e || (!e->colsum && !e->dot)) return 0;
+        GIF_REQUIRE(e->red_ws, "%s: colsum / dot need the red_ws workspace (gif_conv_epilogue_ws_floats)", who);
+        GIF_REQUIRE(!e->dot || (e->dot_src && single_phase && hw % 256 == 0),
+                    "%s: the dot fusion needs dot_src, a single-phase op and a multiple of 256 output pixels per sample (got %ld)", who, hw);
+        colsum = e->colsum;
+        dot = e->dot;
+        cap = out_rows / 64 + 16;
+        part_cs = e->red_ws;
+        part_dot = e->red_ws + cap * Co;
+        tmp = e->red_ws + 2 * cap * Co;
+        p.part_cs = colsum ? part_cs : nullptr;
+        p.part_dot = dot ? part_dot : nullptr;
+        p.no_split = dot ? 1 : 0;
+        (void)B;
+        return 0;
+    }
+    int finish(int Co, int B, long hw, hipStream_t s, const char* who) {
+        if (!colsum && !dot) return 0;
+        const int rows = t_part_rows;
+        GIF_REQUIRE(rows > 0 && rows <= cap, "%s: partial-sum rows %d exceed the workspace (%ld)", who, rows, cap);
+        if (colsum)
+            if (int rc = gif::reduce_partials(part_cs, colsum, 1, rows, Co, tmp, s)) return rc;
+        if (dot) {
+            GIF_REQUIRE(t_last_bm > 0 && hw % t_last_bm == 0 && (long)rows * t_last_bm == (long)B * hw,
+                        "%s: dot fusion: tiles of %d rows do not partition the %d samples of %ld pixels", who, t_last_bm, B, hw);
+            if (int rc = gif::reduce_partials(part_dot, dot, B, (int)(hw / t_last_bm), Co, tmp, s)) return rc;
+        }
+        return 0;
+    }
+};
 
 
 template <typename T>
@@ -984,8 +1096,11 @@ int conv2d_fwd_impl(const void* big, const void* wp, void* small, const gif_conv
     p.M = p.B * p.Hp * p.Wp;
     double flops = 2.0 * p.M * (double)p.Co * p.Ci * p.ntaps;
     const int fam = sizeof(T) == 2 ? 6 : x3 ? 8 : (p.Ci >= 32 ? 0 : 5);
+    FusedSums sums;
+    if (int rc = sums.begin(p, e, p.M, p.Co, p.B, (long)p.Hp * p.Wp, true, who)) return rc;
     gif::ProfScope prof(fam, flops, gif::as_stream(stream), p.M, p.Co, p.Ci, p.ntaps * 10 + g->stride);
     if (int rc = launch<T>(p, gif::as_stream(stream))) return rc;
+    if (int rc = sums.finish(p.Co, p.B, (long)p.Hp * p.Wp, gif::as_stream(stream), who)) return rc;
     return gif::check_launch(who);
 }
 
@@ -1004,6 +1119,8 @@ int conv2d_bwd_data_impl(const void* small, const void* wp, void* big, const gif
     base.Ho = g->Hb; base.Wo = g->Wb; base.Co = g->Cb;
     pack_dims<T>(base.Co, base.Ci, &base.RP, &base.CP, x3);
     const int st = g->stride;
+    FusedSums sums;
+    if (int rc = sums.begin(base, e, (long)g->B * g->Hb * g->Wb, base.Co, g->B, (long)g->Hb * g->Wb, st == 1, who)) return rc;
     auto pmod = [st](int a) { return ((a % st) + st) % st; };
     // Build the (up to 4) output-parity phases; phases with no tap (e.g. 1x1 stride 2) are zero-filled.
     GatherParams ph[4];
@@ -1028,7 +1145,7 @@ int conv2d_bwd_data_impl(const void* small, const void* wp, void* big, const gif
             ph[nph++] = p;
         }
     if (need_zero) {
-        GIF_REQUIRE(!(e && (e->bias || e->residual || e->act)), "%s: epilogue unsupported with empty phases", who);
+        GIF_REQUIRE(!(e && (e->bias || e->residual || e->act || e->mask_src || e->colsum || e->dot)), "%s: epilogue unsupported with empty phases", who);
         hipError_t me = hipMemsetAsync(big, 0, (size_t)g->B * g->Hb * g->Wb * g->Cb * sizeof(T), s);
         if (me != hipSuccess) { gif::set_error("%s memset: %s", who, hipGetErrorString(me)); return (int)me; }
     }
@@ -1053,6 +1170,7 @@ int conv2d_bwd_data_impl(const void* small, const void* wp, void* big, const gif
         if (!merged)
             for (int i = 0; i < nph; ++i)
                 if (int rc = launch<T>(ph[i], s)) return rc;
+        if (int rc = sums.finish(base.Co, g->B, (long)g->Hb * g->Wb, s, who)) return rc;
     }
     return gif::check_launch(who);
 }

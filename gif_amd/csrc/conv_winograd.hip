@@ -190,7 +190,60 @@ struct WinoParams {
     int act;
     float slope, gain;
     int tiles_m, tiles_n;
+    // gradient-producer fusions (gif_conv_epilogue ABI 2): see conv_igemm.hip; partial rows = GEMM row tiles
+    const float* mask_src;
+    const float* dot_src;
+    float mask_slope, mask_gain;
+    float* part_cs;
+    float* part_dot;
 };
+
+// the fused tail of both GEMM kernels' epilogues: modulation-gradient dot product, out_scale, residual, bias, activation,
+// leaky-ReLU-backward mask, running column sums
+__device__ __forceinline__ f32x4 wino_epilogue_value(const WinoParams& p, f32x4 v, size_t off, int b, int n, const f32x4& bias4,
+                                                     f32x4& cs, f32x4& ds) {
+    f32x4 xs = (f32x4)(0.f);
+    if (p.dot_src) {
+        xs = *reinterpret_cast<const f32x4*>(p.dot_src + off);
+        ds += v * xs;
+    }
+    if (p.out_scale) v *= *reinterpret_cast<const f32x4*>(p.out_scale + (size_t)b * p.Co + n);
+    if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + off);
+    v += bias4;
+    if (p.act) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (v[e] > 0.f ? v[e] : v[e] * p.slope) * p.gain;
+    }
+    if (p.mask_src) {
+        if (p.mask_src != p.dot_src) xs = *reinterpret_cast<const f32x4*>(p.mask_src + off);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= p.mask_gain * (xs[e] > 0.f ? 1.f : p.mask_slope);
+    }
+    cs += v;
+    return v;
+}
+
+// per-tile partial sums of one workgroup -> row `prow` of part_cs / part_dot (fixed order; smem is free by now)
+template <int THREADS, int C4_ROW, int EROWS>
+__device__ __forceinline__ void wino_write_partials(const WinoParams& p, float* smem, int tid, int n, int prow, f32x4 cs, f32x4 ds) {
+    if (!p.part_cs && !p.part_dot) return;  // workgroup-uniform
+    __syncthreads();
+    f32x4* red = reinterpret_cast<f32x4*>(smem);  // [2][THREADS]
+    red[tid] = cs;
+    red[THREADS + tid] = ds;
+    __syncthreads();
+    if (tid < C4_ROW && n < p.Co) {
+        f32x4 a = red[tid], b = red[THREADS + tid];
+#pragma unroll
+        for (int k = 1; k < EROWS; ++k) {
+            a += red[k * C4_ROW + tid];
+            b += red[THREADS + k * C4_ROW + tid];
+        }
+        const size_t o = (size_t)prow * p.Co + n;
+        if (p.part_cs) *reinterpret_cast<f32x4*>(p.part_cs + o) = a;
+        if (p.part_dot) *reinterpret_cast<f32x4*>(p.part_dot + o) = b;
+    }
+}
 
 // A^T = [1 1 1 0; 0 1 -1 -1]: coefficient of M[xi][nu] in Y[a][b] is cA(a,xi) * cA(b,nu)
 __device__ __forceinline__ float wino_coef(int a, int xi) {
@@ -365,6 +418,7 @@ __global__ void __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) wino_gemm_mfma(cons
     const int n = n0 + e_c;
     f32x4 bias4 = (f32x4)(0.f);
     if (p.bias && n < p.Co) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+    f32x4 cs = (f32x4)(0.f), ds = (f32x4)(0.f);
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
         __syncthreads();
@@ -388,17 +442,12 @@ __global__ void __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) wino_gemm_mfma(cons
                 int ty = t2 % p.TH, b = t2 / p.TH;
                 size_t off = (((size_t)b * p.H + 2 * ty + oa) * p.W + 2 * tx + ob) * p.Co + n;
                 f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * LDC + e_c);
-                if (p.out_scale) v *= *reinterpret_cast<const f32x4*>(p.out_scale + (size_t)b * p.Co + n);
-                if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + off);
-                v += bias4;
-                if (p.act) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = (v[e] > 0.f ? v[e] : v[e] * p.slope) * p.gain;
-                }
+                v = wino_epilogue_value(p, v, off, b, n, bias4, cs, ds);
                 *reinterpret_cast<f32x4*>(p.y + off) = v;
             }
         }
     }
+    wino_write_partials<THREADS, C4_ROW, EROWS>(p, smem, tid, n, tm, cs, ds);
 }
 
 
@@ -600,6 +649,7 @@ __global__ void __launch_bounds__(512, 1) wino_gemm_x3(const WinoParams p) {
     const int n = n0 + e_c;
     f32x4 bias4 = (f32x4)(0.f);
     if (p.bias && n < p.Co) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+    f32x4 cs = (f32x4)(0.f), ds = (f32x4)(0.f);
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
         __syncthreads();
@@ -623,17 +673,12 @@ __global__ void __launch_bounds__(512, 1) wino_gemm_x3(const WinoParams p) {
                 int ty = t2 % p.TH, b = t2 / p.TH;
                 size_t off = (((size_t)b * p.H + 2 * ty + oa) * p.W + 2 * tx + ob) * p.Co + n;
                 f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * LDC + e_c);
-                if (p.out_scale) v *= *reinterpret_cast<const f32x4*>(p.out_scale + (size_t)b * p.Co + n);
-                if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + off);
-                v += bias4;
-                if (p.act) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = (v[e] > 0.f ? v[e] : v[e] * p.slope) * p.gain;
-                }
+                v = wino_epilogue_value(p, v, off, b, n, bias4, cs, ds);
                 *reinterpret_cast<f32x4*>(p.y + off) = v;
             }
         }
     }
+    wino_write_partials<THREADS, C4_ROW, EROWS>(p, smem, tid, n, tm, cs, ds);
 }
 
 // U3 = the three bf16 terms of G g G^T: [16][3][RP][CP]
@@ -737,6 +782,48 @@ int gif_winograd_weight_f32(const float* w, float* U, int R, int C, int RP, int 
     return gif::check_launch("winograd_weight");
 }
 
+}  // extern "C"
+
+namespace {
+
+// gradient-producer fusions of a Winograd launch: partial-sum rows = GEMM row tiles of `bm` Winograd tiles each
+struct WinoSums {
+    float *colsum = nullptr, *dot = nullptr, *tmp = nullptr;
+    int begin(WinoParams& p, const gif_conv_epilogue* e, int B, int H, int W, int Co, int bm, const char* who) {
+        p.mask_src = e ? static_cast<const float*>(e->mask_src) : nullptr;
+        p.mask_slope = e ? e->mask_slope : 1.f;
+        p.mask_gain = e ? e->mask_gain : 1.f;
+        p.dot_src = e ? static_cast<const float*>(e->dot_src) : nullptr;
+        if (!e || (!e->colsum && !e->dot)) return 0;
+        GIF_REQUIRE(e->red_ws, "%s: colsum / dot need the red_ws workspace (gif_conv_epilogue_ws_floats)", who);
+        const long per_sample = (long)(H / 2) * (W / 2);
+        GIF_REQUIRE(!e->dot || (e->dot_src && per_sample % bm == 0),
+                    "%s: the dot fusion needs dot_src and a multiple of %d 2x2 tiles per sample (got %ld)", who, bm, per_sample);
+        const long cap = (long)B * H * W / 64 + 16;
+        GIF_REQUIRE(p.tiles_m <= cap, "%s: partial-sum rows exceed the workspace", who);
+        colsum = e->colsum;
+        dot = e->dot;
+        p.part_cs = colsum ? e->red_ws : nullptr;
+        p.part_dot = dot ? e->red_ws + cap * Co : nullptr;
+        tmp = e->red_ws + 2 * cap * Co;
+        return 0;
+    }
+    int finish(const WinoParams& p, int B, int H, int W, int Co, int bm, hipStream_t s) {
+        if (colsum)
+            if (int rc = gif::reduce_partials(p.part_cs, colsum, 1, p.tiles_m, Co, tmp, s)) return rc;
+        if (dot) {
+            // the row padding of the last tile block holds no pixels: ntiles = B * per_sample is a multiple of bm here
+            const int per = (int)((long)(H / 2) * (W / 2) / bm);
+            if (int rc = gif::reduce_partials(p.part_dot, dot, B, per, Co, tmp, s)) return rc;
+        }
+        return 0;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
 // y [B,H,W,Co] = act(out_scale * conv3x3_s1_p1(in_scale * x [B,H,W,C], weights behind U) + residual + bias).
 // V is scratch of gif_winograd_workspace_floats(B,H,W,C) floats.  H, W even; C, Co multiples of 4.
 int gif_conv3x3_winograd_f32(const float* x, const float* U, float* y, float* V, int B, int H, int W, int C, int Co,
@@ -779,6 +866,8 @@ int gif_conv3x3_winograd_f32(const float* x, const float* U, float* y, float* V,
                                     : (force_wn == 2 ? false : (Co % 128 == 0 && (long)p.tiles_m * (p.RP / 128) >= 512));
     const int bn = wide ? 128 : 64;
     p.tiles_n = p.RP / bn;
+    WinoSums sums;
+    if (int rc = sums.begin(p, e, B, H, W, Co, WBM, "conv3x3_winograd")) return rc;
     const size_t lds = (size_t)WNSTAGE * (WBM + bn) * WBK * sizeof(float);
     static gif::LdsAttr attr2, attr4;
     if (wide) attr4.ensure(reinterpret_cast<const void*>(wino_gemm_mfma<4>), lds);
@@ -786,6 +875,7 @@ int gif_conv3x3_winograd_f32(const float* x, const float* U, float* y, float* V,
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
     if (wide) hipLaunchKernelGGL(wino_gemm_mfma<4>, grid, dim3(512), lds, s, p);
     else hipLaunchKernelGGL(wino_gemm_mfma<2>, grid, dim3(256), lds, s, p);
+    if (int rc = sums.finish(p, B, H, W, Co, WBM, s)) return rc;
     return gif::check_launch("conv3x3_winograd");
 }
 // ---- bf16x3 variants: same contract; U3 = [16][3][RP][CP] bf16 from gif_winograd_weight_f32x3, RP a multiple of 128
@@ -840,6 +930,8 @@ int gif_conv3x3_winograd_f32x3(const float* x, const void* U3, float* y, float* 
     const int bm = sq ? 128 : 256, bn = sq ? 128 : 64;
     p.tiles_m = (int)(ntiles_pad / bm);
     p.tiles_n = p.RP / bn;
+    WinoSums sums;
+    if (int rc = sums.begin(p, e, B, H, W, Co, bm, "conv3x3_winograd_f32x3")) return rc;
     const size_t lds = (size_t)WNSTAGE * ((size_t)bm * WBK * sizeof(float) + 3 * (size_t)bn * 64);
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
 #define GIF_WINO_X3_LAUNCH(D, BM_, BN_)                                                        \
@@ -855,6 +947,7 @@ int gif_conv3x3_winograd_f32x3(const float* x, const void* U3, float* y, float* 
     else if (dbg == 7) GIF_WINO_X3_LAUNCH(7, 128, 128)
     else GIF_WINO_X3_LAUNCH(0, 128, 128)
 #undef GIF_WINO_X3_LAUNCH
+    if (int rc = sums.finish(p, B, H, W, Co, bm, s)) return rc;
     return gif::check_launch("conv3x3_winograd_f32x3");
 }
 }

@@ -32,7 +32,37 @@ struct UpfirdnParams {
     const T* residual;
     int B, Hi, Wi, C, Ho, Wo, up, down, padx0, pady0, KH, KW, flip, act;
     float slope, gain;
+    // gradient-producer fusions (gif_conv_epilogue ABI 2): y *= mask_gain * (mask_src > 0 ? 1 : mask_slope) after the activation;
+    // part_cs [gridDim.x][C] = per-workgroup column sums of the stored values (blur kernels only, C/4 a divisor of 256)
+    const T* mask_src;
+    float mask_slope, mask_gain;
+    float* part_cs;
 };
+
+// FIR epilogue tail shared by the blur kernels: leaky-ReLU-backward mask of the tensor this gradient flows into + the running
+// column sum of what is stored
+template <typename T>
+__device__ __forceinline__ void fir_mask_sum(const UpfirdnParams<T>& p, size_t o, float4& v, float4& cs) {
+    if (p.mask_src) {
+        const float4 m = gif::load4(p.mask_src + o);
+        v.x *= p.mask_gain * (m.x > 0.f ? 1.f : p.mask_slope); v.y *= p.mask_gain * (m.y > 0.f ? 1.f : p.mask_slope);
+        v.z *= p.mask_gain * (m.z > 0.f ? 1.f : p.mask_slope); v.w *= p.mask_gain * (m.w > 0.f ? 1.f : p.mask_slope);
+    }
+    cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
+}
+
+// per-workgroup column sums: thread t owns channel quad t % C4 for the whole grid-stride loop (256 % C4 == 0), so the sums of
+// the 256 / C4 threads per quad are added through LDS in a fixed order and written to row blockIdx.x of the partial buffer
+__device__ __forceinline__ void fir_block_colsum(float* part_cs, float4 cs, int C4) {
+    __shared__ float4 red[256];
+    red[threadIdx.x] = cs;
+    __syncthreads();
+    if ((int)threadIdx.x < C4) {
+        float4 a = red[threadIdx.x];
+        for (int k = threadIdx.x + C4; k < 256; k += C4) a = f4add(a, red[k]);
+        reinterpret_cast<float4*>(part_cs)[(size_t)blockIdx.x * C4 + threadIdx.x] = a;
+    }
+}
 
 template <typename T>
 __global__ void __launch_bounds__(256) upfirdn2d_kernel(const UpfirdnParams<T> p) {
@@ -171,6 +201,7 @@ __global__ void __launch_bounds__(256) blur4x4_tiled_kernel(const UpfirdnParams<
     const int C4 = p.C >> 2;
     const int nyb = (p.Ho + TY - 1) / TY, nxb = (p.Wo + TX - 1) / TX;
     const long total = (long)p.B * nyb * nxb * C4;
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         int c4 = (int)(idx % C4);
         long t = idx / C4;
@@ -224,10 +255,12 @@ __global__ void __launch_bounds__(256) blur4x4_tiled_kernel(const UpfirdnParams<
                     v.x = lrelu(v.x, p.slope, p.gain); v.y = lrelu(v.y, p.slope, p.gain);
                     v.z = lrelu(v.z, p.slope, p.gain); v.w = lrelu(v.w, p.slope, p.gain);
                 }
+                fir_mask_sum(p, o, v, cs);
                 gif::store4(p.y + o, v);
             }
         }
     }
+    if (p.part_cs) fir_block_colsum(p.part_cs, cs, C4);
 }
 
 // Sliding-window variant for tall images: one lane walks down TYL output rows of a TX-wide column strip (4 channels),
@@ -249,6 +282,7 @@ __global__ void __launch_bounds__(256) blur4x4_rows_kernel(const UpfirdnParams<T
     const long total = (long)p.B * nyb * nxb * C4;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 bias4 = zero4;
+    float4 cs = zero4;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         int c4 = (int)(idx % C4);
         long t = idx / C4;
@@ -303,6 +337,7 @@ __global__ void __launch_bounds__(256) blur4x4_rows_kernel(const UpfirdnParams<T
                             vv.x = lrelu(vv.x, p.slope, p.gain); vv.y = lrelu(vv.y, p.slope, p.gain);
                             vv.z = lrelu(vv.z, p.slope, p.gain); vv.w = lrelu(vv.w, p.slope, p.gain);
                         }
+                        fir_mask_sum(p, o, vv, cs);
                         gif::store4(p.y + o, vv);
                     }
                 }
@@ -311,6 +346,7 @@ __global__ void __launch_bounds__(256) blur4x4_rows_kernel(const UpfirdnParams<T
             }
         }
     }
+    if (p.part_cs) fir_block_colsum(p.part_cs, cs, C4);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -598,16 +634,34 @@ int upfirdn2d_impl(const T* x, const float* k, T* y, int B, int Hi, int Wi, int 
     p.gain = e ? e->gain : 1.f;
     p.B = B; p.Hi = Hi; p.Wi = Wi; p.C = C; p.Ho = Ho; p.Wo = Wo; p.up = up; p.down = down;
     p.padx0 = padx0; p.pady0 = pady0; p.KH = KH; p.KW = KW; p.flip = flip;
-    if (up == 1 && down == 1 && KH == 4 && KW == 4 && (long)B * ((Ho + 15) / 16) * ((Wo + 3) / 4) * (C / 4) >= 256L * 256 * 2) {
+    // gradient-producer fusions (blur kernels): leaky-ReLU-backward mask + bias-gradient column sums in the epilogue
+    const bool blur = up == 1 && down == 1 && KH == 4 && KW == 4;
+    const bool fused = e && (e->mask_src || e->colsum || e->dot || e->dot_src);
+    float* colsum_out = nullptr;
+    if (fused) {
+        GIF_REQUIRE(!e->dot && !e->dot_src, "upfirdn2d: the dot fusion is a convolution epilogue only");
+        GIF_REQUIRE(blur, "upfirdn2d: mask / colsum fusions need the 4x4 blur form (up = down = 1)");
+        GIF_REQUIRE(!e->colsum || (e->red_ws && (C & (C - 1)) == 0 && C <= 1024), "upfirdn2d: colsum needs red_ws and a power-of-two C <= 1024");
+        p.mask_src = static_cast<const T*>(e->mask_src);
+        p.mask_slope = e->mask_slope; p.mask_gain = e->mask_gain;
+        colsum_out = e->colsum;
+        p.part_cs = colsum_out ? e->red_ws : nullptr;
+    }
+    hipStream_t s = gif::as_stream(stream);
+    if (blur && (long)B * ((Ho + 15) / 16) * ((Wo + 3) / 4) * (C / 4) >= 256L * 256 * 2) {
         // enough columns strips to fill the chip with 16-row sliding windows
         long total = (long)B * ((Ho + 15) / 16) * ((Wo + 3) / 4) * (C / 4);
-        blur4x4_rows_kernel<T, 16, 4><<<ew_grid(total), 256, 0, gif::as_stream(stream)>>>(p);
+        const int grid = ew_grid(total);
+        blur4x4_rows_kernel<T, 16, 4><<<grid, 256, 0, s>>>(p);
+        if (colsum_out) return gif::reduce_partials(p.part_cs, colsum_out, 1, grid, C, p.part_cs + (size_t)grid * C, s);
         return gif::check_launch("upfirdn2d(blur rows)");
     }
-    if (up == 1 && down == 1 && KH == 4 && KW == 4) {
+    if (blur) {
         constexpr int TY = 2, TX = 4;
         long total = (long)B * ((Ho + TY - 1) / TY) * ((Wo + TX - 1) / TX) * (C / 4);
-        blur4x4_tiled_kernel<T, TY, TX><<<ew_grid(total), 256, 0, gif::as_stream(stream)>>>(p);
+        const int grid = ew_grid(total);
+        blur4x4_tiled_kernel<T, TY, TX><<<grid, 256, 0, s>>>(p);
+        if (colsum_out) return gif::reduce_partials(p.part_cs, colsum_out, 1, grid, C, p.part_cs + (size_t)grid * C, s);
         return gif::check_launch("upfirdn2d(blur)");
     }
     long total = (long)B * Ho * Wo * (C / 4);
@@ -660,6 +714,30 @@ int colsum_impl(const T* x, float* out, float* partial, int64_t npix, int C, gif
     colsum_stage2<<<dim3(gif::cdiv(C, 64), 1), 256, 0, s>>>(partial, out, nblk, C);
     return gif::check_launch("colsum");
 }
+
+}  // namespace
+
+namespace gif {
+
+int reduce_partials(const float* partial, float* out, int Y, int nblk, int C, float* tmp, hipStream_t s) {
+    if (Y <= 0 || nblk <= 0) return 0;
+    if (Y == 1 && nblk > 512) {  // one long reduction: 64 groups first (two blocks of 64 channels alone would crawl through it)
+        const int S = 64, per = (nblk + S - 1) / S;
+        // groups of `per` rows; the last group may be short: pad by reducing [k*per, min((k+1)*per, nblk)) — stage 2 takes a row
+        // count per group, so run the full groups and the tail separately
+        const int full = nblk / per, tail = nblk - full * per;
+        colsum_stage2<<<dim3(cdiv(C, 64), full), 256, 0, s>>>(partial, tmp, per, C);
+        if (tail) colsum_stage2<<<dim3(cdiv(C, 64), 1), 256, 0, s>>>(partial + (size_t)full * per * C, tmp + (size_t)full * C, tail, C);
+        colsum_stage2<<<dim3(cdiv(C, 64), 1), 256, 0, s>>>(tmp, out, full + (tail ? 1 : 0), C);
+    } else {
+        colsum_stage2<<<dim3(cdiv(C, 64), Y), 256, 0, s>>>(partial, out, nblk, C);
+    }
+    return check_launch("reduce_partials");
+}
+
+}  // namespace gif
+
+namespace {
 
 inline int mul_reduce_chunks(int64_t HW) { return colsum_blocks(HW, 32) > 64 ? 64 : colsum_blocks(HW, 32); }
 
@@ -718,6 +796,11 @@ int gif_bias_act_f16(const void* x, const float* bias, const void* residual, voi
                      float gain, gif_stream_t stream) {
     return bias_act_impl<gif::f16>(static_cast<const gif::f16*>(x), bias, static_cast<const gif::f16*>(residual),
                                    static_cast<gif::f16*>(y), npix, C, slope, gain, stream);
+}
+
+int64_t gif_conv_epilogue_ws_floats(int64_t out_rows, int cout) {
+    if (out_rows <= 0 || cout <= 0) return 0;
+    return gif::epilogue_ws_rows(out_rows) * (int64_t)((cout + 3) / 4 * 4);
 }
 
 int64_t gif_colsum_partial_floats(int64_t npix, int C) {

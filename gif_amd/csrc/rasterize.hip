@@ -4,8 +4,8 @@
 //   my_utils/standard_rasterize_cuda/standard_rasterize_cuda_kernel.cu:111-233 (+ host :237-320),
 // with a different, race-free formulation built around the CU's LDS (160 KB): the image is cut into 64x64-pixel tiles whose
 // z-buffers live in LDS; depth test and winner selection are ONE 64-bit LDS atomic-min of (ordered_bits(zp) << 32) | face per
-// covered pixel, so the reference's second launch (:252-269, a race work-around) is not needed, no atomic ever reaches HBM,
-// and exact-depth ties deterministically go to the lowest face index.  See raster_setup / raster_tiles below.  (The
+// covered pixel, so the reference's second launch (:252-269, a race work-around) is not needed, no per-pixel atomic ever
+// reaches HBM, and exact-depth ties deterministically go to the lowest face index.  See raster_bin / raster_tiles below.  (The
 // reference runs one thread per face over its whole bounding box, :111-167: one large triangle serialises a lane while
 // its 63 neighbours idle, and every pixel test is a global atomic.)
 // Arithmetic follows the reference operation by operation with FP contraction off, so results are
@@ -91,42 +91,80 @@ __device__ __forceinline__ void face_bbox(const Face<T>& f, int H, int W, int& x
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Kernel 1, raster_setup: one lane per (image, face): front-facing test + clamped bounding box, packed into 4 x u16
-// (x_min, x_max, y_min, y_max; culled / empty => x_min = y_min = 0xFFFF, x_max = y_max = 0, which overlaps no tile).
+// Kernel 1, raster_bin: one lane per (image, face): front-facing test + clamped bounding box, then the face index is
+// appended to the list of every 64x64-pixel tile its box overlaps.  A 256-face workgroup first counts per tile in LDS, takes
+// ONE global atomicAdd per touched tile for the whole group, and scatters with LDS-ranked offsets — ~7 k global atomics for
+// 32 x 13 776 faces instead of one per face.  (List order is not deterministic; the rasterised result is: see raster_tiles.)
+//   workspace: count[B][T] (zeroed by the caller's memset node) | list[B][T][F]   (T = tiles per image)
 // ---------------------------------------------------------------------------------------------------------------------
+constexpr int kBinThreads = 256;
+constexpr int kMaxLdsTiles = 1024;  // images up to 2048 x 2048 count in LDS; larger ones fall back to one global atomic per entry
+
 template <typename T>
-__global__ void __launch_bounds__(256) raster_setup(const T* __restrict__ fv, uint2* __restrict__ box, long nfaces, int H, int W) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nfaces) return;
-    const Face<T> f = load_face(fv + i * 9);
-    uint2 b = make_uint2(0x0000FFFFu, 0x0000FFFFu);  // lo 16 bits = min, hi 16 bits = max
-    if (front_facing(f)) {
-        int x_min, x_max, y_min, y_max;
-        face_bbox(f, H, W, x_min, x_max, y_min, y_max);
-        if (x_min <= x_max && y_min <= y_max) b = make_uint2((unsigned)x_min | ((unsigned)x_max << 16), (unsigned)y_min | ((unsigned)y_max << 16));
+__global__ void __launch_bounds__(kBinThreads)
+raster_bin(const T* __restrict__ fv, uint32_t* __restrict__ count, uint32_t* __restrict__ list, int F, int H, int W, int tiles_x,
+           int tiles_y) {
+    __shared__ uint32_t cnt[kMaxLdsTiles], base[kMaxLdsTiles];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int nt = tiles_x * tiles_y;
+    const bool lds = nt <= kMaxLdsTiles;
+    const int fi = blockIdx.x * kBinThreads + tid;
+    int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
+    if (fi < F) {
+        const Face<T> f = load_face(fv + ((long)b * F + fi) * 9);
+        if (front_facing(f)) {
+            int x_min, x_max, y_min, y_max;
+            face_bbox(f, H, W, x_min, x_max, y_min, y_max);
+            if (x_min <= x_max && y_min <= y_max) {
+                tx0 = x_min >> 6; tx1 = x_max >> 6; ty0 = y_min >> 6; ty1 = y_max >> 6;
+            }
+        }
     }
-    box[i] = b;
+    uint32_t* cb = count + (long)b * nt;
+    uint32_t* lb = list + (long)b * nt * F;
+    if (!lds) {
+        for (int ty = ty0; ty <= ty1; ++ty)
+            for (int tx = tx0; tx <= tx1; ++tx) {
+                const int t = ty * tiles_x + tx;
+                lb[(long)t * F + atomicAdd(cb + t, 1u)] = (uint32_t)fi;
+            }
+        return;
+    }
+    for (int t = tid; t < nt; t += kBinThreads) cnt[t] = 0;
+    __syncthreads();
+    for (int ty = ty0; ty <= ty1; ++ty)
+        for (int tx = tx0; tx <= tx1; ++tx) atomicAdd(&cnt[ty * tiles_x + tx], 1u);
+    __syncthreads();
+    for (int t = tid; t < nt; t += kBinThreads) {
+        const uint32_t c = cnt[t];
+        base[t] = c ? atomicAdd(cb + t, c) : 0u;
+        cnt[t] = 0;
+    }
+    __syncthreads();
+    for (int ty = ty0; ty <= ty1; ++ty)
+        for (int tx = tx0; tx <= tx1; ++tx) {
+            const int t = ty * tiles_x + tx;
+            lb[(long)t * F + base[t] + atomicAdd(&cnt[t], 1u)] = (uint32_t)fi;
+        }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Kernel 2, raster_tiles: one 512-thread workgroup per (image, 64x64-pixel tile); the tile's z-buffer lives in LDS.
 //   seed   : key[p] = (ordered_bits(depth_in[p]) << 32) | 0xFFFFFFFF from the caller's depth buffer
-//   scan   : the workgroup streams the image's packed boxes (8 B per face, L2-resident) in chunks of 4096 faces and
-//            compacts the faces whose box overlaps the tile into an LDS list
-//   shade  : listed faces, box clipped to the tile: <= 16 px => the lane walks it; larger => the wave walks it together,
-//            8x8 pixels per step (face broadcast by shuffles).  Every covered pixel does ONE 64-bit LDS atomic-min of
-//            (ordered_bits(zp) << 32) | face.  Per-pixel arithmetic is identical in both classes and to the oracle.
+//   shade  : the tile's face list, one face per lane, box clipped to the tile: <= 16 px => the lane walks it; larger => the
+//            wave walks it together, 8x8 pixels per step (face broadcast by shuffles).  Every covered pixel does ONE 64-bit
+//            LDS atomic-min of (ordered_bits(zp) << 32) | face.  Per-pixel arithmetic is identical in both classes and to
+//            the oracle, and min() is order independent: the result does not depend on the list order.
 //   resolve: per pixel of the tile, re-evaluate the winner (same fp operation order => same bits), write depth / face
 //            index / barycentrics or colours; untouched pixels keep the caller's contents.
-// No global atomics, no key buffer in HBM, no second launch; a screen-filling triangle costs every tile 64 wave-steps.
+// No global atomic per pixel, no key buffer in HBM, no second launch; a screen-filling triangle costs every tile 64 wave-steps.
 // float64 (the reference dispatches AT_DISPATCH_FLOATING_TYPES, .cu:252,295): a 64-bit depth and a face index do not fit
-// one 64-bit atomic, so scan + shade run twice: (PASS 0) atomic-min of the ordered depth bits, (PASS 1) among the faces
+// one 64-bit atomic, so shade runs twice: (PASS 0) atomic-min of the ordered depth bits, (PASS 1) among the faces
 // whose depth at the pixel EQUALS that minimum (recomputed: same arithmetic, same bits) a 32-bit atomic-min of the face
 // index — the same deterministic "lowest face index wins an exact tie" rule as the float path.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kTile = 64;          // pixels per tile edge
 constexpr int kTilePix = kTile * kTile;
-constexpr int kChunk = 4096;       // faces scanned per round (= capacity of the LDS candidate list)
 constexpr int kThreads = 512;
 constexpr int kSmallArea = 16;     // clipped boxes up to this many pixels are walked by their own lane
 
@@ -181,13 +219,11 @@ __device__ __forceinline__ Face<T> shfl_face(const Face<T>& f, int src) {
 
 template <typename T, bool COLORS>
 __global__ void __launch_bounds__(kThreads)
-raster_tiles(const T* __restrict__ fv, const T* __restrict__ fc, const uint2* __restrict__ box, T* __restrict__ depth,
-             int32_t* __restrict__ tri, T* __restrict__ out3, int F, int H, int W, int tiles_x, int tiles_y) {
+raster_tiles(const T* __restrict__ fv, const T* __restrict__ fc, const uint32_t* __restrict__ count, const uint32_t* __restrict__ list,
+             T* __restrict__ depth, int32_t* __restrict__ tri, T* __restrict__ out3, int F, int H, int W, int tiles_x, int tiles_y) {
     constexpr bool F64 = sizeof(T) == 8;
     __shared__ unsigned long long key[kTilePix];
     __shared__ uint32_t fkey[F64 ? kTilePix : 1];
-    __shared__ uint32_t cand[kChunk];
-    __shared__ uint32_t ncand;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = blockIdx.x % (tiles_x * tiles_y), b = blockIdx.x / (tiles_x * tiles_y);
     const int tx0 = (tile % tiles_x) * kTile, ty0 = (tile / tiles_x) * kTile;
@@ -208,26 +244,14 @@ raster_tiles(const T* __restrict__ fv, const T* __restrict__ fc, const uint2* __
             key[p] = in ? (((unsigned long long)ordered_bits(depth[img + (long)y * W + x]) << 32) | kNoFace) : 0ull;
         }
     }
-    if (tid == 0) ncand = 0;
     __syncthreads();
 
-    const uint2* bx = box + (long)b * F;
+    const int n = (int)count[blockIdx.x];  // blockIdx.x == b * tiles + tile
+    const uint32_t* cand = list + (long)blockIdx.x * F;
     const T* fvb = fv + (long)b * F * 9;
     const int lx = lane & 7, ly = lane >> 3;
     for (int pass = 0; pass < (F64 ? 2 : 1); ++pass) {
-        for (int c0 = 0; c0 < F; c0 += kChunk) {
-            // ---- scan: compact the faces of this chunk whose box overlaps the tile
-#pragma unroll
-            for (int k = 0; k < kChunk / kThreads; ++k) {
-                const int fi = c0 + tid + k * kThreads;
-                if (fi < F) {
-                    const uint2 q = bx[fi];
-                    const int x_min = q.x & 0xFFFF, x_max = q.x >> 16, y_min = q.y & 0xFFFF, y_max = q.y >> 16;
-                    if (x_min <= tx1 && x_max >= tx0 && y_min <= ty1 && y_max >= ty0) cand[atomicAdd(&ncand, 1u)] = (uint32_t)fi;
-                }
-            }
-            __syncthreads();
-            const int n = (int)ncand;
+        {
             // ---- shade: one candidate per lane; every wave runs the same number of rounds
             for (int j0 = wave * 64; j0 < n; j0 += kThreads) {
                 const int j = j0 + lane;
@@ -237,10 +261,10 @@ raster_tiles(const T* __restrict__ fv, const T* __restrict__ fc, const uint2* __
                 if (j < n) {
                     fidx = cand[j];
                     f = load_face(fvb + (long)fidx * 9);
-                    const uint2 q = bx[fidx];
-                    x_min = max((int)(q.x & 0xFFFF), tx0); x_max = min((int)(q.x >> 16), tx1);
-                    y_min = max((int)(q.y & 0xFFFF), ty0); y_max = min((int)(q.y >> 16), ty1);
-                    area = (x_max - x_min + 1) * (y_max - y_min + 1);
+                    face_bbox(f, H, W, x_min, x_max, y_min, y_max);
+                    x_min = max(x_min, tx0); x_max = min(x_max, tx1);
+                    y_min = max(y_min, ty0); y_max = min(y_max, ty1);
+                    area = (x_max >= x_min && y_max >= y_min) ? (x_max - x_min + 1) * (y_max - y_min + 1) : 0;
                 }
                 if (area > 0 && area <= kSmallArea) {
                     const BaryCtx<T> c = bary_setup(f);
@@ -263,9 +287,7 @@ raster_tiles(const T* __restrict__ fv, const T* __restrict__ fc, const uint2* __
                         }
                 }
             }
-            __syncthreads();
-            if (tid == 0) ncand = 0;
-            __syncthreads();
+            __syncthreads();  // float64: every depth key is final before the face keys are taken
         }
     }
 
@@ -298,6 +320,8 @@ raster_tiles(const T* __restrict__ fv, const T* __restrict__ fc, const uint2* __
     }
 }
 
+inline long pad2(long n) { return (n + 1) / 2 * 2; }  // keeps the list 8-byte aligned behind the counters
+
 template <typename T>
 int run(const T* fv, const T* fc, T* depth, int32_t* tri, T* out3, int B, int F, int H, int W, void* workspace,
         gif_stream_t stream, const char* who) {
@@ -305,16 +329,18 @@ int run(const T* fv, const T* fc, T* depth, int32_t* tri, T* out3, int B, int F,
     if ((long)B * H * W == 0 || F == 0) return 0;
     GIF_REQUIRE(fv && depth && tri && out3 && workspace, "%s: null pointer", who);
     GIF_REQUIRE(((uintptr_t)workspace & 7) == 0, "%s: workspace must be 8-byte aligned", who);
-    GIF_REQUIRE(H <= 65535 && W <= 65535, "%s: images larger than 65535 pixels per side are not supported (16-bit boxes)", who);
     const int tiles_x = (W + kTile - 1) / kTile, tiles_y = (H + kTile - 1) / kTile;
-    GIF_REQUIRE((long)B * tiles_x * tiles_y < (1L << 31) && (long)B * F < (1L << 40), "%s: too many tiles / faces", who);
+    const long nt = (long)tiles_x * tiles_y;
+    GIF_REQUIRE(B <= 65535 && B * nt < (1L << 31) && B * nt * F < (1L << 40), "%s: too many images / tiles / faces", who);
     hipStream_t s = gif::as_stream(stream);
-    uint2* box = reinterpret_cast<uint2*>(workspace);
-    const long nfaces = (long)B * F;
-    raster_setup<T><<<gif::cdiv(nfaces, 256), 256, 0, s>>>(fv, box, nfaces, H, W);
-    const dim3 grid((unsigned)((long)B * tiles_x * tiles_y));
-    if (fc) raster_tiles<T, true><<<grid, kThreads, 0, s>>>(fv, fc, box, depth, tri, out3, F, H, W, tiles_x, tiles_y);
-    else raster_tiles<T, false><<<grid, kThreads, 0, s>>>(fv, nullptr, box, depth, tri, out3, F, H, W, tiles_x, tiles_y);
+    uint32_t* count = reinterpret_cast<uint32_t*>(workspace);
+    uint32_t* list = count + pad2(B * nt);
+    hipError_t me = hipMemsetAsync(count, 0, (size_t)B * nt * sizeof(uint32_t), s);
+    if (me != hipSuccess) { gif::set_error("%s memset: %s", who, hipGetErrorString(me)); return (int)me; }
+    raster_bin<T><<<dim3((unsigned)gif::cdiv(F, kBinThreads), (unsigned)B), kBinThreads, 0, s>>>(fv, count, list, F, H, W, tiles_x, tiles_y);
+    const dim3 grid((unsigned)(B * nt));
+    if (fc) raster_tiles<T, true><<<grid, kThreads, 0, s>>>(fv, fc, count, list, depth, tri, out3, F, H, W, tiles_x, tiles_y);
+    else raster_tiles<T, false><<<grid, kThreads, 0, s>>>(fv, nullptr, count, list, depth, tri, out3, F, H, W, tiles_x, tiles_y);
     return gif::check_launch(who);
 }
 
@@ -322,11 +348,11 @@ int run(const T* fv, const T* fc, T* depth, int32_t* tri, T* out3, int B, int F,
 
 extern "C" {
 
-// 8 bytes (one packed bounding box) per face; the z-buffer itself never leaves LDS
+// per (image, 64x64 tile): one counter + a face list that can hold every face; the z-buffer itself never leaves LDS
 int64_t gif_rasterize_workspace_bytes(int B, int F, int H, int W) {
-    (void)H; (void)W;
-    const int64_t n = (int64_t)B * F * 8;
-    return n > 8 ? n : 8;
+    if (B <= 0 || F <= 0 || H <= 0 || W <= 0) return 8;
+    const int64_t nt = (int64_t)((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile);
+    return (pad2(B * nt) + B * nt * F) * 4;
 }
 
 int gif_rasterize_f32(const float* face_vertices, float* depth, int32_t* tri, float* bary, int B, int F, int H,

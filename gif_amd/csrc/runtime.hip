@@ -107,7 +107,7 @@ ProfScope::~ProfScope() {
 extern "C" {
 
 const char* gif_last_error(void) { return gif::g_err; }
-int gif_abi_version(void) { return 1; }
+int gif_abi_version(void) { return 2; }  // 2: gif_conv_epilogue gradient-producer fusions, rasteriser workspace (B, F, H, W)
 
 int gif_set_fp32_mfma_mode(int mode) {
     if (mode != GIF_FP32_MFMA_NATIVE && mode != GIF_FP32_MFMA_BF16X3) {

@@ -23,6 +23,87 @@ from .ops import ConvSpec
 
 
 # --------------------------------------------------------------------------------------------------------
+# Activation ports: FusedLeakyReLU's backward inside the kernel that PRODUCES the gradient
+# --------------------------------------------------------------------------------------------------------
+# A layer whose epilogue applies bias + leaky ReLU (ConvBiasActFn, ModConvActFn, BlurBiasActFn) hands out, next to its
+# output y, an ALIAS of y as a second autograd output — the layer's "port" — and tags y with it (y._gif_port).  A consumer
+# that knows the protocol (the convolutions and the blur below) takes BOTH y and the alias as autograd inputs and, in a
+# first-order backward, returns nothing for y and, for the alias, the gradient ALREADY multiplied by gain * (y > 0 ? 1 : slope):
+# the mask is applied in the epilogue of the data-gradient / FIR kernel that produces that gradient (ops.GradFuse; the
+# consumer has y saved as its own input), the bias-gradient column sums come out of the same epilogue and travel through
+# `parts`.  The producing layer then finds its pre-activation gradient ready-made on the port and skips the stand-alone pass
+# (reference: FusedLeakyReLUFunctionBackward, stylegan2_common_layers.py:22-39, as its own kernel: read g, read y, write g' —
+# three full-resolution tensors per layer).  Gradients from consumers that do not know the protocol arrive on y as before and
+# take the stand-alone pass; both add up.  Under create_graph (R1, the path-length / direct-gradient regularisers) consumers
+# return the plain, differentiable gradient on y and leave the port alone: a port only ever carries first-order gradients.
+class ActPort:
+    __slots__ = ("alias", "slope", "gain", "want_bias", "parts")
+
+    def __init__(self, slope, gain, want_bias):
+        self.alias, self.slope, self.gain, self.want_bias = None, float(slope), float(gain), bool(want_bias)
+        self.parts = []  # [C] bias-gradient contributions appended by the consumers' backward passes
+
+    def cfg(self):
+        """What a consumer's backward needs (no reference to the alias: the autograd node must not own a cycle)."""
+        return (self.slope, self.gain, self.want_bias, self.parts)
+
+
+def _take_port(x):
+    """(port alias or None, port cfg or None) for a consumer's input x."""
+    port = getattr(x, "_gif_port", None)
+    if (port is None or not ops.FUSE_GRAD or not torch.is_grad_enabled() or port.alias is None or not port.alias.requires_grad
+            or x.dtype != torch.float32):
+        return None, None
+    return port.alias, port.cfg()
+
+
+def _port_on(ctx):
+    """This backward delivers to the input's port (first-order pass) instead of to the input itself."""
+    return ctx.in_port is not None and not torch.is_grad_enabled()
+
+
+def _tag(y, alias, port):
+    if port is not None:
+        port.alias = alias
+        y._gif_port = port
+    return y
+
+
+def _new_port(x_requires_grad, slope, gain, bias):
+    """Port of an activation layer's output, or None when nothing will be back-propagated through it."""
+    if not ops.FUSE_GRAD or not torch.is_grad_enabled() or (slope == 1.0 and gain == 1.0):
+        return None
+    return ActPort(slope, gain, bias is not None and bias.requires_grad)
+
+
+def _mask_into_port(cfg, gx, x):
+    """Stand-alone form of a consumer's duty (differentiable to any order): mask gx with the activation of x, file the bias part."""
+    slope, gain, want_b, parts = cfg
+    gxm, gb = BiasActBwdFn.apply(gx, x, want_b, slope, gain)
+    if want_b:
+        parts.append(gb)
+    return gxm
+
+
+def _producer_gpre(gy, g_port, y, want_b, slope, gain, parts):
+    """Pre-activation gradient (and bias gradient) of an activation layer from what arrived on y (unmasked) and on its port
+    (masked by the consumers)."""
+    gpre = gb = None
+    if gy is not None:
+        gpre, gb = BiasActBwdFn.apply(gy, y, want_b, slope, gain)
+        if not want_b:
+            gb = None
+    if g_port is not None:
+        gpre = g_port if gpre is None else gpre + g_port
+        if want_b and parts:
+            for part in parts:
+                gb = part if gb is None else gb + part
+    if parts is not None:
+        parts.clear()
+    return gpre, gb
+
+
+# --------------------------------------------------------------------------------------------------------
 # plain convolution family (twice differentiable)
 # --------------------------------------------------------------------------------------------------------
 class Conv2dFn(Function):
@@ -84,42 +165,64 @@ class WgradFn(Function):
 class ConvBiasActFn(Function):
     """y = gain*lrelu(conv2d(x, w*wscale) + bias): bias and activation run in the conv kernel's epilogue (ConvLayer =
     EqualConv2d + FusedLeakyReLU, stylegan2_common_layers.py:752-799).  The backward is composed of BiasActBwdFn,
-    Conv2dFn and WgradFn, hence differentiable to any order (R1).
+    Conv2dFn and WgradFn, hence differentiable to any order (R1); its first-order form fuses the activation backward of the
+    layer that produced x into the data-gradient kernel (in_port, see ActPort).
 
-    passthrough=True returns (y, x'), x' an alias of x for a SECOND consumer of x (the ResBlock's skip branch): that
-    consumer's gradient then arrives here, in this node's backward, and is added by the data-gradient kernel's epilogue
-    (`residual`) instead of by a separate gradient-accumulation pass over two full-resolution tensors."""
+    Outputs (y, port alias of y, x'): x' (passthrough=True, else None) is an alias of x for a SECOND consumer of x (the
+    ResBlock's skip branch): that consumer's gradient then arrives here, in this node's backward, and is added by the
+    data-gradient kernel's epilogue (`residual`) instead of by a separate gradient-accumulation pass over two
+    full-resolution tensors."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, spec, wscale, slope, gain, passthrough=False):
-        ctx.set_materialize_grads(False)  # an unused output (y or the alias) arrives as None, not as a zero tensor
+    def forward(ctx, x, w, bias, spec, wscale, slope, gain, passthrough=False, in_port=None, parts=None, x_port=None):
+        ctx.set_materialize_grads(False)  # an unused output (y, its port or the alias) arrives as None, not as a zero tensor
         x = ops.nhwc(x)
         y, v = ops.conv_fwd(x, w, spec, wscale, keep_v=True, bias=bias, act=True, slope=slope, gain=gain)
         ctx.v = v if ctx.needs_input_grad[1] else None  # Winograd-transformed x, reused by the weight gradient
         ctx.cfg = (spec, wscale, slope, gain, bias is not None)
+        ctx.in_port, ctx.parts = in_port, parts
         ctx.save_for_backward(x, w, y)
-        return (y, x.view_as(x)) if passthrough else y
+        return y, y.view_as(y), (x.view_as(x) if passthrough else None)
 
     @staticmethod
-    def backward(ctx, gy, g_alias=None):
+    def backward(ctx, gy, g_port=None, g_alias=None):
         x, w, y = ctx.saved_tensors
         spec, ws, slope, gain, has_bias = ctx.cfg
         want_b = has_bias and ctx.needs_input_grad[2]
-        gx = gw = gb = None
-        if gy is not None:
-            gpre, gb = BiasActBwdFn.apply(gy, y, want_b, slope, gain)
+        gx = gw = None
+        port = _port_on(ctx)
+        gpre, gb = _producer_gpre(gy, g_port, y, want_b, slope, gain, ctx.parts)
+        if gpre is not None:
             if ctx.needs_input_grad[0]:
-                gx = Conv2dFn.apply(gpre, w, spec, True, tuple(x.shape[2:]), ws, g_alias)
+                gx = _conv_dgrad(gpre, w, spec, tuple(x.shape[2:]), ws, g_alias, ctx.in_port if port else None, x)
             if ctx.needs_input_grad[1]:
                 gw = WgradFn.apply(gpre, x, spec, w.shape[0], w.shape[1], ws, ctx.v)
-        elif ctx.needs_input_grad[0]:
-            gx = g_alias
-        return gx, gw, (gb if want_b else None), None, None, None, None, None
+        elif ctx.needs_input_grad[0] and g_alias is not None:
+            gx = _mask_into_port(ctx.in_port, g_alias, x) if port else g_alias
+        return (None if port else gx), gw, (gb if want_b else None), None, None, None, None, None, None, None, (gx if port else None)
+
+
+def _conv_dgrad(gpre, w, spec, big_hw, ws, residual, in_port, x):
+    """Data gradient of conv2d(x, w) (+ residual); with in_port (first-order passes only) the result is masked by the activation
+    that produced x, and the bias-gradient column sums are taken, in the kernel's epilogue."""
+    if in_port is None:
+        return Conv2dFn.apply(gpre, w, spec, True, big_hw, ws, residual)
+    slope, gain, want_b, parts = in_port
+    fuse = ops.GradFuse(mask_src=x, mask_slope=slope, mask_gain=gain, want_colsum=want_b)
+    gx = ops.conv_bwd_data(gpre, w, spec, big_hw, ws, residual=None if residual is None else ops.nhwc(residual), fuse=fuse)
+    if want_b:
+        parts.append(fuse.colsum)
+    return gx
 
 
 def conv2d_bias_act(x, w, bias, stride=1, pad=0, wscale=1.0, slope=0.2, gain=2 ** 0.5, passthrough=False):
     """passthrough=True: returns (y, alias of x) — see ConvBiasActFn."""
-    return ConvBiasActFn.apply(x, w, bias, ConvSpec(w.shape[2], w.shape[3], stride, pad), wscale, slope, gain, bool(passthrough))
+    x_port, in_port = _take_port(x)
+    port = _new_port(True, slope, gain, bias)
+    y, alias, x_alias = ConvBiasActFn.apply(x, w, bias, ConvSpec(w.shape[2], w.shape[3], stride, pad), wscale, slope, gain,
+                                            bool(passthrough), in_port, None if port is None else port.parts, x_port)
+    _tag(y, alias, port)
+    return (y, x_alias) if passthrough else y
 
 
 def conv2d(x, w, stride=1, pad=0, wscale=1.0, residual=None):
@@ -289,53 +392,72 @@ def bias_act(x, bias=None, residual=None, slope=0.2, gain=2 ** 0.5):
 # upfirdn2d (stylegan2_common_layers.py:42-72)
 # --------------------------------------------------------------------------------------------------------
 class Upfirdn2dFn(Function):
+    """in_port: x is the output of a fused leaky ReLU whose backward this op's backward applies to the gradient it produces
+    (the blur between ConvLayer conv1 and the stride-2 conv2 of a ResBlock) — see ActPort."""
+
     @staticmethod
-    def forward(ctx, x, k, up, down, pad0, out_hw, flip):
+    def forward(ctx, x, k, up, down, pad0, out_hw, flip, in_port=None, x_port=None):
         x = ops.nhwc(x)
         ctx.cfg = (up, down, pad0, flip, tuple(x.shape[2:]))
-        ctx.save_for_backward(k)
+        ctx.in_port = in_port
+        ctx.save_for_backward(k, *((x,) if in_port is not None else ()))
         return ops.upfirdn2d(x, k, up, down, pad0, tuple(out_hw), flip)
 
     @staticmethod
     def backward(ctx, gy):
-        (k,) = ctx.saved_tensors
+        k = ctx.saved_tensors[0]
         up, down, pad0, flip, in_hw = ctx.cfg
         # adjoint of a FIR resampler is a FIR resampler: swap up/down, reverse the taps, pad0' = K-1-pad0
-        gx = Upfirdn2dFn.apply(gy, k, down, up, k.shape[0] - 1 - pad0, in_hw, not flip)
-        return gx, None, None, None, None, None, None
+        if not _port_on(ctx):
+            return Upfirdn2dFn.apply(gy, k, down, up, k.shape[0] - 1 - pad0, in_hw, not flip), None, None, None, None, None, None, None, None
+        x = ctx.saved_tensors[1]
+        slope, gain, want_b, parts = ctx.in_port
+        if not ops.fir_fusable(x.shape[1], down, up, k.shape, x.dtype):
+            gx = _mask_into_port(ctx.in_port, Upfirdn2dFn.apply(gy, k, down, up, k.shape[0] - 1 - pad0, in_hw, not flip), x)
+        else:
+            fuse = ops.GradFuse(mask_src=x, mask_slope=slope, mask_gain=gain, want_colsum=want_b)
+            gx = ops.upfirdn2d(ops.nhwc(gy), k, down, up, k.shape[0] - 1 - pad0, in_hw, not flip, fuse=fuse)
+            if want_b:
+                parts.append(fuse.colsum)
+        return None, None, None, None, None, None, None, None, gx
 
 
 class BlurBiasActFn(Function):
     """y = gain*lrelu(upfirdn2d(x) + residual + bias): the FIR kernel's epilogue adds the condition-noise, the bias and
-    applies the leaky ReLU (StyledConv with upsample: Blur -> NoiseInjection -> FusedLeakyReLU, :322-333, :479-486)."""
+    applies the leaky ReLU (StyledConv with upsample: Blur -> NoiseInjection -> FusedLeakyReLU, :322-333, :479-486).
+    Outputs (y, port alias of y) — see ActPort."""
 
     @staticmethod
-    def forward(ctx, x, k, pad0, out_hw, residual, bias, slope, gain):
+    def forward(ctx, x, k, pad0, out_hw, residual, bias, slope, gain, parts=None):
+        ctx.set_materialize_grads(False)
         x = ops.nhwc(x)
         y = ops.upfirdn2d(x, k, 1, 1, pad0, tuple(out_hw), True, bias=bias, residual=residual, act=True, slope=slope,
                           gain=gain)
         ctx.cfg = (pad0, tuple(x.shape[2:]), slope, gain, residual is not None, bias is not None)
+        ctx.parts = parts
         ctx.save_for_backward(k, y)
-        return y
+        return y, y.view_as(y)
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, g_port=None):
         k, y = ctx.saved_tensors
         pad0, in_hw, slope, gain, has_res, has_bias = ctx.cfg
         want_b = has_bias and ctx.needs_input_grad[5]
-        gpre, gb = BiasActBwdFn.apply(gy, y, want_b, slope, gain)
+        gpre, gb = _producer_gpre(gy, g_port, y, want_b, slope, gain, ctx.parts)
         gx = None
-        if ctx.needs_input_grad[0]:
+        if gpre is not None and ctx.needs_input_grad[0]:
             gx = Upfirdn2dFn.apply(gpre, k, 1, 1, k.shape[0] - 1 - pad0, in_hw, False)
         return (gx, None, None, None, gpre if (has_res and ctx.needs_input_grad[4]) else None,
-                gb if want_b else None, None, None)
+                gb if want_b else None, None, None, None)
 
 
 def blur_bias_act(x, kernel, pad, residual, bias, slope=0.2, gain=2 ** 0.5):
     kh = kernel.shape[0]
     H, W = x.shape[2:]
     out_hw = (H + pad[0] + pad[1] - kh + 1, W + pad[0] + pad[1] - kh + 1)
-    return BlurBiasActFn.apply(x, kernel, pad[0], out_hw, residual, bias, slope, gain)
+    port = _new_port(True, slope, gain, bias)
+    y, alias = BlurBiasActFn.apply(x, kernel, pad[0], out_hw, residual, bias, slope, gain, None if port is None else port.parts)
+    return _tag(y, alias, port)
 
 
 def upfirdn2d(x, kernel, up=1, down=1, pad=(0, 0)):
@@ -345,7 +467,8 @@ def upfirdn2d(x, kernel, up=1, down=1, pad=(0, 0)):
     H, W = x.shape[2:]
     Ho = (H * up + pad[0] + pad[1] - kh) // down + 1
     Wo = (W * up + pad[0] + pad[1] - kw) // down + 1
-    return Upfirdn2dFn.apply(x, kernel, up, down, pad[0], (Ho, Wo), True)
+    x_port, in_port = _take_port(x)
+    return Upfirdn2dFn.apply(x, kernel, up, down, pad[0], (Ho, Wo), True, in_port, x_port)
 
 
 # --------------------------------------------------------------------------------------------------------
@@ -475,12 +598,30 @@ def _recorded_backward(inputs, needs, gy, build):
     return out
 
 
+def _modconv_dgrad_fused(g, w, spec, tr, x, s, d, ws, in_port, want_gs):
+    """Gradient of y = d * conv(s * x, w) w.r.t. x (and the modulation gradient gs = sum_hw dxs * x) in ONE launch: the adjoint
+    convolution of d * g with the modulation s as its output scale, gs as a dot product against x and — with in_port — the
+    backward of the leaky ReLU that produced x, all in the kernel's epilogue (ops.GradFuse).  Replaces data gradient -> dxs,
+    mul_reduce(dxs, x) -> (gs, s * dxs) [three full-resolution tensors] and the activation's own backward pass [three more]."""
+    slope, gain, want_b, parts = in_port if in_port is not None else (1.0, 1.0, False, None)
+    fuse = ops.GradFuse(mask_src=x if in_port is not None else None, mask_slope=slope, mask_gain=gain, want_colsum=want_b,
+                        dot_src=x if want_gs else None)
+    if not tr:
+        gx = ops.conv_bwd_data(g, w, spec, tuple(x.shape[2:]), ws, in_scale=d, out_scale=s, fuse=fuse)
+    else:
+        gx = ops.conv_fwd(g, w, spec, ws, in_scale=d, out_scale=s, fuse=fuse)
+    if want_b:
+        parts.append(fuse.colsum)
+    return gx, fuse.dot
+
+
 class ModConvFn(Function):
     """y = d * conv(s * x, w * wscale) with per-sample s [B,Cin] (modulation) and d [B,Cout] (demodulation, or None).
-    transposed=True runs the stride-2 up-sampling branch (conv_transpose2d, stylegan2_common_layers.py:322-330)."""
+    transposed=True runs the stride-2 up-sampling branch (conv_transpose2d, stylegan2_common_layers.py:322-330).
+    in_port: x is the output of a fused leaky ReLU (see ActPort)."""
 
     @staticmethod
-    def forward(ctx, x, w, s, d, spec, transposed, out_hw, wscale):
+    def forward(ctx, x, w, s, d, spec, transposed, out_hw, wscale, in_port=None, x_port=None):
         x_in, s_in, d_in = x, s, d  # saved as given (a layout copy made in here would cut the graph of a recorded backward)
         x = ops.nhwc(x)
         s = s.contiguous()
@@ -493,6 +634,7 @@ class ModConvFn(Function):
             y = ops.conv_bwd_data(x, w, spec, tuple(out_hw), wscale, in_scale=s, out_scale=d)
         ctx.spec, ctx.transposed, ctx.wscale = spec, transposed, wscale
         ctx.out_hw = tuple(y.shape[2:])
+        ctx.in_port = in_port
         none = x.new_empty(())  # placeholder for absent tensors (never read): no fill kernel
         ctx.save_for_backward(x_in, w, s_in, d_in if d is not None else none, y if d is not None else none)
         ctx.has_d = d is not None
@@ -507,18 +649,24 @@ class ModConvFn(Function):
             gx, gw, gs, gd = _recorded_backward(
                 (x, w, s, d), ctx.needs_input_grad[:4], gy,
                 lambda x_, w_, s_, d_: _modconv_composite(x_, w_, s_, d_, spec, tr, ctx.out_hw, ws))
-            return gx, gw, gs, gd, None, None, None, None
+            return gx, gw, gs, gd, None, None, None, None, None, None
+        port = ctx.in_port is not None
         x, s, gy = ops.nhwc(x), s.contiguous(), ops.nhwc(gy)
         d = None if d is None else d.contiguous()
         O, I = w.shape[:2]
         gx = gs = gd = gw = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
-            # gradient w.r.t. (s*x): adjoint conv applied to d*gy (d enters as the input scale of the adjoint)
-            if not tr:
-                dxs = ops.conv_bwd_data(gy, w, spec, tuple(x.shape[2:]), ws, in_scale=d)
+            if ops.dot_fusable(x.shape[2], x.shape[3], x.dtype):
+                gx, gs = _modconv_dgrad_fused(gy, w, spec, tr, x, s, d, ws, ctx.in_port, ctx.needs_input_grad[2])
             else:
-                dxs = ops.conv_fwd(gy, w, spec, ws, in_scale=d)
-            gs, gx = ops.mul_reduce(dxs, x, scale=s, want_scaled=True)
+                # gradient w.r.t. (s*x): adjoint conv applied to d*gy (d enters as the input scale of the adjoint)
+                if not tr:
+                    dxs = ops.conv_bwd_data(gy, w, spec, tuple(x.shape[2:]), ws, in_scale=d)
+                else:
+                    dxs = ops.conv_fwd(gy, w, spec, ws, in_scale=d)
+                gs, gx = ops.mul_reduce(dxs, x, scale=s, want_scaled=True)
+                if ctx.in_port is not None:
+                    gx = _mask_into_port(ctx.in_port, gx, x)
         if ctx.needs_input_grad[1]:
             if not tr:
                 gw = ops.conv_wgrad(gy, x, spec, O, I, ws, small_scale=d, big_scale=s, big_v=ctx.v)
@@ -527,17 +675,19 @@ class ModConvFn(Function):
         if ctx.has_d and ctx.needs_input_grad[3]:
             num, _ = ops.mul_reduce(gy, y)
             gd = num / d
-        return gx, gw, gs, gd, None, None, None, None
+        return (None if port else gx), gw, gs, gd, None, None, None, None, None, (gx if port else None)
 
 
 class ModConvActFn(Function):
     """y = gain*lrelu(d * conv(s * x, w*wscale) + residual + bias): the whole StyledConv (same-resolution branch,
     stylegan2_common_layers.py:479-486) as ONE MFMA kernel launch — modulation on the A-tile load, demodulation,
     condition-noise add, bias and leaky ReLU in the epilogue.  First-order backward = raw fused launches; a recorded
-    backward (create_graph=True) differentiates _modconv_composite instead."""
+    backward (create_graph=True) differentiates _modconv_composite instead.  Outputs (y, port alias of y); in_port: x is itself
+    the output of a fused leaky ReLU (see ActPort)."""
 
     @staticmethod
-    def forward(ctx, x, w, s, d, residual, bias, spec, wscale, slope, gain):
+    def forward(ctx, x, w, s, d, residual, bias, spec, wscale, slope, gain, in_port=None, parts=None, x_port=None):
+        ctx.set_materialize_grads(False)
         saved_in = (x, s, d, residual)  # saved as given (see ModConvFn.forward)
         x = ops.nhwc(x)
         s, d = s.contiguous(), d.contiguous()
@@ -547,44 +697,60 @@ class ModConvActFn(Function):
         ctx.v = v if ctx.needs_input_grad[1] else None  # Winograd-transformed s*x, reused by the weight gradient
         ctx.cfg = (spec, wscale, slope, gain)
         ctx.has = (residual is not None, bias is not None)
+        ctx.in_port, ctx.parts = in_port, parts
         z = x.new_empty(())  # placeholder for absent tensors (never read): no fill kernel
         x_in, s_in, d_in, r_in = saved_in
         ctx.save_for_backward(x_in, w, s_in, d_in, y, r_in if residual is not None else z, bias if bias is not None else z)
-        return y
+        return y, y.view_as(y)
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, g_port=None):
         x, w, s, d, y, residual, bias = ctx.saved_tensors
         spec, ws, slope, gain = ctx.cfg
         has_res, has_bias = ctx.has
         residual = residual if has_res else None
         bias = bias if has_bias else None
         O, I = w.shape[:2]
-        if torch.is_grad_enabled():  # create_graph=True: the gradients must carry history
+        none7 = (None,) * 7
+        if torch.is_grad_enabled():  # create_graph=True: the gradients must carry history (ports carry first-order gradients only)
+            assert g_port is None, "an activation port received a gradient inside a recorded backward"
             gx, gw, gs, gd, gr, gb = _recorded_backward(
                 (x, w, s, d, residual, bias), ctx.needs_input_grad[:6], gy,
                 lambda x_, w_, s_, d_, r_, b_: _modconv_composite(x_, w_, s_, d_, spec, False, None, ws, r_, b_, (slope, gain)))
-            return gx, gw, gs, gd, gr, gb, None, None, None, None
+            return (gx, gw, gs, gd, gr, gb) + none7
+        port = ctx.in_port is not None
         x, s, d = ops.nhwc(x), s.contiguous(), d.contiguous()
         residual = None if residual is None else ops.nhwc(residual)
         want_b = has_bias and ctx.needs_input_grad[5]
-        gpre, gb = ops.bias_act_bwd(gy, y, want_b, slope, gain)
+        gpre, gb = _producer_gpre(gy, g_port, y, want_b, slope, gain, ctx.parts)
         gx = gs = gd = gw = None
+        if gpre is None:
+            return (None,) * 13
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
-            dxs = ops.conv_bwd_data(gpre, w, spec, tuple(x.shape[2:]), ws, in_scale=d)
-            gs, gx = ops.mul_reduce(dxs, x, scale=s, want_scaled=True)
+            if ops.dot_fusable(x.shape[2], x.shape[3], x.dtype):
+                gx, gs = _modconv_dgrad_fused(gpre, w, spec, False, x, s, d, ws, ctx.in_port, ctx.needs_input_grad[2])
+            else:
+                dxs = ops.conv_bwd_data(gpre, w, spec, tuple(x.shape[2:]), ws, in_scale=d)
+                gs, gx = ops.mul_reduce(dxs, x, scale=s, want_scaled=True)
+                if ctx.in_port is not None:
+                    gx = _mask_into_port(ctx.in_port, gx, x)
         if ctx.needs_input_grad[1]:
             gw = ops.conv_wgrad(gpre, x, spec, O, I, ws, small_scale=d, big_scale=s, big_v=ctx.v)
         if ctx.needs_input_grad[3]:
             # d * z = act^-1(y) - residual - bias  =>  gd = sum_hw gpre * z
             gd = ops.act_inv_mul_reduce(gpre, y, residual, bias, slope, gain) / d
-        return (gx, gw, gs, gd, gpre if (has_res and ctx.needs_input_grad[4]) else None, gb if want_b else None,
-                None, None, None, None)
+        return ((None if port else gx), gw, gs, gd, gpre if (has_res and ctx.needs_input_grad[4]) else None,
+                gb if want_b else None) + (None,) * 6 + (gx if port else None,)
 
 
 def modulated_conv2d_act(x, w, s, d, residual, bias, pad, wscale=1.0, slope=0.2, gain=2 ** 0.5):
-    return ModConvActFn.apply(x, w, s, d, residual, bias, ConvSpec(w.shape[2], w.shape[3], 1, pad), wscale, slope, gain)
+    x_port, in_port = _take_port(x)
+    port = _new_port(True, slope, gain, bias)
+    y, alias = ModConvActFn.apply(x, w, s, d, residual, bias, ConvSpec(w.shape[2], w.shape[3], 1, pad), wscale, slope, gain,
+                                  in_port, None if port is None else port.parts, x_port)
+    return _tag(y, alias, port)
 
 
 def modulated_conv2d(x, w, s, d, stride=1, pad=0, transposed=False, out_hw=None, wscale=1.0):
-    return ModConvFn.apply(x, w, s, d, ConvSpec(w.shape[2], w.shape[3], stride, pad), transposed, out_hw, wscale)
+    x_port, in_port = _take_port(x)
+    return ModConvFn.apply(x, w, s, d, ConvSpec(w.shape[2], w.shape[3], stride, pad), transposed, out_hw, wscale, in_port, x_port)

@@ -106,8 +106,55 @@ def _geom(B, Hb, Wb, Cb, Hs, Ws, Cs, spec: ConvSpec):
     return _lib.ConvGeom(B, Hb, Wb, Cb, Hs, Ws, Cs, spec.KH, spec.KW, spec.stride, spec.pad)
 
 
-def _epilogue(in_scale=None, out_scale=None, bias=None, residual=None, act=False, slope=0.2, gain=2 ** 0.5):
-    return _lib.ConvEpilogue(_p(in_scale), _p(out_scale), _p(bias), _p(residual), 1 if act else 0, slope, gain)
+# Gradient-producer fusions (gif_conv_epilogue ABI 2).  GIF_FUSE_GRAD=0 keeps every backward on the stand-alone passes (A/B).
+FUSE_GRAD = os.environ.get("GIF_FUSE_GRAD", "1") != "0"
+
+
+class GradFuse:
+    """Work a gradient-producing launch does in its epilogue instead of leaving it to stand-alone passes (include/gif_hip.h,
+    gif_conv_epilogue ABI 2):
+      mask_src (+ slope, gain): the op's output is the gradient w.r.t. a tensor that a fused leaky ReLU produced — multiply by
+                                gain * (mask_src > 0 ? 1 : slope), i.e. FusedLeakyReLU's backward (stylegan2_common_layers.py:22-39);
+      want_colsum             : .colsum [C] = sum over all pixels of the stored output (the bias gradient of that layer);
+      dot_src                 : .dot [B,C] = sum_hw contraction * dot_src, taken BEFORE out_scale (the modulation gradient of
+                                ModulatedConv2d, :311-320).
+    After the launch the results are in .colsum / .dot (fp32)."""
+
+    def __init__(self, mask_src=None, mask_slope=1.0, mask_gain=1.0, want_colsum=False, dot_src=None):
+        self.mask_src, self.mask_slope, self.mask_gain = mask_src, float(mask_slope), float(mask_gain)
+        self.want_colsum, self.dot_src = bool(want_colsum), dot_src
+        self.colsum = self.dot = self._ws = None
+
+
+def dot_fusable(H, W, dtype=torch.float32):
+    """The modulation-gradient dot product can ride in a convolution epilogue: every tile (<= 256 rows; Winograd: 256 2x2
+    tiles) stays inside one sample."""
+    return FUSE_GRAD and dtype == torch.float32 and (H * W) % 1024 == 0
+
+
+def _epilogue(in_scale=None, out_scale=None, bias=None, residual=None, act=False, slope=0.2, gain=2 ** 0.5, fuse=None,
+              out_bchw=None, dtype=torch.float32):
+    e = _lib.ConvEpilogue(_p(in_scale), _p(out_scale), _p(bias), _p(residual), 1 if act else 0, slope, gain)
+    if fuse is not None:
+        B, C, H, W = out_bchw
+        for t, what in ((fuse.mask_src, "mask_src"), (fuse.dot_src, "dot_src")):
+            if t is not None and (tuple(t.shape) != (B, C, H, W) or t.dtype != dtype or not t.is_contiguous(memory_format=CL)):
+                raise _lib.GifHipError(f"GradFuse.{what}: expected an NHWC {dtype} tensor of shape {(B, C, H, W)}, got {tuple(t.shape)} {t.dtype}")
+        e.mask_src, e.mask_slope, e.mask_gain = _p(fuse.mask_src), fuse.mask_slope, fuse.mask_gain
+        e.dot_src = _p(fuse.dot_src)
+        if fuse.mask_src is None and fuse.dot_src is None:
+            raise _lib.GifHipError("GradFuse: nothing to fuse (the plain column sum of a gradient is ops.colsum)")
+        device = fuse.mask_src.device if fuse.mask_src is not None else fuse.dot_src.device
+        if fuse.dot_src is not None:
+            fuse.dot = torch.empty((B, C), device=device, dtype=torch.float32)
+            e.dot = fuse.dot.data_ptr()
+        if fuse.want_colsum:
+            fuse.colsum = torch.empty((C,), device=device, dtype=torch.float32)
+            e.colsum = fuse.colsum.data_ptr()
+        if fuse.dot is not None or fuse.colsum is not None:
+            fuse._ws = torch.empty((_lib.load().gif_conv_epilogue_ws_floats(B * H * W, C),), device=device, dtype=torch.float32)
+            e.red_ws = fuse._ws.data_ptr()
+    return e
 
 
 # Packed / transformed weights are a pure function of (the parameter's current contents, view geometry, layout arguments):
@@ -236,7 +283,7 @@ def conv3x3_winograd(x, w, rows_are_out: bool, cout_act: int, wscale=1.0, keep_v
     U = _cached_weight_op(w, ("wino", rows_are_out, cout_act, C, float(wscale), x3), build)
     V = torch.empty((lib.gif_winograd_workspace_floats(B, H, W, C),), device=x.device, dtype=torch.float32)
     out = empty_nhwc(B, cout_act, H, W, x.device)
-    e = _epilogue(**epi)
+    e = _epilogue(out_bchw=(B, cout_act, H, W), **epi)
     fn = lib.gif_conv3x3_winograd_f32x3 if x3 else lib.gif_conv3x3_winograd_f32
     _lib.check(fn(x.data_ptr(), U.data_ptr(), out.data_ptr(), V.data_ptr(), B, H, W, C, cout_act, ctypes.byref(e), _stream()),
                "conv3x3_winograd")
@@ -269,7 +316,7 @@ def conv_fwd(big, w, spec: ConvSpec, wscale=1.0, keep_v=False, **epi):
     wp = pack_weight(w, True, Cs, Cb, wscale, dt, x3=x3)
     out = empty_nhwc(B, Cs, Hs, Ws, big.device, dt)
     g = _geom(B, Hb, Wb, Cb, Hs, Ws, Cs, spec)
-    e = _epilogue(**epi)
+    e = _epilogue(out_bchw=(B, Cs, Hs, Ws), dtype=dt, **epi)
     fn = _lib.load().gif_conv2d_fwd_f32x3 if x3 else _fn("conv2d_fwd", dt)
     _lib.check(fn(big.data_ptr(), wp.data_ptr(), out.data_ptr(), ctypes.byref(g), ctypes.byref(e), _stream()), "conv2d_fwd")
     return out
@@ -290,7 +337,7 @@ def conv_bwd_data(small, w, spec: ConvSpec, big_hw, wscale=1.0, **epi):
     wp = pack_weight(w, False, Cb, Cs, wscale, dt, x3=x3)
     out = empty_nhwc(B, Cb, Hb, Wb, small.device, dt)
     g = _geom(B, Hb, Wb, Cb, Hs, Ws, Cs, spec)
-    e = _epilogue(**epi)
+    e = _epilogue(out_bchw=(B, Cb, Hb, Wb), dtype=dt, **epi)
     fn = _lib.load().gif_conv2d_bwd_data_f32x3 if x3 else _fn("conv2d_bwd_data", dt)
     _lib.check(fn(small.data_ptr(), wp.data_ptr(), out.data_ptr(), ctypes.byref(g), ctypes.byref(e), _stream()), "conv2d_bwd_data")
     return out
@@ -363,7 +410,12 @@ def conv_wgrad(small, big, spec: ConvSpec, O, I, wscale=1.0, small_scale=None, b
     return dw
 
 
-def upfirdn2d(x, k, up, down, pad0, out_hw, flip=True, bias=None, residual=None, act=False, slope=0.2, gain=2 ** 0.5):
+def fir_fusable(C, up, down, kshape, dtype=torch.float32):
+    """The blur kernels (4x4 FIR, up = down = 1) take the mask / column-sum fusions for power-of-two channel counts."""
+    return FUSE_GRAD and dtype == torch.float32 and up == 1 and down == 1 and tuple(kshape) == (4, 4) and C & (C - 1) == 0 and C <= 1024
+
+
+def upfirdn2d(x, k, up, down, pad0, out_hw, flip=True, bias=None, residual=None, act=False, slope=0.2, gain=2 ** 0.5, fuse=None):
     x = nhwc(x)
     B, C, Hi, Wi = x.shape
     Ho, Wo = out_hw
@@ -372,7 +424,7 @@ def upfirdn2d(x, k, up, down, pad0, out_hw, flip=True, bias=None, residual=None,
     if residual is not None:
         _same_dtype(x, residual, "upfirdn2d residual")
     y = empty_nhwc(B, C, Ho, Wo, x.device, x.dtype)
-    e = _epilogue(bias=bias, residual=residual, act=act, slope=slope, gain=gain)
+    e = _epilogue(bias=bias, residual=residual, act=act, slope=slope, gain=gain, fuse=fuse, out_bchw=(B, C, Ho, Wo), dtype=x.dtype)
     _lib.check(_fn("upfirdn2d", x.dtype)(x.data_ptr(), k.data_ptr(), y.data_ptr(), B, Hi, Wi, C, Ho, Wo, up, down, pad0, pad0,
                                          KH, KW, 1 if flip else 0, ctypes.byref(e), _stream()), "upfirdn2d")
     return y

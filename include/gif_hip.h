@@ -61,10 +61,12 @@ int gif_pack_weight_f32x3(const float* w, void* wp3, int R, int C, int KH, int K
  * bary / images [B,H,W,3]: caller-allocated, caller-initialised, updated IN PLACE exactly like the
  * reference (depth=min, tri=face index of the min, bary/colour of that face).  Exact-depth ties are
  * resolved deterministically to the lowest face index (the reference leaves them to a race).
- * Two launches: per-face set-up (front-facing test + clamped bounding box, 8 bytes per face into `workspace`), then one
- * workgroup per (image, 64x64-pixel tile) whose z-buffer stays in LDS from the seeding by the caller's depth buffer to the
- * final write of depth / face / attributes (no global atomics, no key buffer in HBM).  H, W <= 65535.
- * `workspace`: gif_rasterize_workspace_bytes(B, F, H, W) bytes, 8-byte aligned (float32 and float64 entry points alike).
+ * Two kernels (+ a memset of the tile counters): faces are binned into per-(image, 64x64-pixel tile) lists (front-facing test +
+ * clamped bounding box; LDS-aggregated counting, one global atomic per workgroup and touched tile), then one workgroup per tile
+ * keeps the tile's z-buffer in LDS from the seeding by the caller's depth buffer to the final write of depth / face /
+ * attributes (LDS 64-bit atomic-min per covered pixel; no per-pixel global atomic, no key buffer in HBM).
+ * `workspace`: gif_rasterize_workspace_bytes(B, F, H, W) bytes, 8-byte aligned (float32 and float64 entry points alike):
+ * a counter and an F-entry list per tile — sized for the worst case, touched only where faces land (288 GB of HBM).
  * ---------------------------------------------------------------------------------------------- */
 int64_t gif_rasterize_workspace_bytes(int B, int F, int H, int W);
 int gif_rasterize_f32(const float* face_vertices, float* depth, int32_t* tri, float* bary, int B, int F,
@@ -139,7 +141,25 @@ typedef struct {
     const void* residual;   /* same shape AND element type as the output, or NULL (added before the activation) */
     int32_t act;            /* 0: identity, 1: gain * leaky_relu(., slope) */
     float slope, gain;
+    /* ---- ABI 2: gradient-producer fusions (all optional: NULL / 0 = off).  When the op computes a GRADIENT w.r.t. a tensor t
+     * that the forward pass produced with a fused leaky ReLU and / or consumed under a per-sample modulation, the passes that
+     * used to follow — FusedLeakyReLU's backward (stylegan2_common_layers.py:22-39: mask, bias-gradient column sum) and the
+     * modulation gradient of ModulatedConv2d (:311-320: sum_hw g * x) — run in this op's epilogue instead:
+     *   v = contraction;  dot[b,c] += v * dot_src;  v = out_scale * v + residual + bias;  v = act(v);
+     *   v *= mask_gain * (mask_src > 0 ? 1 : mask_slope);  store v;  colsum[c] += v
+     * mask_src / dot_src: tensors of the OUTPUT's shape and element type (they may be the same tensor: it is then read once).
+     * dot [B,Cout] and colsum [Cout] are written (not accumulated), deterministically (per-tile partial sums in red_ws, fixed
+     * order reduction, no atomics).  red_ws: gif_conv_epilogue_ws_floats(B*Ho*Wo, Cout) floats, needed when dot or colsum is
+     * set.  dot needs every sample's output pixels to be a multiple of 256 (a tile never straddles two samples) and a
+     * single-phase op (not the stride-2 data gradient); the FIR kernels support mask_src / colsum only (power-of-two C). */
+    const void* mask_src;
+    float mask_slope, mask_gain;
+    const void* dot_src;
+    float* dot;
+    float* colsum;
+    float* red_ws;
 } gif_conv_epilogue;
+int64_t gif_conv_epilogue_ws_floats(int64_t out_rows, int cout);
 
 /* rows/cols padding (RP, CP) of the packed weight for an op with `cout` output and `cin` input channels */
 int gif_conv2d_pack_dims(int cout, int cin, int* RP, int* CP);

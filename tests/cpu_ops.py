@@ -27,8 +27,11 @@ def _pad_c(x, c):
     return x if x.shape[1] == c else F.pad(x, (0, 0, 0, 0, 0, c - x.shape[1]))
 
 
-def _epilogue(z, cact, in_scale=None, out_scale=None, bias=None, residual=None, act=False, slope=0.2, gain=2 ** 0.5):
+def _epilogue(z, cact, in_scale=None, out_scale=None, bias=None, residual=None, act=False, slope=0.2, gain=2 ** 0.5, fuse=None):
+    """fuse: gif_amd.ops.GradFuse — the gradient-producer fusions of gif_conv_epilogue ABI 2 (include/gif_hip.h)."""
     z = _pad_c(z, cact)
+    if fuse is not None and fuse.dot_src is not None:
+        fuse.dot = (z * fuse.dot_src).sum(dim=(2, 3))  # contraction * dot_src, BEFORE out_scale
     if out_scale is not None:
         z = z * out_scale[:, :, None, None]
     if residual is not None:
@@ -37,6 +40,12 @@ def _epilogue(z, cact, in_scale=None, out_scale=None, bias=None, residual=None, 
         z = z + bias[None, :, None, None]
     if act:
         z = gain * F.leaky_relu(z, slope)
+    if fuse is not None:
+        if fuse.mask_src is not None:
+            m = fuse.mask_src
+            z = z * fuse.mask_gain * torch.where(m > 0, torch.ones_like(m), torch.full_like(m, fuse.mask_slope))
+        if fuse.want_colsum:
+            fuse.colsum = z.sum(dim=(0, 2, 3))
     return z.contiguous(memory_format=CL)
 
 
@@ -74,7 +83,7 @@ def conv_wgrad(small, big, spec, O, I, wscale=1.0, small_scale=None, big_scale=N
     return gw * wscale
 
 
-def upfirdn2d(x, k, up, down, pad0, out_hw, flip=True, bias=None, residual=None, act=False, slope=0.2, gain=2 ** 0.5):
+def upfirdn2d(x, k, up, down, pad0, out_hw, flip=True, bias=None, residual=None, act=False, slope=0.2, gain=2 ** 0.5, fuse=None):
     B, C, H, W = x.shape
     KH, KW = k.shape
     Ho, Wo = out_hw
@@ -85,7 +94,7 @@ def upfirdn2d(x, k, up, down, pad0, out_hw, flip=True, bias=None, residual=None,
     kf = torch.flip(k, [0, 1]) if flip else k
     z = F.conv2d(z, kf.reshape(1, 1, KH, KW), stride=down)
     z = z.reshape(B, C, Ho, Wo)
-    return _epilogue(z, C, bias=bias, residual=residual, act=act, slope=slope, gain=gain)
+    return _epilogue(z, C, bias=bias, residual=residual, act=act, slope=slope, gain=gain, fuse=fuse)
 
 
 def bias_act(x, bias=None, residual=None, slope=0.2, gain=2 ** 0.5):

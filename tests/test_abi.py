@@ -27,12 +27,12 @@ def test_header_symbols_exported_and_bound():
         assert hasattr(lib, n), f"{n} declared in gif_hip.h but not exported by libgif_hip.so"
         assert n in _lib.PROTOTYPES, f"{n} has no ctypes prototype"
     assert sorted(_lib.PROTOTYPES) == names
-    assert lib.gif_abi_version() == 1
+    assert lib.gif_abi_version() == 2
 
 
 def test_argument_validation_without_gpu():
     lib = _lib.load()
-    assert lib.gif_rasterize_workspace_bytes(2, 100, 16, 8) == 2 * 100 * 8  # one packed bounding box per face
+    assert lib.gif_rasterize_workspace_bytes(2, 100, 65, 8) == (2 * 2 + 2 * 2 * 100) * 4  # per (image, 64x64 tile): counter + F-entry list
     rp, cp = ctypes.c_int(), ctypes.c_int()
     assert lib.gif_conv2d_pack_dims(512, 512, ctypes.byref(rp), ctypes.byref(cp)) == 0
     assert (rp.value, cp.value) == (512, 512)

@@ -68,6 +68,65 @@ def test_generator_and_discriminator_first_order_vs_oracle(cpu):
     assert_grads_close(got, ref, gk, tight=1e-4, max_outlier_frac=0.0, what="G grads through D")
 
 
+def test_gradient_epilogue_fusions_equal_the_standalone_passes(cpu, monkeypatch):
+    """The activation ports (leaky-ReLU backward + bias gradient + modulation gradient delivered by the kernel that produces
+    the gradient, functional.ActPort / ops.GradFuse) against the same model with GIF_FUSE_GRAD off: same parameter gradients
+    of G through D, and the fused routes were really taken (the dot-product fusion is forced on: at 16x16 the kernels' tile
+    constraint would route it to the stand-alone pass, the contract restatement has no such constraint)."""
+    from gif_amd import ops
+    torch.manual_seed(0)
+    g, d = _build_g(), _build_d(16)
+    _seeded(g, 1), _seeded(d, 101)
+    gen = torch.Generator().manual_seed(11)
+    cond = torch.rand(4, 6, 16, 16, generator=gen) * 2 - 1
+    idx = torch.tensor([1, 5, 9, 13])
+    params = list(g.parameters()) + list(d.parameters())
+    calls = {"mask": 0, "dot": 0, "colsum": 0, "bias_act_bwd": 0, "mul_reduce": 0}
+    real_fuse = ops.GradFuse
+
+    class CountingFuse(real_fuse):
+        def __init__(self, **kw):
+            super().__init__(**kw)
+            calls["mask"] += self.mask_src is not None
+            calls["dot"] += self.dot_src is not None
+            calls["colsum"] += self.want_colsum
+
+    def counted(name):
+        fn = getattr(ops, name)
+
+        def wrapped(*a, **k):
+            calls[name] += 1
+            return fn(*a, **k)
+        return wrapped
+
+    monkeypatch.setattr(ops, "GradFuse", CountingFuse)
+    monkeypatch.setattr(ops, "bias_act_bwd", counted("bias_act_bwd"))
+    monkeypatch.setattr(ops, "mul_reduce", counted("mul_reduce"))
+
+    def grads(fused):
+        monkeypatch.setattr(ops, "FUSE_GRAD", fused)
+        monkeypatch.setattr(ops, "dot_fusable", (lambda H, W, dtype=torch.float32: True) if fused else (lambda H, W, dtype=torch.float32: False))
+        for k in calls:
+            calls[k] = 0
+        fake = g(cond, None, step=2, alpha=1, input_indices=idx)
+        loss = F.softplus(-d(fake, condition=cond)[0]).mean()
+        out = torch.autograd.grad(loss, params, allow_unused=True)
+        return out, dict(calls)
+
+    ref, c0 = grads(False)
+    got, c1 = grads(True)
+    assert c0["mask"] == 0 and c0["dot"] == 0 and c0["bias_act_bwd"] > 10 and c0["mul_reduce"] > 8
+    assert c1["mask"] > 10 and c1["dot"] >= 8 and c1["colsum"] > 5, c1
+    assert c1["bias_act_bwd"] < c0["bias_act_bwd"] // 2, (c0, c1)
+    n = 0
+    for a, b, (k, _) in zip(got, ref, list(g.named_parameters()) + list(d.named_parameters())):
+        assert (a is None) == (b is None), k
+        if b is not None:
+            assert_close(a, b, 2e-5, k)
+            n += 1
+    assert n > 80
+
+
 def test_r1_double_backward_vs_oracle(cpu):
     from gif_amd import losses
     torch.manual_seed(0)

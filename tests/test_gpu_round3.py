@@ -1,4 +1,4 @@
-"""-m gpu, round 3: the re-distributed rasteriser (lane / wave / queued-tile face classes), the gradient-producer epilogue
+"""-m gpu, round 3: the LDS-tile rasteriser (lane / wave work classes), the gradient-producer epilogue
 fusions (leaky-ReLU backward, bias gradient and modulation gradient inside the kernel that produces the gradient), and the
 adversarial accuracy cases of the bf16x3 contraction mode."""
 import os
@@ -24,7 +24,7 @@ def _need_gpu():
 
 # ------------------------------------------------------------------------------------------------ rasteriser work classes
 def _mixed_mesh(batch, seed):
-    """body.obj + screen-filling back-drop faces (queued class) + random medium faces (wave class) per image."""
+    """body.obj + screen-filling back-drop faces (every tile, wave class) + random medium faces (wave class) per image."""
     from tools.raster_bench import body_mesh, random_medium, with_backdrop
     v, f = with_backdrop(*body_mesh(batch, seed), n_big=4)
     mv, mf = random_medium(batch, nfaces=400, size=0.2, seed=seed + 1)
@@ -41,7 +41,7 @@ def test_rasterize_all_face_classes_bit_exact(dtype):
     fv = ro.face_vertices(ro.to_image_space(v, H, W), f).astype(dtype)
     bb = (np.floor(fv[..., 0].max(-1)).clip(0, W - 1) - np.ceil(fv[..., 0].min(-1)).clip(0, W - 1) + 1).clip(0) * \
          (np.floor(fv[..., 1].max(-1)).clip(0, H - 1) - np.ceil(fv[..., 1].min(-1)).clip(0, H - 1) + 1).clip(0)
-    assert (bb <= 16).sum() > 1000 and ((bb > 16) & (bb <= 4096)).sum() > 300 and (bb > 4096).sum() >= 4 * B, "all three classes present"
+    assert (bb <= 16).sum() > 1000 and ((bb > 16) & (bb <= 4096)).sum() > 300 and (bb > 4096).sum() >= 4 * B, "small, medium and screen-filling boxes present"
     d0 = np.zeros((B, H, W), dtype) + dtype(1e6)
     t0 = np.zeros((B, H, W), np.int32) - 1
     b0 = np.zeros((B, H, W, 3), dtype)
@@ -60,15 +60,15 @@ def test_rasterize_all_face_classes_bit_exact(dtype):
     assert (t0 >= 0).mean() > 0.9  # the back-drop covers the image
 
 
-def test_rasterize_big_face_queue_overflow():
-    """More queued-class faces than the queue holds (capacity max(1024, B*H*W/64)): the surplus is walked by its wave instead —
-    same pixels, same bits."""
+def test_rasterize_many_large_faces():
+    """1500 overlapping faces that each cover most of the image: every tile's candidate list is (almost) the whole chunk and every
+    face is walked by a wave — same pixels, same bits, exact-depth ties to the lowest index."""
     from gif_amd import standard_rasterize as sr
     from oracle import rasterize_oracle as ro
     B, H, W, F = 1, 128, 128, 1500
     rng = np.random.RandomState(3)
     c = rng.uniform(40, 88, (B, F, 1, 2)).astype(np.float32)
-    ang = rng.uniform(0, 2 * np.pi, (B, F, 1)).astype(np.float32) + np.array([0, 2.1, 4.2], np.float32)
+    ang = rng.uniform(0, 2 * np.pi, (B, F, 1)).astype(np.float32) + rng.choice([-1.0, 1.0], (B, F, 1)).astype(np.float32) * np.array([0, 2.1, 4.2], np.float32)  # both windings
     xy = c + 60 * np.stack([np.cos(ang), np.sin(ang)], -1).astype(np.float32)
     z = rng.uniform(1, 3, (B, F, 3, 1)).astype(np.float32)
     fv = np.ascontiguousarray(np.concatenate([xy, z], -1))
@@ -80,3 +80,170 @@ def test_rasterize_big_face_queue_overflow():
     assert np.array_equal(t1.cpu().numpy(), t0)
     assert np.array_equal(d1.cpu().numpy().view(np.int32), d0.view(np.int32))
     assert np.array_equal(b1.cpu().numpy().view(np.int32), b0.view(np.int32))
+
+
+# ------------------------------------------------------------------------------------------------ gradient-producer epilogue fusions
+def _cl(t):
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+def _check_fused(out_f, fuse, plain, x_dot, s_out, residual, mask_src, slope, gain, what):
+    """out_f / fuse.dot / fuse.colsum of a fused launch against float64 math on the PLAIN launch's output (same kernels, no
+    fusion): v = plain; dot = sum_hw v * x; v = s * v + residual; v *= gain * (mask > 0 ? 1 : slope); colsum = sum v."""
+    v = plain.double()
+    if fuse.dot_src is not None:
+        dot = (v * x_dot.double()).sum(dim=(2, 3))
+        e = ((fuse.dot.double() - dot).abs().max() / dot.abs().max()).item()
+        assert e < 2e-5, f"{what}: dot rel err {e:.2e}"
+    if s_out is not None:
+        v = v * s_out.double()[:, :, None, None]
+    if residual is not None:
+        v = v + residual.double()
+    if mask_src is not None:
+        v = v * gain * torch.where(mask_src > 0, 1.0, slope).double()
+    e = ((out_f.double() - v).abs().max() / v.abs().max()).item()
+    assert e < 2e-6, f"{what}: output rel err {e:.2e}"
+    if fuse.want_colsum:
+        cs = v.sum(dim=(0, 2, 3))
+        e = ((fuse.colsum.double() - cs).abs().max() / cs.abs().max()).item()
+        assert e < 2e-5, f"{what}: colsum rel err {e:.2e}"
+
+
+# (B, C_small, C_big, K, stride, pad, H_big, op, winograd, mode)   op: "dgrad" = conv_bwd_data small -> big, "fwd" = conv_fwd big -> small
+FUSE_CASES = [
+    (8, 128, 128, 3, 1, 1, 64, "dgrad", True, "bf16x3"),    # Winograd bf16x3 GEMM epilogue (8192 tiles)
+    (8, 128, 128, 3, 1, 1, 64, "dgrad", True, "native"),    # Winograd native GEMM epilogue
+    (8, 64, 64, 3, 1, 1, 64, "dgrad", True, "bf16x3"),      # Winograd, 64 output channels: native GEMM, narrow N tile
+    (8, 128, 128, 3, 1, 1, 128, "dgrad", False, "bf16x3"),  # direct 256x128 tiles (8 waves)
+    (4, 256, 256, 3, 1, 1, 32, "dgrad", False, "bf16x3"),   # direct, 64x64 tiles
+    (32, 512, 512, 3, 1, 1, 32, "dgrad", False, "bf16x3"),  # direct, 128x64 tiles of the low-resolution layers
+    (8, 128, 128, 3, 1, 1, 64, "dgrad", False, "native"),   # direct native fp32 MFMA, 128x128 tiles
+    (4, 128, 24, 3, 1, 1, 64, "dgrad", False, "bf16x3"),    # 256x32 tiles (<= 32 output channels)
+    (4, 4, 128, 1, 1, 0, 64, "dgrad", False, "bf16x3"),     # ToRGB's data gradient: 4 contraction channels, register-staged kernel
+    (4, 128, 64, 3, 2, 0, 65, "fwd", False, "bf16x3"),      # stride-2 forward conv = data gradient of the up-sampling conv_transpose
+    (4, 128, 64, 3, 2, 0, 65, "dgrad", False, "bf16x3"),    # transposed stride 2: four phases (mask + colsum only)
+    (4, 512, 512, 3, 2, 0, 9, "dgrad", False, "bf16x3"),    # transposed stride 2, phases merged into one launch
+    (32, 256, 128, 3, 2, 0, 129, "dgrad", False, "bf16x3"), # transposed stride 2, bulk + remainder launches per phase
+]
+
+
+@pytest.mark.parametrize("case", FUSE_CASES)
+def test_grad_fuse_conv_epilogues(case, monkeypatch):
+    from gif_amd import ops
+    B, Cs, Cb, K, st, pad, Hb, op, wino, mode = case
+    monkeypatch.setattr(ops, "WINOGRAD", wino)
+    prev = ops.get_fp32_mfma_mode()
+    ops.set_fp32_mfma_mode(mode)
+    try:
+        g = torch.Generator().manual_seed(Hb + Cs)
+        spec = ops.ConvSpec(K, K, st, pad)
+        Hs = spec.small_hw(Hb, Hb)[0]
+        w = (torch.randn(Cs, Cb, K, K, generator=g) / (Cb * K * K) ** 0.5).cuda()
+        if op == "dgrad":
+            Cin, Cout, Hin, Hout = Cs, Cb, Hs, Hb
+            run = lambda src, **epi: ops.conv_bwd_data(src, w, spec, (Hb, Hb), **epi)  # noqa: E731
+        else:
+            Cin, Cout, Hin, Hout = Cb, Cs, Hb, Hs
+            run = lambda src, **epi: ops.conv_fwd(src, w, spec, **epi)  # noqa: E731
+        src = _cl(torch.randn(B, Cin, Hin, Hin, generator=g).cuda())
+        x = _cl(torch.randn(B, Cout, Hout, Hout, generator=g).cuda())  # the tensor the gradient belongs to (activation output)
+        res = _cl(torch.randn(B, Cout, Hout, Hout, generator=g).cuda())
+        d_in = (torch.rand(B, Cin, generator=g) + 0.5).cuda()
+        s_out = (torch.rand(B, Cout, generator=g) + 0.5).cuda()
+        single = not (op == "dgrad" and st == 2)
+        can_dot = single and (Hout * Hout) % 1024 == 0
+        plain = run(src, in_scale=d_in)
+        if wino and op == "dgrad":
+            n0 = ops.prof_winograd_calls()
+        # (a) everything at once: modulation output scale, dot product, mask, column sums, residual
+        fuse = ops.GradFuse(mask_src=x, mask_slope=0.2, mask_gain=2 ** 0.5, want_colsum=True, dot_src=x if can_dot else None)
+        out = run(src, in_scale=d_in, out_scale=s_out, residual=res, fuse=fuse)
+        if wino and op == "dgrad":
+            assert ops.prof_winograd_calls() > n0, "the Winograd path was expected to run"
+        _check_fused(out, fuse, plain, x, s_out, res, x, 0.2, 2 ** 0.5, f"{case} all")
+        # (b) mask only, no sums (the discriminator in the G step: no bias gradient wanted); ReLU-style slope 0
+        fuse = ops.GradFuse(mask_src=x, mask_slope=0.0, mask_gain=1.0)
+        out = run(src, in_scale=d_in, fuse=fuse)
+        _check_fused(out, fuse, plain, None, None, None, x, 0.0, 1.0, f"{case} mask")
+        # (c) dot only, different tensor than the mask
+        if can_dot:
+            other = _cl(torch.randn(B, Cout, Hout, Hout, generator=g).cuda())
+            fuse = ops.GradFuse(dot_src=other)
+            out = run(src, in_scale=d_in, out_scale=s_out, fuse=fuse)
+            _check_fused(out, fuse, plain, other, s_out, None, None, 1.0, 1.0, f"{case} dot")
+            # determinism of the partial-sum reduction
+            fuse2 = ops.GradFuse(dot_src=other)
+            run(src, in_scale=d_in, out_scale=s_out, fuse=fuse2)
+            assert torch.equal(fuse.dot, fuse2.dot)
+        else:
+            with pytest.raises(Exception, match="dot fusion"):
+                run(src, in_scale=d_in, fuse=ops.GradFuse(dot_src=x))
+    finally:
+        ops.set_fp32_mfma_mode(prev)
+
+
+@pytest.mark.parametrize("shape", [(16, 128, 129), (4, 256, 33), (2, 512, 9), (3, 64, 40)])
+def test_grad_fuse_blur_adjoint(shape):
+    """The blur's adjoint (the gradient w.r.t. ConvLayer conv1's activated output inside a ResBlock) with the leaky-ReLU mask and
+    the bias-gradient column sums in the FIR kernels' epilogue (sliding-window kernel at the first shape, tiled kernel below)."""
+    from gif_amd import ops
+    B, C, H = shape
+    g = torch.Generator().manual_seed(H)
+    k1 = torch.tensor([1., 3., 3., 1.])
+    k = (k1[:, None] * k1[None, :] / 64).cuda()
+    gy = _cl(torch.randn(B, C, H, H, generator=g).cuda())      # gradient w.r.t. the blurred map (pad (2,2): H = Hin + 1)
+    y = _cl(torch.randn(B, C, H - 1, H - 1, generator=g).cuda())  # conv1's activated output
+    plain = ops.upfirdn2d(gy, k, 1, 1, 1, (H - 1, H - 1), False)
+    fuse = ops.GradFuse(mask_src=y, mask_slope=0.2, mask_gain=2 ** 0.5, want_colsum=True)
+    out = ops.upfirdn2d(gy, k, 1, 1, 1, (H - 1, H - 1), False, fuse=fuse)
+    _check_fused(out, fuse, plain, None, None, None, y, 0.2, 2 ** 0.5, f"blur adjoint {shape}")
+    fuse = ops.GradFuse(mask_src=y, mask_slope=0.2, mask_gain=2 ** 0.5)
+    out = ops.upfirdn2d(gy, k, 1, 1, 1, (H - 1, H - 1), False, fuse=fuse)
+    _check_fused(out, fuse, plain, None, None, None, y, 0.2, 2 ** 0.5, f"blur adjoint {shape} mask only")
+
+
+@pytest.mark.parametrize("res,step", [(32, 3), (64, 4)])
+def test_model_gradients_fused_equal_standalone(res, step, monkeypatch):
+    """Whole G-through-D and D gradients with the activation ports on (default) against GIF_FUSE_GRAD off — the same kernels
+    minus the stand-alone passes: agreement at accumulation-order level, and the stand-alone passes really disappear."""
+    import contextlib
+    import io
+    from gif_amd import ops
+    from gif_amd.discriminator import Discriminator
+    from gif_amd.generator import StyledGenerator
+    import torch.nn.functional as F
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        G = StyledGenerator(embedding_vocab_size=16, rendered_flame_ascondition=True, normal_maps_as_cond=True).cuda()
+        D = Discriminator(size=res, num_color_chnls=9).cuda()
+    B = 8
+    cond = (torch.rand(B, 6, res, res) * 2 - 1).cuda()
+    real = (torch.rand(B, 3, res, res) * 2 - 1).cuda()
+    idx = torch.randint(0, 16, (B,)).cuda()
+    gp = [p for n, p in G.named_parameters() if not any(f"progression.{i}." in n or f"to_rgb.{i}." in n for i in range(step + 1, 9))]
+    dp = list(D.parameters())
+    calls = {"bias_act_bwd": 0, "mul_reduce": 0}
+    for name in calls:
+        fn = getattr(ops, name)
+        monkeypatch.setattr(ops, name, (lambda f, n: (lambda *a, **k: (calls.__setitem__(n, calls[n] + 1), f(*a, **k))[1]))(fn, name))
+
+    def run(fused):
+        monkeypatch.setattr(ops, "FUSE_GRAD", fused)
+        for n in calls:
+            calls[n] = 0
+        fake = G(cond, None, step=step, alpha=1, input_indices=idx)
+        lg = F.softplus(-D(fake, condition=cond, step=step, alpha=1)[0]).mean()
+        gg = torch.autograd.grad(lg, gp, allow_unused=True)
+        ld = F.softplus(-D([real], condition=cond, step=step, alpha=1)[0]).mean() + F.softplus(D([fake[0].detach()], condition=cond, step=step, alpha=1)[0]).mean()
+        gd = torch.autograd.grad(ld, dp)
+        return gg, gd, dict(calls)
+
+    gg0, gd0, c0 = run(False)
+    gg1, gd1, c1 = run(True)
+    assert c1["bias_act_bwd"] < c0["bias_act_bwd"] // 2 and c1["mul_reduce"] < c0["mul_reduce"], (c0, c1)
+    worst = 0.0
+    for a, b in list(zip(gg1, gg0)) + list(zip(gd1, gd0)):
+        assert (a is None) == (b is None)
+        if b is not None:
+            worst = max(worst, ((a - b).abs().max() / (b.abs().max() + 1e-20)).item())
+    assert worst < 5e-5, worst
