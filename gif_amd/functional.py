@@ -182,7 +182,10 @@ class ConvBiasActFn(Function):
         ctx.cfg = (spec, wscale, slope, gain, bias is not None)
         ctx.in_port, ctx.parts = in_port, parts
         ctx.save_for_backward(x, w, y)
-        return y, y.view_as(y), (x.view_as(x) if passthrough else None)
+        # the port alias is y.detach(), NOT a view of y: a view keeps its base alive, and y's Python object (kept alive by the
+        # C++ tensor once it carries the _gif_port attribute) references the alias through the port — with a view that is a
+        # reference cycle through C++ that no collector sees, and every iteration's graph would leak (tests/test_cpu_wiring.py)
+        return y, y.detach(), (x.view_as(x) if passthrough else None)
 
     @staticmethod
     def backward(ctx, gy, g_port=None, g_alias=None):
@@ -436,7 +439,7 @@ class BlurBiasActFn(Function):
         ctx.cfg = (pad0, tuple(x.shape[2:]), slope, gain, residual is not None, bias is not None)
         ctx.parts = parts
         ctx.save_for_backward(k, y)
-        return y, y.view_as(y)
+        return y, y.detach()  # (not a view of y: see ConvBiasActFn.forward)
 
     @staticmethod
     def backward(ctx, gy, g_port=None):
@@ -701,7 +704,7 @@ class ModConvActFn(Function):
         z = x.new_empty(())  # placeholder for absent tensors (never read): no fill kernel
         x_in, s_in, d_in, r_in = saved_in
         ctx.save_for_backward(x_in, w, s_in, d_in, y, r_in if residual is not None else z, bias if bias is not None else z)
-        return y, y.view_as(y)
+        return y, y.detach()  # (not a view of y: see ConvBiasActFn.forward)
 
     @staticmethod
     def backward(ctx, gy, g_port=None):

@@ -127,6 +127,33 @@ def test_gradient_epilogue_fusions_equal_the_standalone_passes(cpu, monkeypatch)
     assert n > 80
 
 
+def test_activation_ports_do_not_leak_the_graph(cpu):
+    """The port protocol hangs Python attributes on activation tensors; a reference cycle through them would keep every
+    iteration's activations alive (found on the GPU as an out-of-memory after a few steps).  The number of live tensors must
+    not grow from one iteration to the next — with the cyclic garbage collector off."""
+    import gc
+    torch.manual_seed(0)
+    g, d = _build_g(), _build_d(16)
+    cond = torch.rand(2, 6, 16, 16) * 2 - 1
+    idx = torch.tensor([1, 5])
+
+    def live():
+        return sum(1 for o in gc.get_objects() if isinstance(o, torch.Tensor))
+
+    gc.collect()
+    gc.disable()
+    try:
+        counts = []
+        for _ in range(3):
+            fake = g(cond, None, step=2, alpha=1, input_indices=idx)
+            F.softplus(-d(fake, condition=cond)[0]).mean().backward()
+            del fake
+            counts.append(live())
+    finally:
+        gc.enable()
+    assert counts[1] == counts[2], counts
+
+
 def test_r1_double_backward_vs_oracle(cpu):
     from gif_amd import losses
     torch.manual_seed(0)
