@@ -31,7 +31,22 @@ import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_f16 dense peak (not the 2:1-sparse figure)
+PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s is what a float4 copy reaches)
 PMC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # written by tools/pmc_to_json.py from rocprofv3 --pmc passes
+
+
+def kernel_source_digest():
+    """sha1 over the kernel sources (gif_amd/csrc/*.hip, *.h, include/*.h): what profiles/pmc_traffic.json was measured on vs what
+    this run executes (the GPU box has no .git, so a commit hash cannot be compared there)."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    for path in sorted(glob.glob(os.path.join(ROOT, "gif_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "gif_amd", "csrc", "*.h"))
+                       + glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def parse():
@@ -58,6 +73,10 @@ def parse():
     ap.add_argument("--cpu-timeout", type=int, default=240)
     ap.add_argument("--cpu-baseline-worker", type=str, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--no-prof", action="store_true", help="skip per-kernel HIP-event timing")
+    ap.add_argument("--no-overlap-comm", action="store_true", help="complete each gradient exchange + optimiser step in place "
+                    "(default with > 1 rank: deferred to where the network is next used)")
+    ap.add_argument("--check-replicas", action="store_true",
+                    help="after the run: sha1 of every rank's G / D / G_ema parameters -> `param_digest`, `replicas_identical`")
     return ap.parse_args()
 
 
@@ -91,7 +110,8 @@ def cpu_baseline_worker(res, step_idx, batch, threads):
     """Runs in a child process: oracle ("port") timed on the host cores — full G+D training iterations at the benchmark
     resolution on a small batch (batch 32 needs ~80 GB of activations on the CPU): a plain iteration and an R1 iteration,
     weighted 15:1 like the benchmark's R1-every-16th schedule.  Bounded: the R1 iteration is only run when the plain one
-    took < 60 s; otherwise its cost is extrapolated with the 45.2 s / 32.6 s ratio measured in BASELINE.md §3."""
+    took < 60 s; otherwise the value is the PLAIN-iteration rate alone and `kind` says so ("port, plain iterations only": an upper
+    bound of the CPU rate, nothing is extrapolated)."""
     threads, calib = _pick_threads(threads)
     torch.set_num_threads(threads)
     from oracle import stylegan2_ref as R
@@ -115,15 +135,18 @@ def cpu_baseline_worker(res, step_idx, batch, threads):
         tr.step(1, real, cond, idx)  # i = 1: R1 iteration (r1_every = 2 here)
         t_r1 = time.time() - t0
         r1_note = f"R1 iteration {t_r1:.1f} s"
+        kind = "port"
+        per_step = (15 * t_plain + t_r1) / 16
     else:
-        t_r1 = t_plain * 45.2 / 32.6
-        r1_note = f"R1 iteration extrapolated x45.2/32.6 = {t_r1:.1f} s (BASELINE.md §3)"
-    per_step = (15 * t_plain + t_r1) / 16
-    print(json.dumps({"value": batch / per_step, "unit": "images/s", "cores": threads, "kind": "port",
+        t_r1 = None
+        r1_note = "R1 iteration not run (plain iteration took >= 60 s): value = plain-iteration rate, an upper bound"
+        kind = "port, plain iterations only"
+        per_step = t_plain
+    print(json.dumps({"value": batch / per_step, "unit": "images/s", "cores": threads, "kind": kind,
                       "sample": f"full G+D train steps at {res}x{res}, batch {batch}, oracle/train_ref.py (torch CPU fp32, "
                                 f"{threads} threads of {os.cpu_count()} host cores"
                                 + (f", fastest of a thread-count probe {calib}" if calib else "")
-                                + f"): plain {t_plain:.1f} s, {r1_note}; value = batch / ((15*plain + R1)/16)",
+                                + f"): plain {t_plain:.1f} s, {r1_note}; value = batch / ((15*plain + R1)/16) when both ran",
                       "plain_step_s": t_plain, "r1_step_s": t_r1}))
 
 
@@ -189,39 +212,58 @@ def load_pmc():
         return None
 
 
-def roofline_objects(ops, steps, wall_s):
-    """Per-family HIP-event timings -> the `roofline` object of the dominant kernel + one object per other MFMA family.
+def family_ceiling(fam, exec_frac, mfma_peak):
+    """(TFLOP/s ceiling of the ALGORITHMIC rate, its name): the dense peak of the MFMA type the family feeds, divided by the MFMA
+    FLOPs it executes per algorithmic (direct-convolution, fp32) FLOP."""
+    if fam in (8, 9):
+        return mfma_peak / exec_frac, "bf16x3 fp32-exact = 2500 / 6 (six bf16 MFMA products per fp32 product, bf16 dense peak 2500 TFLOP/s)"
+    if fam in (10, 11):
+        return mfma_peak / exec_frac, "Winograd on bf16x3 = 2500 / (6 * 16/36) (F(2x2,3x3) executes 16/36 of the products, each as six bf16 MFMA products)"
+    if fam in (2, 3):
+        return mfma_peak / exec_frac, "Winograd on fp32 MFMA = 157.3 / (16/36)"
+    if fam in (6, 7):
+        return mfma_peak, "f16 MFMA dense peak 2500 TFLOP/s"
+    return mfma_peak, "fp32-input MFMA dense peak 157.3 TFLOP/s"
 
-    `achieved` is what the MFMA pipe actually executed per second (<= peak); for the Winograd GEMMs the ALGORITHMIC
-    (direct-convolution) rate, which is 36/16 of that, is reported next to it as `algorithmic_achieved`."""
+
+def roofline_objects(ops, steps, wall_s):
+    """Per-family HIP-event timings -> the `roofline` object of the dominant kernel family + one object per other MFMA family.
+
+    SURVEY §8(d): `achieved` = ALGORITHMIC FLOPs (direct-convolution count, fp32) per launch / average launch duration; `peak` =
+    the named ceiling of that algorithmic rate (`ceiling`: the dense MFMA peak of the type the kernels feed divided by the MFMA
+    FLOPs executed per algorithmic FLOP); `frac` = achieved / peak.  The raw matrix-pipe view is next to it: `executed_achieved`
+    (MFMA FLOP/s actually issued), `executed_peak` (data-sheet dense peak of that MFMA type), `executed_frac` — numerically the
+    same ratio — and `frac_of_mfma_type_peak` = algorithmic rate / that data-sheet peak (what the fp32 workload gets out of a bf16
+    pipe that is 16x faster than the fp32 one)."""
     pmc = load_pmc()
+    digest = kernel_source_digest()
     objs, executed_flops, executed_peak_s, mfma_ms = {}, 0.0, 0.0, 0.0
     for fam, (name, exec_frac, pmc_key) in FAMILIES.items():
         ms, fl, n = ops.prof_read(fam)
         if n == 0 or ms <= 0:
             continue
-        peak = FAMILY_PEAK.get(fam, PEAK_F32_MFMA_TFLOPS)
+        mfma_peak = FAMILY_PEAK.get(fam, PEAK_F32_MFMA_TFLOPS)
         executed_flops += fl * exec_frac
-        executed_peak_s += fl * exec_frac / (peak * 1e12)  # seconds this work takes at the peak of the MFMA type it ran on
+        executed_peak_s += fl * exec_frac / (mfma_peak * 1e12)  # seconds this work takes at the peak of the MFMA type it ran on
         mfma_ms += ms
         alg = fl / (ms * 1e-3) / 1e12
-        o = {"bound": "mfma", "kernel": name, "achieved": alg * exec_frac, "peak": peak, "unit": "TFLOP/s",
-             "frac": alg * exec_frac / peak, "traffic": None, "launches": n, "avg_ms": ms / n,
+        ceiling, ceiling_name = family_ceiling(fam, exec_frac, mfma_peak)
+        o = {"bound": "mfma", "kernel": name, "achieved": alg, "peak": ceiling, "unit": "TFLOP/s", "frac": alg / ceiling,
+             "ceiling": ceiling_name, "executed_achieved": alg * exec_frac, "executed_peak": mfma_peak,
+             "executed_frac": alg * exec_frac / mfma_peak, "frac_of_mfma_type_peak": alg / mfma_peak,
+             "executed_mfma_flop_per_algorithmic_flop": exec_frac, "traffic": None, "launches": n, "avg_ms": ms / n,
              "gpu_ms_per_step": ms / steps, "algorithmic_flop_per_launch": fl / n}
-        if exec_frac != 1.0:
-            o["algorithmic_achieved"] = alg
-            o["algorithmic_frac"] = alg / peak
-            o["note"] = (f"achieved = executed bf16 MFMA FLOP/s ({exec_frac:.3g}x the algorithmic fp32 direct-convolution FLOPs: 6 bf16 "
-                         "products per fp32 product" + (", 16/36 of the products with Winograd" if exec_frac != 6 else "")
-                         + "), priced at the 2.5 PFLOP/s bf16 peak" if exec_frac > 1 else "achieved = executed MFMA FLOP/s (16/36 of the algorithmic direct-convolution FLOPs)")
         fam_pmc = (pmc or {}).get("families", {}).get(pmc_key)
         if fam_pmc:
             o["traffic"] = fam_pmc["hbm_bytes_per_launch"]
+            stale = pmc.get("kernel_source_digest") != digest
             o["traffic_source"] = {"file": "profiles/pmc_traffic.json", "kernels": fam_pmc.get("kernels"),
                                    "launches_profiled": fam_pmc.get("launches"), "commit": pmc.get("commit"),
-                                   "command": pmc.get("command"),
+                                   "kernel_source_digest": pmc.get("kernel_source_digest"), "this_run_digest": digest,
+                                   "stale": stale, "command": pmc.get("command"),
                                    "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (2*FETCH + WRITE, gfx950 correction), "
-                                           "family average over one profiled training iteration"}
+                                           "family average over one profiled training iteration"
+                                           + ("; STALE: the kernel sources changed since it was measured" if stale else "")}
         objs[fam] = o
     out = {}
     if objs:
@@ -232,11 +274,12 @@ def roofline_objects(ops, steps, wall_s):
     ms, by, n = ops.prof_read(4)
     if n:
         o = {"bound": "hbm", "kernel": "wino_input_transform / wino_gy_transform", "achieved": by / (ms * 1e-3) / 1e9,
-             "peak": 8000.0, "unit": "GB/s", "frac": by / (ms * 1e-3) / 1e9 / 8000.0, "traffic": None, "launches": n,
+             "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": by / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None, "launches": n,
              "avg_ms": ms / n, "gpu_ms_per_step": ms / steps}
         fam_pmc = (pmc or {}).get("families", {}).get("wino_transforms")
         if fam_pmc:
             o["traffic"] = fam_pmc["hbm_bytes_per_launch"]
+            o["traffic_stale"] = pmc.get("kernel_source_digest") != digest
         out["roofline_winograd_transforms"] = o
     # what the MFMA pipe really did over the WALL time of the timed region (Winograd's skipped multiplies not counted)
     out["executed_mfma_frac_wall"] = {
@@ -249,6 +292,37 @@ def roofline_objects(ops, steps, wall_s):
                 "at the dense peak of the MFMA type it ran on (fp32 157.3 TF, f16 / bf16 2500 TF; bf16x3: 6 executed per algorithmic): time at peak / wall time of the "
                 "timed region"}
     return out
+
+
+def rasterize_roofline(batch, dev):
+    """`roofline_rasterize`: gif_rasterize_f32 (gif_amd/csrc/rasterize.hip) on the reference's own test mesh (body.obj, one random
+    yaw per image) at 256x256 — SURVEY §8(d): triangles/s, covered pixels/s and the algorithmic bytes (36 F + 20 H W) B per
+    call against HBM peak — timed OUTSIDE the training-step region (HIP-graph replays, so that the figure is GPU time and not
+    Python launch overhead), with the C oracle (oracle/rasterize_ref.c, ONE host thread) on the same meshes as its CPU baseline."""
+    from tools import raster_bench as rb
+    res = 256
+    v, f = rb.body_mesh(batch)
+    fv_np = rb.face_vertices_np(v, f, res)
+    fv = torch.from_numpy(fv_np).to(dev)
+    ms, out = rb.time_hip(fv, res)
+    F_ = f.shape[1]
+    covered = int((out[1] >= 0).sum())
+    alg_bytes = (36.0 * F_ + 20.0 * res * res) * batch
+    o = {"bound": "hbm", "kernel": "raster_bin + raster_tiles (LDS-resident 64x64-pixel z-buffer tiles)", "achieved": alg_bytes / ms / 1e6,
+         "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": alg_bytes / ms / 1e6 / PEAK_HBM_GBS, "traffic": None, "avg_ms": ms,
+         "workload": f"body.obj (F = {F_} faces) x {batch} images at {res}x{res}", "Mtri_per_s": batch * F_ / ms / 1e3,
+         "covered_Mpix_per_s": covered / ms / 1e3, "covered_frac": covered / (batch * res * res),
+         "algorithmic_bytes_per_call": alg_bytes,
+         "note": "latency / launch bound at this size (a call is ~16 MB of faces + 8 MB of depth): frac of HBM peak is reported as "
+                 "SURVEY §8(d) asks, the absolute time is what matters (bit-exact vs the C oracle: tests/test_gpu_kernels.py)"}
+    try:
+        s_img, n_img, _ = rb.time_oracle(fv_np, res)
+        o["cpu_baseline"] = {"value": F_ / s_img / 1e6, "unit": "Mtri/s", "cores": 1, "kind": "port",
+                             "sample": f"oracle/rasterize_ref.c on the first {n_img} images of the same batch: {s_img * 1e3:.2f} ms per image",
+                             "gpu_over_one_cpu_thread": (s_img * 1e3) / (ms / batch)}
+    except Exception as e:  # the oracle .so is test infrastructure: never block the GPU numbers
+        o["cpu_baseline"] = {"value": None, "unit": "Mtri/s", "cores": 1, "kind": "port", "sample": f"oracle not available ({type(e).__name__})"}
+    return o
 
 
 class MeshConditions:
@@ -314,7 +388,8 @@ def main():
     G_ema.load_state_dict(G.state_dict())
     G, G_ema, D = G.to(dev), G_ema.to(dev), D.to(dev)
     trainer = GifTrainer(G, D, G_ema, step=res_step, alpha=1.0, r1_every=args.r1_every, gen_reg_type=args.gen_reg,
-                         act_dtype=torch.float16 if args.dtype == "f16" else None)
+                         act_dtype=torch.float16 if args.dtype == "f16" else None,
+                         overlap_comm=False if args.no_overlap_comm else None)
 
     from gif_amd.data import SyntheticBatches
     B = args.batch
@@ -341,6 +416,8 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    for bk in (trainer.g_bucket, trainer.d_bucket):
+        bk.comm_events = []  # (start, end) event pairs around every wait for an exchange: exposed communication time
     data = [batch() for _ in range(min(args.steps, 4))]  # synthetic batches resident in HBM before the timed region
     if not args.no_prof:
         for fam in range(12):
@@ -356,10 +433,26 @@ def main():
     dt = time.perf_counter() - t0
     ops.prof_enable(False)
 
-    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    comm_ms = sum(e0.elapsed_time(e1) for bk in (trainer.g_bucket, trainer.d_bucket) for e0, e1 in bk.comm_events)
+    t = torch.tensor([dt, comm_ms], device=dev, dtype=torch.float64)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = t.item()
+    dt, comm_ms = t[0].item(), t[1].item()
+
+    replicas = None
+    if args.check_replicas:
+        import hashlib
+        h = hashlib.sha1()
+        for m in (G, D, G_ema):
+            for p in m.parameters():
+                h.update(p.detach().cpu().numpy().tobytes())
+        mine = h.hexdigest()
+        allr = [mine]
+        if use_dist:
+            allr = [None] * world
+            dist.all_gather_object(allr, mine)
+        replicas = {"param_digest": allr[0], "replicas_identical": len(set(allr)) == 1, "ranks": len(allr),
+                    "backend": dist.get_backend() if use_dist else None}
 
     if rank == 0:
         imgs = world * B * args.steps
@@ -374,7 +467,8 @@ def main():
                        "(BASELINE configs[4])" if f16 else
                        "fp32 tensors and fp32 accumulation; contractions on "
                        + ("the bf16 matrix cores via the exact 3-way bf16 split (bf16x3: 6 products per fp32 product, error vs fp64 <= "
-                          "the native fp32 MFMA path); Winograd fwd/dgrad GEMMs and the < 32-channel layers on native fp32 MFMA"
+                          "the native fp32 MFMA path) for every direct, weight-gradient and Winograd GEMM with >= 24 contraction "
+                          "channels; the 6->12->24 condition-noise convs and the 9-channel D input layer on native fp32 MFMA"
                           if fp32_mode == "bf16x3" else "native fp32 MFMA") + " (BASELINE configs[1]/[3] shape)"))
         if args.render_cond:
             workload += "; condition rasterised from a posed mesh inside the timed region (configs[2])"
@@ -388,7 +482,14 @@ def main():
             "config": {"workload": workload, "global_batch": world * B, "resolution": args.res, "parallelism": f"dp{world}",
                        "fp32_mfma": None if f16 else fp32_mode,
                        "algorithmic_tflop_per_image": fl_img / 1e12,
+                       "grad_bucket_mb": {"G": trainer.g_bucket.flat.numel() * 4 / 1e6, "D": trainer.d_bucket.flat.numel() * 4 / 1e6},
+                       "overlap_comm": bool(trainer.overlap_comm),
                        "peak_hbm_allocated_gb": torch.cuda.max_memory_allocated() / 2 ** 30},
+            "comm_exposed_ms": comm_ms / args.steps,
+            "comm_note": ("one RCCL all-reduce (AVG) per optimiser step over each flat gradient bucket, enqueued right after the backward and "
+                          "waited for where the network is next used; comm_exposed_ms = GPU time per step the compute stream spent in those "
+                          "waits (HIP events around FlatGradBucket.wait, max over ranks)" if use_dist else
+                          "single process: no gradient exchange"),
             "step_mfma_roofline": {"achieved": step_tflops, "peak": peak, "unit": "TFLOP/s",
                                    "frac": step_tflops / peak,
                                    "note": "whole step, ALGORITHMIC direct-convolution FLOPs (Winograd executes fewer, bf16x3 six "
@@ -398,6 +499,12 @@ def main():
         }
         if not args.no_prof:
             out.update(roofline_objects(ops, args.steps, dt))
+            try:
+                out["roofline_rasterize"] = rasterize_roofline(B, dev)
+            except Exception as e:  # never lose the headline line to the side measurement
+                out["roofline_rasterize"] = {"error": f"{type(e).__name__}: {e}"}
+        if replicas is not None:
+            out["replicas"] = replicas
         if f16:
             out["loss_scaler"] = {"g_scale": trainer.g_scaler.scale.item(), "d_scale": trainer.d_scaler.scale.item(),
                                   "skipped_g_steps": trainer.g_scaler.skipped.item(), "skipped_d_steps": trainer.d_scaler.skipped.item()}

@@ -86,6 +86,7 @@ class FlatGradBucket:
         self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
         self.views = [self.flat[off:off + p.numel()].view_as(p) for p, off in zip(self.params, self.offsets)]
         self._pending = None
+        self.comm_events = None  # bench.py: a list collects (start, end) HIP-event pairs around every wait for an exchange
         self.attach()
 
     def attach(self):
@@ -142,7 +143,14 @@ class FlatGradBucket:
         if self._pending is not None:
             work, div = self._pending
             self._pending = None
+            ev = None
+            if self.comm_events is not None and self.flat.is_cuda:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             work.wait()
+            if ev is not None:
+                ev[1].record()
+                self.comm_events.append(ev)
             if div:
                 self.flat.div_(div)
 

@@ -247,3 +247,50 @@ def test_model_gradients_fused_equal_standalone(res, step, monkeypatch):
         if b is not None:
             worst = max(worst, ((a - b).abs().max() / (b.abs().max() + 1e-20)).item())
     assert worst < 5e-5, worst
+
+
+# ------------------------------------------------------------------------------------------------ RCCL with more than one rank
+def _run_bench(nproc, extra, port):
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(nproc), "--steps", "3", "--warmup", "1", "--res", "64",
+           "--batch", "8", "--vocab", "64", "--r1-every", "2", "--no-cpu-baseline", "--no-prof", "--check-replicas"] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs of one node (RCCL over xGMI); the round's boxes have one")
+def test_bench_two_ranks_on_rccl_replicas_identical_and_overlap_equals_in_place():
+    """bench.py under torch.distributed.run with two ranks on RCCL: the replicas stay bit-identical, RCCL reports two ranks, and
+    the deferred (overlapped) exchange + optimiser schedule gives exactly the weights of the in-place schedule."""
+    a = _run_bench(2, [], 29631)
+    assert a["n_gpus"] == 2 and a["replicas"]["ranks"] == 2 and a["replicas"]["backend"] == "nccl"
+    assert a["replicas"]["replicas_identical"]
+    assert a["config"]["overlap_comm"] is True and a["comm_exposed_ms"] >= 0.0
+    b = _run_bench(2, ["--no-overlap-comm"], 29633)
+    assert b["config"]["overlap_comm"] is False and b["replicas"]["replicas_identical"]
+    assert a["replicas"]["param_digest"] == b["replicas"]["param_digest"], "overlapped and in-place schedules must give identical weights"
+
+
+def test_bench_single_rank_collective_code_path_and_line_contract():
+    """One rank with GIF_FORCE_DIST=1: process-group initialisation on RCCL, the construction-time broadcast, the asynchronous AVG
+    all-reduce and its waits all execute; the JSON line carries the round-3 fields (named roofline ceiling, comm accounting)."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GIF_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--res", "64", "--batch", "8",
+                          "--vocab", "64", "--no-cpu-baseline", "--check-replicas"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["replicas"]["backend"] == "nccl" and line["replicas"]["replicas_identical"]
+    assert line["config"]["overlap_comm"] is True and line["comm_exposed_ms"] >= 0.0
+    r = line["roofline"]
+    assert r["unit"] == "TFLOP/s" and "ceiling" in r and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert abs(r["executed_frac"] - r["executed_achieved"] / r["executed_peak"]) < 1e-9
+    rr = line["roofline_rasterize"]
+    assert rr.get("error") is None and rr["unit"] == "GB/s" and rr["Mtri_per_s"] > 0 and rr["cpu_baseline"]["value"] > 0

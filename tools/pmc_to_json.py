@@ -16,9 +16,24 @@ import argparse
 import collections
 import csv
 import glob
+import hashlib
 import json
+import os
 import re
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_source_digest():
+    """Same digest as bench.py's: bench.py marks the relayed traffic as stale when the kernel sources have changed since."""
+    h = hashlib.sha1()
+    for path in sorted(glob.glob(os.path.join(ROOT, "gif_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "gif_amd", "csrc", "*.h"))
+                       + glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 FAMILY_OF = [  # (regex on the kernel name, family key used by bench.py); first match wins
     (r"conv_gather_mfma_glds(_multi)?<_Float16", "conv_gather_mfma_glds_f16"),
@@ -83,7 +98,7 @@ def main():
     for f in fams.values():
         f["hbm_bytes_per_launch"] = f["hbm_bytes"] / f["launches"] if f["launches"] else None
     top = sorted(kernels.items(), key=lambda kv: -(kv[1]["hbm_bytes_per_launch"] or 0) * kv[1]["launches"])[:25]
-    json.dump({"commit": a.commit, "command": a.command,
+    json.dump({"commit": a.commit, "kernel_source_digest": kernel_source_digest(), "command": a.command,
                "units": "HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (counters in KiB; gfx950 FETCH_SIZE halving corrected)",
                "families": fams, "top_kernels_by_traffic": dict(top)}, sys.stdout, indent=1)
     print()
