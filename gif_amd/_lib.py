@@ -32,9 +32,12 @@ GP, EP = ctypes.POINTER(ConvGeom), ctypes.POINTER(ConvEpilogue)
 PROTOTYPES = {
     "gif_last_error": (ctypes.c_char_p, []),
     "gif_abi_version": (c_int, []),
+    "gif_f16_overflow_clear": (c_int, [P]),
+    "gif_f16_overflow_or_into": (c_int, [P, P]),
     "gif_set_fp32_mfma_mode": (c_int, [c_int]),
     "gif_get_fp32_mfma_mode": (c_int, []),
     "gif_rasterize_workspace_bytes": (c_i64, [c_int, c_int, c_int, c_int]),
+    "gif_rasterize_assume_clean_workspace": (c_int, [c_int]),
     "gif_rasterize_f32": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P]),
     "gif_rasterize_colors_f32": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P, P]),
     "gif_rasterize_f64": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P]),
@@ -103,7 +106,7 @@ PROTOTYPES = {
     "gif_linear_tn_f32": (c_int, [P, P, P] + [c_int] * 6 + [c_float, P]),
     "gif_adam_chunk_floats": (c_int, []),
     "gif_adam_ema_step_f32": (c_int, [P, c_int, P, P, P, c_float, c_float, c_float, c_float, ctypes.c_double, ctypes.c_double,
-                                      c_float, c_int, P, P, P]),
+                                      c_float, c_int, P, P, P, P]),
     "gif_prof_enable": (c_int, [c_int]),
     "gif_prof_read": (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64)]),
 }

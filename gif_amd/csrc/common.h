@@ -37,6 +37,7 @@ inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 constexpr int kMaxDevices = 64;
 int current_device();           // hipGetDevice(), validated against kMaxDevices
 const float* zero_page16();     // 16 zero bytes in the CURRENT device's memory (source of out-of-range LDS-DMA lanes)
+unsigned* f16_sat_flag();       // the CURRENT device's "an f16 store saturated" word (gif_f16_overflow_clear / _or_into)
 // "this kernel may use `bytes` of dynamic LDS on the current device": hipFuncSetAttribute once per (kernel, device, size step)
 struct LdsAttr {
     unsigned long granted[kMaxDevices] = {};
@@ -96,6 +97,17 @@ __device__ __forceinline__ void store4(f16* p, float4 v) {
     f16x4_t h;
     h[0] = (f16)sat_f16(v.x); h[1] = (f16)sat_f16(v.y); h[2] = (f16)sat_f16(v.z); h[3] = (f16)sat_f16(v.w);
     *reinterpret_cast<f16x4_t*>(p) = h;
+}
+// Stores that may carry GRADIENTS: a saturating store hides an overflow from the loss scaler (the fp32 weight gradients
+// computed from clamped activations gradients stay finite), so the clamp — or a non-finite value — raises the device's flag
+// word; the trainer clears it before backward() and ORs it into found_inf afterwards (gif_f16_overflow_*).  fp32: plain store.
+__device__ __forceinline__ void store4_flag(float* p, float4 v, unsigned*) { store4(p, v); }
+__device__ __forceinline__ void store4_flag(f16* p, float4 v, unsigned* flag) {
+    if (flag) {
+        const float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+        if (!(m <= 65504.f)) atomicOr(flag, 1u);  // also true for NaN
+    }
+    store4(p, v);
 }
 
 // ---- bf16x3: three-way split of fp32 operands for the bf16 matrix cores -------------------------------------------

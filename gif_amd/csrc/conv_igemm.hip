@@ -72,6 +72,7 @@ struct GatherParams {
     float* part_dot;
     int part_row0;
     int no_split;              // keep the launch in ONE tile size (per-sample partial sums need uniform rows)
+    unsigned* sat_flag;        // f16: "a store saturated" flag word of the device (common.h store4_flag), else NULL
 };
 
 // partial-sum rows handed out to the launches of one op (bulk + remainder launches, transposed-conv phases), and the tile height
@@ -166,7 +167,7 @@ __device__ __forceinline__ void conv_epilogue(const GatherParams& p, f32x16 (&ac
                     v.z *= p.mask_gain * (xs.z > 0.f ? 1.f : p.mask_slope); v.w *= p.mask_gain * (xs.w > 0.f ? 1.f : p.mask_slope);
                 }
                 cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
-                gif::store4(yout + o, v);
+                gif::store4_flag(yout + o, v, p.sat_flag);
             }
         }
     }
@@ -1015,6 +1016,7 @@ void fill_epilogue(GatherParams& p, const gif_conv_epilogue* e) {
     p.mask_slope = e ? e->mask_slope : 1.f;
     p.mask_gain = e ? e->mask_gain : 1.f;
     p.dot_src = e ? e->dot_src : nullptr;
+    p.sat_flag = nullptr;
 }
 
 // Gradient-producer fusions of one op: validate, carve the partial-sum buffers out of red_ws (before the launches) and reduce
@@ -1086,6 +1088,7 @@ int conv2d_fwd_impl(const void* big, const void* wp, void* small, const gif_conv
     GatherParams p{};
     p.x = big; p.wp = wp; p.y = small; p.x3 = x3 ? 1 : 0;
     fill_epilogue(p, e);
+    if (sizeof(T) == 2) p.sat_flag = gif::f16_sat_flag();
     p.B = g->B; p.Hi = g->Hb; p.Wi = g->Wb; p.Ci = g->Cb;
     p.Ho = g->Hs; p.Wo = g->Ws; p.Co = g->Cs;
     p.Hp = g->Hs; p.Wp = g->Ws; p.os = 1; p.ooy = 0; p.oox = 0; p.is = g->stride;
@@ -1115,6 +1118,7 @@ int conv2d_bwd_data_impl(const void* small, const void* wp, void* big, const gif
     GatherParams base{};
     base.x = small; base.wp = wp; base.y = big; base.x3 = x3 ? 1 : 0;
     fill_epilogue(base, e);
+    if (sizeof(T) == 2) base.sat_flag = gif::f16_sat_flag();
     base.B = g->B; base.Hi = g->Hs; base.Wi = g->Ws; base.Ci = g->Cs;
     base.Ho = g->Hb; base.Wo = g->Wb; base.Co = g->Cb;
     pack_dims<T>(base.Co, base.Ci, &base.RP, &base.CP, x3);

@@ -37,6 +37,7 @@ struct UpfirdnParams {
     const T* mask_src;
     float mask_slope, mask_gain;
     float* part_cs;
+    unsigned* sat_flag;  // f16: "a store saturated" flag word (common.h store4_flag), else NULL
 };
 
 // FIR epilogue tail shared by the blur kernels: leaky-ReLU-backward mask of the tensor this gradient flows into + the running
@@ -105,7 +106,7 @@ __global__ void __launch_bounds__(256) upfirdn2d_kernel(const UpfirdnParams<T> p
             acc.x = lrelu(acc.x, p.slope, p.gain); acc.y = lrelu(acc.y, p.slope, p.gain);
             acc.z = lrelu(acc.z, p.slope, p.gain); acc.w = lrelu(acc.w, p.slope, p.gain);
         }
-        gif::store4(p.y + o, acc);
+        gif::store4_flag(p.y + o, acc, p.sat_flag);
     }
 }
 
@@ -180,7 +181,7 @@ __global__ void __launch_bounds__(256) fir4x4_resample_kernel(const UpfirdnParam
             acc.x = lrelu(acc.x, p.slope, p.gain); acc.y = lrelu(acc.y, p.slope, p.gain);
             acc.z = lrelu(acc.z, p.slope, p.gain); acc.w = lrelu(acc.w, p.slope, p.gain);
         }
-        gif::store4(p.y + o, acc);
+        gif::store4_flag(p.y + o, acc, p.sat_flag);
     }
 }
 
@@ -256,7 +257,7 @@ __global__ void __launch_bounds__(256) blur4x4_tiled_kernel(const UpfirdnParams<
                     v.z = lrelu(v.z, p.slope, p.gain); v.w = lrelu(v.w, p.slope, p.gain);
                 }
                 fir_mask_sum(p, o, v, cs);
-                gif::store4(p.y + o, v);
+                gif::store4_flag(p.y + o, v, p.sat_flag);
             }
         }
     }
@@ -338,7 +339,7 @@ __global__ void __launch_bounds__(256) blur4x4_rows_kernel(const UpfirdnParams<T
                             vv.z = lrelu(vv.z, p.slope, p.gain); vv.w = lrelu(vv.w, p.slope, p.gain);
                         }
                         fir_mask_sum(p, o, vv, cs);
-                        gif::store4(p.y + o, vv);
+                        gif::store4_flag(p.y + o, vv, p.sat_flag);
                     }
                 }
 #pragma unroll
@@ -376,7 +377,7 @@ __global__ void __launch_bounds__(256)
 colsum_stage1(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out_ew,
               const float* __restrict__ scale, float* __restrict__ partial, long nrows, int C4, long rows_per_block,
               float slope, float gain, int want_sum, const T* __restrict__ res = nullptr,
-              const float* __restrict__ bias = nullptr) {
+              const float* __restrict__ bias = nullptr, unsigned* sat_flag = nullptr) {
     __shared__ float4 red[256];
     const int R = 256 / C4;  // row lanes (C4 <= 256)
     const int col = threadIdx.x % C4, rl = threadIdx.x / C4;
@@ -400,10 +401,10 @@ colsum_stage1(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ 
                 float4 yv = gif::load4(b + 4 * i);
                 v.x *= gain * (yv.x > 0.f ? 1.f : slope); v.y *= gain * (yv.y > 0.f ? 1.f : slope);
                 v.z *= gain * (yv.z > 0.f ? 1.f : slope); v.w *= gain * (yv.w > 0.f ? 1.f : slope);
-                gif::store4(out_ew + 4 * i, v);
+                gif::store4_flag(out_ew + 4 * i, v, sat_flag);
             } else if (MODE == 2) {
                 float4 bv = gif::load4(b + 4 * i);
-                if (out_ew) gif::store4(out_ew + 4 * i, make_float4(sc.x * v.x, sc.y * v.y, sc.z * v.z, sc.w * v.w));
+                if (out_ew) gif::store4_flag(out_ew + 4 * i, make_float4(sc.x * v.x, sc.y * v.y, sc.z * v.z, sc.w * v.w), sat_flag);
                 v.x *= bv.x; v.y *= bv.y; v.z *= bv.z; v.w *= bv.w;
             } else if (MODE == 3) {
                 float4 yv = gif::load4(b + 4 * i);
@@ -634,6 +635,7 @@ int upfirdn2d_impl(const T* x, const float* k, T* y, int B, int Hi, int Wi, int 
     p.gain = e ? e->gain : 1.f;
     p.B = B; p.Hi = Hi; p.Wi = Wi; p.C = C; p.Ho = Ho; p.Wo = Wo; p.up = up; p.down = down;
     p.padx0 = padx0; p.pady0 = pady0; p.KH = KH; p.KW = KW; p.flip = flip;
+    p.sat_flag = sizeof(T) == 2 ? gif::f16_sat_flag() : nullptr;
     // gradient-producer fusions (blur kernels): leaky-ReLU-backward mask + bias-gradient column sums in the epilogue
     const bool blur = up == 1 && down == 1 && KH == 4 && KW == 4;
     const bool fused = e && (e->mask_src || e->colsum || e->dot || e->dot_src);
@@ -698,7 +700,8 @@ int bias_act_bwd_impl(const T* gy, const T* y, T* gx, float* gbias, float* parti
     int C4 = C / 4;
     int nblk = colsum_blocks(npix, C4);
     long rpb = (npix + nblk - 1) / nblk;
-    colsum_stage1<1, T><<<dim3(nblk, 1), 256, 0, s>>>(gy, y, gx, nullptr, partial, npix, C4, rpb, slope, gain, gbias != nullptr);
+    colsum_stage1<1, T><<<dim3(nblk, 1), 256, 0, s>>>(gy, y, gx, nullptr, partial, npix, C4, rpb, slope, gain, gbias != nullptr, nullptr, nullptr,
+                                                       sizeof(T) == 2 ? gif::f16_sat_flag() : nullptr);
     if (gbias) colsum_stage2<<<dim3(gif::cdiv(C, 64), 1), 256, 0, s>>>(partial, gbias, nblk, C);
     return gif::check_launch("bias_act_bwd");
 }
@@ -751,7 +754,8 @@ int mul_reduce_impl(const T* a, const T* b, const float* scale, T* scaled, float
     hipStream_t s = gif::as_stream(stream);
     int nchunk = mul_reduce_chunks(HW);
     long rpb = (HW + nchunk - 1) / nchunk;
-    colsum_stage1<2, T><<<dim3(nchunk, B), 256, 0, s>>>(a, b, scaled, scale, partial, HW, C / 4, rpb, 0.f, 1.f, 1);
+    colsum_stage1<2, T><<<dim3(nchunk, B), 256, 0, s>>>(a, b, scaled, scale, partial, HW, C / 4, rpb, 0.f, 1.f, 1, nullptr, nullptr,
+                                                         sizeof(T) == 2 ? gif::f16_sat_flag() : nullptr);
     colsum_stage2<<<dim3(gif::cdiv(C, 64), B), 256, 0, s>>>(partial, out, nchunk, C);
     return gif::check_launch("mul_reduce");
 }

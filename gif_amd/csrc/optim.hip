@@ -23,6 +23,8 @@ struct AdamArgs {
     int has_ema;
     const float* inv_scale;  // device scalar: gradients are multiplied by it (loss scaling of the f16 path), or NULL
     const float* found_inf;  // device scalar: non-zero => a gradient overflowed, the whole update is skipped, or NULL
+    const float* dev_step;   // device scalar: number of APPLIED steps incl. this one (the bias corrections follow it), or NULL
+    float lr;
 };
 
 __device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v, const AdamArgs& a) {
@@ -33,8 +35,13 @@ __device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v,
     p = p - a.step_size * (m / denom);
 }
 
-__global__ void __launch_bounds__(256) adam_ema_kernel(const AdamArgs a) {
+__global__ void __launch_bounds__(256) adam_ema_kernel(AdamArgs a) {
     if (a.found_inf && *a.found_inf != 0.f) return;  // uniform over the grid: nobody updates (GradScaler semantics)
+    if (a.dev_step) {  // loss-scaled run: skipped steps do not advance the count, so the corrections come from the device
+        const double t = (double)*a.dev_step;
+        a.step_size = (float)((double)a.lr / (1.0 - pow((double)a.b1, t)));
+        a.bc2_sqrt = (float)sqrt(1.0 - pow((double)a.b2, t));
+    }
     const float gs = a.inv_scale ? *a.inv_scale : 1.f;
     const gif_adam_chunk c = a.chunks[blockIdx.x];
     float* __restrict__ p = c.param;
@@ -94,7 +101,7 @@ int gif_adam_chunk_floats(void) { return CHUNK; }
 int gif_adam_ema_step_f32(const gif_adam_chunk* chunks, int nchunks, const float* grad_flat, float* exp_avg_flat,
                           float* exp_avg_sq_flat, float lr, float beta1, float beta2, float eps, double bias_correction1,
                           double bias_correction2, float ema_decay, int has_ema, const float* inv_grad_scale,
-                          const float* found_inf, gif_stream_t stream) {
+                          const float* found_inf, const float* dev_step, gif_stream_t stream) {
     GIF_REQUIRE(chunks && grad_flat && exp_avg_flat && exp_avg_sq_flat && nchunks >= 0, "adam_ema_step: null pointer");
     GIF_REQUIRE(bias_correction1 > 0.0 && bias_correction2 > 0.0, "adam_ema_step: bias corrections must be positive");
     if (nchunks == 0) return 0;
@@ -105,6 +112,7 @@ int gif_adam_ema_step_f32(const gif_adam_chunk* chunks, int nchunks, const float
     a.bc2_sqrt = (float)sqrt(bias_correction2);
     a.ema_decay = ema_decay; a.has_ema = has_ema;
     a.inv_scale = inv_grad_scale; a.found_inf = found_inf;
+    a.dev_step = dev_step; a.lr = lr;
     adam_ema_kernel<<<nchunks, 256, 0, gif::as_stream(stream)>>>(a);
     return gif::check_launch("adam_ema_step");
 }

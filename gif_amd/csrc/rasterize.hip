@@ -10,6 +10,8 @@
 // its 63 neighbours idle, and every pixel test is a global atomic.)
 // Arithmetic follows the reference operation by operation with FP contraction off, so results are
 // bit-identical to oracle/rasterize_ref.c.
+#include <atomic>
+
 #include "common.h"
 
 #pragma clang fp contract(off)
@@ -149,7 +151,7 @@ raster_bin(const T* __restrict__ fv, uint32_t* __restrict__ count, uint32_t* __r
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Kernel 2, raster_tiles: one 512-thread workgroup per (image, 64x64-pixel tile); the tile's z-buffer lives in LDS.
+// Kernel 2, raster_tiles: one 1024-thread workgroup per (image, 64x64-pixel tile); the tile's z-buffer lives in LDS.
 //   seed   : key[p] = (ordered_bits(depth_in[p]) << 32) | 0xFFFFFFFF from the caller's depth buffer
 //   shade  : the tile's face list, one face per lane, box clipped to the tile: <= 16 px => the lane walks it; larger => the
 //            wave walks it together, 8x8 pixels per step (face broadcast by shuffles).  Every covered pixel does ONE 64-bit
@@ -165,7 +167,7 @@ raster_bin(const T* __restrict__ fv, uint32_t* __restrict__ count, uint32_t* __r
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kTile = 64;          // pixels per tile edge
 constexpr int kTilePix = kTile * kTile;
-constexpr int kThreads = 512;
+constexpr int kThreads = 1024;    // 4 pixels per thread in the seed / resolve passes, up to 1024 listed faces per shade round
 constexpr int kSmallArea = 16;     // clipped boxes up to this many pixels are walked by their own lane
 
 __device__ __forceinline__ unsigned long long ordered_bits64(double d) {
@@ -219,11 +221,12 @@ __device__ __forceinline__ Face<T> shfl_face(const Face<T>& f, int src) {
 
 template <typename T, bool COLORS>
 __global__ void __launch_bounds__(kThreads)
-raster_tiles(const T* __restrict__ fv, const T* __restrict__ fc, const uint32_t* __restrict__ count, const uint32_t* __restrict__ list,
+raster_tiles(const T* __restrict__ fv, const T* __restrict__ fc, uint32_t* __restrict__ count, const uint32_t* __restrict__ list,
              T* __restrict__ depth, int32_t* __restrict__ tri, T* __restrict__ out3, int F, int H, int W, int tiles_x, int tiles_y) {
     constexpr bool F64 = sizeof(T) == 8;
     __shared__ unsigned long long key[kTilePix];
     __shared__ uint32_t fkey[F64 ? kTilePix : 1];
+    __shared__ int n_sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = blockIdx.x % (tiles_x * tiles_y), b = blockIdx.x / (tiles_x * tiles_y);
     const int tx0 = (tile % tiles_x) * kTile, ty0 = (tile / tiles_x) * kTile;
@@ -233,20 +236,35 @@ raster_tiles(const T* __restrict__ fv, const T* __restrict__ fc, const uint32_t*
     keys.key = key;
     if constexpr (F64) keys.fkey = fkey;
 
-    // ---- seed the tile's keys from the caller's depth buffer
-    for (int p = tid; p < kTilePix; p += kThreads) {
-        const int x = tx0 + (p & (kTile - 1)), y = ty0 + (p >> 6);
-        const bool in = x <= tx1 && y <= ty1;
-        if constexpr (F64) {
-            key[p] = in ? ordered_bits64(depth[img + (long)y * W + x]) : 0ull;
-            fkey[p] = kNoFace;
-        } else {
-            key[p] = in ? (((unsigned long long)ordered_bits(depth[img + (long)y * W + x]) << 32) | kNoFace) : 0ull;
+    // the tile's list length; the counter is handed back ZERO, so a caller that keeps its workspace needs no memset per call
+    if (tid == 0) {
+        n_sh = (int)count[blockIdx.x];  // blockIdx.x == b * tiles + tile
+        count[blockIdx.x] = 0;
+    }
+    // ---- seed the tile's keys from the caller's depth buffer (all loads of a thread in flight together)
+    constexpr int PPT = kTilePix / kThreads;  // pixels per thread
+    {
+        T dv[PPT];
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            const int p = tid + i * kThreads;
+            const int x = tx0 + (p & (kTile - 1)), y = ty0 + (p >> 6);
+            dv[i] = (x <= tx1 && y <= ty1) ? depth[img + (long)y * W + x] : T(0);
+        }
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            const int p = tid + i * kThreads;
+            if constexpr (F64) {
+                key[p] = ordered_bits64(dv[i]);
+                fkey[p] = kNoFace;
+            } else {
+                key[p] = ((unsigned long long)ordered_bits(dv[i]) << 32) | kNoFace;
+            }
         }
     }
     __syncthreads();
 
-    const int n = (int)count[blockIdx.x];  // blockIdx.x == b * tiles + tile
+    const int n = n_sh;
     const uint32_t* cand = list + (long)blockIdx.x * F;
     const T* fvb = fv + (long)b * F * 9;
     const int lx = lane & 7, ly = lane >> 3;
@@ -291,26 +309,36 @@ raster_tiles(const T* __restrict__ fv, const T* __restrict__ fc, const uint32_t*
         }
     }
 
-    // ---- resolve
-    for (int p = tid; p < kTilePix; p += kThreads) {
+    // ---- resolve: the winners' face data of a thread's pixels is fetched in one batch (one memory latency, not PPT of them)
+    uint32_t fid[PPT];
+    unsigned long long kk[PPT];
+    Face<T> ff[PPT];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int p = tid + i * kThreads;
         const int x = tx0 + (p & (kTile - 1)), y = ty0 + (p >> 6);
-        if (x > tx1 || y > ty1) continue;
-        const unsigned long long k = key[p];
-        uint32_t fidx;
-        if constexpr (F64) fidx = fkey[p];
-        else fidx = (uint32_t)(k & 0xFFFFFFFFu);
-        if (fidx == kNoFace) continue;  // pixel keeps the caller's depth / tri / payload
+        kk[i] = key[p];
+        if constexpr (F64) fid[i] = fkey[p];
+        else fid[i] = (uint32_t)(kk[i] & 0xFFFFFFFFu);
+        if (x > tx1 || y > ty1) fid[i] = kNoFace;  // pixel keeps the caller's depth / tri / payload
+    }
+#pragma unroll
+    for (int i = 0; i < PPT; ++i)
+        if (fid[i] != kNoFace) ff[i] = load_face(fvb + (long)fid[i] * 9);
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        if (fid[i] == kNoFace) continue;
+        const int p = tid + i * kThreads;
+        const int x = tx0 + (p & (kTile - 1)), y = ty0 + (p >> 6);
         const long gp = img + (long)y * W + x;
-        const long fi = (long)b * F + fidx;
-        const Face<T> f = load_face(fv + fi * 9);
-        const BaryCtx<T> c = bary_setup(f);
+        const BaryCtx<T> c = bary_setup(ff[i]);
         T w[3];
-        bary_at(f, c, (T)x, (T)y, w);
-        if constexpr (F64) depth[gp] = from_ordered_bits64(k);
-        else depth[gp] = from_ordered_bits((uint32_t)(k >> 32));
-        tri[gp] = (int32_t)fidx;
+        bary_at(ff[i], c, (T)x, (T)y, w);
+        if constexpr (F64) depth[gp] = from_ordered_bits64(kk[i]);
+        else depth[gp] = from_ordered_bits((uint32_t)(kk[i] >> 32));
+        tri[gp] = (int32_t)fid[i];
         if (COLORS) {
-            const T* cl = fc + fi * 9;  // [3 verts][3 channels], .cu:189-194
+            const T* cl = fc + ((long)b * F + fid[i]) * 9;  // [3 verts][3 channels], .cu:189-194
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) out3[gp * 3 + ch] = w[0] * cl[ch] + w[1] * cl[3 + ch] + w[2] * cl[6 + ch];
         } else {
@@ -321,6 +349,9 @@ raster_tiles(const T* __restrict__ fv, const T* __restrict__ fc, const uint32_t*
 }
 
 inline long pad2(long n) { return (n + 1) / 2 * 2; }  // keeps the list 8-byte aligned behind the counters
+
+// 1: the caller guarantees zeroed tile counters on entry (raster_tiles leaves them zero): no memset node per call
+std::atomic<int> g_clean_workspace{0};
 
 template <typename T>
 int run(const T* fv, const T* fc, T* depth, int32_t* tri, T* out3, int B, int F, int H, int W, void* workspace,
@@ -335,8 +366,10 @@ int run(const T* fv, const T* fc, T* depth, int32_t* tri, T* out3, int B, int F,
     hipStream_t s = gif::as_stream(stream);
     uint32_t* count = reinterpret_cast<uint32_t*>(workspace);
     uint32_t* list = count + pad2(B * nt);
-    hipError_t me = hipMemsetAsync(count, 0, (size_t)B * nt * sizeof(uint32_t), s);
-    if (me != hipSuccess) { gif::set_error("%s memset: %s", who, hipGetErrorString(me)); return (int)me; }
+    if (!g_clean_workspace.load(std::memory_order_relaxed)) {
+        hipError_t me = hipMemsetAsync(count, 0, (size_t)B * nt * sizeof(uint32_t), s);
+        if (me != hipSuccess) { gif::set_error("%s memset: %s", who, hipGetErrorString(me)); return (int)me; }
+    }
     raster_bin<T><<<dim3((unsigned)gif::cdiv(F, kBinThreads), (unsigned)B), kBinThreads, 0, s>>>(fv, count, list, F, H, W, tiles_x, tiles_y);
     const dim3 grid((unsigned)(B * nt));
     if (fc) raster_tiles<T, true><<<grid, kThreads, 0, s>>>(fv, fc, count, list, depth, tri, out3, F, H, W, tiles_x, tiles_y);
@@ -347,6 +380,11 @@ int run(const T* fv, const T* fc, T* depth, int32_t* tri, T* out3, int B, int F,
 }  // namespace
 
 extern "C" {
+
+int gif_rasterize_assume_clean_workspace(int on) {
+    g_clean_workspace.store(on ? 1 : 0, std::memory_order_relaxed);
+    return 0;
+}
 
 // per (image, 64x64 tile): one counter + a face list that can hold every face; the z-buffer itself never leaves LDS
 int64_t gif_rasterize_workspace_bytes(int B, int F, int H, int W) {

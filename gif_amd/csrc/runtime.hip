@@ -14,6 +14,11 @@ namespace gif {
 static thread_local char g_err[512] = "";
 
 __device__ __attribute__((aligned(16))) float g_zero_page[4];
+__device__ unsigned g_f16_sat_flag;
+
+__global__ void f16_flag_or_into(const unsigned* flag, float* found_inf) {
+    if (*flag) *found_inf = 1.f;
+}
 
 int current_device() {
     int d = 0;
@@ -32,6 +37,19 @@ const float* zero_page16() {
         page[d] = static_cast<const float*>(zp);
     }
     return page[d];
+}
+
+unsigned* f16_sat_flag() {
+    static std::mutex mu;
+    static unsigned* flag[kMaxDevices] = {};
+    const int d = current_device();
+    std::lock_guard<std::mutex> lk(mu);
+    if (!flag[d]) {
+        void* fp = nullptr;
+        if (hipGetSymbolAddress(&fp, HIP_SYMBOL(g_f16_sat_flag)) != hipSuccess) return nullptr;
+        flag[d] = static_cast<unsigned*>(fp);
+    }
+    return flag[d];
 }
 
 void LdsAttr::ensure(const void* kernel, size_t bytes) {
@@ -107,6 +125,21 @@ ProfScope::~ProfScope() {
 extern "C" {
 
 const char* gif_last_error(void) { return gif::g_err; }
+
+int gif_f16_overflow_clear(gif_stream_t stream) {
+    unsigned* f = gif::f16_sat_flag();
+    GIF_REQUIRE(f, "f16_overflow_clear: no flag word on this device");
+    hipError_t e = hipMemsetAsync(f, 0, sizeof(unsigned), gif::as_stream(stream));
+    if (e != hipSuccess) { gif::set_error("f16_overflow_clear: %s", hipGetErrorString(e)); return (int)e; }
+    return 0;
+}
+
+int gif_f16_overflow_or_into(float* found_inf, gif_stream_t stream) {
+    unsigned* f = gif::f16_sat_flag();
+    GIF_REQUIRE(f && found_inf, "f16_overflow_or_into: null pointer");
+    gif::f16_flag_or_into<<<1, 1, 0, gif::as_stream(stream)>>>(f, found_inf);
+    return gif::check_launch("f16_overflow_or_into");
+}
 int gif_abi_version(void) { return 2; }  // 2: gif_conv_epilogue gradient-producer fusions, rasteriser workspace (B, F, H, W)
 
 int gif_set_fp32_mfma_mode(int mode) {

@@ -37,6 +37,12 @@ class _ResizeBwdFn(Function):  # linear map: its backward is the forward resize 
         return _ResizeFn.apply(ggx, ctx.out_hw, ctx.mode), None, None, None
 
 
+def resize_image(x, out_hw, mode='bilinear'):
+    """F.interpolate(x, size=out_hw, mode=mode, align_corners=False) for any ratio, up or down (fp32 [B,C,H,W]; NCHW result);
+    differentiable to any order."""
+    return _ResizeFn.apply(x, tuple(out_hw), mode)
+
+
 def fast_image_reshape(in_img_batch, height_out, width_out, non_diff_allowed=False, mode='bicubic'):
     """Reference dataset_loaders.py:26-34.  Like the reference, the target size is passed to interpolate as
     (width_out, height_out) — i.e. rows = width_out — which only matters for non-square targets."""

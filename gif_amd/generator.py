@@ -16,6 +16,7 @@ from torch.nn import functional as F
 
 from . import functional as GF
 from . import ops
+from .data import resize_image
 from .layers import StyledConv, ToRGB, get_w_frm_z
 
 
@@ -156,9 +157,9 @@ class StyledGenerator(nn.Module):
         for i in range(step + 1):
             size = 4 * 2 ** i
             if H == W and H % size == 0 and (H == size or (H // size) % 2 == 0):
-                levels.append(GF.bilinear_down(cond, size))  # HIP: integer ratio, taps are exact 0.5/0.5
-            else:  # arbitrary ratio (e.g. a 2x2 dummy condition): ATen's generic bilinear resampler
-                lvl = F.interpolate(cond, size=(size, size), mode='bilinear', align_corners=False)
+                levels.append(GF.bilinear_down(cond, size))  # integer ratio: the taps are exact 0.5/0.5 (NHWC kernel)
+            else:  # arbitrary ratio (e.g. a 2x2 dummy condition, non-square renders): the generic HIP resampler (csrc/resize.hip)
+                lvl = resize_image(cond, (size, size), 'bilinear')
                 levels.append(lvl.contiguous(memory_format=torch.channels_last))
         if self.act_dtype != torch.float32:
             levels = [lvl.to(self.act_dtype) for lvl in levels]

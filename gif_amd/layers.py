@@ -18,8 +18,6 @@ from . import functional as GF
 from .ops import cpad, pad4
 
 
-# A/B benchmarking switch only (GIF_HIP_LINEAR=0): EqualLinear through torch's library GEMM instead of the HIP conv kernels
-_HIP_LINEAR = os.environ.get("GIF_HIP_LINEAR", "1") != "0"
 _SKINNY_MAX_ROWS = int(os.environ.get("GIF_SKINNY_MAX_ROWS", "512"))  # above: the implicit-GEMM conv kernels take over
 
 
@@ -139,11 +137,6 @@ class EqualLinear(nn.Module):
         self.apply_sqrt2_fac_in_eq_lin = apply_sqrt2_fac_in_eq_lin
 
     def forward(self, input):
-        if not _HIP_LINEAR and input.is_cuda:
-            out = F.linear(input, self.weight * self.scale, bias=None if self.bias is None else self.bias * self.lr_mul)
-            if self.activation:
-                out = F.leaky_relu(out, negative_slope=0.2) * (1.41421356237 if self.apply_sqrt2_fac_in_eq_lin else 1.0)
-            return out
         out_dim, in_dim = self.weight.shape
         lead = input.shape[:-1]
         x = input.reshape(-1, in_dim)
@@ -227,8 +220,6 @@ class ModulatedConv2d(nn.Module):
         d = None
         if self.demodulate:
             wsq = self.weight[0].pow(2).sum(dim=(2, 3))  # [Cout, Cin]
-            if not _HIP_LINEAR:
-                return s, torch.rsqrt((self.scale ** 2) * (s.pow(2) @ wsq.t()) + self.eps)
             # sum_ci s^2 * wsq on the MFMA kernels (like EqualLinear): d = rsqrt(scale^2 * (s^2 @ wsq^T) + eps)
             cin, cout = s.shape[1], wsq.shape[0]
             s2 = s.pow(2)

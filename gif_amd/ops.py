@@ -167,6 +167,11 @@ _weight_cache = {}
 _WEIGHT_CACHE_MAX = 512
 
 
+def clear_weight_cache():
+    """Forget every packed / transformed weight (call after writing parameters through .data, which bumps no version counter)."""
+    _weight_cache.clear()
+
+
 def _cached_weight_op(w, tag, build):
     if not WEIGHT_CACHE:
         return build()
@@ -556,12 +561,32 @@ def sqnorm_per_sample(g):
     return out
 
 
+# One zero-initialised rasteriser workspace per (device, stream, problem size), kept across calls: the tile kernel hands the
+# counters back zeroed, so the per-call memset node is switched off (gif_rasterize_assume_clean_workspace).  A failed call drops
+# its entry (the counters may be dirty).
+_raster_ws = {}
+_RASTER_WS_MAX = 8
+
+
+def _raster_workspace(lib, dev, B, F, h, w):
+    if not _raster_ws:
+        lib.gif_rasterize_assume_clean_workspace(1)
+    key = (dev.index, torch.cuda.current_stream().cuda_stream, B, F, h, w)
+    ws = _raster_ws.get(key)
+    if ws is None:
+        if len(_raster_ws) >= _RASTER_WS_MAX:
+            _raster_ws.pop(next(iter(_raster_ws)))
+        ws = torch.zeros((max(lib.gif_rasterize_workspace_bytes(B, F, h, w) // 8, 1),), device=dev, dtype=torch.int64)
+        _raster_ws[key] = ws
+    return key, ws
+
+
 def rasterize(face_vertices, depth, tri, out3, h, w, face_colors=None):
     """float32 or float64 buffers (all floating tensors of one dtype, like the reference's AT_DISPATCH_FLOATING_TYPES)."""
     lib = _lib.load()
     B, F = face_vertices.shape[:2]
     f64 = face_vertices.dtype == torch.float64
-    ws = torch.empty((max(lib.gif_rasterize_workspace_bytes(B, F, h, w) // 8, 1),), device=face_vertices.device, dtype=torch.int64)
+    key, ws = _raster_workspace(lib, face_vertices.device, B, F, h, w)
     plain, colors = (lib.gif_rasterize_f64, lib.gif_rasterize_colors_f64) if f64 else (lib.gif_rasterize_f32,
                                                                                         lib.gif_rasterize_colors_f32)
     if face_colors is None:
@@ -570,6 +595,8 @@ def rasterize(face_vertices, depth, tri, out3, h, w, face_colors=None):
     else:
         rc = colors(face_vertices.data_ptr(), face_colors.data_ptr(), depth.data_ptr(), tri.data_ptr(), out3.data_ptr(), B, F,
                     h, w, ws.data_ptr(), _stream())
+    if rc != 0:
+        _raster_ws.pop(key, None)
     _lib.check(rc, "rasterize")
 
 

@@ -33,6 +33,9 @@ class FlatAdam(torch.optim.Adam):
         self._m = torch.zeros_like(bucket.flat)
         self._v = torch.zeros_like(bucket.flat)
         self._step_t = torch.tensor(0.0)  # shared by every parameter's state (torch keeps one CPU scalar per parameter)
+        # loss-scaled runs (found_inf given): the step count lives on the device and only advances on steps that were applied,
+        # like torch's GradScaler-aware Adam; _step_t is refreshed from it when a state_dict is taken
+        self._step_dev = None
         index = {id(p): i for i, p in enumerate(params)}
         self._ema = None
         if ema_params is not None:
@@ -91,9 +94,20 @@ class FlatAdam(torch.optim.Adam):
         if g["weight_decay"] != 0 or g["amsgrad"] or g["maximize"]:
             raise _lib.GifHipError("FlatAdam implements plain Adam only (no weight decay / amsgrad / maximize)")
         self.bucket.attach()  # gradients must live in the bucket (re-aliases after zero_grad(set_to_none=True))
-        self._step_t += 1
-        t = int(self._step_t.item())
         b1, b2 = g["betas"]
+        dev_step = None
+        if found_inf is not None:
+            if self._step_dev is None:
+                self._step_dev = torch.full((), float(self._step_t.item()), device=self.bucket.flat.device)
+            self._step_dev.add_(1.0 - found_inf.clamp(0.0, 1.0))  # a skipped step does not advance the bias corrections
+            dev_step = self._step_dev
+            t = 1  # (host-side corrections unused: the kernel derives them from the device counter)
+        else:
+            if self._step_dev is not None:  # leaving a loss-scaled phase: continue from the device count
+                self._step_t.fill_(float(self._step_dev.item()))
+                self._step_dev = None
+            self._step_t += 1
+            t = int(self._step_t.item())
         table, n = self._chunks()
         has_ema = self._ema is not None and ema_decay is not None
         lib = _lib.load()
@@ -103,16 +117,31 @@ class FlatAdam(torch.optim.Adam):
                                                  1.0 - b1 ** t, 1.0 - b2 ** t, float(ema_decay or 0.0), 1 if has_ema else 0,
                                                  None if inv_grad_scale is None else inv_grad_scale.data_ptr(),
                                                  None if found_inf is None else found_inf.data_ptr(),
+                                                 None if dev_step is None else dev_step.data_ptr(),
                                                  torch.cuda.current_stream().cuda_stream), "adam_ema_step")
         # the kernel wrote through raw pointers: tell autograd the tensors changed (saved-tensor checks, caches keyed on it)
         torch.autograd.graph.increment_version(self.bucket.params)
         if has_ema:
             torch.autograd.graph.increment_version(self._ema)
-            if self._ema_rest and found_inf is None:
+            if self._ema_rest:
                 e, p = [a for a, _ in self._ema_rest], [b for _, b in self._ema_rest]
-                torch._foreach_mul_(e, ema_decay)
-                torch._foreach_add_(e, p, alpha=1 - ema_decay)
+                if found_inf is None:
+                    torch._foreach_mul_(e, ema_decay)
+                    torch._foreach_add_(e, p, alpha=1 - ema_decay)
+                else:  # e += w * (p - e) with w = (1 - decay) on applied steps and 0 on skipped ones, decided on the device
+                    w = (1.0 - ema_decay) * (1.0 - found_inf.clamp(0.0, 1.0))
+                    torch._foreach_lerp_(e, p, [w] * len(e))
         return loss
+
+    def zero_grad(self, set_to_none=True):
+        """The gradients live in the flat bucket: clearing them means zeroing the bucket (a plain set-to-None would leave the
+        previous step's values in the bucket for any parameter the next backward does not reach)."""
+        self.bucket.zero()
+
+    def state_dict(self):
+        if self._step_dev is not None:
+            self._step_t.fill_(float(self._step_dev.item()))
+        return super().state_dict()
 
     # ---- checkpoint compatibility --------------------------------------------------------------------------------
     def load_state_dict(self, state_dict):

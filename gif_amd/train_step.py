@@ -57,6 +57,10 @@ def broadcast_module_state(modules, src=0, group=None):
                 t.data.copy_(h)
             else:
                 dist.broadcast(t.data, src=src, group=group)
+    # writes through .data do not bump the tensors' version counters: packed / transformed weights cached from a forward that
+    # ran before this broadcast would otherwise survive it on the non-source ranks
+    from . import ops
+    ops.clear_weight_cache()
 
 
 class FlatGradBucket:
@@ -86,6 +90,7 @@ class FlatGradBucket:
         self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
         self.views = [self.flat[off:off + p.numel()].view_as(p) for p, off in zip(self.params, self.offsets)]
         self._pending = None
+        self._known_zero = True  # the whole buffer is zero (fresh / after zero()): attach() need not clear gradient-less views
         self.comm_events = None  # bench.py: a list collects (start, end) HIP-event pairs around every wait for an exchange
         self.attach()
 
@@ -93,17 +98,22 @@ class FlatGradBucket:
         """(Re-)alias every active p.grad to its bucket view; gradients that live elsewhere are moved in first — all of them
         in ONE multi-tensor copy (after zero() that is every gradient of the backward pass: autograd hands a fresh tensor to a
         parameter whose .grad is None, where it would otherwise launch one accumulation add per parameter into the view)."""
-        dst, src = [], []
+        dst, src, stale = [], [], []
         for p, v in zip(self.params, self.views):
             g = p.grad
             if g is None or g.data_ptr() != v.data_ptr():
                 if g is not None:
                     dst.append(v)
                     src.append(g.detach())
+                else:
+                    stale.append(v)  # no gradient this round: the view must not expose whatever the bucket held before
                 p.grad = v
-        if dst:
-            with torch.no_grad():
+        with torch.no_grad():
+            if dst:
                 torch._foreach_copy_(dst, src)
+            if stale and not self._known_zero:
+                torch._foreach_zero_(stale)
+        self._known_zero = False
         for p in self.inactive:
             p.grad = None
 
@@ -112,6 +122,7 @@ class FlatGradBucket:
         the optimiser) gathers what the backward pass produced."""
         self.wait()
         self.flat.zero_()
+        self._known_zero = True
         for p in self.params:
             p.grad = None
         for p in self.inactive:
@@ -169,11 +180,23 @@ class DeviceLossScaler:
         self.growth_interval, self.max_scale = float(growth_interval), float(max_scale)
         self.skipped = torch.zeros((), device=device)  # number of skipped steps (read it after a synchronize)
 
+    def begin_backward(self):
+        """Call right before backward(): clears the device's "an f16 gradient store saturated" flag (gif_f16_overflow_clear).
+        f16 stores clamp at +-65504, so an overflowing ACTIVATION gradient never shows up as inf in the fp32 weight gradients;
+        the kernels raise the flag instead and update() treats it like a non-finite gradient."""
+        from . import _lib
+        with torch.cuda.device(self.scale.device):
+            _lib.check(_lib.load().gif_f16_overflow_clear(torch.cuda.current_stream().cuda_stream), "f16_overflow_clear")
+
     @torch.no_grad()
     def update(self, flat):
         """Call once per optimiser step BEFORE the Adam launch, with the (already exchanged) gradient bucket."""
-        bad = (~torch.isfinite(flat).all()).to(torch.float32)
-        self.found_inf.copy_(bad)
+        from . import _lib
+        self.found_inf.copy_((~torch.isfinite(flat).all()).to(torch.float32))
+        with torch.cuda.device(self.scale.device):  # |= a saturated f16 gradient store since begin_backward()
+            _lib.check(_lib.load().gif_f16_overflow_or_into(self.found_inf.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                       "f16_overflow_or_into")
+        bad = self.found_inf.clone()
         self.inv_scale.copy_(1.0 / self.scale)  # the scale the gradients in `flat` were produced with
         self.skipped.add_(bad)
         good = (self._good + 1.0) * (1.0 - bad)
@@ -277,6 +300,12 @@ class GifTrainer:
         self._finish_d_update()
         self._finish_g_update()
 
+    def ema_generator(self):
+        """The running-average generator with every deferred update applied (overlap_comm defers G's exchange + Adam + EMA to the
+        next use of G): use this — or call flush() — before sampling from G_ema / reading weights mid-training."""
+        self.flush()
+        return self.G_ema
+
     def _finish_g_update(self):
         if self._g_update_pending:
             self._g_update_pending = False
@@ -327,6 +356,8 @@ class GifTrainer:
         fake_scores, _ = D([fake.detach()], condition=cond, step=self.res_step, alpha=self.alpha)
         fake_loss = F.softplus(fake_scores).mean()
         d_loss = real_loss + fake_loss
+        if self.d_scaler is not None:
+            self.d_scaler.begin_backward()
         (d_loss if self.d_scaler is None else d_loss * self.d_scaler.scale).backward()
         if self.overlap_comm:
             self.d_bucket.all_reduce_mean(async_op=True)
@@ -362,6 +393,8 @@ class GifTrainer:
             loss = loss + 1e-8 * 8 * losses.grad_penalty_loss([cond], torch.pow(fake[-1], 2), step=None).mean()
         if self.embedding_reg_weight:
             loss = loss + self.embedding_reg_weight * losses.l2_reg(G.z_to_w)
+        if self.g_scaler is not None:
+            self.g_scaler.begin_backward()
         (loss if self.g_scaler is None else loss * self.g_scaler.scale).backward()
         self._g_update()
         requires_grad(G, False)

@@ -30,6 +30,14 @@ typedef void* gif_stream_t;
 const char* gif_last_error(void);
 int gif_abi_version(void);
 
+/* f16-activation path (BASELINE configs[4]): every f16 activation store saturates at +-65504, which would hide an overflowing
+ * activation GRADIENT from a dynamic loss scaler (the fp32 weight gradients computed from clamped values stay finite).  The
+ * stores that can carry gradients (convolution / FIR epilogues, the leaky-ReLU backward, the modulation-gradient pass) raise a
+ * per-device flag word when they clamp or see a non-finite value: clear it before backward(), OR it into the scaler's found_inf
+ * scalar afterwards (both on the stream, no host synchronisation). */
+int gif_f16_overflow_clear(gif_stream_t stream);
+int gif_f16_overflow_or_into(float* found_inf, gif_stream_t stream);
+
 /* How the fp32 convolution contractions reach the matrix cores (process-wide; fp32 tensors in, fp32 tensors out either way):
  *   NATIVE : v_mfma_f32_32x32x2_f32 on the fp32 operands (157 TFLOP/s peak).
  *   BF16X3 : every fp32 operand element a is split into three bf16 terms a = hi + mid + lo (round-to-nearest at each level,
@@ -69,6 +77,10 @@ int gif_pack_weight_f32x3(const float* w, void* wp3, int R, int C, int KH, int K
  * a counter and an F-entry list per tile — sized for the worst case, touched only where faces land (288 GB of HBM).
  * ---------------------------------------------------------------------------------------------- */
 int64_t gif_rasterize_workspace_bytes(int B, int F, int H, int W);
+/* The tile counters at the head of the workspace (4 bytes per image and tile) are zeroed by a memset node at the start of every
+ * call and handed back zero by the tile kernel.  A host that keeps ONE zero-initialised workspace per (stream, problem size)
+ * and never shares it between concurrent calls may switch the memset off (process-wide): on != 0. */
+int gif_rasterize_assume_clean_workspace(int on);
 int gif_rasterize_f32(const float* face_vertices, float* depth, int32_t* tri, float* bary, int B, int F,
                       int H, int W, void* workspace, gif_stream_t stream);
 int gif_rasterize_colors_f32(const float* face_vertices, const float* face_colors, float* depth,
@@ -401,7 +413,7 @@ int gif_adam_chunk_floats(void);
 int gif_adam_ema_step_f32(const gif_adam_chunk* chunks, int nchunks, const float* grad_flat, float* exp_avg_flat,
                           float* exp_avg_sq_flat, float lr, float beta1, float beta2, float eps, double bias_correction1,
                           double bias_correction2, float ema_decay, int has_ema, const float* inv_grad_scale,
-                          const float* found_inf, gif_stream_t stream);
+                          const float* found_inf, const float* dev_step, gif_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -136,6 +136,16 @@ def bilinear_down(x, S, backward_to=None):
     return g.contiguous(memory_format=CL)
 
 
+def resize(x, out_hw, mode, backward_to=None):
+    if backward_to is None:
+        return F.interpolate(x, size=tuple(out_hw), mode=mode, align_corners=False)
+    with torch.enable_grad():
+        full = torch.zeros(x.shape[0], x.shape[1], *backward_to, requires_grad=True)
+        y = F.interpolate(full, size=tuple(x.shape[2:]), mode=mode, align_corners=False)
+        (g,) = torch.autograd.grad(y, full, x.detach())
+    return g
+
+
 def _mbstd_stat(x, G):
     B, C, H, W = x.shape
     s = x.reshape(G, B // G, C, H, W)
@@ -189,7 +199,7 @@ def linear_tn(a, b, scale=1.0, n_valid=None, k_valid=None):
     return scale * (a[:, :N].t() @ b[:, :K])
 
 
-OPS = dict(linear_nt=linear_nt, linear_nn=linear_nn, linear_tn=linear_tn, nhwc=nhwc, conv_fwd=conv_fwd, conv_bwd_data=conv_bwd_data, conv_wgrad=conv_wgrad, upfirdn2d=upfirdn2d,
+OPS = dict(resize=resize, linear_nt=linear_nt, linear_nn=linear_nn, linear_tn=linear_tn, nhwc=nhwc, conv_fwd=conv_fwd, conv_bwd_data=conv_bwd_data, conv_wgrad=conv_wgrad, upfirdn2d=upfirdn2d,
            bias_act=bias_act, bias_act_bwd=bias_act_bwd, colsum=colsum, mul_reduce=mul_reduce,
            act_inv_mul_reduce=act_inv_mul_reduce, bilinear_down=bilinear_down, mbstd_fwd=mbstd_fwd, mbstd_bwd=mbstd_bwd,
            sqnorm_per_sample=sqnorm_per_sample)

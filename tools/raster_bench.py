@@ -95,6 +95,8 @@ def _timeit(fn, calls=20, replays=5):
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
+        fn()  # (per-stream state of the callee — the rasteriser's persistent workspace — exists before the capture starts)
+        torch.cuda.synchronize()
         with torch.cuda.graph(g, stream=side):
             for _ in range(calls):
                 fn()
