@@ -188,3 +188,22 @@ def test_bucket_moves_a_detached_gradient_back_in():
         assert p.grad.data_ptr() == v.data_ptr()
         if id(p) in stray:
             assert torch.equal(v, stray[id(p)])
+
+
+def test_attach_does_not_expose_stale_gradients_after_set_to_none():
+    """The reference loop clears gradients with zero_grad() (set_to_none): a parameter the NEXT backward does not reach must then
+    see a zero gradient in the bucket, not the previous step's values (advisor finding, round 2)."""
+    m = _model()
+    b = FlatGradBucket(m.parameters())
+    m(torch.ones(2, 8)).sum().backward()
+    b.attach()
+    assert b.flat.abs().sum() > 0
+    m.zero_grad(set_to_none=True)  # NOT bucket.zero(): the bucket still holds the old numbers
+    first = next(iter(m.parameters()))
+    others = [p for p in m.parameters() if p is not first]
+    # a backward that reaches only `first`
+    (first * 2.0).sum().backward()
+    b.attach()
+    assert torch.equal(first.grad, torch.full_like(first, 2.0))
+    for p in others:
+        assert p.grad is not None and p.grad.abs().max().item() == 0.0, "stale gradient exposed"

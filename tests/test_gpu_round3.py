@@ -294,3 +294,93 @@ def test_bench_single_rank_collective_code_path_and_line_contract():
     assert abs(r["executed_frac"] - r["executed_achieved"] / r["executed_peak"]) < 1e-9
     rr = line["roofline_rasterize"]
     assert rr.get("error") is None and rr["unit"] == "GB/s" and rr["Mtri_per_s"] > 0 and rr["cpu_baseline"]["value"] > 0
+
+
+# ------------------------------------------------------------------------------------------------ advisor findings of round 2
+def test_f16_gradient_store_saturation_raises_the_overflow_flag():
+    """f16 activation stores clamp at +-65504: an overflowing activation GRADIENT would never reach the loss scaler as inf.  The
+    gradient-carrying stores raise a device flag instead (gif_f16_overflow_clear / _or_into), which DeviceLossScaler ORs into
+    found_inf: an overflow now halves the scale and skips the step."""
+    from gif_amd import _lib, ops
+    from gif_amd.train_step import DeviceLossScaler
+    lib = _lib.load()
+    stream = torch.cuda.current_stream().cuda_stream
+    B, C, H = 2, 64, 16
+    w = (torch.randn(C, C, 3, 3) / 24).cuda()
+    spec = ops.ConvSpec(3, 3, 1, 1)
+    found = torch.zeros((), device="cuda")
+
+    def flag_after(fn):
+        assert lib.gif_f16_overflow_clear(stream) == 0
+        fn()
+        found.zero_()
+        assert lib.gif_f16_overflow_or_into(found.data_ptr(), stream) == 0
+        return found.item()
+
+    small = _cl(torch.randn(B, C, H, H).cuda().half())
+    huge = _cl((torch.randn(B, C, H, H) * 3e4).cuda().half())
+    assert flag_after(lambda: ops.conv_bwd_data(small, w, spec, (H, H))) == 0.0
+    out = ops.conv_bwd_data(huge, w, spec, (H, H))
+    assert out.abs().max().item() == 65504.0, "the store saturates"
+    assert flag_after(lambda: ops.conv_bwd_data(huge, w, spec, (H, H))) == 1.0, "data-gradient epilogue"
+    y = _cl(torch.randn(B, C, H, H).cuda().half())
+    assert flag_after(lambda: ops.bias_act_bwd(small, y, True)) == 0.0
+    assert flag_after(lambda: ops.bias_act_bwd(huge * 2, y, True)) == 1.0, "leaky-ReLU backward"
+    k1 = torch.tensor([1., 3., 3., 1.])
+    k = (k1[:, None] * k1[None, :] / 4).cuda()  # gain 16: drives the FIR output past the f16 range
+    assert flag_after(lambda: ops.upfirdn2d(huge, k, 1, 1, 1, (H - 1, H - 1), False)) == 1.0, "FIR adjoint"
+    s = torch.full((B, C), 4.0, device="cuda")
+    assert flag_after(lambda: ops.mul_reduce(huge, small, scale=s, want_scaled=True)) == 1.0, "modulation-gradient pass"
+    # the scaler: finite fp32 bucket + raised flag => found_inf, scale halves
+    sc = DeviceLossScaler(torch.device("cuda"), init_scale=1024.0)
+    sc.begin_backward()
+    ops.conv_bwd_data(huge, w, spec, (H, H))
+    sc.update(torch.ones(16, device="cuda"))
+    assert sc.found_inf.item() == 1.0 and sc.scale.item() == 512.0 and sc.skipped.item() == 1.0
+    sc.begin_backward()
+    ops.conv_bwd_data(small, w, spec, (H, H))
+    sc.update(torch.ones(16, device="cuda"))
+    assert sc.found_inf.item() == 0.0 and sc.scale.item() == 512.0
+
+
+def test_flat_adam_under_loss_scaling_counts_applied_steps_only():
+    """A skipped (overflowed) step must not advance Adam's bias corrections, and the EMA of parameters outside the gradient bucket
+    still runs on applied steps (advisor finding, round 2).  Reference: torch.optim.Adam stepping only on the applied steps."""
+    from gif_amd.optim import FlatAdam
+    from gif_amd.train_step import FlatGradBucket
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.Linear(32, 8)).cuda()
+    ema = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.Linear(32, 8)).cuda()
+    ema.load_state_dict(net.state_dict())
+    ref = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.Linear(32, 8)).cuda()
+    ref.load_state_dict(net.state_dict())
+    ref_ema = [p.detach().clone() for p in ref.parameters()]
+    frozen = net[1].bias  # outside the bucket: no gradient, still part of the EMA
+    bucket = FlatGradBucket(net.parameters(), active=lambda p: p is not frozen)
+    opt = FlatAdam(net.parameters(), lr=0.01, betas=(0.5, 0.9), bucket=bucket, ema_params=list(ema.parameters()))
+    ropt = torch.optim.Adam([p for p in ref.parameters()], lr=0.01, betas=(0.5, 0.9))
+    scale = 8.0
+    inv = torch.tensor(1.0 / scale, device="cuda")
+    decay = 0.9
+    x = torch.randn(5, 4, 16, device="cuda")
+    for it, overflow in enumerate([True, False, False, True, False]):
+        bucket.zero()
+        (net(x[it]).pow(2).mean() * scale).backward()
+        with torch.no_grad():  # an externally changed frozen parameter must reach the EMA on applied steps
+            frozen.add_(0.01)
+            list(ref.parameters())[3].add_(0.01)
+        found = torch.tensor(1.0 if overflow else 0.0, device="cuda")
+        opt.step(ema_decay=decay, inv_grad_scale=inv, found_inf=found)
+        if not overflow:
+            ropt.zero_grad()
+            ref(x[it]).pow(2).mean().backward()
+            list(ref.parameters())[3].grad = None
+            ropt.step()
+            with torch.no_grad():
+                for e, p in zip(ref_ema, ref.parameters()):
+                    e.mul_(decay).add_(p, alpha=1 - decay)
+    for a, b in zip(net.parameters(), ref.parameters()):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+    for a, b in zip(ema.parameters(), ref_ema):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+    assert float(opt.state_dict()["state"][0]["step"]) == 3.0, "three applied steps"
