@@ -104,6 +104,11 @@ PROTOTYPES = {
     "gif_linear_nt_f32": (c_int, [P, P, P, P] + [c_int] * 7 + [c_float, c_int, c_float, c_float, P]),
     "gif_linear_nn_f32": (c_int, [P, P, P] + [c_int] * 7 + [c_float, P]),
     "gif_linear_tn_f32": (c_int, [P, P, P] + [c_int] * 6 + [c_float, P]),
+    "gif_weight_sq_sum_f32": (c_int, [P, P, c_int, c_int, c_int, P]),
+    "gif_style_demod_f32": (c_int, [P, P, P] + [c_int] * 7 + [c_float, c_float, P]),
+    "gif_style_demod_bwd_s_f32": (c_int, [P] * 6 + [c_int] * 7 + [c_float, P]),
+    "gif_style_demod_bwd_w_f32": (c_int, [P] * 4 + [c_int] * 5 + [c_float, P]),
+    "gif_demod_wgrad_f32": (c_int, [P, P, P, c_int, c_int, c_int, P]),
     "gif_adam_chunk_floats": (c_int, []),
     "gif_adam_ema_step_f32": (c_int, [P, c_int, P, P, P, c_float, c_float, c_float, c_float, ctypes.c_double, ctypes.c_double,
                                       c_float, c_int, P, P, P, P]),

@@ -30,6 +30,15 @@ struct SkinnyParams {
     float scale;
     int act;
     float slope, gain;
+    // ---- style path (ModulatedConv2d's demodulation, stylegan2_common_layers.py:311-320, forward and backward as GEMM pro-/epilogues)
+    const float* A2;  // a_mode 2: second factor of the A operand, same layout as A
+    int a_mode;       // 0: A   1: A^2 (s^2)   2: A * A2^3 (gd * d^3: the demodulation gradient w.r.t. its accumulator, up to -scale^2/2)
+    int b_sq;         // TN: B^2
+    int epi;          // 0: bias / activation   1: rsqrt(v + eps)   2: E1 + 2 * E2 * v   (E1 may be NULL)
+    float eps, pad_value;
+    const float* E1;
+    const float* E2;
+    int lde;
 };
 
 constexpr int SK_WAVES = 16;  // waves per workgroup = ways the reduction axis is split
@@ -48,10 +57,15 @@ __device__ __forceinline__ void reduce_store(const SkinnyParams& p, f32x16 acc, 
     for (int w = 0; w < SK_WAVES; ++w) s += red[w][r][lane];
     const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lh, col = col0 + li;
     if (row < rows_valid && col < cols_pad) {
-        float v = 0.f;
+        float v = p.pad_value;
         if (col < cols_valid) {
             v = s * p.scale;
-            if (epilogue) {
+            if (p.epi == 1) {
+                v = rsqrtf(v + p.eps);
+            } else if (p.epi == 2) {
+                v = 2.f * p.E2[(size_t)row * p.lde + col] * v;
+                if (p.E1) v += p.E1[(size_t)row * p.lde + col];
+            } else if (epilogue) {
                 if (p.bias) v += p.bias[col];
                 if (p.act) v = (v > 0.f ? v : v * p.slope) * p.gain;
             }
@@ -81,6 +95,7 @@ __global__ void __launch_bounds__(64 * SK_WAVES) skinny_nt_kernel(const SkinnyPa
             const bool ok = k < p.K;  // K % 4 == 0: a float4 is inside or outside as a whole
             av[u] = (ok && a_ok) ? *reinterpret_cast<const f32x4*>(ap + 8 * (c0 + u)) : (f32x4)(0.f);
             bv[u] = (ok && b_ok) ? *reinterpret_cast<const f32x4*>(bp + 8 * (c0 + u)) : (f32x4)(0.f);
+            if (p.a_mode == 1) av[u] *= av[u];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -97,6 +112,7 @@ __global__ void __launch_bounds__(64 * SK_WAVES) skinny_nn_kernel(const SkinnyPa
     const int k0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
     const bool a_ok = m0 + li < p.M, b_ok = k0 + li < p.K;
     const float* ap = p.A + (size_t)(a_ok ? m0 + li : 0) * p.lda + 4 * lh;  // A[m][n]: float4 along n
+    const float* ap2 = p.a_mode == 2 ? p.A2 + (size_t)(a_ok ? m0 + li : 0) * p.lda + 4 * lh : ap;
     const float* bp = p.B + (b_ok ? k0 + li : 0);                           // B[n][k0 + li]: one dword per n
     const int nchunks = (p.N + 7) / 8;
     f32x16 acc;
@@ -110,6 +126,10 @@ __global__ void __launch_bounds__(64 * SK_WAVES) skinny_nn_kernel(const SkinnyPa
         for (int u = 0; u < U; ++u) {
             const int n = 8 * (c0 + u) + 4 * lh;
             av[u] = (n < p.N && a_ok) ? *reinterpret_cast<const f32x4*>(ap + 8 * (c0 + u)) : (f32x4)(0.f);  // in-row: lda >= pad4(N)
+            if (p.a_mode == 2) {
+                const f32x4 d = (n < p.N && a_ok) ? *reinterpret_cast<const f32x4*>(ap2 + 8 * (c0 + u)) : (f32x4)(0.f);
+                av[u] *= d * d * d;
+            }
 #pragma unroll
             for (int t = 0; t < 4; ++t) bv[u][t] = (n + t < p.N && b_ok) ? bp[(size_t)(n + t) * p.ldb] : 0.f;
         }
@@ -132,6 +152,7 @@ __global__ void __launch_bounds__(256) skinny_tn_kernel(const SkinnyParams p) {
     if (n0 >= p.N) return;
     const bool a_ok = n0 + li < p.N, b_ok = k0 + li < p.K;
     const float* ap = p.A + (a_ok ? n0 + li : 0);  // A[m][n0 + li]
+    const float* ap2 = p.a_mode == 2 ? p.A2 + (a_ok ? n0 + li : 0) : ap;
     const float* bp = p.B + (b_ok ? k0 + li : 0);  // B[m][k0 + li]
     f32x16 acc;
 #pragma unroll
@@ -144,6 +165,11 @@ __global__ void __launch_bounds__(256) skinny_tn_kernel(const SkinnyParams p) {
             const int m = m0 + 2 * u + lh;
             av[u] = (m < p.M && a_ok) ? ap[(size_t)m * p.lda] : 0.f;
             bv[u] = (m < p.M && b_ok) ? bp[(size_t)m * p.ldb] : 0.f;
+            if (p.a_mode == 2) {
+                const float d = (m < p.M && a_ok) ? ap2[(size_t)m * p.lda] : 0.f;
+                av[u] *= d * d * d;
+            }
+            if (p.b_sq) bv[u] *= bv[u];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
@@ -155,9 +181,83 @@ __global__ void __launch_bounds__(256) skinny_tn_kernel(const SkinnyParams p) {
     }
 }
 
+// wsq[co][ci] = sum_taps W[co][ci][t]^2 (the weight factor of the demodulation, :318) and its gradient back into the weight:
+// gW[co][ci][t] = 2 * W[co][ci][t] * g_wsq[co][ci].  W / gW: contiguous [Cout][Cin][taps].
+__global__ void __launch_bounds__(256) weight_sq_sum_kernel(const float* __restrict__ w, float* __restrict__ wsq, long n, int taps) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float acc = 0.f;
+    for (int t = 0; t < taps; ++t) {
+        const float v = w[i * taps + t];
+        acc += v * v;
+    }
+    wsq[i] = acc;
+}
+
+__global__ void __launch_bounds__(256) demod_wgrad_kernel(const float* __restrict__ w, const float* __restrict__ g_wsq, float* __restrict__ gw,
+                                                          long n, int taps) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * taps) return;
+    gw[i] = 2.f * w[i] * g_wsq[i / taps];
+}
+
 }  // namespace
 
 extern "C" {
+
+int gif_weight_sq_sum_f32(const float* w, float* wsq, int cout, int cin, int taps, gif_stream_t stream) {
+    GIF_REQUIRE(w && wsq && cout > 0 && cin > 0 && taps > 0, "weight_sq_sum: bad arguments");
+    const long n = (long)cout * cin;
+    weight_sq_sum_kernel<<<gif::cdiv(n, 256), 256, 0, gif::as_stream(stream)>>>(w, wsq, n, taps);
+    return gif::check_launch("weight_sq_sum");
+}
+
+int gif_demod_wgrad_f32(const float* w, const float* g_wsq, float* gw, int cout, int cin, int taps, gif_stream_t stream) {
+    GIF_REQUIRE(w && g_wsq && gw && cout > 0 && cin > 0 && taps > 0, "demod_wgrad: bad arguments");
+    const long n = (long)cout * cin;
+    demod_wgrad_kernel<<<gif::cdiv(n * taps, 256), 256, 0, gif::as_stream(stream)>>>(w, g_wsq, gw, n, taps);
+    return gif::check_launch("demod_wgrad");
+}
+
+// d[b][co] = rsqrt(scale2 * sum_ci s[b][ci]^2 * wsq[co][ci] + eps); columns cout..cout_pad of d are written as 1
+int gif_style_demod_f32(const float* s, const float* wsq, float* d, int B, int cout, int cin, int lds, int ldw, int ldd, int cout_pad,
+                        float scale2, float eps, gif_stream_t stream) {
+    GIF_REQUIRE(s && wsq && d && B >= 0 && cout > 0 && cin > 0, "style_demod: bad arguments");
+    GIF_REQUIRE(cin % 4 == 0 && lds % 4 == 0 && ldw % 4 == 0 && ((uintptr_t)s & 15) == 0 && ((uintptr_t)wsq & 15) == 0,
+                "style_demod: cin and the row strides must be multiples of 4 floats, operands 16-byte aligned");
+    GIF_REQUIRE(cout_pad >= cout && ldd >= cout_pad, "style_demod: cout_pad / ldd too small");
+    if (B == 0) return 0;
+    SkinnyParams p{s, wsq, d, nullptr, B, cout, cin, lds, ldw, ldd, cout_pad, scale2, 0, 1.f, 1.f};
+    p.a_mode = 1; p.epi = 1; p.eps = eps; p.pad_value = 1.f;
+    skinny_nt_kernel<<<dim3(gif::cdiv(cout_pad, 32), gif::cdiv(B, 32)), 64 * SK_WAVES, 0, gif::as_stream(stream)>>>(p);
+    return gif::check_launch("style_demod");
+}
+
+// Backward of the demodulation w.r.t. the modulation: with g_acc = gd * (-scale2 / 2) * d^3 (d = (scale2 * acc + eps)^-1/2),
+//   gs_total[b][ci] = gs_in[b][ci] + 2 * s[b][ci] * sum_co g_acc[b][co] * wsq[co][ci]      (gs_in may be NULL; columns cin..cin_pad zero)
+int gif_style_demod_bwd_s_f32(const float* gd, const float* d, const float* wsq, const float* s, const float* gs_in, float* gs_total,
+                              int B, int cout, int cin, int ldg, int ldw, int lds, int cin_pad, float scale2, gif_stream_t stream) {
+    GIF_REQUIRE(gd && d && wsq && s && gs_total && B >= 0 && cout > 0 && cin > 0, "style_demod_bwd_s: bad arguments");
+    GIF_REQUIRE(ldg % 4 == 0 && ldg >= (cout + 3) / 4 * 4 && ((uintptr_t)gd & 15) == 0 && ((uintptr_t)d & 15) == 0,
+                "style_demod_bwd_s: gd / d rows must be 16-byte aligned multiples of 4 floats covering cout");
+    GIF_REQUIRE(cin_pad >= cin && lds >= cin_pad, "style_demod_bwd_s: cin_pad / lds too small");
+    if (B == 0) return 0;
+    SkinnyParams p{gd, wsq, gs_total, nullptr, B, cout, cin, ldg, ldw, lds, cin_pad, -0.5f * scale2, 0, 1.f, 1.f};
+    p.A2 = d; p.a_mode = 2; p.epi = 2; p.E1 = gs_in; p.E2 = s; p.lde = lds;
+    skinny_nn_kernel<<<dim3(gif::cdiv(cin_pad, 32), gif::cdiv(B, 32)), 64 * SK_WAVES, 0, gif::as_stream(stream)>>>(p);
+    return gif::check_launch("style_demod_bwd_s");
+}
+
+// ... and w.r.t. the weight factor: g_wsq[co][ci] = sum_b g_acc[b][co] * s[b][ci]^2
+int gif_style_demod_bwd_w_f32(const float* gd, const float* d, const float* s, float* g_wsq, int B, int cout, int cin, int ldg, int lds,
+                              float scale2, gif_stream_t stream) {
+    GIF_REQUIRE(gd && d && s && g_wsq && B >= 0 && cout > 0 && cin > 0, "style_demod_bwd_w: bad arguments");
+    SkinnyParams p{gd, s, g_wsq, nullptr, B, cout, cin, ldg, lds, cin, cin, -0.5f * scale2, 0, 1.f, 1.f};
+    p.A2 = d; p.a_mode = 2; p.b_sq = 1;
+    const int tiles = gif::cdiv(cout, 32) * gif::cdiv(cin, 32);
+    skinny_tn_kernel<<<gif::cdiv(tiles, 4), 256, 0, gif::as_stream(stream)>>>(p);
+    return gif::check_launch("style_demod_bwd_w");
+}
 
 int gif_linear_nt_f32(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                       int cpad, float scale, int act, float slope, float gain, gif_stream_t stream) {

@@ -151,7 +151,7 @@ raster_bin(const T* __restrict__ fv, uint32_t* __restrict__ count, uint32_t* __r
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Kernel 2, raster_tiles: one 1024-thread workgroup per (image, 64x64-pixel tile); the tile's z-buffer lives in LDS.
+// Kernel 2, raster_tiles: one 512-thread workgroup per (image, 64x64-pixel tile); the tile's z-buffer lives in LDS.
 //   seed   : key[p] = (ordered_bits(depth_in[p]) << 32) | 0xFFFFFFFF from the caller's depth buffer
 //   shade  : the tile's face list, one face per lane, box clipped to the tile: <= 16 px => the lane walks it; larger => the
 //            wave walks it together, 8x8 pixels per step (face broadcast by shuffles).  Every covered pixel does ONE 64-bit
@@ -167,7 +167,7 @@ raster_bin(const T* __restrict__ fv, uint32_t* __restrict__ count, uint32_t* __r
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kTile = 64;          // pixels per tile edge
 constexpr int kTilePix = kTile * kTile;
-constexpr int kThreads = 1024;    // 4 pixels per thread in the seed / resolve passes, up to 1024 listed faces per shade round
+constexpr int kThreads = 512;     // 8 pixels per thread in the seed / resolve passes, up to 512 listed faces per shade round
 constexpr int kSmallArea = 16;     // clipped boxes up to this many pixels are walked by their own lane
 
 __device__ __forceinline__ unsigned long long ordered_bits64(double d) {
@@ -241,6 +241,15 @@ raster_tiles(const T* __restrict__ fv, const T* __restrict__ fc, uint32_t* __res
         n_sh = (int)count[blockIdx.x];  // blockIdx.x == b * tiles + tile
         count[blockIdx.x] = 0;
     }
+    // first round's face of this lane, fetched speculatively (list entry -> face data: two dependent memory latencies that
+    // would otherwise start only after the seeding barrier).  Entries beyond the list length are stale or uninitialised:
+    // the index is clamped to a valid face and the lane ignores the data if j >= n.
+    constexpr int NW = kThreads / 64;
+    const uint32_t* cand = list + (long)blockIdx.x * F;
+    const T* fvb = fv + (long)b * F * 9;
+    const int j_first = lane * NW + wave;
+    const uint32_t pre_idx = j_first < F ? min(cand[j_first], (uint32_t)(F - 1)) : 0u;
+    const Face<T> pre_face = load_face(fvb + (long)pre_idx * 9);
     // ---- seed the tile's keys from the caller's depth buffer (all loads of a thread in flight together)
     constexpr int PPT = kTilePix / kThreads;  // pixels per thread
     {
@@ -265,20 +274,24 @@ raster_tiles(const T* __restrict__ fv, const T* __restrict__ fc, uint32_t* __res
     __syncthreads();
 
     const int n = n_sh;
-    const uint32_t* cand = list + (long)blockIdx.x * F;
-    const T* fvb = fv + (long)b * F * 9;
     const int lx = lane & 7, ly = lane >> 3;
     for (int pass = 0; pass < (F64 ? 2 : 1); ++pass) {
         {
-            // ---- shade: one candidate per lane; every wave runs the same number of rounds
-            for (int j0 = wave * 64; j0 < n; j0 += kThreads) {
-                const int j = j0 + lane;
+            // ---- shade: one listed face per lane, dealt round-robin over the WAVES (a short list of 100 faces keeps every wave
+            // busy with a few lanes instead of two waves with all of them: a wave walks its larger faces one after the other)
+            for (int j0 = 0; j0 < n; j0 += kThreads) {
+                const int j = j0 + lane * NW + wave;
                 uint32_t fidx = 0;
                 Face<T> f{};
                 int x_min = 0, x_max = -1, y_min = 0, y_max = -1, area = 0;
                 if (j < n) {
-                    fidx = cand[j];
-                    f = load_face(fvb + (long)fidx * 9);
+                    if (j0 == 0) {
+                        fidx = pre_idx;
+                        f = pre_face;
+                    } else {
+                        fidx = cand[j];
+                        f = load_face(fvb + (long)fidx * 9);
+                    }
                     face_bbox(f, H, W, x_min, x_max, y_min, y_max);
                     x_min = max(x_min, tx0); x_max = min(x_max, tx1);
                     y_min = max(y_min, ty0); y_max = min(y_max, ty1);

@@ -334,6 +334,53 @@ def linear_bias_act(x, w, bias=None, scale=1.0, act=False, slope=0.2, gain=1.0, 
 
 
 # --------------------------------------------------------------------------------------------------------
+# style path of ModulatedConv2d (stylegan2_common_layers.py:311-320): demodulation d = rsqrt(scale^2 * s^2 @ wsq^T + eps)
+# --------------------------------------------------------------------------------------------------------
+def _demod_reference(s, w, scale2, eps, cout_pad):
+    """The same function out of any-order pieces (LinearNtFn + torch pointwise ops): what a recorded backward differentiates."""
+    wsq = w.pow(2).sum(dim=(2, 3))
+    cin = wsq.shape[1]
+    acc = LinearNtFn.apply(s[:, :cin].pow(2), wsq, scale2, wsq.shape[0])
+    d = torch.rsqrt(acc + eps)
+    return d if cout_pad == d.shape[1] else torch.nn.functional.pad(d, (0, cout_pad - d.shape[1]), value=1.0)
+
+
+class DemodFn(Function):
+    """d [B, cout_pad] from the modulation s [B, cin_pad] and the conv weight w [Cout, Cin, k, k]: ONE skinny GEMM with the
+    square of s in its operand load and rsqrt in its epilogue (+ wsq = sum_taps w^2, cached per weight version); backward = two
+    GEMMs with the chain-rule factors in their operand loads and one pass over the weight.  The reference (and round 2) spent ~10
+    tiny ATen launches per layer and direction on this.  A recorded backward (create_graph) differentiates _demod_reference."""
+
+    @staticmethod
+    def forward(ctx, s, w, scale2, eps, cout_pad):
+        wsq = ops.weight_sq_sum(w)
+        d = ops.style_demod(s, wsq, scale2, eps, cout_pad)
+        ctx.cfg = (scale2, eps, cout_pad)
+        ctx.save_for_backward(s, w, d)
+        return d
+
+    @staticmethod
+    def backward(ctx, gd):
+        s, w, d = ctx.saved_tensors
+        scale2, eps, cout_pad = ctx.cfg
+        if torch.is_grad_enabled():
+            gs, gw = _recorded_backward((s, w), ctx.needs_input_grad[:2], gd, lambda s_, w_: _demod_reference(s_, w_, scale2, eps, cout_pad))
+            return gs, gw, None, None, None
+        gs = gw = None
+        cout, cin = w.shape[:2]
+        gd = gd.contiguous()
+        if ctx.needs_input_grad[0]:
+            gs = ops.style_demod_bwd_s(gd, d, ops.weight_sq_sum(w), s, None, scale2)
+        if ctx.needs_input_grad[1]:
+            gw = ops.demod_wgrad(w, ops.style_demod_bwd_w(gd, d, s, cout, cin, scale2))
+        return gs, gw, None, None, None
+
+
+def demodulation(s, w, scale, eps, cout_pad):
+    return DemodFn.apply(s, w, float(scale) ** 2, float(eps), int(cout_pad))
+
+
+# --------------------------------------------------------------------------------------------------------
 # fused bias + leaky ReLU (FusedLeakyReLU, stylegan2_common_layers.py:22-39)
 # --------------------------------------------------------------------------------------------------------
 class BiasActFn(Function):

@@ -214,34 +214,43 @@ class ModulatedConv2d(nn.Module):
         return (f'{self.__class__.__name__}({self.in_channel}, {self.out_channel}, {self.kernel_size}, '
                 f'upsample={self.upsample}, downsample={self.downsample})')
 
-    def scales(self, style):
-        """(s [B,Cin_act], d [B,Cout_act] or None) in fp32; tiny [B,512]-sized torch math, differentiable."""
-        s = self.modulation(style)
+    def scales(self, style, in_act=None, out_act=None):
+        """(s [B, in_act], d [B, out_act] or None) in fp32, padded to the activations' channel counts (padded s lanes meet zero
+        activations, padded d lanes are 1).  s: one skinny GEMM (EqualLinear); d: one more with the square / rsqrt in its operand
+        load and epilogue (GF.demodulation)."""
+        in_act = self.in_channel if in_act is None else in_act
+        out_act = self.out_channel if out_act is None else out_act
+        mod = self.modulation
+        x = style.reshape(-1, style.shape[-1])
+        if x.dtype != torch.float32:
+            x = x.float()
+        fast = x.shape[0] <= _SKINNY_MAX_ROWS and self.in_channel % 4 == 0 and in_act <= 1024 and mod.weight.shape[1] % 4 == 0
+        if fast:
+            bias = None if mod.bias is None else _pad_vec(mod.bias if mod.lr_mul == 1 else mod.bias * mod.lr_mul, in_act)
+            s = GF.linear_bias_act(x, mod.weight, bias, mod.scale, False, 0.2, 1.0, in_act)  # columns >= in_channel: zero
+        else:
+            s = mod(style)
+            if in_act != self.in_channel:
+                s = F.pad(s, (0, in_act - self.in_channel), value=1.0)
         d = None
         if self.demodulate:
-            wsq = self.weight[0].pow(2).sum(dim=(2, 3))  # [Cout, Cin]
-            # sum_ci s^2 * wsq on the MFMA kernels (like EqualLinear): d = rsqrt(scale^2 * (s^2 @ wsq^T) + eps)
-            cin, cout = s.shape[1], wsq.shape[0]
-            s2 = s.pow(2)
-            if cin % 4 == 0 and s.shape[0] <= _SKINNY_MAX_ROWS:
-                acc = GF.linear_bias_act(s2, wsq, None, self.scale ** 2, n_pad=cout)
+            if fast and out_act <= 1024:
+                d = GF.demodulation(s, self.weight[0], self.scale, self.eps, out_act)
             else:
+                wsq = self.weight[0].pow(2).sum(dim=(2, 3))  # [Cout, Cin]
+                cin, cout = self.in_channel, wsq.shape[0]
+                s2 = s[:, :cin].pow(2)
                 if pad4(cin) != cin:
                     s2 = F.pad(s2, (0, pad4(cin) - cin))
                 acc = GF.conv2d(s2.reshape(s.shape[0], -1, 1, 1), wsq.view(cout, cin, 1, 1), 1, 0, wscale=self.scale ** 2)
-                acc = acc.reshape(s.shape[0], -1)[:, :cout]
-            d = torch.rsqrt(acc + self.eps)
+                d = torch.rsqrt(acc.reshape(s.shape[0], -1)[:, :cout] + self.eps)
+                if out_act != self.out_channel:
+                    d = F.pad(d, (0, out_act - self.out_channel), value=1.0)
         return s, d
 
     def _padded_scales(self, style, in_act, dtype=torch.float32):
         """fp32 scales padded to the activation's channel counts (multiples of 4 for fp32, 8 for f16 activations)."""
-        s, d = self.scales(style)
-        if in_act != self.in_channel:  # channel-padded activation: padded lanes are zero, scale is irrelevant
-            s = F.pad(s, (0, in_act - self.in_channel), value=1.0)
-        out_act = cpad(self.out_channel, dtype)
-        if d is not None and out_act != self.out_channel:
-            d = F.pad(d, (0, out_act - self.out_channel), value=1.0)
-        return s, d
+        return self.scales(style, in_act, cpad(self.out_channel, dtype))
 
     def forward_fused_act(self, input, style, residual, bias, slope=0.2, gain=2 ** 0.5):
         """act(modconv(input, style) + residual + bias) with everything after the contraction fused into the kernel

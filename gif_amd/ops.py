@@ -710,7 +710,78 @@ def linear_tn(a, b, scale=1.0, n_valid=None, k_valid=None):
     return c
 
 
-for _name in ("linear_nt", "linear_nn", "linear_tn"):
+# ---- style path of ModulatedConv2d (csrc/linear.hip; include/gif_hip.h "Style path") ----
+def weight_sq_sum(w):
+    """wsq [Cout, Cin] = sum_taps w[Cout, Cin, kh, kw]^2, cached per parameter version like the packed weights."""
+    lib = _lib.load()
+    if not w.is_cuda or w.dtype != torch.float32 or w.dim() != 4:
+        raise _lib.GifHipError("weight_sq_sum: need a 4-D fp32 device weight (no CPU fallback)")
+
+    def build():
+        wc = w.contiguous()
+        O, I, KH, KW = wc.shape
+        out = torch.empty((O, I), device=w.device, dtype=torch.float32)
+        _lib.check(lib.gif_weight_sq_sum_f32(wc.data_ptr(), out.data_ptr(), O, I, KH * KW, _stream()), "weight_sq_sum")
+        return out
+    return _cached_weight_op(w, ("wsq",), build)
+
+
+def style_demod(s, wsq, scale2, eps, cout_pad):
+    """d [B, cout_pad] = rsqrt(scale2 * s[:, :Cin]^2 @ wsq^T + eps); padding columns 1."""
+    lib = _lib.load()
+    s, wsq = _mat(s, "style_demod"), _mat(wsq, "style_demod")
+    B = s.shape[0]
+    cout, cin = wsq.shape
+    d = torch.empty((B, cout_pad), device=s.device, dtype=torch.float32)
+    _lib.check(lib.gif_style_demod_f32(s.data_ptr(), wsq.data_ptr(), d.data_ptr(), B, cout, cin, s.stride(0), wsq.stride(0), cout_pad,
+                                       cout_pad, float(scale2), float(eps), _stream()), "style_demod")
+    return d
+
+
+def style_demod_bwd_s(gd, d, wsq, s, gs_in, scale2):
+    """gs_total [B, cin_pad] = gs_in + 2 * s * ((gd * (-scale2/2) * d^3)[:, :Cout] @ wsq); cin_pad = s.shape[1]."""
+    lib = _lib.load()
+    gd, d, wsq, s = _mat(gd, "style_demod_bwd_s"), _mat(d, "style_demod_bwd_s"), _mat(wsq, "style_demod_bwd_s"), _mat(s, "style_demod_bwd_s")
+    B, cin_pad = s.shape
+    cout, cin = wsq.shape
+    if gd.shape != d.shape or gd.stride(0) != d.stride(0):
+        gd, d = gd.contiguous(), d.contiguous()
+    if gs_in is not None:
+        gs_in = gs_in.contiguous()
+        assert gs_in.shape == s.shape
+    s = s.contiguous()
+    out = torch.empty((B, cin_pad), device=s.device, dtype=torch.float32)
+    _lib.check(lib.gif_style_demod_bwd_s_f32(gd.data_ptr(), d.data_ptr(), wsq.data_ptr(), s.data_ptr(), _p(gs_in), out.data_ptr(), B, cout,
+                                             cin, gd.stride(0), wsq.stride(0), cin_pad, cin_pad, float(scale2), _stream()),
+               "style_demod_bwd_s")
+    return out
+
+
+def style_demod_bwd_w(gd, d, s, cout, cin, scale2):
+    """g_wsq [Cout, Cin] = (gd * (-scale2/2) * d^3)[:, :Cout]^T @ s[:, :Cin]^2."""
+    lib = _lib.load()
+    gd, d, s = _mat(gd, "style_demod_bwd_w"), _mat(d, "style_demod_bwd_w"), _mat(s, "style_demod_bwd_w")
+    if gd.stride(0) != d.stride(0):
+        gd, d = gd.contiguous(), d.contiguous()
+    B = s.shape[0]
+    out = torch.empty((cout, cin), device=s.device, dtype=torch.float32)
+    _lib.check(lib.gif_style_demod_bwd_w_f32(gd.data_ptr(), d.data_ptr(), s.data_ptr(), out.data_ptr(), B, cout, cin, gd.stride(0),
+                                             s.stride(0), float(scale2), _stream()), "style_demod_bwd_w")
+    return out
+
+
+def demod_wgrad(w, g_wsq):
+    """gW [Cout, Cin, kh, kw] = 2 * w * g_wsq[:, :, None, None]."""
+    lib = _lib.load()
+    wc = w.contiguous()
+    O, I, KH, KW = wc.shape
+    g_wsq = g_wsq.contiguous()
+    out = torch.empty_like(wc)
+    _lib.check(lib.gif_demod_wgrad_f32(wc.data_ptr(), g_wsq.data_ptr(), out.data_ptr(), O, I, KH * KW, _stream()), "demod_wgrad")
+    return out
+
+
+for _name in ("linear_nt", "linear_nn", "linear_tn", "weight_sq_sum", "style_demod", "style_demod_bwd_s", "style_demod_bwd_w", "demod_wgrad"):
     globals()[_name] = _device_guard(globals()[_name])
 del _name
 

@@ -289,6 +289,25 @@ int gif_act_inv_mul_reduce_f32(const float* g, const float* y, const float* resi
                                float* partial, int B, int64_t HW, int C, float slope, float gain, gif_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Style path of ModulatedConv2d (stylegan2_common_layers.py:311-320): s = modulation(style) is gif_linear_nt_f32; the
+ * demodulation d[b,co] = rsqrt(scale2 * sum_ci s[b,ci]^2 * wsq[co,ci] + eps), wsq[co,ci] = sum_taps W[co,ci,.]^2, and its backward
+ * run as skinny GEMMs with the squares / rsqrt / chain-rule factors in their operand loads and epilogues (the reference
+ * materialises the per-sample weight tensor [B,Cout,Cin,k,k] for this).  With g_acc = gd * (-scale2/2) * d^3:
+ *   gif_style_demod_bwd_s_f32: gs_total = gs_in + 2 * s * (g_acc @ wsq)   (gs_in: the modulation gradient from the conv, or NULL)
+ *   gif_style_demod_bwd_w_f32: g_wsq = g_acc^T @ s^2;   gif_demod_wgrad_f32: gW[co,ci,t] = 2 * W[co,ci,t] * g_wsq[co,ci]
+ * Row strides in floats (multiples of 4, 16-byte aligned rows); padded columns: d -> 1, gs_total -> 0.
+ * ---------------------------------------------------------------------------------------------- */
+int gif_weight_sq_sum_f32(const float* w, float* wsq, int cout, int cin, int taps, gif_stream_t stream);
+int gif_style_demod_f32(const float* s, const float* wsq, float* d, int B, int cout, int cin, int lds, int ldw, int ldd,
+                        int cout_pad, float scale2, float eps, gif_stream_t stream);
+int gif_style_demod_bwd_s_f32(const float* gd, const float* d, const float* wsq, const float* s, const float* gs_in,
+                              float* gs_total, int B, int cout, int cin, int ldg, int ldw, int lds, int cin_pad, float scale2,
+                              gif_stream_t stream);
+int gif_style_demod_bwd_w_f32(const float* gd, const float* d, const float* s, float* g_wsq, int B, int cout, int cin, int ldg,
+                              int lds, float scale2, gif_stream_t stream);
+int gif_demod_wgrad_f32(const float* w, const float* g_wsq, float* gw, int cout, int cin, int taps, gif_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Minibatch standard deviation — replaces stg2_discriminator.py:59-65.
  * x [B,H,W,C] -> y [B,H,W,Cy] (Cy >= C+1): y[..., :C] = x, y[..., C] = stat[b % M], rest 0, with
  * M = B/G, stat[m] = mean_{c,h,w} sqrt(var_{g}(x[g*M+m]) + 1e-8) (biased variance over the G members).

@@ -199,7 +199,36 @@ def linear_tn(a, b, scale=1.0, n_valid=None, k_valid=None):
     return scale * (a[:, :N].t() @ b[:, :K])
 
 
-OPS = dict(resize=resize, linear_nt=linear_nt, linear_nn=linear_nn, linear_tn=linear_tn, nhwc=nhwc, conv_fwd=conv_fwd, conv_bwd_data=conv_bwd_data, conv_wgrad=conv_wgrad, upfirdn2d=upfirdn2d,
+def weight_sq_sum(w):
+    return w.pow(2).sum(dim=(2, 3))
+
+
+def style_demod(s, wsq, scale2, eps, cout_pad):
+    cout, cin = wsq.shape
+    d = torch.rsqrt(scale2 * (s[:, :cin].pow(2) @ wsq.t()) + eps)
+    return F.pad(d, (0, cout_pad - cout), value=1.0)
+
+
+def _g_acc(gd, d, cout, scale2):
+    return gd[:, :cout] * (-0.5 * scale2) * d[:, :cout].pow(3)
+
+
+def style_demod_bwd_s(gd, d, wsq, s, gs_in, scale2):
+    cout, cin = wsq.shape
+    g = F.pad(2.0 * s[:, :cin] * (_g_acc(gd, d, cout, scale2) @ wsq), (0, s.shape[1] - cin))
+    return g if gs_in is None else g + gs_in
+
+
+def style_demod_bwd_w(gd, d, s, cout, cin, scale2):
+    return _g_acc(gd, d, cout, scale2).t() @ s[:, :cin].pow(2)
+
+
+def demod_wgrad(w, g_wsq):
+    return 2.0 * w * g_wsq[:, :, None, None]
+
+
+OPS = dict(weight_sq_sum=weight_sq_sum, style_demod=style_demod, style_demod_bwd_s=style_demod_bwd_s, style_demod_bwd_w=style_demod_bwd_w,
+           demod_wgrad=demod_wgrad, resize=resize, linear_nt=linear_nt, linear_nn=linear_nn, linear_tn=linear_tn, nhwc=nhwc, conv_fwd=conv_fwd, conv_bwd_data=conv_bwd_data, conv_wgrad=conv_wgrad, upfirdn2d=upfirdn2d,
            bias_act=bias_act, bias_act_bwd=bias_act_bwd, colsum=colsum, mul_reduce=mul_reduce,
            act_inv_mul_reduce=act_inv_mul_reduce, bilinear_down=bilinear_down, mbstd_fwd=mbstd_fwd, mbstd_bwd=mbstd_bwd,
            sqnorm_per_sample=sqnorm_per_sample)

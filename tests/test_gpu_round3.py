@@ -364,11 +364,11 @@ def test_flat_adam_under_loss_scaling_counts_applied_steps_only():
     decay = 0.9
     x = torch.randn(5, 4, 16, device="cuda")
     for it, overflow in enumerate([True, False, False, True, False]):
-        bucket.zero()
-        (net(x[it]).pow(2).mean() * scale).backward()
         with torch.no_grad():  # an externally changed frozen parameter must reach the EMA on applied steps
             frozen.add_(0.01)
             list(ref.parameters())[3].add_(0.01)
+        bucket.zero()
+        (net(x[it]).pow(2).mean() * scale).backward()
         found = torch.tensor(1.0 if overflow else 0.0, device="cuda")
         opt.step(ema_decay=decay, inv_grad_scale=inv, found_inf=found)
         if not overflow:
@@ -384,3 +384,65 @@ def test_flat_adam_under_loss_scaling_counts_applied_steps_only():
     for a, b in zip(ema.parameters(), ref_ema):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
     assert float(opt.state_dict()["state"][0]["step"]) == 3.0, "three applied steps"
+
+
+# ------------------------------------------------------------------------------------------------ fused style path (demodulation)
+@pytest.mark.parametrize("shape", [(32, 512, 512, 3), (8, 128, 256, 3), (5, 64, 32, 3), (4, 256, 3, 1)])
+def test_demodulation_kernels_and_function(shape):
+    """d = rsqrt(scale^2 * s^2 @ wsq^T + eps) as one skinny GEMM (squares in the operand load, rsqrt in the epilogue), its
+    backward as two GEMMs + one pass over the weight, against float64 math; DemodFn against the any-order reference
+    composition to first and second order (stylegan2_common_layers.py:311-320)."""
+    from gif_amd import functional as GF
+    from gif_amd import ops
+    B, cin, cout, k = shape
+    g = torch.Generator().manual_seed(cin + cout)
+    cin_pad, cout_pad = cin + 4, ops.pad4(cout) + 4
+    s = torch.zeros(B, cin_pad)
+    s[:, :cin] = torch.randn(B, cin, generator=g) + 1.0
+    w = torch.randn(cout, cin, k, k, generator=g)
+    gd = torch.randn(B, cout_pad, generator=g)
+    gs_in = torch.randn(B, cin_pad, generator=g)
+    scale2, eps = 1.0 / (cin * k * k), 1e-8
+    sd, wd = s.double(), w.double()
+    wsq_ref = wd.pow(2).sum(dim=(2, 3))
+    d_ref = torch.rsqrt(scale2 * (sd[:, :cin].pow(2) @ wsq_ref.t()) + eps)
+    sc, wc, gdc = s.cuda(), w.cuda(), gd.cuda()
+    wsq = ops.weight_sq_sum(wc)
+    assert ((wsq.double().cpu() - wsq_ref).abs().max() / wsq_ref.abs().max()).item() < 1e-6
+    d = ops.style_demod(sc, wsq, scale2, eps, cout_pad)
+    assert d.shape == (B, cout_pad) and (d[:, cout:] == 1).all()
+    assert ((d[:, :cout].double().cpu() - d_ref).abs().max() / d_ref.abs().max()).item() < 2e-6
+    g_acc = gd.double()[:, :cout] * (-0.5 * scale2) * d_ref.pow(3)
+    gs_ref = gs_in.double().clone()
+    gs_ref[:, :cin] += 2 * sd[:, :cin] * (g_acc @ wsq_ref)
+    gs = ops.style_demod_bwd_s(gdc, d, wsq, sc, gs_in.cuda(), scale2)
+    assert ((gs.double().cpu() - gs_ref).abs().max() / gs_ref.abs().max()).item() < 5e-6
+    gs0 = ops.style_demod_bwd_s(gdc, d, wsq, sc, None, scale2)
+    assert (gs0[:, cin:] == 0).all()
+    assert ((gs0.double().cpu() - (gs_ref - gs_in.double())).abs().max() / gs_ref.abs().max()).item() < 5e-6
+    gwsq_ref = g_acc.t() @ sd[:, :cin].pow(2)
+    gwsq = ops.style_demod_bwd_w(gdc, d, sc, cout, cin, scale2)
+    assert ((gwsq.double().cpu() - gwsq_ref).abs().max() / gwsq_ref.abs().max()).item() < 5e-6
+    gw = ops.demod_wgrad(wc, gwsq)
+    gw_ref = 2 * wd * gwsq_ref[:, :, None, None]
+    assert ((gw.double().cpu() - gw_ref).abs().max() / gw_ref.abs().max()).item() < 5e-6
+    # the Function: first order (fused kernels) and second order (recorded composition) vs autograd through the reference
+    s1 = sc.clone().requires_grad_(True)
+    w1 = wc.clone().requires_grad_(True)
+    s2 = sc.clone().requires_grad_(True)
+    w2 = wc.clone().requires_grad_(True)
+    d1 = GF.demodulation(s1, w1, scale2 ** 0.5, eps, cout_pad)
+    d2 = GF._demod_reference(s2, w2, scale2, eps, cout_pad)
+    assert ((d1 - d2).abs().max() / d2.abs().max()).item() < 2e-6
+    a1 = torch.autograd.grad(d1, [s1, w1], gdc)
+    a2 = torch.autograd.grad(d2, [s2, w2], gdc)
+    for x1, x2 in zip(a1, a2):
+        assert ((x1 - x2).abs().max() / x2.abs().max()).item() < 1e-5
+    d1 = GF.demodulation(s1, w1, scale2 ** 0.5, eps, cout_pad)
+    d2 = GF._demod_reference(s2, w2, scale2, eps, cout_pad)
+    (g1,) = torch.autograd.grad(d1, s1, gdc, create_graph=True)
+    (g2,) = torch.autograd.grad(d2, s2, gdc, create_graph=True)
+    h1 = torch.autograd.grad(g1.pow(2).sum(), [s1, w1])
+    h2 = torch.autograd.grad(g2.pow(2).sum(), [s2, w2])
+    for x1, x2 in zip(h1, h2):
+        assert ((x1 - x2).abs().max() / x2.abs().max()).item() < 1e-4
