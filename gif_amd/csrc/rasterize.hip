@@ -151,7 +151,7 @@ raster_bin(const T* __restrict__ fv, uint32_t* __restrict__ count, uint32_t* __r
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Kernel 2, raster_tiles: one 512-thread workgroup per (image, 64x64-pixel tile); the tile's z-buffer lives in LDS.
+// Kernel 2, raster_tiles: one 512- or 1024-thread workgroup per (image, 64x64-pixel tile); the tile's z-buffer lives in LDS.
 //   seed   : key[p] = (ordered_bits(depth_in[p]) << 32) | 0xFFFFFFFF from the caller's depth buffer
 //   shade  : the tile's face list, one face per lane, box clipped to the tile: <= 16 px => the lane walks it; larger => the
 //            wave walks it together, 8x8 pixels per step (face broadcast by shuffles).  Every covered pixel does ONE 64-bit
@@ -167,7 +167,6 @@ raster_bin(const T* __restrict__ fv, uint32_t* __restrict__ count, uint32_t* __r
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kTile = 64;          // pixels per tile edge
 constexpr int kTilePix = kTile * kTile;
-constexpr int kThreads = 512;     // 8 pixels per thread in the seed / resolve passes, up to 512 listed faces per shade round
 constexpr int kSmallArea = 16;     // clipped boxes up to this many pixels are walked by their own lane
 
 __device__ __forceinline__ unsigned long long ordered_bits64(double d) {
@@ -219,7 +218,9 @@ __device__ __forceinline__ Face<T> shfl_face(const Face<T>& f, int src) {
     return g;
 }
 
-template <typename T, bool COLORS>
+// kThreads: 1024 (4 pixels per thread in the seed / resolve passes) when the image's faces average >= 256 per tile, else 512:
+// measured 28 vs 35 us (body.obj x 32 at 256^2, ~860 faces per tile) and 185 vs 161 us (512^2, ~215 per tile).
+template <typename T, bool COLORS, int kThreads>
 __global__ void __launch_bounds__(kThreads)
 raster_tiles(const T* __restrict__ fv, const T* __restrict__ fc, uint32_t* __restrict__ count, const uint32_t* __restrict__ list,
              T* __restrict__ depth, int32_t* __restrict__ tri, T* __restrict__ out3, int F, int H, int W, int tiles_x, int tiles_y) {
@@ -385,8 +386,14 @@ int run(const T* fv, const T* fc, T* depth, int32_t* tri, T* out3, int B, int F,
     }
     raster_bin<T><<<dim3((unsigned)gif::cdiv(F, kBinThreads), (unsigned)B), kBinThreads, 0, s>>>(fv, count, list, F, H, W, tiles_x, tiles_y);
     const dim3 grid((unsigned)(B * nt));
-    if (fc) raster_tiles<T, true><<<grid, kThreads, 0, s>>>(fv, fc, count, list, depth, tri, out3, F, H, W, tiles_x, tiles_y);
-    else raster_tiles<T, false><<<grid, kThreads, 0, s>>>(fv, nullptr, count, list, depth, tri, out3, F, H, W, tiles_x, tiles_y);
+    const bool wide = F / nt >= 256;
+    if (fc) {
+        if (wide) raster_tiles<T, true, 1024><<<grid, 1024, 0, s>>>(fv, fc, count, list, depth, tri, out3, F, H, W, tiles_x, tiles_y);
+        else raster_tiles<T, true, 512><<<grid, 512, 0, s>>>(fv, fc, count, list, depth, tri, out3, F, H, W, tiles_x, tiles_y);
+    } else {
+        if (wide) raster_tiles<T, false, 1024><<<grid, 1024, 0, s>>>(fv, nullptr, count, list, depth, tri, out3, F, H, W, tiles_x, tiles_y);
+        else raster_tiles<T, false, 512><<<grid, 512, 0, s>>>(fv, nullptr, count, list, depth, tri, out3, F, H, W, tiles_x, tiles_y);
+    }
     return gif::check_launch(who);
 }
 

@@ -48,11 +48,12 @@ class ActPort:
         return (self.slope, self.gain, self.want_bias, self.parts)
 
 
-def _take_port(x):
-    """(port alias or None, port cfg or None) for a consumer's input x."""
+def _take_port(x, identity=False):
+    """(port alias or None, port cfg or None) for a consumer's input x.  identity selects the kind of port the consumer can
+    serve: False = a real activation (mask in the gradient kernel's epilogue), True = bias-only layers (residual inputs)."""
     port = getattr(x, "_gif_port", None)
     if (port is None or not ops.FUSE_GRAD or not torch.is_grad_enabled() or port.alias is None or not port.alias.requires_grad
-            or x.dtype != torch.float32):
+            or x.dtype != torch.float32 or (port.slope == 1.0 and port.gain == 1.0) != identity):
         return None, None
     return port.alias, port.cfg()
 
@@ -71,9 +72,22 @@ def _tag(y, alias, port):
 
 def _new_port(x_requires_grad, slope, gain, bias):
     """Port of an activation layer's output, or None when nothing will be back-propagated through it."""
-    if not ops.FUSE_GRAD or not torch.is_grad_enabled() or (slope == 1.0 and gain == 1.0):
+    if not ops.FUSE_GRAD or not torch.is_grad_enabled():
         return None
-    return ActPort(slope, gain, bias is not None and bias.requires_grad)
+    want_bias = bias is not None and bias.requires_grad
+    if slope == 1.0 and gain == 1.0 and not want_bias:
+        return None  # identity activation without a bias gradient: nothing a consumer could take over
+    return ActPort(slope, gain, want_bias)
+
+
+def _deliver_residual(r_port, gpre, gb):
+    """A layer's `residual` input is the output of an identity-activation layer (the last condition-noise conv: conv + bias):
+    its gradient IS this layer's pre-activation gradient gpre, and its bias gradient is the same column sum gb this layer takes
+    for its own bias — both are handed over (first-order passes) instead of the producer launching a column-sum pass over gpre."""
+    _, _, want_b, parts = r_port
+    if want_b:
+        parts.append(gb if gb is not None else ops.colsum(gpre))
+    return gpre
 
 
 def _mask_into_port(cfg, gx, x):
@@ -478,13 +492,13 @@ class BlurBiasActFn(Function):
     Outputs (y, port alias of y) — see ActPort."""
 
     @staticmethod
-    def forward(ctx, x, k, pad0, out_hw, residual, bias, slope, gain, parts=None):
+    def forward(ctx, x, k, pad0, out_hw, residual, bias, slope, gain, parts=None, r_port=None, r_alias=None):
         ctx.set_materialize_grads(False)
         x = ops.nhwc(x)
         y = ops.upfirdn2d(x, k, 1, 1, pad0, tuple(out_hw), True, bias=bias, residual=residual, act=True, slope=slope,
                           gain=gain)
         ctx.cfg = (pad0, tuple(x.shape[2:]), slope, gain, residual is not None, bias is not None)
-        ctx.parts = parts
+        ctx.parts, ctx.r_port = parts, r_port
         ctx.save_for_backward(k, y)
         return y, y.detach()  # (not a view of y: see ConvBiasActFn.forward)
 
@@ -494,11 +508,15 @@ class BlurBiasActFn(Function):
         pad0, in_hw, slope, gain, has_res, has_bias = ctx.cfg
         want_b = has_bias and ctx.needs_input_grad[5]
         gpre, gb = _producer_gpre(gy, g_port, y, want_b, slope, gain, ctx.parts)
-        gx = None
+        gx = gr = gra = None
         if gpre is not None and ctx.needs_input_grad[0]:
             gx = Upfirdn2dFn.apply(gpre, k, 1, 1, k.shape[0] - 1 - pad0, in_hw, False)
-        return (gx, None, None, None, gpre if (has_res and ctx.needs_input_grad[4]) else None,
-                gb if want_b else None, None, None, None)
+        if gpre is not None and has_res and ctx.needs_input_grad[4]:
+            if ctx.r_port is not None and not torch.is_grad_enabled():
+                gra = _deliver_residual(ctx.r_port, gpre, gb)
+            else:
+                gr = gpre
+        return gx, None, None, None, gr, (gb if want_b else None), None, None, None, None, gra
 
 
 def blur_bias_act(x, kernel, pad, residual, bias, slope=0.2, gain=2 ** 0.5):
@@ -506,7 +524,9 @@ def blur_bias_act(x, kernel, pad, residual, bias, slope=0.2, gain=2 ** 0.5):
     H, W = x.shape[2:]
     out_hw = (H + pad[0] + pad[1] - kh + 1, W + pad[0] + pad[1] - kh + 1)
     port = _new_port(True, slope, gain, bias)
-    y, alias = BlurBiasActFn.apply(x, kernel, pad[0], out_hw, residual, bias, slope, gain, None if port is None else port.parts)
+    r_alias, r_port = (None, None) if residual is None else _take_port(residual, identity=True)
+    y, alias = BlurBiasActFn.apply(x, kernel, pad[0], out_hw, residual, bias, slope, gain, None if port is None else port.parts,
+                                   r_port, r_alias)
     return _tag(y, alias, port)
 
 
@@ -736,7 +756,8 @@ class ModConvActFn(Function):
     the output of a fused leaky ReLU (see ActPort)."""
 
     @staticmethod
-    def forward(ctx, x, w, s, d, residual, bias, spec, wscale, slope, gain, in_port=None, parts=None, x_port=None):
+    def forward(ctx, x, w, s, d, residual, bias, spec, wscale, slope, gain, in_port=None, parts=None, x_port=None, r_port=None,
+                r_alias=None):
         ctx.set_materialize_grads(False)
         saved_in = (x, s, d, residual)  # saved as given (see ModConvFn.forward)
         x = ops.nhwc(x)
@@ -747,7 +768,7 @@ class ModConvActFn(Function):
         ctx.v = v if ctx.needs_input_grad[1] else None  # Winograd-transformed s*x, reused by the weight gradient
         ctx.cfg = (spec, wscale, slope, gain)
         ctx.has = (residual is not None, bias is not None)
-        ctx.in_port, ctx.parts = in_port, parts
+        ctx.in_port, ctx.parts, ctx.r_port = in_port, parts, r_port
         z = x.new_empty(())  # placeholder for absent tensors (never read): no fill kernel
         x_in, s_in, d_in, r_in = saved_in
         ctx.save_for_backward(x_in, w, s_in, d_in, y, r_in if residual is not None else z, bias if bias is not None else z)
@@ -761,13 +782,13 @@ class ModConvActFn(Function):
         residual = residual if has_res else None
         bias = bias if has_bias else None
         O, I = w.shape[:2]
-        none7 = (None,) * 7
+        none9 = (None,) * 9
         if torch.is_grad_enabled():  # create_graph=True: the gradients must carry history (ports carry first-order gradients only)
             assert g_port is None, "an activation port received a gradient inside a recorded backward"
             gx, gw, gs, gd, gr, gb = _recorded_backward(
                 (x, w, s, d, residual, bias), ctx.needs_input_grad[:6], gy,
                 lambda x_, w_, s_, d_, r_, b_: _modconv_composite(x_, w_, s_, d_, spec, False, None, ws, r_, b_, (slope, gain)))
-            return (gx, gw, gs, gd, gr, gb) + none7
+            return (gx, gw, gs, gd, gr, gb) + none9
         port = ctx.in_port is not None
         x, s, d = ops.nhwc(x), s.contiguous(), d.contiguous()
         residual = None if residual is None else ops.nhwc(residual)
@@ -775,7 +796,7 @@ class ModConvActFn(Function):
         gpre, gb = _producer_gpre(gy, g_port, y, want_b, slope, gain, ctx.parts)
         gx = gs = gd = gw = None
         if gpre is None:
-            return (None,) * 13
+            return (None,) * 15
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
             if ops.dot_fusable(x.shape[2], x.shape[3], x.dtype):
                 gx, gs = _modconv_dgrad_fused(gpre, w, spec, False, x, s, d, ws, ctx.in_port, ctx.needs_input_grad[2])
@@ -789,15 +810,21 @@ class ModConvActFn(Function):
         if ctx.needs_input_grad[3]:
             # d * z = act^-1(y) - residual - bias  =>  gd = sum_hw gpre * z
             gd = ops.act_inv_mul_reduce(gpre, y, residual, bias, slope, gain) / d
-        return ((None if port else gx), gw, gs, gd, gpre if (has_res and ctx.needs_input_grad[4]) else None,
-                gb if want_b else None) + (None,) * 6 + (gx if port else None,)
+        gr = gra = None
+        if has_res and ctx.needs_input_grad[4]:
+            if ctx.r_port is not None:
+                gra = _deliver_residual(ctx.r_port, gpre, gb)
+            else:
+                gr = gpre
+        return ((None if port else gx), gw, gs, gd, gr, gb if want_b else None) + (None,) * 6 + (gx if port else None, None, gra)
 
 
 def modulated_conv2d_act(x, w, s, d, residual, bias, pad, wscale=1.0, slope=0.2, gain=2 ** 0.5):
     x_port, in_port = _take_port(x)
     port = _new_port(True, slope, gain, bias)
+    r_alias, r_port = (None, None) if residual is None else _take_port(residual, identity=True)
     y, alias = ModConvActFn.apply(x, w, s, d, residual, bias, ConvSpec(w.shape[2], w.shape[3], 1, pad), wscale, slope, gain,
-                                  in_port, None if port is None else port.parts, x_port)
+                                  in_port, None if port is None else port.parts, x_port, r_port, r_alias)
     return _tag(y, alias, port)
 
 

@@ -81,7 +81,7 @@ def test_gradient_epilogue_fusions_equal_the_standalone_passes(cpu, monkeypatch)
     cond = torch.rand(4, 6, 16, 16, generator=gen) * 2 - 1
     idx = torch.tensor([1, 5, 9, 13])
     params = list(g.parameters()) + list(d.parameters())
-    calls = {"mask": 0, "dot": 0, "colsum": 0, "bias_act_bwd": 0, "mul_reduce": 0}
+    calls = {"mask": 0, "dot": 0, "colsum": 0, "bias_act_bwd": 0, "mul_reduce": 0, "colsum_op": 0}
     real_fuse = ops.GradFuse
 
     class CountingFuse(real_fuse):
@@ -102,6 +102,12 @@ def test_gradient_epilogue_fusions_equal_the_standalone_passes(cpu, monkeypatch)
     monkeypatch.setattr(ops, "GradFuse", CountingFuse)
     monkeypatch.setattr(ops, "bias_act_bwd", counted("bias_act_bwd"))
     monkeypatch.setattr(ops, "mul_reduce", counted("mul_reduce"))
+    plain_colsum = ops.colsum
+
+    def colsum_counted(x):
+        calls["colsum_op"] += 1
+        return plain_colsum(x)
+    monkeypatch.setattr(ops, "colsum", colsum_counted)
 
     def grads(fused):
         monkeypatch.setattr(ops, "FUSE_GRAD", fused)
@@ -118,6 +124,8 @@ def test_gradient_epilogue_fusions_equal_the_standalone_passes(cpu, monkeypatch)
     assert c0["mask"] == 0 and c0["dot"] == 0 and c0["bias_act_bwd"] > 10 and c0["mul_reduce"] > 8
     assert c1["mask"] > 10 and c1["dot"] >= 8 and c1["colsum"] > 5, c1
     assert c1["bias_act_bwd"] < c0["bias_act_bwd"] // 2, (c0, c1)
+    # the last condition-noise conv of every StyledConv (conv + bias, no activation) gets its bias gradient from the layer it feeds
+    assert c0["colsum_op"] - c1["colsum_op"] >= 5, (c0, c1)  # five StyledConvs at step 2
     n = 0
     for a, b, (k, _) in zip(got, ref, list(g.named_parameters()) + list(d.named_parameters())):
         assert (a is None) == (b is None), k
