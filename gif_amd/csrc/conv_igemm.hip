@@ -721,7 +721,7 @@ struct MultiParams {
 };
 
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool SCALE, int BK, bool X3 = false>
-__global__ void __launch_bounds__(256) conv_gather_mfma_glds_multi(const MultiParams mp) {
+__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_gather_mfma_glds_multi(const MultiParams mp) {
     const int b = (int)blockIdx.x;
     int k = 0;
     while (k + 1 < mp.nph && b >= mp.wg_end[k]) ++k;  // wave-uniform
@@ -803,10 +803,11 @@ int launch_glds_impl(GatherParams& p, hipStream_t s) {
     return 0;
 }
 
-// all phases in one launch (64x64 tiles); returns -100 if the configuration does not fit
-template <typename T, bool SCALE, bool X3 = false>
+// all phases in one launch (64x64 tiles for the low-resolution layers, 256x128 / 8 waves for the big bf16x3 ones: one grid
+// instead of up to eight launches with a partly filled last round each); returns -100 if the configuration does not fit
+template <typename T, bool SCALE, bool X3 = false, int BM = 64, int BN = 64, int WMv = 2, int WNv = 2>
 int launch_glds_multi(GatherParams* ph, int nph, hipStream_t s) {
-    constexpr int BM = 64, BN = 64, BK = 128 / sizeof(T);
+    constexpr int BK = 128 / sizeof(T);
     static gif::LdsAttr attr;
     const float* zero_page = gif::zero_page16();
     if (!zero_page) return -101;
@@ -833,9 +834,9 @@ int launch_glds_multi(GatherParams* ph, int nph, hipStream_t s) {
     if (lds_max > 160 * 1024) return -100;
     t_part_rows += rows;
     t_last_bm = BM;
-    auto kern = conv_gather_mfma_glds_multi<T, BM, BN, 2, 2, SCALE, BK, X3>;
+    auto kern = conv_gather_mfma_glds_multi<T, BM, BN, WMv, WNv, SCALE, BK, X3>;
     attr.ensure(reinterpret_cast<const void*>(kern), lds_max);
-    hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), lds_max, s, mp);
+    hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(64 * WMv * WNv), lds_max, s, mp);
     return 0;
 }
 
@@ -1170,6 +1171,18 @@ int conv2d_bwd_data_impl(const void* small, const void* wp, void* big, const gif
                             (long)ph[i].B * ph[i].Ho * ph[i].Wo * ph[i].Co < (1L << 31);
             if (small_all)
                 merged = launch_multi<T>(ph, nph, base.in_scale != nullptr, s) == 0;
+            if constexpr (sizeof(T) == 4) {
+                // big bf16x3 transposed convs: every phase would run 256x128 tiles on its own (bulk + remainder launch each)
+                static const int big_multi_off = getenv("GIF_X3_MULTI_BIG") ? atoi(getenv("GIF_X3_MULTI_BIG")) == 0 : 0;
+                bool big_all = x3 && !small_all && !big_multi_off && c.BN == 128;
+                for (int i = 0; i < nph && big_all; ++i)
+                    big_all = (long)gif::cdiv(ph[i].M, 256) * (ph[i].RP / 128) >= 512 &&
+                              (long)ph[i].B * ph[i].Hi * ph[i].Wi * ph[i].Ci < (1L << 31) &&
+                              (long)ph[i].B * ph[i].Ho * ph[i].Wo * ph[i].Co < (1L << 31);
+                if (big_all)
+                    merged = (base.in_scale ? launch_glds_multi<T, true, true, 256, 128, 8, 1>(ph, nph, s)
+                                            : launch_glds_multi<T, false, true, 256, 128, 8, 1>(ph, nph, s)) == 0;
+            }
         }
         if (!merged)
             for (int i = 0; i < nph; ++i)

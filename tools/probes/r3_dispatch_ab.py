@@ -1,7 +1,8 @@
-"""Round-3 dispatch experiments on one MI355X (the env knobs are read once per process => one child per configuration):
-  GIF_X3_BIG_MIN_STEPS : short-K transposed-conv phases on 128x128 tiles (2 workgroups / CU) instead of 256x128 (1 / CU)
-  GIF_X3_SMALL=12864   : 4^2..16^2 bf16x3 layers on 128x64 tiles of 4x1 waves instead of 64x64 tiles of 2x2
-  GIF_BLUR_TYL=32      : 32-row sliding windows in the 4x4 blur
+"""Round-3 dispatch experiments on one MI355X (the env knobs are read once per process => one child per configuration).
+First series (profiles/r3_dispatch_ab.txt; knobs removed again): short-K transposed phases on 128x128 tiles (no gain, modulated
+layers slower), 128x64 tiles of 4x1 waves for the 4^2..16^2 bf16x3 layers (+15 %: adopted), 32-row blur windows (slower).
+Second series:
+  GIF_X3_MULTI_BIG=0 : the four phases of a big bf16x3 transposed conv as separate (bulk + remainder) launches instead of one grid
 Usage (GPU): python tools/probes/r3_dispatch_ab.py            (parent: runs every configuration)
 """
 import os
@@ -11,9 +12,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
-CONFIGS = [("baseline", {}), ("big>=9", {"GIF_X3_BIG_MIN_STEPS": "9"}), ("big>=17", {"GIF_X3_BIG_MIN_STEPS": "17"}),
-           ("big>=33", {"GIF_X3_BIG_MIN_STEPS": "33"}), ("big>=37", {"GIF_X3_BIG_MIN_STEPS": "37"}),
-           ("small 128x64", {"GIF_X3_SMALL": "12864"}), ("blur 32 rows", {"GIF_BLUR_TYL": "32"})]
+CONFIGS = [("default (merged big transposed phases)", {}), ("per-phase launches", {"GIF_X3_MULTI_BIG": "0"})]
 
 
 def child():
