@@ -354,7 +354,8 @@ def _demod_reference(s, w, scale2, eps, cout_pad):
     """The same function out of any-order pieces (LinearNtFn + torch pointwise ops): what a recorded backward differentiates."""
     wsq = w.pow(2).sum(dim=(2, 3))
     cin = wsq.shape[1]
-    acc = LinearNtFn.apply(s[:, :cin].pow(2), wsq, scale2, wsq.shape[0])
+    cout = wsq.shape[0]
+    acc = LinearNtFn.apply(s[:, :cin].pow(2), wsq, scale2, ops.pad4(cout))[:, :cout]  # (4-float row granularity of the GEMMs)
     d = torch.rsqrt(acc + eps)
     return d if cout_pad == d.shape[1] else torch.nn.functional.pad(d, (0, cout_pad - d.shape[1]), value=1.0)
 
