@@ -10,8 +10,6 @@
 // its 63 neighbours idle, and every pixel test is a global atomic.)
 // Arithmetic follows the reference operation by operation with FP contraction off, so results are
 // bit-identical to oracle/rasterize_ref.c.
-#include <stdlib.h>
-
 #include <atomic>
 
 #include "common.h"
@@ -220,13 +218,14 @@ __device__ __forceinline__ Face<T> shfl_face(const Face<T>& f, int src) {
     return g;
 }
 
-// kThreads: 1024 (4 pixels per thread in the seed / resolve passes) when the image's faces average >= 256 per tile, else 512:
-// measured 28 vs 35 us (body.obj x 32 at 256^2, ~860 faces per tile) and 185 vs 161 us (512^2, ~215 per tile).
+// Measured (profiles/r3_raster_knobs.txt, body.obj x 32): 512 threads with the listed faces dealt round-robin over the waves is
+// the best or within 10 % of the best of {512, 1024 threads} x {contiguous, round-robin} on all four workloads of
+// tools/raster_bench.py (256^2: 36 vs 33 us; 512^2: 160 vs 194-289 us; screen-filling faces: 57 vs 73-130 us).
+constexpr int kTileThreads = 512;
 template <typename T, bool COLORS, int kThreads>
 __global__ void __launch_bounds__(kThreads)
 raster_tiles(const T* __restrict__ fv, const T* __restrict__ fc, uint32_t* __restrict__ count, const uint32_t* __restrict__ list,
-             T* __restrict__ depth, int32_t* __restrict__ tri, T* __restrict__ out3, int F, int H, int W, int tiles_x, int tiles_y,
-             int deal) {
+             T* __restrict__ depth, int32_t* __restrict__ tri, T* __restrict__ out3, int F, int H, int W, int tiles_x, int tiles_y) {
     constexpr bool F64 = sizeof(T) == 8;
     __shared__ unsigned long long key[kTilePix];
     __shared__ uint32_t fkey[F64 ? kTilePix : 1];
@@ -251,7 +250,7 @@ raster_tiles(const T* __restrict__ fv, const T* __restrict__ fc, uint32_t* __res
     constexpr int NW = kThreads / 64;
     const uint32_t* cand = list + (long)blockIdx.x * F;
     const T* fvb = fv + (long)b * F * 9;
-    const int j_first = deal ? lane * NW + wave : tid;
+    const int j_first = lane * NW + wave;
     const uint32_t pre_idx = j_first < F ? min(cand[j_first], (uint32_t)(F - 1)) : 0u;
     const Face<T> pre_face = load_face(fvb + (long)pre_idx * 9);
     // ---- seed the tile's keys from the caller's depth buffer (all loads of a thread in flight together)
@@ -284,7 +283,7 @@ raster_tiles(const T* __restrict__ fv, const T* __restrict__ fc, uint32_t* __res
             // ---- shade: one listed face per lane, dealt round-robin over the WAVES (a short list of 100 faces keeps every wave
             // busy with a few lanes instead of two waves with all of them: a wave walks its larger faces one after the other)
             for (int j0 = 0; j0 < n; j0 += kThreads) {
-                const int j = j0 + (deal ? lane * NW + wave : tid);
+                const int j = j0 + lane * NW + wave;
                 uint32_t fidx = 0;
                 Face<T> f{};
                 int x_min = 0, x_max = -1, y_min = 0, y_max = -1, area = 0;
@@ -389,18 +388,8 @@ int run(const T* fv, const T* fc, T* depth, int32_t* tri, T* out3, int B, int F,
     }
     raster_bin<T><<<dim3((unsigned)gif::cdiv(F, kBinThreads), (unsigned)B), kBinThreads, 0, s>>>(fv, count, list, F, H, W, tiles_x, tiles_y);
     const dim3 grid((unsigned)(B * nt));
-    // EXPLORATION knobs (tools/raster_bench.py): GIF_RASTER_THREADS = 512 | 1024, GIF_RASTER_DEAL = 0 (contiguous) | 1 (round-robin)
-    static const int env_threads = getenv("GIF_RASTER_THREADS") ? atoi(getenv("GIF_RASTER_THREADS")) : 0;
-    static const int env_deal = getenv("GIF_RASTER_DEAL") ? atoi(getenv("GIF_RASTER_DEAL")) : -1;
-    const bool wide = env_threads ? env_threads == 1024 : F / nt >= 256;
-    const int deal = env_deal >= 0 ? env_deal : (wide ? 0 : 1);
-    if (fc) {
-        if (wide) raster_tiles<T, true, 1024><<<grid, 1024, 0, s>>>(fv, fc, count, list, depth, tri, out3, F, H, W, tiles_x, tiles_y, deal);
-        else raster_tiles<T, true, 512><<<grid, 512, 0, s>>>(fv, fc, count, list, depth, tri, out3, F, H, W, tiles_x, tiles_y, deal);
-    } else {
-        if (wide) raster_tiles<T, false, 1024><<<grid, 1024, 0, s>>>(fv, nullptr, count, list, depth, tri, out3, F, H, W, tiles_x, tiles_y, deal);
-        else raster_tiles<T, false, 512><<<grid, 512, 0, s>>>(fv, nullptr, count, list, depth, tri, out3, F, H, W, tiles_x, tiles_y, deal);
-    }
+    if (fc) raster_tiles<T, true, kTileThreads><<<grid, kTileThreads, 0, s>>>(fv, fc, count, list, depth, tri, out3, F, H, W, tiles_x, tiles_y);
+    else raster_tiles<T, false, kTileThreads><<<grid, kTileThreads, 0, s>>>(fv, nullptr, count, list, depth, tri, out3, F, H, W, tiles_x, tiles_y);
     return gif::check_launch(who);
 }
 

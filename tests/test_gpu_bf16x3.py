@@ -240,9 +240,10 @@ def test_bf16x3_adversarial_operands_vs_fp64(kind, cfg, monkeypatch):
         errs[mode] = (err(ops.conv_fwd(x, w, spec), ref_f), err(ops.conv_bwd_data(gy, w, spec, (h, h)), ref_d),
                       err(ops.conv_wgrad(gy, x, spec, co, ci), ref_w))
     print(f"\n[bf16x3 adversarial] {kind} {cfg}: native {errs['native']}  bf16x3 {errs['bf16x3']}")
-    # cancellation: the result is 2^-20 of its terms, so BOTH modes lose ~20 bits to fp32 accumulation rounding and the split's
-    # dropped cross terms (<= 2^-23 |ab|, typically 2^-25) are of the same order as that rounding: the ratio is bounded, not 1.3
-    ratio = 4.0 if kind == "cancel" else 1.3
+    # cancellation: the result is 2^-20 of its terms, so BOTH modes lose ~20 bits to fp32 accumulation rounding (measured: 3-12 %
+    # error of the forward result in either mode, profiles/r3_bf16x3_adversarial.txt) and the split's dropped cross terms
+    # (<= 2^-23 |ab|, typically 2^-25) are of the same order as that rounding: measured ratios 0.75-1.33, bound 2
+    ratio = 2.0 if kind == "cancel" else 1.3
     for name, en, ex in zip(("fwd", "dgrad", "wgrad"), errs["native"], errs["bf16x3"]):
         assert ex <= ratio * en + 2e-7, (kind, cfg, name, "bf16x3", ex, "native", en)
         if kind != "cancel":
