@@ -27,9 +27,9 @@ def sample():
             if "power" in k.lower() and power is None:
                 m = re.search(r"[\d.]+", str(v))
                 power = float(m.group()) if m else None
-            if k.lower().startswith("sclk"):
+            if k.lower().startswith("sclk") and "speed" in k.lower():
                 m = re.search(r"(\d+)\s*mhz", str(v).lower())
-                sclk = float(m.group(1)) if m else None
+                sclk = float(m.group(1)) if m else sclk
         return power, sclk, None
     except Exception as e:  # noqa: BLE001
         return None, None, repr(e)
