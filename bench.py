@@ -73,6 +73,9 @@ def parse():
     ap.add_argument("--cpu-timeout", type=int, default=240)
     ap.add_argument("--cpu-baseline-worker", type=str, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--no-prof", action="store_true", help="skip per-kernel HIP-event timing")
+    ap.add_argument("--prof-every", type=int, default=4,
+                    help="HIP events bracket every MFMA / transform launch of every N-th timed step (two event records per launch "
+                         "cost ~4 ms per fully instrumented step: measured 231 vs 227 ms); 1 = every step")
     ap.add_argument("--no-overlap-comm", action="store_true", help="complete each gradient exchange + optimiser step in place "
                     "(default with > 1 rank: deferred to where the network is next used)")
     ap.add_argument("--check-replicas", action="store_true",
@@ -419,19 +422,24 @@ def main():
     for bk in (trainer.g_bucket, trainer.d_bucket):
         bk.comm_events = []  # (start, end) event pairs around every wait for an exchange: exposed communication time
     data = [batch() for _ in range(min(args.steps, 4))]  # synthetic batches resident in HBM before the timed region
+    prof_steps = 0
     if not args.no_prof:
         for fam in range(12):
             ops.prof_read(fam)
-        ops.prof_enable(True)
     sync()
     t0 = time.perf_counter()
     for k in range(args.steps):
+        sampled = not args.no_prof and k % max(args.prof_every, 1) == 0
+        if sampled:  # instrument this step's launches (the events are read after the timed region)
+            ops.prof_enable(True)
+            prof_steps += 1
         run_step(it, data[k % len(data)])
+        if sampled:
+            ops.prof_enable(False)
         it += 1
     trainer.flush()
     sync()
     dt = time.perf_counter() - t0
-    ops.prof_enable(False)
 
     comm_ms = sum(e0.elapsed_time(e1) for bk in (trainer.g_bucket, trainer.d_bucket) for e0, e1 in bk.comm_events)
     t = torch.tensor([dt, comm_ms], device=dev, dtype=torch.float64)
@@ -498,7 +506,10 @@ def main():
                                            "workload, not the ceiling of the bf16x3 kernels (2500 / 6 = 417 fp32-equivalent TFLOP/s)"},
         }
         if not args.no_prof:
-            out.update(roofline_objects(ops, args.steps, dt))
+            out.update(roofline_objects(ops, prof_steps, dt * prof_steps / args.steps))
+            out["roofline_sampling"] = {"instrumented_steps": prof_steps, "of": args.steps,
+                                        "note": f"HIP events around every MFMA / Winograd-transform launch of every {max(args.prof_every, 1)}th timed step; "
+                                                "per-step figures are per instrumented step, executed_mfma_frac_wall uses the mean step time"}
             try:
                 out["roofline_rasterize"] = rasterize_roofline(B, dev)
             except Exception as e:  # never lose the headline line to the side measurement
