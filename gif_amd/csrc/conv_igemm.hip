@@ -73,6 +73,7 @@ struct GatherParams {
     int part_row0;
     int no_split;              // keep the launch in ONE tile size (per-sample partial sums need uniform rows)
     unsigned* sat_flag;        // f16: "a store saturated" flag word of the device (common.h store4_flag), else NULL
+    int out_f32;               // f16 kernels: the output tensor is fp32
 };
 
 // partial-sum rows handed out to the launches of one op (bulk + remainder launches, transposed-conv phases), and the tile height
@@ -167,7 +168,8 @@ __device__ __forceinline__ void conv_epilogue(const GatherParams& p, f32x16 (&ac
                     v.z *= p.mask_gain * (xs.z > 0.f ? 1.f : p.mask_slope); v.w *= p.mask_gain * (xs.w > 0.f ? 1.f : p.mask_slope);
                 }
                 cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
-                gif::store4_flag(yout + o, v, p.sat_flag);
+                if (sizeof(T) == 2 && p.out_f32) gif::store4(static_cast<float*>(p.y) + o, v);
+                else gif::store4_flag(yout + o, v, p.sat_flag);
             }
         }
     }
@@ -1018,6 +1020,7 @@ void fill_epilogue(GatherParams& p, const gif_conv_epilogue* e) {
     p.mask_gain = e ? e->mask_gain : 1.f;
     p.dot_src = e ? e->dot_src : nullptr;
     p.sat_flag = nullptr;
+    p.out_f32 = e ? e->out_f32 : 0;
 }
 
 // Gradient-producer fusions of one op: validate, carve the partial-sum buffers out of red_ws (before the launches) and reduce

@@ -692,14 +692,15 @@ class ModConvFn(Function):
     in_port: x is the output of a fused leaky ReLU (see ActPort)."""
 
     @staticmethod
-    def forward(ctx, x, w, s, d, spec, transposed, out_hw, wscale, in_port=None, x_port=None):
+    def forward(ctx, x, w, s, d, spec, transposed, out_hw, wscale, in_port=None, x_port=None, out_f32=False):
         x_in, s_in, d_in = x, s, d  # saved as given (a layout copy made in here would cut the graph of a recorded backward)
         x = ops.nhwc(x)
         s = s.contiguous()
         d = None if d is None else d.contiguous()
         ctx.v = None
         if not transposed:
-            y, v = ops.conv_fwd(x, w, spec, wscale, keep_v=True, in_scale=s, out_scale=d)
+            # out_f32: f16 activations in, fp32 result out (ToRGB: the RGB skip sum stays fp32 in f16-activation mode)
+            y, v = ops.conv_fwd(x, w, spec, wscale, keep_v=True, in_scale=s, out_scale=d, out_f32=out_f32)
             ctx.v = v if ctx.needs_input_grad[1] else None
         else:
             y = ops.conv_bwd_data(x, w, spec, tuple(out_hw), wscale, in_scale=s, out_scale=d)
@@ -720,8 +721,10 @@ class ModConvFn(Function):
             gx, gw, gs, gd = _recorded_backward(
                 (x, w, s, d), ctx.needs_input_grad[:4], gy,
                 lambda x_, w_, s_, d_: _modconv_composite(x_, w_, s_, d_, spec, tr, ctx.out_hw, ws))
-            return gx, gw, gs, gd, None, None, None, None, None, None
+            return gx, gw, gs, gd, None, None, None, None, None, None, None
         port = ctx.in_port is not None
+        if gy.dtype != x.dtype:  # fp32 result of an f16 layer (out_f32): its gradient re-enters the f16 kernels as f16
+            gy = gy.to(x.dtype)
         x, s, gy = ops.nhwc(x), s.contiguous(), ops.nhwc(gy)
         d = None if d is None else d.contiguous()
         O, I = w.shape[:2]
@@ -746,7 +749,7 @@ class ModConvFn(Function):
         if ctx.has_d and ctx.needs_input_grad[3]:
             num, _ = ops.mul_reduce(gy, y)
             gd = num / d
-        return (None if port else gx), gw, gs, gd, None, None, None, None, None, (gx if port else None)
+        return (None if port else gx), gw, gs, gd, None, None, None, None, None, (gx if port else None), None
 
 
 class ModConvActFn(Function):
@@ -829,6 +832,7 @@ def modulated_conv2d_act(x, w, s, d, residual, bias, pad, wscale=1.0, slope=0.2,
     return _tag(y, alias, port)
 
 
-def modulated_conv2d(x, w, s, d, stride=1, pad=0, transposed=False, out_hw=None, wscale=1.0):
+def modulated_conv2d(x, w, s, d, stride=1, pad=0, transposed=False, out_hw=None, wscale=1.0, out_f32=False):
     x_port, in_port = _take_port(x)
-    return ModConvFn.apply(x, w, s, d, ConvSpec(w.shape[2], w.shape[3], stride, pad), transposed, out_hw, wscale, in_port, x_port)
+    return ModConvFn.apply(x, w, s, d, ConvSpec(w.shape[2], w.shape[3], stride, pad), transposed, out_hw, wscale, in_port, x_port,
+                           bool(out_f32) and x.dtype == torch.float16)

@@ -209,6 +209,7 @@ class ModulatedConv2d(nn.Module):
         self.modulation = EqualLinear(style_dim, in_channel, bias_init=1,
                                       apply_sqrt2_fac_in_eq_lin=apply_sqrt2_fac_in_eq_lin)
         self.demodulate = demodulate
+        self.out_fp32 = False  # f16-activation mode: hand the result back as fp32 (set by ToRGB)
 
     def __repr__(self):
         return (f'{self.__class__.__name__}({self.in_channel}, {self.out_channel}, {self.kernel_size}, '
@@ -280,7 +281,7 @@ class ModulatedConv2d(nn.Module):
         elif self.downsample:
             out = GF.modulated_conv2d(self.blur(input), w, s, d, stride=2, pad=0, wscale=self.scale)
         else:
-            out = GF.modulated_conv2d(input, w, s, d, stride=1, pad=self.padding, wscale=self.scale)
+            out = GF.modulated_conv2d(input, w, s, d, stride=1, pad=self.padding, wscale=self.scale, out_f32=self.out_fp32)
         return out
 
 
@@ -365,6 +366,9 @@ class ToRGB(nn.Module):
             self.upsample = Upsample(blur_kernel)
         self.conv = ModulatedConv2d(in_channel, 3, 1, style_dim, demodulate=False,
                                     apply_sqrt2_fac_in_eq_lin=apply_sqrt2_fac_in_eq_lin)
+        # f16 activations: the running RGB image (|v| up to ~8, where half resolves 3.9e-3) is accumulated in fp32 — it is three
+        # channels; the feature maps stay f16 (profiles/r3_f16_error_by_layer.txt)
+        self.conv.out_fp32 = True
         self.bias = nn.Parameter(torch.zeros(1, 3, 1, 1))
 
     def forward(self, input, style, skip=None):

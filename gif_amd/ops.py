@@ -133,8 +133,9 @@ def dot_fusable(H, W, dtype=torch.float32):
 
 
 def _epilogue(in_scale=None, out_scale=None, bias=None, residual=None, act=False, slope=0.2, gain=2 ** 0.5, fuse=None,
-              out_bchw=None, dtype=torch.float32):
+              out_bchw=None, dtype=torch.float32, out_f32=False):
     e = _lib.ConvEpilogue(_p(in_scale), _p(out_scale), _p(bias), _p(residual), 1 if act else 0, slope, gain)
+    e.out_f32 = 1 if out_f32 else 0
     if fuse is not None:
         B, C, H, W = out_bchw
         for t, what in ((fuse.mask_src, "mask_src"), (fuse.dot_src, "dot_src")):
@@ -313,13 +314,16 @@ def conv_fwd(big, w, spec: ConvSpec, wscale=1.0, keep_v=False, **epi):
     Cs = cpad(O, dt)
     Hs, Ws = spec.small_hw(Hb, Wb)
     _epi_check(big, epi)
+    if dt != torch.float16:
+        epi.pop("out_f32", None)  # (fp32 activations: the result is fp32 anyway)
     if winograd_eligible(spec, B, Hb, Wb, Cb, Cs, dtype=dt):
         return conv3x3_winograd(big, w, True, Cs, wscale, keep_v=keep_v, **epi)
     if keep_v:
         return conv_fwd(big, w, spec, wscale, **epi), None
     x3 = x3_conv(dt, Cb)
     wp = pack_weight(w, True, Cs, Cb, wscale, dt, x3=x3)
-    out = empty_nhwc(B, Cs, Hs, Ws, big.device, dt)
+    # out_f32 (f16 activations only): fp32 result, e.g. the RGB image of ToRGB
+    out = empty_nhwc(B, Cs, Hs, Ws, big.device, torch.float32 if epi.get("out_f32") else dt)
     g = _geom(B, Hb, Wb, Cb, Hs, Ws, Cs, spec)
     e = _epilogue(out_bchw=(B, Cs, Hs, Ws), dtype=dt, **epi)
     fn = _lib.load().gif_conv2d_fwd_f32x3 if x3 else _fn("conv2d_fwd", dt)

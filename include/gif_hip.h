@@ -170,6 +170,9 @@ typedef struct {
     float* dot;
     float* colsum;
     float* red_ws;
+    /* f16 entry points only: store the output as fp32 [B,Ho,Wo,Cout] instead of f16 (ToRGB in f16-activation mode: the running RGB
+     * image reaches |v| ~ 8, where half precision resolves 3.9e-3 — the skip-connection sum is kept in fp32, it is 3 channels) */
+    int32_t out_f32;
 } gif_conv_epilogue;
 int64_t gif_conv_epilogue_ws_floats(int64_t out_rows, int cout);
 

@@ -27,7 +27,8 @@ def _pad_c(x, c):
     return x if x.shape[1] == c else F.pad(x, (0, 0, 0, 0, 0, c - x.shape[1]))
 
 
-def _epilogue(z, cact, in_scale=None, out_scale=None, bias=None, residual=None, act=False, slope=0.2, gain=2 ** 0.5, fuse=None):
+def _epilogue(z, cact, in_scale=None, out_scale=None, bias=None, residual=None, act=False, slope=0.2, gain=2 ** 0.5, fuse=None,
+              out_f32=False):
     """fuse: gif_amd.ops.GradFuse — the gradient-producer fusions of gif_conv_epilogue ABI 2 (include/gif_hip.h)."""
     z = _pad_c(z, cact)
     if fuse is not None and fuse.dot_src is not None:
