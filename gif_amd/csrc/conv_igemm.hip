@@ -116,6 +116,7 @@ __device__ __forceinline__ void conv_epilogue(const GatherParams& p, f32x16 (&ac
     if (p.bias && n < p.Co) bias4 = *reinterpret_cast<const float4*>(p.bias + n);
     const T* const msk = static_cast<const T*>(p.mask_src);
     const T* const dsrc = static_cast<const T*>(p.dot_src);
+    const bool fused = msk || dsrc || p.part_cs || p.part_dot;  // workgroup-uniform
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), ds = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int c = 0; c < EPI_CHUNKS; ++c) {
@@ -134,43 +135,52 @@ __device__ __forceinline__ void conv_epilogue(const GatherParams& p, f32x16 (&ac
         }
         __syncthreads();
         if (n < p.Co) {
+            // two copies of the row loop: the plain one carries none of the gradient-producer work (measured on the f16 step, whose
+            // MFMA phase is 8x shorter: the extra branches and the running sums cost 2 % of the whole step when they ran always)
+            auto rows = [&](auto fused_tag) __attribute__((always_inline)) {
+                constexpr bool FUSED = decltype(fused_tag)::value;
 #pragma unroll 4
-            for (int it = 0; it < E_IT; ++it) {
-                const int row = e_row0 + it * EROWS;
-                const int m = m0 + c * CR + row;
-                if (m >= p.M) break;
-                int b = m / HWp;
-                int rr = m - b * HWp;
-                int oy = rr / p.Wp, ox = rr - oy * p.Wp;
-                size_t o = (((size_t)b * p.Ho + (oy * p.os + p.ooy)) * p.Wo + (ox * p.os + p.oox)) * p.Co + n;
-                float4 v = *reinterpret_cast<const float4*>(Cs + row * LDC + e_c);
-                float4 xs = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (dsrc) {  // modulation gradient: sum_pixels contraction * x
-                    xs = gif::load4(dsrc + o);
-                    ds.x += v.x * xs.x; ds.y += v.y * xs.y; ds.z += v.z * xs.z; ds.w += v.w * xs.w;
+                for (int it = 0; it < E_IT; ++it) {
+                    const int row = e_row0 + it * EROWS;
+                    const int m = m0 + c * CR + row;
+                    if (m >= p.M) break;
+                    int b = m / HWp;
+                    int rr = m - b * HWp;
+                    int oy = rr / p.Wp, ox = rr - oy * p.Wp;
+                    size_t o = (((size_t)b * p.Ho + (oy * p.os + p.ooy)) * p.Wo + (ox * p.os + p.oox)) * p.Co + n;
+                    float4 v = *reinterpret_cast<const float4*>(Cs + row * LDC + e_c);
+                    float4 xs = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (FUSED && dsrc) {  // modulation gradient: sum_pixels contraction * x
+                        xs = gif::load4(dsrc + o);
+                        ds.x += v.x * xs.x; ds.y += v.y * xs.y; ds.z += v.z * xs.z; ds.w += v.w * xs.w;
+                    }
+                    if (p.out_scale) {
+                        float4 d = *reinterpret_cast<const float4*>(p.out_scale + (size_t)b * p.Co + n);
+                        v.x *= d.x; v.y *= d.y; v.z *= d.z; v.w *= d.w;
+                    }
+                    if (res) {
+                        float4 rv = gif::load4(res + o);
+                        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                    }
+                    v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+                    if (p.act) {
+                        v.x = (v.x > 0.f ? v.x : v.x * p.slope) * p.gain; v.y = (v.y > 0.f ? v.y : v.y * p.slope) * p.gain;
+                        v.z = (v.z > 0.f ? v.z : v.z * p.slope) * p.gain; v.w = (v.w > 0.f ? v.w : v.w * p.slope) * p.gain;
+                    }
+                    if (FUSED) {
+                        if (msk) {  // backward of the leaky ReLU that produced the tensor this gradient belongs to
+                            if (msk != dsrc) xs = gif::load4(msk + o);
+                            v.x *= p.mask_gain * (xs.x > 0.f ? 1.f : p.mask_slope); v.y *= p.mask_gain * (xs.y > 0.f ? 1.f : p.mask_slope);
+                            v.z *= p.mask_gain * (xs.z > 0.f ? 1.f : p.mask_slope); v.w *= p.mask_gain * (xs.w > 0.f ? 1.f : p.mask_slope);
+                        }
+                        cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
+                    }
+                    if (sizeof(T) == 2 && p.out_f32) gif::store4(static_cast<float*>(p.y) + o, v);
+                    else gif::store4_flag(yout + o, v, p.sat_flag);
                 }
-                if (p.out_scale) {
-                    float4 d = *reinterpret_cast<const float4*>(p.out_scale + (size_t)b * p.Co + n);
-                    v.x *= d.x; v.y *= d.y; v.z *= d.z; v.w *= d.w;
-                }
-                if (res) {
-                    float4 rv = gif::load4(res + o);
-                    v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-                }
-                v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
-                if (p.act) {
-                    v.x = (v.x > 0.f ? v.x : v.x * p.slope) * p.gain; v.y = (v.y > 0.f ? v.y : v.y * p.slope) * p.gain;
-                    v.z = (v.z > 0.f ? v.z : v.z * p.slope) * p.gain; v.w = (v.w > 0.f ? v.w : v.w * p.slope) * p.gain;
-                }
-                if (msk) {  // backward of the leaky ReLU that produced the tensor this gradient belongs to
-                    if (msk != dsrc) xs = gif::load4(msk + o);
-                    v.x *= p.mask_gain * (xs.x > 0.f ? 1.f : p.mask_slope); v.y *= p.mask_gain * (xs.y > 0.f ? 1.f : p.mask_slope);
-                    v.z *= p.mask_gain * (xs.z > 0.f ? 1.f : p.mask_slope); v.w *= p.mask_gain * (xs.w > 0.f ? 1.f : p.mask_slope);
-                }
-                cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
-                if (sizeof(T) == 2 && p.out_f32) gif::store4(static_cast<float*>(p.y) + o, v);
-                else gif::store4_flag(yout + o, v, p.sat_flag);
-            }
+            };
+            if (fused) rows(std::true_type{});
+            else rows(std::false_type{});
         }
     }
     if (p.part_cs || p.part_dot) {  // workgroup-uniform: per-tile partial sums, fixed order

@@ -200,10 +200,11 @@ struct WinoParams {
 
 // the fused tail of both GEMM kernels' epilogues: modulation-gradient dot product, out_scale, residual, bias, activation,
 // leaky-ReLU-backward mask, running column sums
+template <bool FUSED>
 __device__ __forceinline__ f32x4 wino_epilogue_value(const WinoParams& p, f32x4 v, size_t off, int b, int n, const f32x4& bias4,
                                                      f32x4& cs, f32x4& ds) {
     f32x4 xs = (f32x4)(0.f);
-    if (p.dot_src) {
+    if (FUSED && p.dot_src) {
         xs = *reinterpret_cast<const f32x4*>(p.dot_src + off);
         ds += v * xs;
     }
@@ -214,12 +215,14 @@ __device__ __forceinline__ f32x4 wino_epilogue_value(const WinoParams& p, f32x4 
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (v[e] > 0.f ? v[e] : v[e] * p.slope) * p.gain;
     }
-    if (p.mask_src) {
-        if (p.mask_src != p.dot_src) xs = *reinterpret_cast<const f32x4*>(p.mask_src + off);
+    if (FUSED) {
+        if (p.mask_src) {
+            if (p.mask_src != p.dot_src) xs = *reinterpret_cast<const f32x4*>(p.mask_src + off);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= p.mask_gain * (xs[e] > 0.f ? 1.f : p.mask_slope);
+            for (int e = 0; e < 4; ++e) v[e] *= p.mask_gain * (xs[e] > 0.f ? 1.f : p.mask_slope);
+        }
+        cs += v;
     }
-    cs += v;
     return v;
 }
 
@@ -419,6 +422,7 @@ __global__ void __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) wino_gemm_mfma(cons
     f32x4 bias4 = (f32x4)(0.f);
     if (p.bias && n < p.Co) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
     f32x4 cs = (f32x4)(0.f), ds = (f32x4)(0.f);
+    const bool fused = p.mask_src || p.dot_src || p.part_cs || p.part_dot;  // workgroup-uniform
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
         __syncthreads();
@@ -442,7 +446,7 @@ __global__ void __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) wino_gemm_mfma(cons
                 int ty = t2 % p.TH, b = t2 / p.TH;
                 size_t off = (((size_t)b * p.H + 2 * ty + oa) * p.W + 2 * tx + ob) * p.Co + n;
                 f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * LDC + e_c);
-                v = wino_epilogue_value(p, v, off, b, n, bias4, cs, ds);
+                v = fused ? wino_epilogue_value<true>(p, v, off, b, n, bias4, cs, ds) : wino_epilogue_value<false>(p, v, off, b, n, bias4, cs, ds);
                 *reinterpret_cast<f32x4*>(p.y + off) = v;
             }
         }
@@ -650,6 +654,7 @@ __global__ void __launch_bounds__(512, 1) wino_gemm_x3(const WinoParams p) {
     f32x4 bias4 = (f32x4)(0.f);
     if (p.bias && n < p.Co) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
     f32x4 cs = (f32x4)(0.f), ds = (f32x4)(0.f);
+    const bool fused = p.mask_src || p.dot_src || p.part_cs || p.part_dot;  // workgroup-uniform
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
         __syncthreads();
@@ -673,7 +678,7 @@ __global__ void __launch_bounds__(512, 1) wino_gemm_x3(const WinoParams p) {
                 int ty = t2 % p.TH, b = t2 / p.TH;
                 size_t off = (((size_t)b * p.H + 2 * ty + oa) * p.W + 2 * tx + ob) * p.Co + n;
                 f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * LDC + e_c);
-                v = wino_epilogue_value(p, v, off, b, n, bias4, cs, ds);
+                v = fused ? wino_epilogue_value<true>(p, v, off, b, n, bias4, cs, ds) : wino_epilogue_value<false>(p, v, off, b, n, bias4, cs, ds);
                 *reinterpret_cast<f32x4*>(p.y + off) = v;
             }
         }

@@ -49,7 +49,7 @@ __device__ __forceinline__ void fir_mask_sum(const UpfirdnParams<T>& p, size_t o
         v.x *= p.mask_gain * (m.x > 0.f ? 1.f : p.mask_slope); v.y *= p.mask_gain * (m.y > 0.f ? 1.f : p.mask_slope);
         v.z *= p.mask_gain * (m.z > 0.f ? 1.f : p.mask_slope); v.w *= p.mask_gain * (m.w > 0.f ? 1.f : p.mask_slope);
     }
-    cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
+    if (p.part_cs) { cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w; }
 }
 
 // per-workgroup column sums: thread t owns channel quad t % C4 for the whole grid-stride loop (256 % C4 == 0), so the sums of

@@ -39,7 +39,11 @@ const float* zero_page16() {
     return page[d];
 }
 
-unsigned* f16_sat_flag() {
+// Between gif_f16_overflow_clear() and gif_f16_overflow_or_into() (the trainer brackets backward() with them) the f16 launches
+// get the flag pointer; outside that window they get NULL and their stores pay nothing for the check.
+static std::atomic<int> g_f16_watch{0};
+
+unsigned* f16_sat_flag_word() {
     static std::mutex mu;
     static unsigned* flag[kMaxDevices] = {};
     const int d = current_device();
@@ -51,6 +55,8 @@ unsigned* f16_sat_flag() {
     }
     return flag[d];
 }
+
+unsigned* f16_sat_flag() { return g_f16_watch.load(std::memory_order_relaxed) ? f16_sat_flag_word() : nullptr; }
 
 void LdsAttr::ensure(const void* kernel, size_t bytes) {
     static std::mutex mu;
@@ -127,16 +133,18 @@ extern "C" {
 const char* gif_last_error(void) { return gif::g_err; }
 
 int gif_f16_overflow_clear(gif_stream_t stream) {
-    unsigned* f = gif::f16_sat_flag();
+    unsigned* f = gif::f16_sat_flag_word();
     GIF_REQUIRE(f, "f16_overflow_clear: no flag word on this device");
     hipError_t e = hipMemsetAsync(f, 0, sizeof(unsigned), gif::as_stream(stream));
     if (e != hipSuccess) { gif::set_error("f16_overflow_clear: %s", hipGetErrorString(e)); return (int)e; }
+    gif::g_f16_watch.store(1, std::memory_order_relaxed);
     return 0;
 }
 
 int gif_f16_overflow_or_into(float* found_inf, gif_stream_t stream) {
-    unsigned* f = gif::f16_sat_flag();
+    unsigned* f = gif::f16_sat_flag_word();
     GIF_REQUIRE(f && found_inf, "f16_overflow_or_into: null pointer");
+    gif::g_f16_watch.store(0, std::memory_order_relaxed);
     gif::f16_flag_or_into<<<1, 1, 0, gif::as_stream(stream)>>>(f, found_inf);
     return gif::check_launch("f16_overflow_or_into");
 }

@@ -34,7 +34,8 @@ int gif_abi_version(void);
  * activation GRADIENT from a dynamic loss scaler (the fp32 weight gradients computed from clamped values stay finite).  The
  * stores that can carry gradients (convolution / FIR epilogues, the leaky-ReLU backward, the modulation-gradient pass) raise a
  * per-device flag word when they clamp or see a non-finite value: clear it before backward(), OR it into the scaler's found_inf
- * scalar afterwards (both on the stream, no host synchronisation). */
+ * scalar afterwards (both on the stream, no host synchronisation).  Only launches issued BETWEEN the two calls check their
+ * stores (process-wide window): forward passes pay nothing. */
 int gif_f16_overflow_clear(gif_stream_t stream);
 int gif_f16_overflow_or_into(float* found_inf, gif_stream_t stream);
 
