@@ -180,8 +180,15 @@ def _build(res, vocab=16):
 
 @pytest.mark.parametrize("res,step,batch", [(32, 3, 4), (256, 6, 2)])
 def test_f16_generator_and_discriminator_vs_fp32_oracle(res, step, batch):
-    """Stated tolerance of the f16 path: generator image L_inf <= 3e-2 against the fp32 CPU oracle on identical fp32 weights
-    (the fp32 path holds 1e-3); D scores within 3e-2 of their magnitude scale."""
+    """Stated tolerance of the f16 path against the fp32 CPU oracle on identical fp32 weights: generator image
+    L_inf <= 6 * 2^-11 * max|image| (2^-11 = half-precision unit round-off); D scores within 3e-2 of their magnitude scale.
+    Where the number comes from (tools/probes/f16_error_by_layer.py -> profiles/r3_f16_error_by_layer.txt): no layer dominates —
+    every f16-stored feature map adds its storage rounding (rms error / rms grows from 0.5e-3 to 1.2e-3 over the 13 StyledConv
+    outputs of a 256x256 pass, i.e. 1-2.4 unit round-offs), and the image inherits the last block's error through a 1x1 conv:
+    measured 2.6 (32x32) and 2.9 (256x256) unit round-offs of the image range.  The running RGB sum itself is kept in fp32
+    (ToRGB: out_f32) — in f16 it sat at |v| ~ 8 where half resolves 3.9e-3 and cost another 30 % (1.43e-2 -> 1.10e-2).  The
+    north star's 1e-3 (an fp32 figure, met at 1e-5 by the fp32 path) is below the storage rounding of ONE f16 tensor of this
+    range (2e-3 at |v| in [4, 8)), so it is not attainable with f16 activations."""
     from oracle import stylegan2_ref as R
     torch.manual_seed(0)
     g, d = _build(res)
@@ -200,7 +207,7 @@ def test_f16_generator_and_discriminator_vs_fp32_oracle(res, step, batch):
         assert got.dtype == torch.float32 and got.shape == ref.shape
         linf = (got.cpu() - ref).abs().max().item()
         print(f"f16 generator at {res}x{res}: L_inf vs fp32 oracle {linf:.3e} (image max {ref.abs().max().item():.2f})")
-        assert linf <= 3e-2, linf
+        assert linf <= 6 * 2.0 ** -11 * ref.abs().max().item(), (linf, ref.abs().max().item())
         sgot = d(ref.cuda(), condition=cond.cuda())[0]
         e = ((sgot.cpu() - sref).abs().max() / (sref.abs().max() + 1.0)).item()
         print(f"f16 discriminator at {res}x{res}: score error {e:.3e}")
