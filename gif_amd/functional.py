@@ -58,6 +58,36 @@ def _take_port(x, identity=False):
     return port.alias, port.cfg()
 
 
+# --------------------------------------------------------------------------------------------------------
+# inner gradients of the regularisers: no parameter gradients
+# --------------------------------------------------------------------------------------------------------
+# R1 (losses.grad_penalty_loss), the path-length and the direct-gradient regulariser take torch.autograd.grad(..., inputs=[image /
+# style / condition], create_graph=True).  ctx.needs_input_grad of a custom Function is fixed at forward time, so every node
+# would also compute the gradient of its weight and bias in that pass — D's complete weight gradient, thrown away by the
+# engine.  Inside inputs_only_backward() the Functions below skip gradients of inputs that ARE parameters (or views of one).
+_inputs_only = False
+
+
+class inputs_only_backward:
+    def __enter__(self):
+        global _inputs_only
+        self._prev, _inputs_only = _inputs_only, True
+
+    def __exit__(self, *exc):
+        global _inputs_only
+        _inputs_only = self._prev
+
+
+def _param_mask(*tensors):
+    P = torch.nn.Parameter
+    return tuple(isinstance(t, torch.Tensor) and (isinstance(t, P) or isinstance(getattr(t, "_base", None), P)) for t in tensors)
+
+
+def _need(ctx, i):
+    """Input i needs a gradient in THIS backward pass."""
+    return ctx.needs_input_grad[i] and not (_inputs_only and ctx.pmask[i])
+
+
 def _port_on(ctx):
     """This backward delivers to the input's port (first-order pass) instead of to the input itself."""
     return ctx.in_port is not None and not torch.is_grad_enabled()
@@ -127,6 +157,7 @@ class Conv2dFn(Function):
 
     @staticmethod
     def forward(ctx, x, w, spec, transposed, out_hw, wscale, residual=None):
+        ctx.pmask = _param_mask(x, w)
         x = ops.nhwc(x)
         ctx.spec, ctx.transposed, ctx.wscale = spec, transposed, wscale
         ctx.save_for_backward(x, w)
@@ -144,10 +175,10 @@ class Conv2dFn(Function):
         x, w = ctx.saved_tensors
         spec, tr, ws = ctx.spec, ctx.transposed, ctx.wscale
         gx = gw = gr = None
-        if ctx.needs_input_grad[0]:
+        if _need(ctx, 0):
             gx = Conv2dFn.apply(gy, w, spec, not tr, tuple(x.shape[2:]), ws, None)
             assert gx.shape == x.shape, (gx.shape, x.shape)
-        if ctx.needs_input_grad[1]:
+        if _need(ctx, 1):
             O, I = w.shape[:2]
             gw = WgradFn.apply(gy, x, spec, O, I, ws, ctx.v) if not tr else WgradFn.apply(x, gy, spec, O, I, ws)
         if ctx.needs_input_grad[6]:
@@ -190,6 +221,7 @@ class ConvBiasActFn(Function):
     @staticmethod
     def forward(ctx, x, w, bias, spec, wscale, slope, gain, passthrough=False, in_port=None, parts=None, x_port=None):
         ctx.set_materialize_grads(False)  # an unused output (y, its port or the alias) arrives as None, not as a zero tensor
+        ctx.pmask = _param_mask(x, w, bias)
         x = ops.nhwc(x)
         y, v = ops.conv_fwd(x, w, spec, wscale, keep_v=True, bias=bias, act=True, slope=slope, gain=gain)
         ctx.v = v if ctx.needs_input_grad[1] else None  # Winograd-transformed x, reused by the weight gradient
@@ -205,14 +237,14 @@ class ConvBiasActFn(Function):
     def backward(ctx, gy, g_port=None, g_alias=None):
         x, w, y = ctx.saved_tensors
         spec, ws, slope, gain, has_bias = ctx.cfg
-        want_b = has_bias and ctx.needs_input_grad[2]
+        want_b = has_bias and _need(ctx, 2)
         gx = gw = None
         port = _port_on(ctx)
         gpre, gb = _producer_gpre(gy, g_port, y, want_b, slope, gain, ctx.parts)
         if gpre is not None:
             if ctx.needs_input_grad[0]:
                 gx = _conv_dgrad(gpre, w, spec, tuple(x.shape[2:]), ws, g_alias, ctx.in_port if port else None, x)
-            if ctx.needs_input_grad[1]:
+            if _need(ctx, 1):
                 gw = WgradFn.apply(gpre, x, spec, w.shape[0], w.shape[1], ws, ctx.v)
         elif ctx.needs_input_grad[0] and g_alias is not None:
             gx = _mask_into_port(ctx.in_port, g_alias, x) if port else g_alias
@@ -264,6 +296,7 @@ class LinearNtFn(Function):
     @staticmethod
     def forward(ctx, a, b, scale, n_pad):
         ctx.scale = scale
+        ctx.pmask = _param_mask(a, b)
         ctx.save_for_backward(a, b)
         return ops.linear_nt(a, b, None, scale, n_pad=n_pad)
 
@@ -271,8 +304,8 @@ class LinearNtFn(Function):
     def backward(ctx, g):
         a, b = ctx.saved_tensors
         N, K = b.shape
-        ga = LinearNnFn.apply(g, b, ctx.scale, a.shape[1]) if ctx.needs_input_grad[0] else None
-        gb = LinearTnFn.apply(g, a, ctx.scale, N, K) if ctx.needs_input_grad[1] else None
+        ga = LinearNnFn.apply(g, b, ctx.scale, a.shape[1]) if _need(ctx, 0) else None
+        gb = LinearTnFn.apply(g, a, ctx.scale, N, K) if _need(ctx, 1) else None
         return ga, gb, None, None
 
 
@@ -282,6 +315,7 @@ class LinearNnFn(Function):
     @staticmethod
     def forward(ctx, a, b, scale, k_pad):
         ctx.scale = scale
+        ctx.pmask = _param_mask(a, b)
         ctx.save_for_backward(a, b)
         return ops.linear_nn(a, b, scale, k_pad=k_pad)
 
@@ -289,8 +323,8 @@ class LinearNnFn(Function):
     def backward(ctx, g):
         a, b = ctx.saved_tensors
         N, K = b.shape
-        ga = LinearNtFn.apply(g, b, ctx.scale, a.shape[1]) if ctx.needs_input_grad[0] else None
-        gb = LinearTnFn.apply(a, g, ctx.scale, N, K) if ctx.needs_input_grad[1] else None
+        ga = LinearNtFn.apply(g, b, ctx.scale, a.shape[1]) if _need(ctx, 0) else None
+        gb = LinearTnFn.apply(a, g, ctx.scale, N, K) if _need(ctx, 1) else None
         return ga, gb, None, None
 
 
@@ -300,14 +334,15 @@ class LinearTnFn(Function):
     @staticmethod
     def forward(ctx, a, b, scale, N, K):
         ctx.scale = scale
+        ctx.pmask = _param_mask(a, b)
         ctx.save_for_backward(a, b)
         return ops.linear_tn(a, b, scale, n_valid=N, k_valid=K)
 
     @staticmethod
     def backward(ctx, g):
         a, b = ctx.saved_tensors
-        ga = LinearNtFn.apply(b, g, ctx.scale, a.shape[1]) if ctx.needs_input_grad[0] else None
-        gb = LinearNnFn.apply(a, g, ctx.scale, b.shape[1]) if ctx.needs_input_grad[1] else None
+        ga = LinearNtFn.apply(b, g, ctx.scale, a.shape[1]) if _need(ctx, 0) else None
+        gb = LinearNnFn.apply(a, g, ctx.scale, b.shape[1]) if _need(ctx, 1) else None
         return ga, gb, None, None, None
 
 
@@ -318,6 +353,7 @@ class LinearBiasActFn(Function):
     @staticmethod
     def forward(ctx, x, w, bias, scale, act, slope, gain, n_pad):
         y = ops.linear_nt(x, w, bias, scale, act=act, slope=slope, gain=gain, n_pad=n_pad)
+        ctx.pmask = _param_mask(x, w, bias)
         ctx.cfg = (scale, act, slope, gain, bias is not None)
         ctx.save_for_backward(x, w, y)
         return y
@@ -327,15 +363,15 @@ class LinearBiasActFn(Function):
         x, w, y = ctx.saved_tensors
         scale, act, slope, gain, has_bias = ctx.cfg
         N, K = w.shape
-        want_b = has_bias and ctx.needs_input_grad[2]
+        want_b = has_bias and _need(ctx, 2)
         M, n_pad = y.shape
         if act:
             gpre, gb = BiasActBwdFn.apply(gy.reshape(M, n_pad, 1, 1), y.reshape(M, n_pad, 1, 1), want_b, slope, gain)
         else:
             gpre, gb = BiasActBwdFn.apply(gy.reshape(M, n_pad, 1, 1), y.reshape(M, n_pad, 1, 1), want_b, 1.0, 1.0)
         gpre = gpre.reshape(M, n_pad)
-        gx = LinearNnFn.apply(gpre, w, scale, x.shape[1]) if ctx.needs_input_grad[0] else None
-        gw = LinearTnFn.apply(gpre, x, scale, N, K) if ctx.needs_input_grad[1] else None
+        gx = LinearNnFn.apply(gpre, w, scale, x.shape[1]) if _need(ctx, 0) else None
+        gw = LinearTnFn.apply(gpre, x, scale, N, K) if _need(ctx, 1) else None
         return gx, gw, (gb if want_b else None), None, None, None, None, None
 
 
@@ -370,6 +406,7 @@ class DemodFn(Function):
     def forward(ctx, s, w, scale2, eps, cout_pad):
         wsq = ops.weight_sq_sum(w)
         d = ops.style_demod(s, wsq, scale2, eps, cout_pad)
+        ctx.pmask = _param_mask(s, w)
         ctx.cfg = (scale2, eps, cout_pad)
         ctx.save_for_backward(s, w, d)
         return d
@@ -379,14 +416,15 @@ class DemodFn(Function):
         s, w, d = ctx.saved_tensors
         scale2, eps, cout_pad = ctx.cfg
         if torch.is_grad_enabled():
-            gs, gw = _recorded_backward((s, w), ctx.needs_input_grad[:2], gd, lambda s_, w_: _demod_reference(s_, w_, scale2, eps, cout_pad))
+            gs, gw = _recorded_backward((s, w), (_need(ctx, 0), _need(ctx, 1)), gd,
+                                        lambda s_, w_: _demod_reference(s_, w_, scale2, eps, cout_pad))
             return gs, gw, None, None, None
         gs = gw = None
         cout, cin = w.shape[:2]
         gd = gd.contiguous()
         if ctx.needs_input_grad[0]:
             gs = ops.style_demod_bwd_s(gd, d, ops.weight_sq_sum(w), s, None, scale2)
-        if ctx.needs_input_grad[1]:
+        if _need(ctx, 1):
             gw = ops.demod_wgrad(w, ops.style_demod_bwd_w(gd, d, s, cout, cin, scale2))
         return gs, gw, None, None, None
 
@@ -402,6 +440,7 @@ class BiasActFn(Function):
     @staticmethod
     def forward(ctx, x, bias, residual, slope, gain):
         y = ops.bias_act(x, bias, residual, slope, gain)
+        ctx.pmask = _param_mask(x, bias, residual)
         ctx.slope, ctx.gain = slope, gain
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
         ctx.save_for_backward(y)
@@ -410,7 +449,7 @@ class BiasActFn(Function):
     @staticmethod
     def backward(ctx, gy):
         (y,) = ctx.saved_tensors
-        want_b = ctx.has_bias and ctx.needs_input_grad[1]
+        want_b = ctx.has_bias and _need(ctx, 1)
         gx, gb = BiasActBwdFn.apply(gy, y, want_b, ctx.slope, ctx.gain)
         return (gx if ctx.needs_input_grad[0] else None, gb if want_b else None,
                 gx if (ctx.has_res and ctx.needs_input_grad[2]) else None, None, None)
@@ -499,6 +538,7 @@ class BlurBiasActFn(Function):
         y = ops.upfirdn2d(x, k, 1, 1, pad0, tuple(out_hw), True, bias=bias, residual=residual, act=True, slope=slope,
                           gain=gain)
         ctx.cfg = (pad0, tuple(x.shape[2:]), slope, gain, residual is not None, bias is not None)
+        ctx.pmask = _param_mask(x, k, None, None, residual, bias)
         ctx.parts, ctx.r_port = parts, r_port
         ctx.save_for_backward(k, y)
         return y, y.detach()  # (not a view of y: see ConvBiasActFn.forward)
@@ -507,7 +547,7 @@ class BlurBiasActFn(Function):
     def backward(ctx, gy, g_port=None):
         k, y = ctx.saved_tensors
         pad0, in_hw, slope, gain, has_res, has_bias = ctx.cfg
-        want_b = has_bias and ctx.needs_input_grad[5]
+        want_b = has_bias and _need(ctx, 5)
         gpre, gb = _producer_gpre(gy, g_port, y, want_b, slope, gain, ctx.parts)
         gx = gr = gra = None
         if gpre is not None and ctx.needs_input_grad[0]:
@@ -694,6 +734,7 @@ class ModConvFn(Function):
     @staticmethod
     def forward(ctx, x, w, s, d, spec, transposed, out_hw, wscale, in_port=None, x_port=None, out_f32=False):
         x_in, s_in, d_in = x, s, d  # saved as given (a layout copy made in here would cut the graph of a recorded backward)
+        ctx.pmask = _param_mask(x, w, s, d)
         x = ops.nhwc(x)
         s = s.contiguous()
         d = None if d is None else d.contiguous()
@@ -719,7 +760,7 @@ class ModConvFn(Function):
         spec, tr, ws = ctx.spec, ctx.transposed, ctx.wscale
         if torch.is_grad_enabled():  # create_graph=True: the gradients must carry history
             gx, gw, gs, gd = _recorded_backward(
-                (x, w, s, d), ctx.needs_input_grad[:4], gy,
+                (x, w, s, d), tuple(_need(ctx, i) for i in range(4)), gy,
                 lambda x_, w_, s_, d_: _modconv_composite(x_, w_, s_, d_, spec, tr, ctx.out_hw, ws))
             return gx, gw, gs, gd, None, None, None, None, None, None, None
         port = ctx.in_port is not None
@@ -741,7 +782,7 @@ class ModConvFn(Function):
                 gs, gx = ops.mul_reduce(dxs, x, scale=s, want_scaled=True)
                 if ctx.in_port is not None:
                     gx = _mask_into_port(ctx.in_port, gx, x)
-        if ctx.needs_input_grad[1]:
+        if _need(ctx, 1):
             if not tr:
                 gw = ops.conv_wgrad(gy, x, spec, O, I, ws, small_scale=d, big_scale=s, big_v=ctx.v)
             else:
@@ -763,6 +804,7 @@ class ModConvActFn(Function):
     def forward(ctx, x, w, s, d, residual, bias, spec, wscale, slope, gain, in_port=None, parts=None, x_port=None, r_port=None,
                 r_alias=None):
         ctx.set_materialize_grads(False)
+        ctx.pmask = _param_mask(x, w, s, d, residual, bias)
         saved_in = (x, s, d, residual)  # saved as given (see ModConvFn.forward)
         x = ops.nhwc(x)
         s, d = s.contiguous(), d.contiguous()
@@ -790,13 +832,13 @@ class ModConvActFn(Function):
         if torch.is_grad_enabled():  # create_graph=True: the gradients must carry history (ports carry first-order gradients only)
             assert g_port is None, "an activation port received a gradient inside a recorded backward"
             gx, gw, gs, gd, gr, gb = _recorded_backward(
-                (x, w, s, d, residual, bias), ctx.needs_input_grad[:6], gy,
+                (x, w, s, d, residual, bias), tuple(_need(ctx, i) for i in range(6)), gy,
                 lambda x_, w_, s_, d_, r_, b_: _modconv_composite(x_, w_, s_, d_, spec, False, None, ws, r_, b_, (slope, gain)))
             return (gx, gw, gs, gd, gr, gb) + none9
         port = ctx.in_port is not None
         x, s, d = ops.nhwc(x), s.contiguous(), d.contiguous()
         residual = None if residual is None else ops.nhwc(residual)
-        want_b = has_bias and ctx.needs_input_grad[5]
+        want_b = has_bias and _need(ctx, 5)
         gpre, gb = _producer_gpre(gy, g_port, y, want_b, slope, gain, ctx.parts)
         gx = gs = gd = gw = None
         if gpre is None:
@@ -809,7 +851,7 @@ class ModConvActFn(Function):
                 gs, gx = ops.mul_reduce(dxs, x, scale=s, want_scaled=True)
                 if ctx.in_port is not None:
                     gx = _mask_into_port(ctx.in_port, gx, x)
-        if ctx.needs_input_grad[1]:
+        if _need(ctx, 1):
             gw = ops.conv_wgrad(gpre, x, spec, O, I, ws, small_scale=d, big_scale=s, big_v=ctx.v)
         if ctx.needs_input_grad[3]:
             # d * z = act^-1(y) - residual - bias  =>  gd = sum_hw gpre * z

@@ -10,6 +10,7 @@ from torch.autograd import Function, grad
 from torch.autograd.function import once_differentiable
 
 from . import ops
+from .functional import inputs_only_backward
 
 
 class _SqNormFn(Function):
@@ -43,10 +44,11 @@ def grad_penalty_loss(inputs, outs, step, grad_scale=1.0):
     back — used with f16 activations, whose first-backward activation gradients would otherwise underflow."""
     grad_penalty = 0
     for inp_idx, inpt in enumerate(inputs):
-        if grad_scale == 1.0:
-            grad_real = grad(outputs=outs.sum(), inputs=inpt, create_graph=True)[0]
-        else:
-            grad_real = grad(outputs=outs.sum() * grad_scale, inputs=inpt, create_graph=True)[0] / grad_scale
+        with inputs_only_backward():  # the inner pass needs d outs / d input only: no weight / bias gradients (functional.py)
+            if grad_scale == 1.0:
+                grad_real = grad(outputs=outs.sum(), inputs=inpt, create_graph=True)[0]
+            else:
+                grad_real = grad(outputs=outs.sum() * grad_scale, inputs=inpt, create_graph=True)[0] / grad_scale
         if step is not None:
             w = 1 + step - inp_idx
             w = 0.05 / (w * np.log2(1 + w))
@@ -81,12 +83,14 @@ class PathLengthRegularizor:
             fake = generator(cond, None, step=step, alpha=alpha, input_indices=style)[0]
         if self.reference_semantics:
             noise = torch.randn(fake.shape, device=dev) / np.sqrt(np.prod(fake.shape))
-            pl_grads = grad(outputs=torch.sum(fake * noise), inputs=style)[0]
+            with inputs_only_backward():
+                pl_grads = grad(outputs=torch.sum(fake * noise), inputs=style)[0]
             pl_lengths = torch.mean(torch.sqrt(sqnorm_per_sample(pl_grads)))
             self.pl_moving_mean = self.pl_moving_mean + self.pl_decay * pl_lengths - self.pl_moving_mean
             return torch.pow(pl_lengths - self.pl_moving_mean, 2)
         noise = torch.randn(fake.shape, device=dev) / np.sqrt(fake.shape[2] * fake.shape[3])
-        pl_grads = grad(outputs=torch.sum(fake * noise), inputs=style, create_graph=True)[0]
+        with inputs_only_backward():
+            pl_grads = grad(outputs=torch.sum(fake * noise), inputs=style, create_graph=True)[0]
         pl_lengths = torch.sqrt(sqnorm_per_sample(pl_grads))
         mean = self.pl_moving_mean + self.pl_decay * (pl_lengths.mean().detach() - self.pl_moving_mean)
         self.pl_moving_mean = mean

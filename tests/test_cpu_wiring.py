@@ -178,7 +178,20 @@ def test_r1_double_backward_vs_oracle(cpu):
     ref = torch.autograd.grad(F.softplus(-sr).mean() + pen_r.mean(), [dl[k] for k in keys])
     ih = img.clone().requires_grad_(True)
     sh, _ = d([ih], condition=cond)
-    pen = losses.grad_penalty_loss([ih], sh, step=None)
+    # the inner gradient (d scores / d image, create_graph) must not compute D's weight gradients (functional.inputs_only_backward)
+    from gif_amd import ops
+    n_wgrad = [0]
+    real_wgrad = ops.conv_wgrad
+
+    def counted_wgrad(*a, **k):
+        n_wgrad[0] += 1
+        return real_wgrad(*a, **k)
+    ops.conv_wgrad = counted_wgrad
+    try:
+        pen = losses.grad_penalty_loss([ih], sh, step=None)
+        assert n_wgrad[0] == 0, "the R1 inner pass computed weight gradients"
+    finally:
+        ops.conv_wgrad = real_wgrad
     assert_close(pen, pen_r.detach(), 1e-4, "R1 penalty")
     named = dict(d.named_parameters())
     got = torch.autograd.grad(F.softplus(-sh).mean() + pen.mean(), [named[k] for k in keys])
