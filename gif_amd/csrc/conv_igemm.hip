@@ -74,6 +74,7 @@ struct GatherParams {
     int no_split;              // keep the launch in ONE tile size (per-sample partial sums need uniform rows)
     unsigned* sat_flag;        // f16: "a store saturated" flag word of the device (common.h store4_flag), else NULL
     int out_f32;               // f16 kernels: the output tensor is fp32
+    int pair;                  // f16 kernels, Ci <= 32 (CP == 32): one 64-half K chunk = the channels of TWO taps (see glds_body)
 };
 
 // partial-sum rows handed out to the launches of one op (bulk + remainder launches, transposed-conv phases), and the tile height
@@ -435,7 +436,14 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
     // this lane fills LDS row tid/CH + RPP*it, physical 16-B chunk tid%CH, with the LOGICAL chunk (tid%CH)^f(row),
     // f(row) = (row / RB) % CH: the 16 rows of a ds_read_b128 lane group then hit 16 distinct 16-B slots
     const int t_row = tid / CH;
-    const int src_c4 = ((tid % CH) ^ ((t_row / RB) % CH)) * EPC;
+    // f16 layers with <= 32 input channels ("pair" mode, CP == 32): a 64-half K chunk would be half zero padding — half of the
+    // MFMAs and half of the DMA pieces for nothing on the 1024^2 / 512^2 blocks.  Instead one chunk carries the 32 (padded)
+    // channels of TWO consecutive taps: lanes whose logical 16-byte chunk lies in the upper half of the row fetch the second tap's
+    // pixel (and its weight slice); 9 taps = 5 steps instead of 9.
+    const bool pair = F16 && p.pair;
+    const int lchunk = (tid % CH) ^ ((t_row / RB) % CH);
+    const bool pair_hi = pair && lchunk >= CH / 2;
+    const int src_c4 = (pair ? (lchunk & (CH / 2 - 1)) : lchunk) * EPC;
     const bool b_lane_ok = (BN % RPP == 0) || t_row < BN;
 
     int a_iy0[A_IT], a_ix0[A_IT], a_base[A_IT];
@@ -474,7 +482,7 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
         }
         __syncthreads();
     }
-    const int nsteps = p.ntaps * (p.CP / BK);
+    const int nsteps = pair ? (p.ntaps + 1) / 2 : p.ntaps * (p.CP / BK);
     int ld_a = 0, ld_b = 0, ld_kc = 0;
     int cmp_kc = 0;  // K-chunk of the step being computed (for the scale lookup)
     // X3 weight DMA: block = wave + it * NWAVES covers rows (block % (BN/16)) * 16 + lane/4 of term block / (BN/16); this
@@ -491,7 +499,39 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
 
+    // pair mode: taps (ld_a, ld_b) and its successor, chosen per lane
+    auto issue_pair = [&](int buf) __attribute__((always_inline)) {
+        int a1 = ld_a, b1 = ld_b + 1;
+        if (b1 == p.nkx) { b1 = 0; ++a1; }
+        const int ta = pair_hi ? a1 : ld_a, tb = pair_hi ? b1 : ld_b;
+        const bool tap_ok = ta < p.nky && src_c4 < p.Ci;
+        const int dy = p.dy0 + ta * p.ddy, dx = p.dx0 + tb * p.ddx;
+        const int widx = (p.ky0 + ta * p.kstep) * p.KW + p.kx0 + tb * p.kstep;
+        const int tap_off = (dy * p.Wi + dx) * p.Ci;
+        T* Ad = As + buf * BM * LD + wave * RPW * LD;
+        T* Bd = Bs + buf * BN * LD + wave * RPW * LD;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            bool ok = ((row_ok >> it) & 1u) && tap_ok && (unsigned)(a_iy0[it] + dy) < (unsigned)p.Hi &&
+                      (unsigned)(a_ix0[it] + dx) < (unsigned)p.Wi;
+            const T* g = ok ? px + (a_base[it] + tap_off) : pzero;
+            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Ad + it * RPP * LD), 16, 0, 0);
+        }
+        const T* wt = pw + ((size_t)widx * p.RP + n0 + t_row) * p.CP + src_c4;
+        if (BN % RPP == 0 || wave * RPW < BN) {
+#pragma unroll
+            for (int it = 0; it < B_IT; ++it)
+                __builtin_amdgcn_global_load_lds((gptr_t)((b_lane_ok && tap_ok) ? wt + (size_t)it * RPP * p.CP : pzero),
+                                                 (lptr_t)(Bd + it * RPP * LD), 16, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if (++ld_b == p.nkx) { ld_b = 0; ++ld_a; }
+    };
     auto issue = [&](int buf) __attribute__((always_inline)) {
+        if constexpr (F16 && !X3) {
+            if (pair) { issue_pair(buf); return; }
+        }
         const int dy = p.dy0 + ld_a * p.ddy, dx = p.dx0 + ld_b * p.ddx;
         const int widx = (p.ky0 + ld_a * p.kstep) * p.KW + p.kx0 + ld_b * p.kstep;
         const int kc = ld_kc;
@@ -658,7 +698,8 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
         for (int j = 0; j < NT; ++j) bv[slot][j] = *reinterpret_cast<const frag_t*>(Bb + j * 32 * LD + c);
         if (SCALE) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i) av[slot][i] *= *reinterpret_cast<const frag_t*>(Stab + s_row[i] + kc + kk * 2 * EPC);
+            for (int i = 0; i < MT; ++i)  // pair mode: the chunk's upper half holds the second tap's channels 0..31 again
+                av[slot][i] *= *reinterpret_cast<const frag_t*>(Stab + s_row[i] + (pair ? (kk * 2 * EPC) & (BK / 2 - 1) : kc + kk * 2 * EPC));
         }
     };
     auto mfma_group = [&](int slot) __attribute__((always_inline)) {
@@ -1083,6 +1124,7 @@ void pack_dims(int cout, int cin, int* RP, int* CP, bool x3 = false) {
     if (x3) c.BK = 32;  // the bf16x3 kernels only have 32-float K chunks: 24..31 input channels are zero-padded to one chunk
     *RP = (cout + c.BN - 1) / c.BN * c.BN;
     *CP = (cin + c.BK - 1) / c.BK * c.BK;
+    if (sizeof(T) == 2 && cin <= 32) *CP = 32;  // "pair" mode of the f16 kernel: two taps per 64-half K chunk (GatherParams::pair)
 }
 
 template <typename T>
@@ -1110,6 +1152,7 @@ int conv2d_fwd_impl(const void* big, const void* wp, void* small, const gif_conv
     p.dy0 = -g->pad; p.ddy = 1; p.dx0 = -g->pad; p.ddx = 1;
     p.ky0 = 0; p.kx0 = 0; p.kstep = 1; p.KW = g->KW;
     pack_dims<T>(p.Co, p.Ci, &p.RP, &p.CP, x3);
+    p.pair = (sizeof(T) == 2 && p.CP == 32) ? 1 : 0;
     p.M = p.B * p.Hp * p.Wp;
     double flops = 2.0 * p.M * (double)p.Co * p.Ci * p.ntaps;
     const int fam = sizeof(T) == 2 ? 6 : x3 ? 8 : (p.Ci >= 32 ? 0 : 5);
@@ -1136,6 +1179,7 @@ int conv2d_bwd_data_impl(const void* small, const void* wp, void* big, const gif
     base.B = g->B; base.Hi = g->Hs; base.Wi = g->Ws; base.Ci = g->Cs;
     base.Ho = g->Hb; base.Wo = g->Wb; base.Co = g->Cb;
     pack_dims<T>(base.Co, base.Ci, &base.RP, &base.CP, x3);
+    base.pair = (sizeof(T) == 2 && base.CP == 32) ? 1 : 0;
     const int st = g->stride;
     FusedSums sums;
     if (int rc = sums.begin(base, e, (long)g->B * g->Hb * g->Wb, base.Co, g->B, (long)g->Hb * g->Wb, st == 1, who)) return rc;

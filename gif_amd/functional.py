@@ -53,7 +53,7 @@ def _take_port(x, identity=False):
     serve: False = a real activation (mask in the gradient kernel's epilogue), True = bias-only layers (residual inputs)."""
     port = getattr(x, "_gif_port", None)
     if (port is None or not ops.FUSE_GRAD or not torch.is_grad_enabled() or port.alias is None or not port.alias.requires_grad
-            or x.dtype != torch.float32 or (port.slope == 1.0 and port.gain == 1.0) != identity):
+            or (port.slope == 1.0 and port.gain == 1.0) != identity):
         return None, None
     return port.alias, port.cfg()
 

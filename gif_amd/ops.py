@@ -128,8 +128,8 @@ class GradFuse:
 
 def dot_fusable(H, W, dtype=torch.float32):
     """The modulation-gradient dot product can ride in a convolution epilogue: every tile (<= 256 rows; Winograd: 256 2x2
-    tiles) stays inside one sample."""
-    return FUSE_GRAD and dtype == torch.float32 and (H * W) % 1024 == 0
+    tiles) stays inside one sample.  fp32 and f16 activations alike (the sums are fp32 and taken before the store rounds)."""
+    return FUSE_GRAD and dtype in (torch.float32, torch.float16) and (H * W) % 1024 == 0
 
 
 def _epilogue(in_scale=None, out_scale=None, bias=None, residual=None, act=False, slope=0.2, gain=2 ** 0.5, fuse=None,
@@ -421,7 +421,8 @@ def conv_wgrad(small, big, spec: ConvSpec, O, I, wscale=1.0, small_scale=None, b
 
 def fir_fusable(C, up, down, kshape, dtype=torch.float32):
     """The blur kernels (4x4 FIR, up = down = 1) take the mask / column-sum fusions for power-of-two channel counts."""
-    return FUSE_GRAD and dtype == torch.float32 and up == 1 and down == 1 and tuple(kshape) == (4, 4) and C & (C - 1) == 0 and C <= 1024
+    return (FUSE_GRAD and dtype in (torch.float32, torch.float16) and up == 1 and down == 1 and tuple(kshape) == (4, 4)
+            and C & (C - 1) == 0 and C <= 1024)
 
 
 def upfirdn2d(x, k, up, down, pad0, out_hw, flip=True, bias=None, residual=None, act=False, slope=0.2, gain=2 ** 0.5, fuse=None):

@@ -61,6 +61,12 @@ F16_CONV_CASES = [
     (1, 513, 512, 3, 1, 1, 4),    # final_conv (513 -> 520 padded)
     (5, 64, 160, 3, 1, 1, 7),     # ragged everything
     (8, 128, 128, 3, 1, 1, 64),   # enough rows for the 128x128-tile path with bulk/tail split
+    # <= 32 contraction channels: "pair" mode of the f16 kernel (two taps per 64-half K chunk; 9 taps = 5 steps, the last half empty)
+    (2, 32, 32, 3, 1, 1, 64),     # the 1024^2 block's layers: pair mode forward and data gradient, 256x32 tiles
+    (2, 64, 32, 3, 2, 0, 33),     # data gradient = transposed stride 2 with 32 contraction channels: phases of 4 / 2 / 2 / 1 taps
+    (2, 32, 64, 3, 2, 0, 33),     # stride-2 forward in pair mode, 128x64 tiles
+    (3, 16, 24, 3, 1, 1, 40),     # ragged, 16 and 24 channels
+    (2, 32, 128, 1, 1, 0, 32),    # single tap: the chunk's upper half stays zero
 ]
 
 
@@ -126,6 +132,19 @@ def test_f16_conv_scales_epilogue_and_modulated_wgrad():
     (refw,) = torch.autograd.grad(F.conv2d(xs, wl, padding=1), wl, gyd)
     gotw = ops.conv_wgrad(dev16(gy), dev16(x), ops.ConvSpec(3, 3, 1, 1), Co, Ci, small_scale=d.cuda(), big_scale=s.cuda())
     assert_close(gotw, refw, 1e-3, "f16 modulated wgrad")
+    # pair mode (<= 32 contraction channels) with modulation scales: forward, and the transposed conv's phases
+    Cp = 32
+    xp, wp_ = r16(torch.randn(B, Cp, H, H, generator=g)), torch.randn(64, Cp, 3, 3, generator=g) / 17
+    sp, dp = torch.rand(B, Cp, generator=g) + 0.5, torch.rand(B, 64, generator=g) + 0.5
+    xsp = r16(xp * r16(sp)[:, :, None, None])
+    refp = F.conv2d(xsp, r16(wp_), padding=1) * dp[:, :, None, None]
+    gotp = ops.conv_fwd(dev16(xp), wp_.cuda(), ops.ConvSpec(3, 3, 1, 1), in_scale=sp.cuda(), out_scale=dp.cuda())
+    assert_close(host(gotp), refp, TOL, "f16 scaled conv, pair mode")
+    wtp = torch.randn(Cp, 64, 3, 3, generator=g) / 17
+    reftp = F.conv_transpose2d(xsp, r16(wtp), stride=2) * dp[:, :, None, None]
+    gottp = ops.conv_bwd_data(dev16(xp), wtp.cuda(), ops.ConvSpec(3, 3, 2, 0), (2 * H + 1, 2 * H + 1), in_scale=sp.cuda(),
+                              out_scale=dp.cuda())
+    assert_close(host(gottp), reftp, TOL, "f16 modulated transposed conv, pair mode")
     # 4x4 maps (16 pixels per sample): the 16-pixel-stage variant of the scale table
     x4 = r16(torch.randn(4, 64, 4, 4, generator=g))
     gy4 = r16(torch.randn(4, 64, 4, 4, generator=g))

@@ -87,14 +87,15 @@ def _cl(t):
     return t.contiguous(memory_format=torch.channels_last)
 
 
-def _check_fused(out_f, fuse, plain, x_dot, s_out, residual, mask_src, slope, gain, what):
+def _check_fused(out_f, fuse, plain, x_dot, s_out, residual, mask_src, slope, gain, what, tol=1.0):
     """out_f / fuse.dot / fuse.colsum of a fused launch against float64 math on the PLAIN launch's output (same kernels, no
-    fusion): v = plain; dot = sum_hw v * x; v = s * v + residual; v *= gain * (mask > 0 ? 1 : slope); colsum = sum v."""
+    fusion): v = plain; dot = sum_hw v * x; v = s * v + residual; v *= gain * (mask > 0 ? 1 : slope); colsum = sum v.
+    tol: 1 for fp32 tensors; f16 tensors: the plain output and the fused output are each rounded to 11 bits (2^-11 = 4.9e-4)."""
     v = plain.double()
     if fuse.dot_src is not None:
         dot = (v * x_dot.double()).sum(dim=(2, 3))
         e = ((fuse.dot.double() - dot).abs().max() / dot.abs().max()).item()
-        assert e < 2e-5, f"{what}: dot rel err {e:.2e}"
+        assert e < 2e-5 * tol, f"{what}: dot rel err {e:.2e}"
     if s_out is not None:
         v = v * s_out.double()[:, :, None, None]
     if residual is not None:
@@ -102,11 +103,11 @@ def _check_fused(out_f, fuse, plain, x_dot, s_out, residual, mask_src, slope, ga
     if mask_src is not None:
         v = v * gain * torch.where(mask_src > 0, 1.0, slope).double()
     e = ((out_f.double() - v).abs().max() / v.abs().max()).item()
-    assert e < 2e-6, f"{what}: output rel err {e:.2e}"
+    assert e < (2e-6 if tol == 1.0 else 1.5e-3), f"{what}: output rel err {e:.2e}"
     if fuse.want_colsum:
         cs = v.sum(dim=(0, 2, 3))
         e = ((fuse.colsum.double() - cs).abs().max() / cs.abs().max()).item()
-        assert e < 2e-5, f"{what}: colsum rel err {e:.2e}"
+        assert e < 2e-5 * tol, f"{what}: colsum rel err {e:.2e}"
 
 
 # (B, C_small, C_big, K, stride, pad, H_big, op, winograd, mode)   op: "dgrad" = conv_bwd_data small -> big, "fwd" = conv_fwd big -> small
@@ -182,6 +183,51 @@ def test_grad_fuse_conv_epilogues(case, monkeypatch):
         ops.set_fp32_mfma_mode(prev)
 
 
+# f16 activations: the same epilogues read the mask / dot source as halfs; sums are fp32 and taken before the store rounds
+F16_FUSE_CASES = [
+    (8, 128, 128, 3, 1, 1, 64, "dgrad"),   # 128x128 tiles
+    (4, 256, 256, 3, 1, 1, 16, "dgrad"),   # 64x64 tiles
+    (4, 128, 24, 3, 1, 1, 64, "dgrad"),    # 256x32 tiles
+    (4, 64, 64, 3, 1, 1, 64, "dgrad"),     # 128x64 tiles
+    (4, 8, 128, 1, 1, 0, 64, "dgrad"),     # ToRGB's data gradient (3 colour channels padded to 8)
+    (4, 128, 64, 3, 2, 0, 65, "fwd"),      # stride-2 forward conv = data gradient of the up-sampling conv_transpose
+    (4, 128, 64, 3, 2, 0, 65, "dgrad"),    # transposed stride 2: four phases (mask + colsum only)
+]
+
+
+@pytest.mark.parametrize("case", F16_FUSE_CASES)
+def test_grad_fuse_conv_epilogues_f16(case):
+    from gif_amd import ops
+    B, Cs, Cb, K, st, pad, Hb, op = case
+    g = torch.Generator().manual_seed(Hb + Cs)
+    spec = ops.ConvSpec(K, K, st, pad)
+    Hs = spec.small_hw(Hb, Hb)[0]
+    w = (torch.randn(Cs, Cb, K, K, generator=g) / (Cb * K * K) ** 0.5).cuda()
+    if op == "dgrad":
+        Cin, Cout, Hin, Hout = Cs, Cb, Hs, Hb
+        run = lambda src, **epi: ops.conv_bwd_data(src, w, spec, (Hb, Hb), **epi)  # noqa: E731
+    else:
+        Cin, Cout, Hin, Hout = Cb, Cs, Hb, Hs
+        run = lambda src, **epi: ops.conv_fwd(src, w, spec, **epi)  # noqa: E731
+    h = lambda *shape: _cl(torch.randn(*shape, generator=g).cuda().half())  # noqa: E731
+    src, x, res = h(B, Cin, Hin, Hin), h(B, Cout, Hout, Hout), h(B, Cout, Hout, Hout)
+    d_in = (torch.rand(B, Cin, generator=g) + 0.5).cuda()
+    s_out = (torch.rand(B, Cout, generator=g) + 0.5).cuda()
+    can_dot = not (op == "dgrad" and st == 2) and (Hout * Hout) % 1024 == 0
+    # reference: the same launch with an fp32 result is not available for every op, so the plain f16 launch stands in (its own
+    # rounding is inside the tolerance); the fp32 sums of the fused launch are held to the sums of those rounded values
+    plain = run(src, in_scale=d_in)
+    fuse = ops.GradFuse(mask_src=x, mask_slope=0.2, mask_gain=2 ** 0.5, want_colsum=True, dot_src=x if can_dot else None)
+    out = run(src, in_scale=d_in, out_scale=s_out, residual=res, fuse=fuse)
+    assert out.dtype == torch.float16
+    _check_fused(out, fuse, plain, x, s_out, res, x, 0.2, 2 ** 0.5, f"f16 {case} all", tol=50.0)
+    fuse = ops.GradFuse(mask_src=x, mask_slope=0.0, mask_gain=1.0)
+    out = run(src, in_scale=d_in, fuse=fuse)
+    _check_fused(out, fuse, plain, None, None, None, x, 0.0, 1.0, f"f16 {case} mask", tol=50.0)
+    fuse2 = ops.GradFuse(mask_src=x, mask_slope=0.0, mask_gain=1.0)
+    assert torch.equal(run(src, in_scale=d_in, fuse=fuse2), out)
+
+
 @pytest.mark.parametrize("shape", [(16, 128, 129), (4, 256, 33), (2, 512, 9), (3, 64, 40)])
 def test_grad_fuse_blur_adjoint(shape):
     """The blur's adjoint (the gradient w.r.t. ConvLayer conv1's activated output inside a ResBlock) with the leaky-ReLU mask and
@@ -200,10 +246,16 @@ def test_grad_fuse_blur_adjoint(shape):
     fuse = ops.GradFuse(mask_src=y, mask_slope=0.2, mask_gain=2 ** 0.5)
     out = ops.upfirdn2d(gy, k, 1, 1, 1, (H - 1, H - 1), False, fuse=fuse)
     _check_fused(out, fuse, plain, None, None, None, y, 0.2, 2 ** 0.5, f"blur adjoint {shape} mask only")
+    # f16 activations through the same kernels
+    gy, y = gy.half(), y.half()
+    plain = ops.upfirdn2d(gy, k, 1, 1, 1, (H - 1, H - 1), False)
+    fuse = ops.GradFuse(mask_src=y, mask_slope=0.2, mask_gain=2 ** 0.5, want_colsum=True)
+    out = ops.upfirdn2d(gy, k, 1, 1, 1, (H - 1, H - 1), False, fuse=fuse)
+    _check_fused(out, fuse, plain, None, None, None, y, 0.2, 2 ** 0.5, f"blur adjoint f16 {shape}", tol=50.0)
 
 
-@pytest.mark.parametrize("res,step", [(32, 3), (64, 4)])
-def test_model_gradients_fused_equal_standalone(res, step, monkeypatch):
+@pytest.mark.parametrize("res,step,f16", [(32, 3, False), (64, 4, False), (64, 4, True)])
+def test_model_gradients_fused_equal_standalone(res, step, f16, monkeypatch):
     """Whole G-through-D and D gradients with the activation ports on (default) against GIF_FUSE_GRAD off — the same kernels
     minus the stand-alone passes: agreement at accumulation-order level, and the stand-alone passes really disappear."""
     import contextlib
@@ -238,9 +290,24 @@ def test_model_gradients_fused_equal_standalone(res, step, monkeypatch):
         gd = torch.autograd.grad(ld, dp)
         return gg, gd, dict(calls)
 
+    if f16:
+        # f16 activations: same ports, masks read as halfs.  The two runs round at different points, so they differ by f16 rounding
+        # noise — up to 9 % of the max for the 6->12-channel condition-noise weights, whose f16 gradient is 13 % off the fp32 one
+        # with or without the fusions (tools/probes/f16_fuse_diag.py).  Bound: per tensor, no further from the fp32 gradients than
+        # twice the stand-alone f16 passes are.
+        ggr, gdr, _ = run(False)
+        G.set_activation_dtype(torch.float16), D.set_activation_dtype(torch.float16)
     gg0, gd0, c0 = run(False)
     gg1, gd1, c1 = run(True)
     assert c1["bias_act_bwd"] < c0["bias_act_bwd"] and c1["mul_reduce"] < c0["mul_reduce"], (c0, c1)
+    if f16:
+        for a, b, r in list(zip(gg1, gg0, ggr)) + list(zip(gd1, gd0, gdr)):
+            assert (a is None) == (r is None)
+            if r is not None:
+                m = r.abs().max() + 1e-20
+                e_fused, e_plain = ((a - r).abs().max() / m).item(), ((b - r).abs().max() / m).item()
+                assert e_fused <= 2 * e_plain + 1e-2, (e_fused, e_plain, tuple(r.shape))
+        return
     worst = 0.0
     for a, b in list(zip(gg1, gg0)) + list(zip(gd1, gd0)):
         assert (a is None) == (b is None)
