@@ -964,6 +964,15 @@ int launch(GatherParams& p, hipStream_t s) {
     }
     if constexpr (F16) {
         if (c.BN == 64) return fail_f16(launch_glds<T, 128, 64, 2, 2>(p, s));
+        // f16 MFMAs are 8x shorter than fp32 ones while an LDS-DMA piece costs the same to issue: on 128x128 tiles a wave issues
+        // one 1-KiB piece per two MFMAs and the loop is bound by DMA issue + LDS traffic, not by the matrix pipe.  Layers with
+        // >= 256 output channels and enough rows run 256x256 tiles on 8 waves (2 x 4, wave tile 128x64: one piece per four
+        // MFMAs, 0.75 instead of 1 operand read per MFMA; 128 KB of LDS, one workgroup per CU): 512->512 at 64^2 780 -> 886
+        // TFLOP/s, 256->256 at 128^2 710 -> 752.  GIF_F16_TILE256=0: A/B knob.
+        static const int t256_off = getenv("GIF_F16_TILE256") ? atoi(getenv("GIF_F16_TILE256")) == 0 : 0;
+        if (!t256_off && c.BN == 128 && p.RP % 256 == 0 && (long)gif::cdiv(p.M, 256) * (p.RP / 256) >= 512 &&
+            launch_glds<T, 256, 256, 2, 4>(p, s) == 0)
+            return 0;
     }
     if (c.BN == 128 && (F16 || c.BK == 32)) {
         // low-resolution layers (4x4 .. 16x16 at batch 32): a 128x128 grid would leave most CUs idle behind a

@@ -67,6 +67,11 @@ F16_CONV_CASES = [
     (2, 32, 64, 3, 2, 0, 33),     # stride-2 forward in pair mode, 128x64 tiles
     (3, 16, 24, 3, 1, 1, 40),     # ragged, 16 and 24 channels
     (2, 32, 128, 1, 1, 0, 32),    # single tap: the chunk's upper half stays zero
+    # >= 256 output channels and >= 512 tiles of 256 rows: 256x256 tiles on 8 waves
+    (8, 64, 256, 3, 1, 1, 128),   # forward on 256x256 tiles (the data gradient has 64 output channels: 128x64 tiles)
+    (8, 256, 256, 1, 1, 0, 128),  # both directions on 256x256 tiles
+    (8, 32, 256, 3, 1, 1, 128),   # 256x256 tiles in pair mode
+    (9, 256, 512, 1, 2, 0, 255),  # 512 output channels (two N tiles), ragged M, stride 2
 ]
 
 

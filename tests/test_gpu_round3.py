@@ -192,6 +192,7 @@ F16_FUSE_CASES = [
     (4, 8, 128, 1, 1, 0, 64, "dgrad"),     # ToRGB's data gradient (3 colour channels padded to 8)
     (4, 128, 64, 3, 2, 0, 65, "fwd"),      # stride-2 forward conv = data gradient of the up-sampling conv_transpose
     (4, 128, 64, 3, 2, 0, 65, "dgrad"),    # transposed stride 2: four phases (mask + colsum only)
+    (8, 64, 256, 3, 1, 1, 128, "dgrad"),   # 256x256 tiles (8 waves), modulated, every fusion
 ]
 
 
