@@ -13,6 +13,11 @@ B="python $R/bench.py --no-cpu-baseline"
 DB=$(find $OUT/stats -name "*.db" | head -1)
 [ -n "$DB" ] && python tools/rocpd_stats.py $DB > $OUT/kernel_stats.md
 rm -rf $OUT/stats
+# 1b. the same for the f16-activation step (row N1)
+( cd /tmp && rocprofv3 --kernel-trace --stats -d $R/$OUT/stats16 -- $B --steps 5 --warmup 2 --no-prof --dtype f16 > $R/$OUT/stats_bench_f16.json 2> $R/$OUT/stats16.err )
+DB=$(find $OUT/stats16 -name "*.db" | head -1)
+[ -n "$DB" ] && python tools/rocpd_stats.py $DB > $OUT/kernel_stats_f16.md
+rm -rf $OUT/stats16
 # 2. HBM traffic per kernel: FETCH_SIZE and WRITE_SIZE in separate passes (TCC slots), one profiled iteration
 for C in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/$OUT/pmc_$C -- $B --steps 1 --warmup 1 --no-prof > /dev/null 2> $R/$OUT/pmc_$C.err )
@@ -28,7 +33,8 @@ $B --steps 12 --warmup 3 --batch 16 > $OUT/bench_config2_batch16.json 2> /dev/nu
 $B --steps 12 --warmup 3 --render-cond --gen-reg PATH_LEN_REG > $OUT/bench_config3_render_plreg.json 2> /dev/null
 $B --steps 12 --warmup 3 --dtype f16 > $OUT/bench_f16_256.json 2> /dev/null
 $B --steps 8 --warmup 2 --dtype f16 --res 1024 --batch 8 > $OUT/bench_f16_1024.json 2> /dev/null
-GIF_PROF_DUMP=$OUT/shapes.csv $B --steps 8 --warmup 2 > $OUT/bench_shapes.json 2> /dev/null
+GIF_PROF_DUMP=$OUT/shapes.csv $B --steps 8 --warmup 2 --prof-every 1 > $OUT/bench_shapes.json 2> /dev/null
+GIF_PROF_DUMP=$OUT/shapes_f16.csv $B --steps 8 --warmup 2 --prof-every 1 --dtype f16 > $OUT/bench_shapes_f16.json 2> /dev/null
 # 4. side measurements
 python tools/raster_bench.py --json $OUT/raster_bench.json > $OUT/raster_bench.txt 2>&1
 python tools/probes/f16_error_by_layer.py > $OUT/f16_error_by_layer.txt 2>&1

@@ -18,4 +18,13 @@ s=$(python -c "import json;print(round(json.load(open('$O/bench_shapes.json'))['
   echo "family 8 = direct conv fwd/dgrad on the bf16x3 LDS-DMA kernel (tag = taps*10+stride, negative = transposed/dgrad), 5 = native register-staged kernel (Cin < 24), 9 / 1 = direct wgrad bf16x3 / native (tag +100 = modulated), 10 = wino_gemm_x3 (tag 2091), 11 = Winograd wgrad plane GEMMs on bf16x3, 4 = Winograd transforms (last column TB/s), 0 = native LDS-DMA kernel (none in this mode)."
   echo "All rates are ALGORITHMIC fp32 TFLOP/s (direct-convolution count); the bf16 pipe executes 6x (families 8, 9) or 6*16/36 = 2.67x (10, 11) of it.  Rows below 0.4 ms/step are folded into the totals."; echo
   python tools/shape_table.py $O/shapes.csv 8; } > profiles/${R}_conv_shapes.md
+if [ -s $O/kernel_stats_f16.md ]; then
+v=$(python -c "import json;d=json.load(open('$O/stats_bench_f16.json'));print(f\"{d['value']:.1f} images/s, {d['ms_per_step']:.1f} ms/step\")")
+{ echo "# rocprofv3 --kernel-trace --stats, round ${R#r} (commit $C), f16 activations: python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-prof --dtype f16"; echo
+  echo "7 training iterations at 256x256, batch 32; bench line of the profiled run: $v (profiler attached)"; echo; cat $O/kernel_stats_f16.md; } > profiles/${R}_kernel_stats_f16.md
+fi
+if [ -s $O/shapes_f16.csv ]; then
+{ echo "# Per-launch-shape timings, f16 activations at 256x256, batch 32 (round ${R#r}, commit $C): family 6 = f16 conv fwd/dgrad, 7 = f16 wgrad; ALGORITHMIC TFLOP/s"; echo
+  python tools/shape_table.py $O/shapes_f16.csv 8; } > profiles/${R}_conv_shapes_f16.md
+fi
 echo published $O at $C as $R

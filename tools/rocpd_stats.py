@@ -1,12 +1,20 @@
 """Summarise a rocprofv3 (ROCm 7.2, rocpd sqlite output) kernel trace into a per-kernel stats table
 (the `--stats` CSV equivalent): calls, total / average / min / max duration, share of GPU time.
 Usage: python tools/rocpd_stats.py gpurun_out/prof/x_results.db [> profiles/name.md]"""
+import os
 import re
+import subprocess
 import sqlite3
 import sys
 
 
+_FILT = "/usr/bin/c++filt"
+
+
 def short(name):
+    if name.startswith("_Z") and os.path.exists(_FILT):  # rocprofv3 leaves _Float16 instantiations (DF16_) mangled; binutils knows Dh
+        name = subprocess.run([_FILT, name.replace("DF16_", "Dh")], capture_output=True, text=True).stdout.strip() or name
+        name = name.replace("__fp16", "f16").replace("_Float16", "f16")
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     name = re.sub(r"^void ", "", name)
     m = re.match(r"([\w:<>, ]+?)\(", name)
