@@ -75,6 +75,7 @@ struct GatherParams {
     unsigned* sat_flag;        // f16: "a store saturated" flag word of the device (common.h store4_flag), else NULL
     int out_f32;               // f16 kernels: the output tensor is fp32
     int pair;                  // f16 kernels, Ci <= 32 (CP == 32): one 64-half K chunk = the channels of TWO taps (see glds_body)
+    int dense;                 // bf16x3 kernels, 8 <= Ci < 32, 3x3: 16-byte chunks per tap (Ci / 4) of the tap-dense K order, else 0
 };
 
 // partial-sum rows handed out to the launches of one op (bulk + remainder launches, transposed-conv phases), and the tile height
@@ -443,7 +444,12 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
     const bool pair = F16 && p.pair;
     const int lchunk = (tid % CH) ^ ((t_row / RB) % CH);
     const bool pair_hi = pair && lchunk >= CH / 2;
-    const int src_c4 = (pair ? (lchunk & (CH / 2 - 1)) : lchunk) * EPC;
+    // bf16x3 layers with 8 <= Ci < 32 ("tap-dense" mode, 3x3 only): a K chunk of 32 floats per tap would be 25 % (Ci = 24) to 75 %
+    // (Ci = 8) zero padding.  Instead K runs densely over (tap, channel): 16-byte chunk q = 8 * step + lane chunk belongs to tap
+    // q / (Ci/4), channels 4 * (q % (Ci/4)).. — each DMA lane fetches its own tap's pixel; the weights are packed in the same order
+    // (gif_pack_weight_f32x3_tapdense).  9 taps of 24 channels = 7 steps instead of 9, of 12 channels = 4, of 8 channels = 3.
+    const int dense_cpt = X3 ? p.dense : 0;
+    const int src_c4 = dense_cpt ? 0 : (pair ? (lchunk & (CH / 2 - 1)) : lchunk) * EPC;
     const bool b_lane_ok = (BN % RPP == 0) || t_row < BN;
 
     int a_iy0[A_IT], a_ix0[A_IT], a_base[A_IT];
@@ -482,7 +488,7 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
         }
         __syncthreads();
     }
-    const int nsteps = pair ? (p.ntaps + 1) / 2 : p.ntaps * (p.CP / BK);
+    const int nsteps = dense_cpt ? (p.ntaps * dense_cpt + CH - 1) / CH : pair ? (p.ntaps + 1) / 2 : p.ntaps * (p.CP / BK);
     int ld_a = 0, ld_b = 0, ld_kc = 0;
     int cmp_kc = 0;  // K-chunk of the step being computed (for the scale lookup)
     // X3 weight DMA: block = wave + it * NWAVES covers rows (block % (BN/16)) * 16 + lane/4 of term block / (BN/16); this
@@ -528,9 +534,40 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
         for (int k = 0; k < 2; ++k)
             if (++ld_b == p.nkx) { ld_b = 0; ++ld_a; }
     };
+    int ld_step = 0;
+    auto issue_dense = [&](int buf) __attribute__((always_inline)) {
+        if constexpr (X3) {
+            const int q = ld_step * CH + lchunk;
+            const int t = (q * ((65536 + dense_cpt - 1) / dense_cpt)) >> 16;  // q / cpt (exact for q < 128)
+            const int ch = (q - t * dense_cpt) * EPC;
+            const int ta = (t * 11) >> 5, tb = t - 3 * ta;  // 3x3 tap grid: t / 3, t % 3 (t < 12)
+            const bool tap_ok = t < p.ntaps;
+            const int dy = p.dy0 + ta * p.ddy, dx = p.dx0 + tb * p.ddx;
+            const int tap_off = (dy * p.Wi + dx) * p.Ci + ch;
+            T* Ad = As + buf * BM * LD + wave * RPW * LD;
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) {
+                bool ok = ((row_ok >> it) & 1u) && tap_ok && (unsigned)(a_iy0[it] + dy) < (unsigned)p.Hi &&
+                          (unsigned)(a_ix0[it] + dx) < (unsigned)p.Wi;
+                const T* g = ok ? px + (a_base[it] + tap_off) : pzero;
+                __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Ad + it * RPP * LD), 16, 0, 0);
+            }
+            const unsigned short* wt = pw3 + (size_t)ld_step * 3 * p.RP * p.CP;
+#pragma unroll
+            for (int it = 0; it < B3_IT; ++it) {
+                const int blk = wave + it * NWAVES;  // wave-uniform
+                if (B3_BLK % NWAVES == 0 || blk < B3_BLK)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(wt + b3_off[it]), (lptr_t)(B3 + (buf * B3_BLK + blk) * 512), 16, 0, 0);
+            }
+            ++ld_step;
+        }
+    };
     auto issue = [&](int buf) __attribute__((always_inline)) {
         if constexpr (F16 && !X3) {
             if (pair) { issue_pair(buf); return; }
+        }
+        if constexpr (X3) {
+            if (dense_cpt) { issue_dense(buf); return; }
         }
         const int dy = p.dy0 + ld_a * p.ddy, dx = p.dx0 + ld_b * p.ddx;
         const int widx = (p.ky0 + ld_a * p.kstep) * p.KW + p.kx0 + ld_b * p.kstep;
@@ -958,7 +995,7 @@ int launch(GatherParams& p, hipStream_t s) {
         if (rc != 0) gif::set_error("conv (%s): launch configuration does not fit (rc=%d)", F16 ? "f16" : "bf16x3", rc);
         return rc == 0 ? 0 : GIF_ENOSUP;
     };
-    if (p.x3 && p.Ci < 24) {
+    if (p.x3 && p.Ci < 24 && !p.dense) {
         gif::set_error("conv (bf16x3): needs >= 24 input channels (gif_conv2d_x3_eligible)");
         return GIF_ENOSUP;
     }
@@ -1083,6 +1120,15 @@ void fill_epilogue(GatherParams& p, const gif_conv_epilogue* e) {
     p.out_f32 = e ? e->out_f32 : 0;
 }
 
+// tap-dense K order of the bf16x3 kernels (GatherParams::dense): 3x3 kernels over the full tap grid, contraction channels 8..28
+int check_tapdense(const gif_conv_geom* g, const gif_conv_epilogue* e, int cin, bool transposed, const char* who) {
+    GIF_REQUIRE(gif_conv2d_x3_tapdense_steps(cin, g->KH, g->KW) > 0, "%s: tap-dense mode needs a 3x3 kernel and 8 <= Cin < 32 (got %dx%d, %d)",
+                who, g->KH, g->KW, cin);
+    GIF_REQUIRE(!transposed || g->stride == 1, "%s: tap-dense mode: a strided data gradient runs tap subsets per output phase", who);
+    GIF_REQUIRE(!(e && e->in_scale), "%s: tap-dense mode has no per-sample input scales", who);
+    return 0;
+}
+
 // Gradient-producer fusions of one op: validate, carve the partial-sum buffers out of red_ws (before the launches) and reduce
 // them in a fixed order (after).  out_rows = B * Ho * Wo of the op's output.
 struct FusedSums {
@@ -1145,7 +1191,7 @@ int check_channels(const gif_conv_geom* g, const char* who) {
 
 template <typename T>
 int conv2d_fwd_impl(const void* big, const void* wp, void* small, const gif_conv_geom* g, const gif_conv_epilogue* e,
-                    gif_stream_t stream, const char* who, bool x3 = false) {
+                    gif_stream_t stream, const char* who, bool x3 = false, bool dense = false) {
     if (int rc = check_geom(g, who)) return rc;
     if (int rc = check_channels<T>(g, who)) return rc;
     if (g->B == 0) return 0;
@@ -1162,6 +1208,10 @@ int conv2d_fwd_impl(const void* big, const void* wp, void* small, const gif_conv
     p.ky0 = 0; p.kx0 = 0; p.kstep = 1; p.KW = g->KW;
     pack_dims<T>(p.Co, p.Ci, &p.RP, &p.CP, x3);
     p.pair = (sizeof(T) == 2 && p.CP == 32) ? 1 : 0;
+    if (dense) {
+        if (int rc = check_tapdense(g, e, g->Cb, false, who)) return rc;
+        p.dense = g->Cb / 4;
+    }
     p.M = p.B * p.Hp * p.Wp;
     double flops = 2.0 * p.M * (double)p.Co * p.Ci * p.ntaps;
     const int fam = sizeof(T) == 2 ? 6 : x3 ? 8 : (p.Ci >= 32 ? 0 : 5);
@@ -1175,7 +1225,7 @@ int conv2d_fwd_impl(const void* big, const void* wp, void* small, const gif_conv
 
 template <typename T>
 int conv2d_bwd_data_impl(const void* small, const void* wp, void* big, const gif_conv_geom* g, const gif_conv_epilogue* e,
-                         gif_stream_t stream, const char* who, bool x3 = false) {
+                         gif_stream_t stream, const char* who, bool x3 = false, bool dense = false) {
     if (int rc = check_geom(g, who)) return rc;
     if (int rc = check_channels<T>(g, who)) return rc;
     if (g->B == 0) return 0;
@@ -1189,6 +1239,10 @@ int conv2d_bwd_data_impl(const void* small, const void* wp, void* big, const gif
     base.Ho = g->Hb; base.Wo = g->Wb; base.Co = g->Cb;
     pack_dims<T>(base.Co, base.Ci, &base.RP, &base.CP, x3);
     base.pair = (sizeof(T) == 2 && base.CP == 32) ? 1 : 0;
+    if (dense) {
+        if (int rc = check_tapdense(g, e, g->Cs, true, who)) return rc;
+        base.dense = g->Cs / 4;
+    }
     const int st = g->stride;
     FusedSums sums;
     if (int rc = sums.begin(base, e, (long)g->B * g->Hb * g->Wb, base.Co, g->B, (long)g->Hb * g->Wb, st == 1, who)) return rc;
@@ -1301,6 +1355,16 @@ int gif_conv2d_fwd_f32x3(const float* big, const void* wp3, float* small, const 
 int gif_conv2d_bwd_data_f32x3(const float* small, const void* wp3, float* big, const gif_conv_geom* g,
                               const gif_conv_epilogue* e, gif_stream_t stream) {
     return conv2d_bwd_data_impl<float>(small, wp3, big, g, e, stream, "conv2d_bwd_data_f32x3", true);
+}
+
+int gif_conv2d_fwd_f32x3_tapdense(const float* big, const void* wp3, float* small, const gif_conv_geom* g,
+                                  const gif_conv_epilogue* e, gif_stream_t stream) {
+    return conv2d_fwd_impl<float>(big, wp3, small, g, e, stream, "conv2d_fwd_f32x3_tapdense", true, true);
+}
+
+int gif_conv2d_bwd_data_f32x3_tapdense(const float* small, const void* wp3, float* big, const gif_conv_geom* g,
+                                       const gif_conv_epilogue* e, gif_stream_t stream) {
+    return conv2d_bwd_data_impl<float>(small, wp3, big, g, e, stream, "conv2d_bwd_data_f32x3_tapdense", true, true);
 }
 
 int gif_conv2d_fwd_f16(const void* big, const void* wp, void* small, const gif_conv_geom* g, const gif_conv_epilogue* e,

@@ -560,6 +560,29 @@ __global__ void pack_weight_x3_kernel(const float* __restrict__ w, unsigned shor
     o[2 * plane] = (unsigned short)(l & 0xffffu);
 }
 
+// tap-dense variant (3x3): wp3[step][term][r][32], K order (tap, channel) without per-tap padding
+__global__ void pack_weight_x3_dense_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp3, int R, int C, int cpt,
+                                            int steps, int RP, long sr, long sc, long sky, long skx, float scale) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)steps * RP * 32;
+    if (idx >= total) return;
+    const int k = (int)(idx % 32);
+    const long rest = idx / 32;
+    const int r = (int)(rest % RP);
+    const int st = (int)(rest / RP);
+    const int q = st * 8 + k / 4;
+    const int t = q / cpt, c = (q - t * cpt) * 4 + k % 4;
+    float v = 0.f;
+    if (t < 9 && r < R && c < C) v = scale * w[r * sr + c * sc + (t / 3) * sky + (t % 3) * skx];
+    unsigned h, m, l;
+    gif::split_pair(v, 0.f, h, m, l);
+    const size_t plane = (size_t)RP * 32;
+    unsigned short* o = wp3 + (size_t)st * 3 * plane + (size_t)r * 32 + k;
+    o[0] = (unsigned short)(h & 0xffffu);
+    o[plane] = (unsigned short)(m & 0xffffu);
+    o[2 * plane] = (unsigned short)(l & 0xffffu);
+}
+
 __global__ void unpack_wgrad_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit, int R, int C,
                                     int KH, int KW, int RP, int CP, long sr, long sc, long sky, long skx,
                                     float scale) {
@@ -782,6 +805,24 @@ int gif_pack_weight_f32x3(const float* w, void* wp3, int R, int C, int KH, int K
     pack_weight_x3_kernel<<<gif::cdiv(total, 256), 256, 0, gif::as_stream(stream)>>>(w, static_cast<unsigned short*>(wp3), R, C,
                                                                                        KH, KW, RP, CP, sr, sc, sky, skx, scale);
     return gif::check_launch("pack_weight_f32x3");
+}
+
+/* K steps (32-float chunks) of the tap-dense order, or 0 if the mode does not apply: 3x3 kernels, 8 <= cin_act < 32, cin_act % 4 == 0 */
+int gif_conv2d_x3_tapdense_steps(int cin_act, int KH, int KW) {
+    if (KH != 3 || KW != 3 || cin_act < 8 || cin_act >= 32 || cin_act % 4 != 0) return 0;
+    return (9 * (cin_act / 4) + 7) / 8;
+}
+
+/* wp3[step][term][RP][32] (bf16 bits): element k of step s is float k % 4 of 16-byte chunk q = 8 s + k / 4, i.e. tap q / (cin_act/4),
+ * channel 4 (q % (cin_act/4)) + k % 4 — the order in which the tap-dense kernels walk K (conv_igemm.hip, GatherParams::dense) */
+int gif_pack_weight_f32x3_tapdense(const float* w, void* wp3, int R, int C, int cin_act, int KH, int KW, int RP, int64_t sr, int64_t sc,
+                                   int64_t sky, int64_t skx, float scale, gif_stream_t stream) {
+    const int steps = gif_conv2d_x3_tapdense_steps(cin_act, KH, KW);
+    GIF_REQUIRE(w && wp3 && R > 0 && C > 0 && RP >= R && cin_act >= C && steps > 0, "pack_weight_f32x3_tapdense: bad arguments");
+    long total = (long)steps * RP * 32;
+    pack_weight_x3_dense_kernel<<<gif::cdiv(total, 256), 256, 0, gif::as_stream(stream)>>>(w, static_cast<unsigned short*>(wp3), R, C,
+                                                                                             cin_act / 4, steps, RP, sr, sc, sky, skx, scale);
+    return gif::check_launch("pack_weight_f32x3_tapdense");
 }
 
 int gif_pack_weight_f16(const float* w, void* wp, int R, int C, int KH, int KW, int RP, int CP, int64_t sr, int64_t sc,

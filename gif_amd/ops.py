@@ -192,6 +192,7 @@ def _cached_weight_op(w, tag, build):
     return out
 
 
+X3_TAPDENSE = os.environ.get("GIF_X3_TAPDENSE", "1") != "0"  # tap-dense K order for 3x3 layers with 8..28 contraction channels (A/B)
 X3_MIN_CIN = int(os.environ.get("GIF_X3_MIN_CIN", "24"))  # gif_conv2d_x3_eligible: >= 24 (one zero-padded 32-float K chunk)
 
 
@@ -200,7 +201,16 @@ def x3_conv(dtype, cin_act: int) -> bool:
     return dtype == torch.float32 and cin_act >= X3_MIN_CIN and get_fp32_mfma_mode() == "bf16x3"
 
 
-def pack_weight(w: torch.Tensor, rows_are_out: bool, cout_act: int, cin_act: int, scale: float = 1.0, dtype=torch.float32, x3=False):
+def x3_tapdense(dtype, cin_act: int, spec, transposed: bool, epi) -> bool:
+    """3x3 fp32 conv with 8 <= cin_act < 32 contraction channels runs the bf16x3 kernel in its tap-dense K order (include/gif_hip.h:
+    the condition-noise convs and the 24 -> C layers; no per-tap padding of K).  Not for strided data gradients (tap subsets per
+    output phase) and not for modulated launches."""
+    return (X3_TAPDENSE and dtype == torch.float32 and get_fp32_mfma_mode() == "bf16x3" and 8 <= cin_act < 32 and cin_act % 4 == 0
+            and (spec.KH, spec.KW) == (3, 3) and not (transposed and spec.stride != 1) and epi.get("in_scale") is None)
+
+
+def pack_weight(w: torch.Tensor, rows_are_out: bool, cout_act: int, cin_act: int, scale: float = 1.0, dtype=torch.float32, x3=False,
+                tapdense=False):
     """Pack a canonical forward-conv weight view w[O,I,KH,KW] (any strides) into [T][RP][CP] of `dtype` (fp32 or f16), or
     (x3=True) into the pre-split bf16x3 operand [T][3][RP][CP] (bf16) of the gif_conv2d_*_f32x3 entry points.
 
@@ -217,8 +227,14 @@ def pack_weight(w: torch.Tensor, rows_are_out: bool, cout_act: int, cin_act: int
 
     def build():
         RP, CP = ctypes.c_int(), ctypes.c_int()
-        dims = lib.gif_conv2d_pack_dims_x3 if x3 else (lib.gif_conv2d_pack_dims_f16 if f16 else lib.gif_conv2d_pack_dims)
+        dims = lib.gif_conv2d_pack_dims_x3 if (x3 or tapdense) else (lib.gif_conv2d_pack_dims_f16 if f16 else lib.gif_conv2d_pack_dims)
         _lib.check(dims(cout_act, cin_act, ctypes.byref(RP), ctypes.byref(CP)), "pack_dims")
+        if tapdense:
+            steps = lib.gif_conv2d_x3_tapdense_steps(cin_act, KH, KW)
+            wp = torch.empty((steps, 3, RP.value, 32), device=w.device, dtype=torch.bfloat16)
+            _lib.check(lib.gif_pack_weight_f32x3_tapdense(w.data_ptr(), wp.data_ptr(), R, C, cin_act, KH, KW, RP.value, sr, sc, sky, skx,
+                                                          float(scale), _stream()), "pack_weight_tapdense")
+            return wp
         if x3:
             wp = torch.empty((KH * KW, 3, RP.value, CP.value), device=w.device, dtype=torch.bfloat16)
             fn = lib.gif_pack_weight_f32x3
@@ -229,7 +245,7 @@ def pack_weight(w: torch.Tensor, rows_are_out: bool, cout_act: int, cin_act: int
                    "pack_weight")
         return wp
 
-    return _cached_weight_op(w, ("pack", rows_are_out, cout_act, cin_act, float(scale), dtype, bool(x3)), build)
+    return _cached_weight_op(w, ("pack", rows_are_out, cout_act, cin_act, float(scale), dtype, bool(x3), bool(tapdense)), build)
 
 
 # Winograd F(2x2,3x3) dispatch for stride-1 / pad-1 3x3 convs (conv_winograd.hip).  GIF_WINOGRAD=0 forces the direct
@@ -321,12 +337,13 @@ def conv_fwd(big, w, spec: ConvSpec, wscale=1.0, keep_v=False, **epi):
     if keep_v:
         return conv_fwd(big, w, spec, wscale, **epi), None
     x3 = x3_conv(dt, Cb)
-    wp = pack_weight(w, True, Cs, Cb, wscale, dt, x3=x3)
+    dense = x3_tapdense(dt, Cb, spec, False, epi)
+    wp = pack_weight(w, True, Cs, Cb, wscale, dt, x3=x3, tapdense=dense)
     # out_f32 (f16 activations only): fp32 result, e.g. the RGB image of ToRGB
     out = empty_nhwc(B, Cs, Hs, Ws, big.device, torch.float32 if epi.get("out_f32") else dt)
     g = _geom(B, Hb, Wb, Cb, Hs, Ws, Cs, spec)
     e = _epilogue(out_bchw=(B, Cs, Hs, Ws), dtype=dt, **epi)
-    fn = _lib.load().gif_conv2d_fwd_f32x3 if x3 else _fn("conv2d_fwd", dt)
+    fn = _lib.load().gif_conv2d_fwd_f32x3_tapdense if dense else _lib.load().gif_conv2d_fwd_f32x3 if x3 else _fn("conv2d_fwd", dt)
     _lib.check(fn(big.data_ptr(), wp.data_ptr(), out.data_ptr(), ctypes.byref(g), ctypes.byref(e), _stream()), "conv2d_fwd")
     return out
 
@@ -343,11 +360,13 @@ def conv_bwd_data(small, w, spec: ConvSpec, big_hw, wscale=1.0, **epi):
     if (Hb, Wb) == (Hs, Ws) and winograd_eligible(spec, B, Hs, Ws, Cs, Cb, dtype=dt):
         return conv3x3_winograd(small, w, False, Cb, wscale, **epi)
     x3 = x3_conv(dt, Cs)
-    wp = pack_weight(w, False, Cb, Cs, wscale, dt, x3=x3)
+    dense = x3_tapdense(dt, Cs, spec, True, epi)
+    wp = pack_weight(w, False, Cb, Cs, wscale, dt, x3=x3, tapdense=dense)
     out = empty_nhwc(B, Cb, Hb, Wb, small.device, dt)
     g = _geom(B, Hb, Wb, Cb, Hs, Ws, Cs, spec)
     e = _epilogue(out_bchw=(B, Cb, Hb, Wb), dtype=dt, **epi)
-    fn = _lib.load().gif_conv2d_bwd_data_f32x3 if x3 else _fn("conv2d_bwd_data", dt)
+    fn = (_lib.load().gif_conv2d_bwd_data_f32x3_tapdense if dense else _lib.load().gif_conv2d_bwd_data_f32x3 if x3
+          else _fn("conv2d_bwd_data", dt))
     _lib.check(fn(small.data_ptr(), wp.data_ptr(), out.data_ptr(), ctypes.byref(g), ctypes.byref(e), _stream()), "conv2d_bwd_data")
     return out
 

@@ -62,6 +62,15 @@ int gif_conv2d_pack_dims_x3(int cout, int cin, int* RP, int* CP); /* like gif_co
 int gif_pack_weight_f32x3(const float* w, void* wp3, int R, int C, int KH, int KW, int RP, int CP, int64_t sr, int64_t sc,
                           int64_t sky, int64_t skx, float scale, gif_stream_t stream);
 /* gif_conv2d_fwd_f32x3 / gif_conv2d_bwd_data_f32x3: declared next to their _f32 namesakes below */
+/* Tap-dense K order for 3x3 layers with 8 <= cin_act < 32 contraction channels (the condition-noise convs 6->12->24 and the 24->C
+ * layers that inject their result, stylegan2_common_layers.py:217-246): K runs over (tap, channel) without padding every tap to a
+ * 32-float chunk — 9 taps of 24 channels take 7 K steps instead of 9, of 12 channels 4, of 8 channels 3.
+ * gif_conv2d_x3_tapdense_steps() = number of steps (0: mode not applicable); gif_pack_weight_f32x3_tapdense writes
+ * wp3[steps][3][RP][32] bf16 (RP from gif_conv2d_pack_dims_x3); the _tapdense convolution entry points (below) consume it.
+ * Not for strided data gradients (their output phases use tap subsets) and not with per-sample input scales. */
+int gif_conv2d_x3_tapdense_steps(int cin_act, int KH, int KW);
+int gif_pack_weight_f32x3_tapdense(const float* w, void* wp3, int R, int C, int cin_act, int KH, int KW, int RP, int64_t sr, int64_t sc,
+                                   int64_t sky, int64_t skx, float scale, gif_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Mesh rasteriser — replaces standard_rasterize_cuda.standard_rasterize / standard_rasterize_colors
@@ -190,6 +199,10 @@ int gif_conv2d_fwd_f32x3(const float* big, const void* wp3, float* small, const 
                          gif_stream_t stream);
 int gif_conv2d_bwd_data_f32x3(const float* small, const void* wp3, float* big, const gif_conv_geom* g,
                               const gif_conv_epilogue* e, gif_stream_t stream);
+int gif_conv2d_fwd_f32x3_tapdense(const float* big, const void* wp3, float* small, const gif_conv_geom* g,
+                                  const gif_conv_epilogue* e, gif_stream_t stream);
+int gif_conv2d_bwd_data_f32x3_tapdense(const float* small, const void* wp3, float* big, const gif_conv_geom* g,
+                                       const gif_conv_epilogue* e, gif_stream_t stream);
 /* Partial weight gradients: ws[nsplit][KH*KW][RP][CP] with rows = small-side channels (o), cols = big-side
  * channels (i); (RP,CP) = gif_conv2d_wgrad_dims(Cs, Cb).  nsplit from gif_conv2d_wgrad_splits().
  * small_scale [B,Cs] / big_scale [B,Cb] (or NULL) are applied to the operands on load. */

@@ -87,6 +87,73 @@ def test_bf16x3_not_less_accurate_than_native_fp32_mfma(case):
         assert ex <= 1.3 * en + 2e-7, (case, name, "bf16x3", ex, "native", en)  # and the split costs no accuracy
 
 
+# tap-dense K order (include/gif_hip.h): 3x3 layers with 8..28 contraction channels, unmodulated
+TAPDENSE_CASES = [
+    (4, 8, 12, 1, 64),     # condition-noise conv 1 (6 -> 8 padded in, 12 out): 3 K steps; 256x32 tiles
+    (4, 12, 24, 1, 64),    # conv 2: 4 K steps
+    (4, 24, 128, 1, 96),   # conv 3 (24 -> C): 7 K steps, 256x128 tiles with a remainder launch
+    (3, 24, 256, 1, 40),   # ragged row count, two N tiles
+    (2, 28, 64, 1, 24),    # 7 chunks per tap (not a divisor of 8), 64x64 tiles
+    (4, 24, 64, 2, 33),    # stride-2 forward keeps the full tap grid: tap-dense; its data gradient (phases) must NOT be
+]
+
+
+@pytest.mark.parametrize("case", TAPDENSE_CASES)
+def test_bf16x3_tapdense_forward_and_data_gradient_vs_fp64(case, monkeypatch):
+    from gif_amd import ops
+    B, ci, co, st, h = case
+    torch.manual_seed(sum(case))
+    dev = "cuda"
+    ops.WINOGRAD = False
+    pad = 1 if st == 1 else 0
+    spec = ops.ConvSpec(3, 3, st, pad)
+    assert ops.x3_tapdense(torch.float32, ci, spec, False, {}) and not ops.x3_tapdense(torch.float32, ci, spec, False, {"in_scale": 1})
+    x = torch.randn(B, ci, h, h, device=dev).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(co, ci, 3, 3, device=dev) / (ci * 9) ** 0.5
+    bias = torch.randn(ops.pad4(co), device=dev)
+    hs = spec.small_hw(h, h)[0]
+    res = torch.randn(B, ops.pad4(co), hs, hs, device=dev).contiguous(memory_format=torch.channels_last)
+    ref = F.conv2d(x.double(), w.double(), stride=st, padding=pad)
+    ref_e = 2 ** 0.5 * F.leaky_relu(ref + res[:, :co].double() + bias[:co].double()[None, :, None, None], 0.2)
+
+    def err(got, r):
+        return float((got.double() - r).abs().max() / r.abs().max())
+
+    e = {}
+    for mode in ("native", "bf16x3"):
+        ops.set_fp32_mfma_mode(mode)
+        e[mode] = (err(ops.conv_fwd(x, w, spec)[:, :co], ref),
+                   err(ops.conv_fwd(x, w, spec, bias=bias, residual=res, act=True)[:, :co], ref_e))
+    for en, ex in zip(e["native"], e["bf16x3"]):
+        assert en < 1e-5 and ex < 1e-5 and ex <= 1.3 * en + 2e-7, (case, e)
+    # the same launch with the dispatch knob off (per-tap padded K chunks / native kernel): same result at fp32 accuracy
+    y_dense = ops.conv_fwd(x, w, spec)
+    monkeypatch.setattr(ops, "X3_TAPDENSE", False)
+    y_plain = ops.conv_fwd(x, w, spec)
+    monkeypatch.setattr(ops, "X3_TAPDENSE", True)
+    assert err(y_dense, y_plain.double()) < 5e-6 and (y_dense[:, co:] == 0).all()
+    # data gradient with `ci` as the OUTPUT side: contraction over co is not tap-dense here; with ci as contraction (a layer co <- ci
+    # seen from its consumer): gradient w.r.t. a [B, co_in = ci ...] tensor — swap roles
+    gy = torch.randn(B, ci, hs, hs, device=dev).contiguous(memory_format=torch.channels_last)  # `ci` small-side (contraction) channels
+    w2 = torch.randn(ci, co, 3, 3, device=dev) / (ci * 9) ** 0.5                                # forward weight [O = ci, I = co]
+    op = h - ((hs - 1) * st + 3 - 2 * pad)
+    ref_d = F.conv_transpose2d(gy.double(), w2.double(), stride=st, padding=pad, output_padding=op)
+    dense_d = ops.x3_tapdense(torch.float32, ci, spec, True, {})
+    assert dense_d == (st == 1)
+    xm = torch.randn(B, ops.pad4(co), h, h, device=dev).contiguous(memory_format=torch.channels_last)
+    ed = {}
+    for mode in ("native", "bf16x3"):
+        ops.set_fp32_mfma_mode(mode)
+        ed[mode] = err(ops.conv_bwd_data(gy, w2, spec, (h, h))[:, :co], ref_d)
+    assert ed["native"] < 1e-5 and ed["bf16x3"] < 1e-5 and ed["bf16x3"] <= 1.3 * ed["native"] + 2e-7, (case, ed)
+    if st == 1:  # gradient-producer epilogue on the tap-dense launch: mask + column sums
+        fuse = ops.GradFuse(mask_src=xm, mask_slope=0.2, mask_gain=2 ** 0.5, want_colsum=True)
+        got = ops.conv_bwd_data(gy, w2, spec, (h, h), fuse=fuse)
+        want = ref_d * 2 ** 0.5 * torch.where(xm[:, :co] > 0, 1.0, 0.2).double()
+        assert err(got[:, :co], want) < 1e-5
+        assert err(fuse.colsum[:co], want.sum(dim=(0, 2, 3))) < 2e-5
+
+
 def test_bf16x3_winograd_plane_gemms_vs_fp64():
     """The 16 plane GEMMs of the Winograd weight gradient run on the same bf16x3 kernel (planes mode)."""
     from gif_amd import ops
