@@ -76,6 +76,10 @@ def parse():
     ap.add_argument("--prof-every", type=int, default=4,
                     help="HIP events bracket every MFMA / transform launch of every N-th timed step (two event records per launch "
                          "cost ~4 ms per fully instrumented step: measured 231 vs 227 ms); 1 = every step")
+    ap.add_argument("--reuse-generator-forward", action="store_true",
+                    help="NOT the headline workload: run the generator forward once per iteration and use it for the D step "
+                         "(detached) and the G step (train.py:155 and :195 call G twice on identical inputs with unchanged weights; "
+                         "bit-identical losses and parameters, tests/test_gpu_models.py).  The line says so and counts one forward less.")
     ap.add_argument("--no-overlap-comm", action="store_true", help="complete each gradient exchange + optimiser step in place "
                     "(default with > 1 rank: deferred to where the network is next used)")
     ap.add_argument("--check-replicas", action="store_true",
@@ -392,7 +396,8 @@ def main():
     G, G_ema, D = G.to(dev), G_ema.to(dev), D.to(dev)
     trainer = GifTrainer(G, D, G_ema, step=res_step, alpha=1.0, r1_every=args.r1_every, gen_reg_type=args.gen_reg,
                          act_dtype=torch.float16 if args.dtype == "f16" else None,
-                         overlap_comm=False if args.no_overlap_comm else None)
+                         overlap_comm=False if args.no_overlap_comm else None,
+                         reuse_generator_forward=args.reuse_generator_forward)
 
     from gif_amd.data import SyntheticBatches
     B = args.batch
@@ -465,7 +470,7 @@ def main():
     if rank == 0:
         imgs = world * B * args.steps
         value = imgs / dt
-        fl_img = flops_per_image(args.res, args.r1_every)
+        fl_img = flops_per_image(args.res, args.r1_every, generator_forwards=1 if args.reuse_generator_forward else 2)
         step_tflops = value * fl_img / 1e12 / world
         f16 = args.dtype == "f16"
         fp32_mode = ops.get_fp32_mfma_mode()
@@ -478,6 +483,9 @@ def main():
                           "the native fp32 MFMA path) for every direct, weight-gradient and Winograd GEMM with >= 24 contraction "
                           "channels; the 6->12->24 condition-noise convs and the 9-channel D input layer on native fp32 MFMA"
                           if fp32_mode == "bf16x3" else "native fp32 MFMA") + " (BASELINE configs[1]/[3] shape)"))
+        if args.reuse_generator_forward:
+            workload += ("; NOT the reference's call order: ONE generator forward per iteration shared by the D and G steps "
+                         "(identical results, one forward less of work)")
         if args.render_cond:
             workload += "; condition rasterised from a posed mesh inside the timed region (configs[2])"
         if args.gen_reg.upper() != "NONE":

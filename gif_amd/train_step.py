@@ -417,11 +417,12 @@ class GifTrainer:
 F_G_256, F_D_256 = 52.33e9, 46.58e9
 
 
-def flops_per_image(res=256, r1_every=16):
+def flops_per_image(res=256, r1_every=16, generator_forwards=2):
+    """generator_forwards: 2 = the reference's iteration (train.py:155, :195); 1 = GifTrainer(reuse_generator_forward=True)"""
     table = {64: (17.34e9, 16.46e9), 128: (33.76e9, 31.51e9), 256: (F_G_256, F_D_256), 512: (75.82e9, 61.69e9),
              1024: (111.71e9, 76.87e9)}
     fg, fd = table[res]
-    fl = 2 * (4 * fg + 8 * fd)
+    fl = 2 * ((2 + generator_forwards) * fg + 8 * fd)
     if r1_every:
         fl += 2 * 3 * fd / r1_every
     return fl

@@ -29,6 +29,9 @@ cp $OUT/pmc_traffic.json profiles/pmc_traffic.json   # the default bench line be
 python bench.py --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err
 $B --steps 12 --warmup 3 --fp32-mfma native > $OUT/bench_native_fp32_mfma.json 2> /dev/null
 GIF_FUSE_GRAD=0 $B --steps 12 --warmup 3 > $OUT/bench_no_gradient_epilogue_fusions.json 2> /dev/null
+$B --steps 12 --warmup 3 > $OUT/bench_default_12steps_no_r1_iteration.json 2> /dev/null
+$B --steps 12 --warmup 3 --reuse-generator-forward > $OUT/bench_one_generator_forward_NOT_headline.json 2> /dev/null
+GIF_X3_TAPDENSE=0 $B --steps 12 --warmup 3 > $OUT/bench_no_tapdense.json 2> /dev/null
 $B --steps 12 --warmup 3 --batch 16 > $OUT/bench_config2_batch16.json 2> /dev/null
 $B --steps 12 --warmup 3 --render-cond --gen-reg PATH_LEN_REG > $OUT/bench_config3_render_plreg.json 2> /dev/null
 $B --steps 12 --warmup 3 --dtype f16 > $OUT/bench_f16_256.json 2> /dev/null

@@ -4,7 +4,7 @@
 set -eu
 O=$1; C=$2; R=$3
 cp $O/pmc_traffic.json profiles/pmc_traffic.json
-for f in default native_fp32_mfma no_gradient_epilogue_fusions config2_batch16 config3_render_plreg f16_256 f16_1024; do
+for f in default default_12steps_no_r1_iteration one_generator_forward_NOT_headline no_tapdense native_fp32_mfma no_gradient_epilogue_fusions config2_batch16 config3_render_plreg f16_256 f16_1024; do
   [ -s $O/bench_$f.json ] && cp $O/bench_$f.json profiles/${R}_bench_$f.json
 done
 for f in raster_bench.txt raster_bench.json f16_error_by_layer.txt x3_power_trace.txt; do [ -s $O/$f ] && cp $O/$f profiles/${R}_$f; done
