@@ -481,7 +481,8 @@ def main():
                        "fp32 tensors and fp32 accumulation; contractions on "
                        + ("the bf16 matrix cores via the exact 3-way bf16 split (bf16x3: 6 products per fp32 product, error vs fp64 <= "
                           "the native fp32 MFMA path) for every direct, weight-gradient and Winograd GEMM with >= 24 contraction "
-                          "channels; the 6->12->24 condition-noise convs and the 9-channel D input layer on native fp32 MFMA"
+                          "channels and, in a tap-dense K order, the 3x3 convs with 8..28 (the 6->12->24 condition-noise convs); the "
+                          "9-channel D input layer (1x1), ToRGB's data gradient and the small-channel weight gradients on native fp32 MFMA"
                           if fp32_mode == "bf16x3" else "native fp32 MFMA") + " (BASELINE configs[1]/[3] shape)"))
         if args.reuse_generator_forward:
             workload += ("; NOT the reference's call order: ONE generator forward per iteration shared by the D and G steps "
