@@ -200,13 +200,16 @@ FAMILIES = {
          "U, fused output transform and epilogue)", BF16X3_EXECUTED * WINOGRAD_EXECUTED, "wino_gemm_x3"),
     11: ("conv_wgrad_mfma<float, bf16x3> in planes mode (Winograd F(3x3,2x2) weight-gradient GEMMs on the bf16 matrix cores)",
          BF16X3_EXECUTED * WINOGRAD_EXECUTED, "conv_wgrad_mfma_x3"),
+    12: ("conv_gather_mfma_glds<float, bf16x3> in the tap-dense K order (3x3 layers with 8..28 contraction channels: the 6->12->24 "
+         "condition-noise convs and the 24->C layers that inject their result; same kernels as the bf16x3 direct family, so no separate "
+         "PMC traffic)", BF16X3_EXECUTED, None),
 }
 FAMILY_KEYS = {0: "roofline_conv_direct", 1: "roofline_wgrad_direct", 2: "roofline_conv_winograd", 3: "roofline_wgrad_winograd",
                5: "roofline_conv_direct_small_cin", 6: "roofline_conv_f16", 7: "roofline_wgrad_f16",
                8: "roofline_conv_direct_bf16x3", 9: "roofline_wgrad_direct_bf16x3", 10: "roofline_conv_winograd_bf16x3",
-               11: "roofline_wgrad_winograd_bf16x3"}
+               11: "roofline_wgrad_winograd_bf16x3", 12: "roofline_conv_direct_bf16x3_tapdense"}
 FAMILY_PEAK = {6: PEAK_F16_MFMA_TFLOPS, 7: PEAK_F16_MFMA_TFLOPS, 8: PEAK_F16_MFMA_TFLOPS, 9: PEAK_F16_MFMA_TFLOPS,
-               10: PEAK_F16_MFMA_TFLOPS, 11: PEAK_F16_MFMA_TFLOPS}
+               10: PEAK_F16_MFMA_TFLOPS, 11: PEAK_F16_MFMA_TFLOPS, 12: PEAK_F16_MFMA_TFLOPS}
 
 
 def load_pmc():
@@ -222,7 +225,7 @@ def load_pmc():
 def family_ceiling(fam, exec_frac, mfma_peak):
     """(TFLOP/s ceiling of the ALGORITHMIC rate, its name): the dense peak of the MFMA type the family feeds, divided by the MFMA
     FLOPs it executes per algorithmic (direct-convolution, fp32) FLOP."""
-    if fam in (8, 9):
+    if fam in (8, 9, 12):
         return mfma_peak / exec_frac, "bf16x3 fp32-exact = 2500 / 6 (six bf16 MFMA products per fp32 product, bf16 dense peak 2500 TFLOP/s)"
     if fam in (10, 11):
         return mfma_peak / exec_frac, "Winograd on bf16x3 = 2500 / (6 * 16/36) (F(2x2,3x3) executes 16/36 of the products, each as six bf16 MFMA products)"
@@ -429,7 +432,7 @@ def main():
     data = [batch() for _ in range(min(args.steps, 4))]  # synthetic batches resident in HBM before the timed region
     prof_steps = 0
     if not args.no_prof:
-        for fam in range(12):
+        for fam in range(13):
             ops.prof_read(fam)
     sync()
     t0 = time.perf_counter()

@@ -53,7 +53,7 @@ int fp32_mfma_mode();
 // 4 Winograd transforms (HBM bytes), 5 direct conv fwd/dgrad on the register-staged kernel (Cin < 32; flops),
 // 6 / 7 f16 conv / wgrad, 8 / 9 bf16x3 conv fwd/dgrad / wgrad (algorithmic flops; the bf16 pipe executes 6x),
 // 10 / 11 bf16x3 Winograd GEMM fwd/dgrad / Winograd wgrad plane GEMMs (algorithmic flops; execute 6 * 16/36 of them)
-#define GIF_PROF_FAMILIES 12
+#define GIF_PROF_FAMILIES 13
 struct ProfScope {
     int family;
     hipStream_t stream;

@@ -1011,7 +1011,11 @@ static int conv2d_wgrad_f32_impl(const float* small, const float* big, float* ws
         const bool tab = (small_scale || big_scale) && (variant != 1 || x3) && tab_fits;
         static const int x3_simple = getenv("GIF_X3_WGRAD_SIMPLE") ? atoi(getenv("GIF_X3_WGRAD_SIMPLE")) : 0;  // A/B: 16-pixel stages, no pipeline
         if (x3_thin) {
-            wgrad_launch<float, 128, 32, 4, 1, true, 32, false, true>(grid, 256, s, p);
+            // two waves of 64x32: 3 fragment splits per 12 MFMAs (four waves of 32x32: 2 per 6 — GIF_X3_WGRAD_THIN=4 for the A/B:
+            // 128x24 at 256^2 76 -> 80 TFLOP/s, 256x24 at 128^2 70 -> 78, 512x24 at 64^2 80 -> 82)
+            static const int thin4 = getenv("GIF_X3_WGRAD_THIN") ? atoi(getenv("GIF_X3_WGRAD_THIN")) == 4 : 0;
+            if (thin4) wgrad_launch<float, 128, 32, 4, 1, true, 32, false, true>(grid, 256, s, p);
+            else wgrad_launch<float, 128, 32, 2, 1, true, 32, false, true>(grid, 128, s, p);
         } else if (x3 && tab && HWs % 32 == 0 && !x3_simple) {
             wgrad_launch<float, 128, 128, 2, 2, true, 32, true, true>(grid, 256, s, p);
         } else if (x3 && tab) {

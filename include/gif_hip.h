@@ -376,6 +376,7 @@ int gif_resize_bwd_f32(const float* gy, float* gx, int64_t planes, int Hi, int W
  *     (2, 3: ALGORITHMIC direct-convolution FLOPs; the kernels execute 16/36 of them)
  *   4 Winograd input / gradient transforms (HBM bytes: tensor read once + transformed planes written once)
  *   5 direct conv on the register-staged kernel (Cin < 32), 6 f16 conv fwd / dgrad, 7 f16 weight gradient
+ *   8 .. 11 the bf16x3 counterparts of 0, 1, 2, 3; 12 bf16x3 direct conv in the tap-dense K order (3x3, 8..28 contraction channels)
  * ---------------------------------------------------------------------------------------------- */
 int gif_prof_enable(int on);
 int gif_prof_read(int family, double* ms, double* flops, int64_t* launches);

@@ -15,7 +15,7 @@ v=$(python -c "import json;d=json.load(open('$O/stats_bench.json'));print(f\"{d[
 s=$(python -c "import json;print(round(json.load(open('$O/bench_shapes.json'))['value'],1))")
 { echo "# Per-launch-shape timings of the profiled MFMA kernel families inside the bench region (round ${R#r}, commit $C, bf16x3 default)"; echo
   echo "\`GIF_PROF_DUMP=file python bench.py --steps 8 --warmup 2 --no-cpu-baseline\` (HIP events around every launch of the 8 timed steps; $s images/s)."
-  echo "family 8 = direct conv fwd/dgrad on the bf16x3 LDS-DMA kernel (tag = taps*10+stride, negative = transposed/dgrad), 5 = native register-staged kernel (Cin < 24), 9 / 1 = direct wgrad bf16x3 / native (tag +100 = modulated), 10 = wino_gemm_x3 (tag 2091), 11 = Winograd wgrad plane GEMMs on bf16x3, 4 = Winograd transforms (last column TB/s), 0 = native LDS-DMA kernel (none in this mode)."
+  echo "family 8 = direct conv fwd/dgrad on the bf16x3 LDS-DMA kernel (tag = taps*10+stride, negative = transposed/dgrad), 12 = the same kernels in the tap-dense K order (3x3 layers with 8..28 contraction channels), 5 = native register-staged kernel (1x1 / ToRGB-gradient layers with < 24 channels), 9 / 1 = direct wgrad bf16x3 / native (tag +100 = modulated), 10 = wino_gemm_x3 (tag 2091), 11 = Winograd wgrad plane GEMMs on bf16x3, 4 = Winograd transforms (last column TB/s), 0 = native LDS-DMA kernel (none in this mode)."
   echo "All rates are ALGORITHMIC fp32 TFLOP/s (direct-convolution count); the bf16 pipe executes 6x (families 8, 9) or 6*16/36 = 2.67x (10, 11) of it.  Rows below 0.4 ms/step are folded into the totals."; echo
   python tools/shape_table.py $O/shapes.csv 8; } > profiles/${R}_conv_shapes.md
 if [ -s $O/kernel_stats_f16.md ]; then
