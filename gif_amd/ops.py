@@ -201,12 +201,17 @@ def x3_conv(dtype, cin_act: int) -> bool:
     return dtype == torch.float32 and cin_act >= X3_MIN_CIN and get_fp32_mfma_mode() == "bf16x3"
 
 
-def x3_tapdense(dtype, cin_act: int, spec, transposed: bool, epi) -> bool:
+def x3_tapdense(dtype, cin_act: int, spec, transposed: bool, epi, cout_act: int = 64) -> bool:
     """3x3 fp32 conv with 8 <= cin_act < 32 contraction channels runs the bf16x3 kernel in its tap-dense K order (include/gif_hip.h:
     the condition-noise convs and the 24 -> C layers; no per-tap padding of K).  Not for strided data gradients (tap subsets per
-    output phase) and not for modulated launches."""
-    return (X3_TAPDENSE and dtype == torch.float32 and get_fp32_mfma_mode() == "bf16x3" and 8 <= cin_act < 32 and cin_act % 4 == 0
-            and (spec.KH, spec.KW) == (3, 3) and not (transposed and spec.stride != 1) and epi.get("in_scale") is None)
+    output phase) and not for modulated launches.  Measured per shape at 256^2, batch 32 (profiles/r3_conv_shapes.md vs the run
+    before the mode existed): 24 -> 128 3.62 vs 4.08 ms per step, 12 -> 24 0.88 vs 1.15 (native kernel); but 8 -> 12 0.76 vs 0.66
+    (native) and 24 -> 12 0.79 vs 0.67 (padded bf16x3): with <= 32 output channels the launch is bound by its gathers, which the
+    dense order scatters over two pixels per 128-byte row — those two keep their old kernels."""
+    if not (X3_TAPDENSE and dtype == torch.float32 and get_fp32_mfma_mode() == "bf16x3" and 8 <= cin_act < 32 and cin_act % 4 == 0
+            and (spec.KH, spec.KW) == (3, 3) and not (transposed and spec.stride != 1) and epi.get("in_scale") is None):
+        return False
+    return cin_act >= 12 and (cout_act > 32 or cin_act < X3_MIN_CIN)
 
 
 def pack_weight(w: torch.Tensor, rows_are_out: bool, cout_act: int, cin_act: int, scale: float = 1.0, dtype=torch.float32, x3=False,
@@ -337,7 +342,7 @@ def conv_fwd(big, w, spec: ConvSpec, wscale=1.0, keep_v=False, **epi):
     if keep_v:
         return conv_fwd(big, w, spec, wscale, **epi), None
     x3 = x3_conv(dt, Cb)
-    dense = x3_tapdense(dt, Cb, spec, False, epi)
+    dense = x3_tapdense(dt, Cb, spec, False, epi, Cs)
     wp = pack_weight(w, True, Cs, Cb, wscale, dt, x3=x3, tapdense=dense)
     # out_f32 (f16 activations only): fp32 result, e.g. the RGB image of ToRGB
     out = empty_nhwc(B, Cs, Hs, Ws, big.device, torch.float32 if epi.get("out_f32") else dt)
@@ -360,7 +365,7 @@ def conv_bwd_data(small, w, spec: ConvSpec, big_hw, wscale=1.0, **epi):
     if (Hb, Wb) == (Hs, Ws) and winograd_eligible(spec, B, Hs, Ws, Cs, Cb, dtype=dt):
         return conv3x3_winograd(small, w, False, Cb, wscale, **epi)
     x3 = x3_conv(dt, Cs)
-    dense = x3_tapdense(dt, Cs, spec, True, epi)
+    dense = x3_tapdense(dt, Cs, spec, True, epi, Cb)
     wp = pack_weight(w, False, Cb, Cs, wscale, dt, x3=x3, tapdense=dense)
     out = empty_nhwc(B, Cb, Hb, Wb, small.device, dt)
     g = _geom(B, Hb, Wb, Cb, Hs, Ws, Cs, spec)

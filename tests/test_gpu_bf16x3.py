@@ -107,7 +107,12 @@ def test_bf16x3_tapdense_forward_and_data_gradient_vs_fp64(case, monkeypatch):
     ops.WINOGRAD = False
     pad = 1 if st == 1 else 0
     spec = ops.ConvSpec(3, 3, st, pad)
-    assert ops.x3_tapdense(torch.float32, ci, spec, False, {}) and not ops.x3_tapdense(torch.float32, ci, spec, False, {"in_scale": 1})
+    assert not ops.x3_tapdense(torch.float32, ci, spec, False, {"in_scale": 1})
+    assert ops.x3_tapdense(torch.float32, 24, spec, False, {}, 128) and not ops.x3_tapdense(torch.float32, 8, spec, False, {}, 12)
+    # the dispatch keeps 8-channel inputs and <= 32-output-channel layers with 24 inputs on their old kernels (measured slower in the
+    # dense order); this test forces the mode for every case so that the kernel paths stay covered
+    monkeypatch.setattr(ops, "x3_tapdense", lambda dt, cin, sp, tr, epi, cout=64: (
+        ops.X3_TAPDENSE and 8 <= cin < 32 and not (tr and sp.stride != 1) and epi.get("in_scale") is None and ops.get_fp32_mfma_mode() == "bf16x3"))
     x = torch.randn(B, ci, h, h, device=dev).contiguous(memory_format=torch.channels_last)
     w = torch.randn(co, ci, 3, 3, device=dev) / (ci * 9) ** 0.5
     bias = torch.randn(ops.pad4(co), device=dev)
@@ -139,7 +144,7 @@ def test_bf16x3_tapdense_forward_and_data_gradient_vs_fp64(case, monkeypatch):
     op = h - ((hs - 1) * st + 3 - 2 * pad)
     ref_d = F.conv_transpose2d(gy.double(), w2.double(), stride=st, padding=pad, output_padding=op)
     dense_d = ops.x3_tapdense(torch.float32, ci, spec, True, {})
-    assert dense_d == (st == 1)
+    assert bool(dense_d) == (st == 1)
     xm = torch.randn(B, ops.pad4(co), h, h, device=dev).contiguous(memory_format=torch.channels_last)
     ed = {}
     for mode in ("native", "bf16x3"):
