@@ -68,6 +68,19 @@ def test_fp32_mfma_mode_api_without_gpu():
     assert lib.gif_conv2d_pack_dims_x3(128, 24, ctypes.byref(rp), ctypes.byref(cp)) == 0 and (rp.value, cp.value) == (128, 32)
     assert lib.gif_winograd_pack_dims_x3(192, 100, ctypes.byref(rp), ctypes.byref(cp)) == 0 and (rp.value, cp.value) == (256, 128)
     assert lib.gif_conv2d_x3_eligible(64, 24) == 1 and lib.gif_conv2d_x3_eligible(64, 20) == 0
+    # tap-dense K order: 32-float steps for 9 taps of cin_act channels, 0 where the mode does not apply
+    steps = lib.gif_conv2d_x3_tapdense_steps
+    assert [steps(c, 3, 3) for c in (8, 12, 24, 28)] == [3, 4, 7, 8]
+    assert steps(32, 3, 3) == 0 and steps(4, 3, 3) == 0 and steps(24, 1, 1) == 0 and steps(10, 3, 3) == 0
+    # (the dispatch itself is narrower: measured per shape, ops.x3_tapdense)
+    spec = ops.ConvSpec(3, 3, 1, 1)
+    ops._fp32_mode_cache = None
+    if ops.get_fp32_mfma_mode() == "bf16x3":
+        import torch
+        assert ops.x3_tapdense(torch.float32, 24, spec, False, {}, 128) and ops.x3_tapdense(torch.float32, 12, spec, True, {}, 24)
+        assert not ops.x3_tapdense(torch.float32, 24, spec, True, {}, 12) and not ops.x3_tapdense(torch.float32, 8, spec, False, {}, 12)
+        assert not ops.x3_tapdense(torch.float32, 24, ops.ConvSpec(3, 3, 2, 0), True, {}, 128)
+        assert not ops.x3_tapdense(torch.float32, 24, spec, False, {"in_scale": object()}, 128)
 
 
 def test_no_cpu_fallback():
