@@ -2,6 +2,7 @@
 """bench.py — G+D train-step images/sec at 256x256, batch 32/GPU (BASELINE.json metric), one process per GPU.
 
     python bench.py --gpus 1 --steps 16 --warmup 2
+    python bench.py --gpus N --steps K --warmup W        (N > 1 without a launcher: re-executes itself under torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -360,16 +361,53 @@ class MeshConditions:
         return self.render.render_condition(v_ndc, self.f, self.tex, self.res, self.res)
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launcher_command(n, argv, port):
+    """The command line `python bench.py --gpus N ...` re-executes itself as when no launcher set WORLD_SIZE: N ranks of ONE node
+    under torch.distributed.run (the form the task contract names), rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (train.py:344-358 wraps the networks in DataParallel inside
+    ONE process; here every GPU gets its own process): spawn the N ranks and relay rank 0's JSON line.  Fails before spawning
+    anything when the node has fewer than N GPUs."""
+    import subprocess
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n:
+        sys.exit(f"bench.py: --gpus {n} but only {have} GPU(s) are visible on this node (one rank per GPU; "
+                 f"HIP_VISIBLE_DEVICES={os.environ.get('HIP_VISIBLE_DEVICES')})")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = launcher_command(n, argv, free_port())
+    print("bench.py: self-launch: " + " ".join(cmd), file=sys.stderr, flush=True)
+    rc = subprocess.run(cmd, env=env).returncode
+    if rc:
+        sys.exit(rc)
+
+
 def main():
     args = parse()
     if args.cpu_baseline_worker:
         r, st, b, th = (int(v) for v in args.cpu_baseline_worker.split(","))
         return cpu_baseline_worker(r, st, b, th)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return self_launch(args.gpus, sys.argv[1:])  # `python bench.py --gpus N`: one rank per GPU under torch.distributed.run
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU path)"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs MI355X GPUs (no CPU path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("GIF_FORCE_DIST") == "1"  # (forced: RCCL code paths on a 1-GPU box, tests)
@@ -455,8 +493,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt, comm_ms = t[0].item(), t[1].item()
 
-    replicas = None
-    if args.check_replicas:
+    replicas = {"ranks": world, "backend": dist.get_backend() if use_dist else None}
+    if args.check_replicas or world > 1:  # (always with > 1 rank: the digests are what shows that the exchange kept the replicas equal)
         import hashlib
         h = hashlib.sha1()
         for m in (G, D, G_ema):
@@ -467,8 +505,7 @@ def main():
         if use_dist:
             allr = [None] * world
             dist.all_gather_object(allr, mine)
-        replicas = {"param_digest": allr[0], "replicas_identical": len(set(allr)) == 1, "ranks": len(allr),
-                    "backend": dist.get_backend() if use_dist else None}
+        replicas.update({"param_digest": allr[0], "replicas_identical": len(set(allr)) == 1, "ranks": len(allr)})
 
     if rank == 0:
         imgs = world * B * args.steps
@@ -526,8 +563,7 @@ def main():
                 out["roofline_rasterize"] = rasterize_roofline(B, dev)
             except Exception as e:  # never lose the headline line to the side measurement
                 out["roofline_rasterize"] = {"error": f"{type(e).__name__}: {e}"}
-        if replicas is not None:
-            out["replicas"] = replicas
+        out["replicas"] = replicas
         if f16:
             out["loss_scaler"] = {"g_scale": trainer.g_scaler.scale.item(), "d_scale": trainer.d_scaler.scale.item(),
                                   "skipped_g_steps": trainer.g_scaler.skipped.item(), "skipped_d_steps": trainer.d_scaler.skipped.item()}

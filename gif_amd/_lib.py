@@ -34,6 +34,7 @@ PROTOTYPES = {
     "gif_abi_version": (c_int, []),
     "gif_f16_overflow_clear": (c_int, [P]),
     "gif_f16_overflow_or_into": (c_int, [P, P]),
+    "gif_f16_overflow_watch": (c_int, [c_int]),
     "gif_set_fp32_mfma_mode": (c_int, [c_int]),
     "gif_get_fp32_mfma_mode": (c_int, []),
     "gif_rasterize_workspace_bytes": (c_i64, [c_int, c_int, c_int, c_int]),

@@ -148,7 +148,15 @@ int gif_f16_overflow_or_into(float* found_inf, gif_stream_t stream) {
     gif::f16_flag_or_into<<<1, 1, 0, gif::as_stream(stream)>>>(f, found_inf);
     return gif::check_launch("f16_overflow_or_into");
 }
-int gif_abi_version(void) { return 2; }  // 2: gif_conv_epilogue gradient-producer fusions, rasteriser workspace (B, F, H, W)
+
+int gif_f16_overflow_watch(int on) {
+    gif::g_f16_watch.store(on ? 1 : 0, std::memory_order_relaxed);
+    return 0;
+}
+
+// 2: gif_conv_epilogue gradient-producer fusions, rasteriser workspace (B, F, H, W)
+// 3: gif_f16_overflow_watch; split-K conv entry points; batched partial-sum reduction; rasteriser per-call clean-workspace flag
+int gif_abi_version(void) { return 3; }
 
 int gif_set_fp32_mfma_mode(int mode) {
     if (mode != GIF_FP32_MFMA_NATIVE && mode != GIF_FP32_MFMA_BF16X3) {

@@ -161,3 +161,4 @@ class FlatAdam(torch.optim.Adam):
                 v.zero_()
             self.state[p] = {"step": self._step_t, "exp_avg": m, "exp_avg_sq": v}
         self._step_t.fill_(step)
+        self._step_dev = None  # a device-side count from before the load is stale: the next loss-scaled step re-seeds it from _step_t

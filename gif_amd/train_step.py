@@ -10,6 +10,7 @@ Semantics that change with DataParallel -> per-rank replicas: param
 from rank 0 ONCE, at construction (DataParallel re-broadcasts them on every forward); minibatch-stddev groups are
 formed inside the per-rank batch.
 """
+import contextlib
 import os
 
 import torch
@@ -87,7 +88,13 @@ class FlatGradBucket:
             self.offsets.append(n)
             n += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
         dev = self.params[0].device
+        # one extra slot behind the last gradient rides along in the exchange: the loss scaler parks "an f16 gradient store
+        # saturated on THIS rank" there as +inf, so the (summed / averaged) bucket is non-finite on EVERY rank and all of them
+        # skip the step together — no second collective (DeviceLossScaler.end_backward).  The optimiser never touches it.
+        self.flag_offset = n
+        n += self.ALIGN
         self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.flag_slot = self.flat[self.flag_offset:self.flag_offset + 1]
         self.views = [self.flat[off:off + p.numel()].view_as(p) for p, off in zip(self.params, self.offsets)]
         self._pending = None
         self._known_zero = True  # the whole buffer is zero (fresh / after zero()): attach() need not clear gradient-less views
@@ -170,32 +177,82 @@ class DeviceLossScaler:
     """Dynamic loss scaling for the f16-activation path, entirely on the device (no host sync per step): the loss is
     multiplied by `scale` before backward(); after the gradient exchange update() looks for non-finite values in the flat
     bucket, and FlatAdam.step(inv_grad_scale=, found_inf=) un-scales the gradients inside the Adam kernel or skips the update.
-    An overflow halves the scale; `growth_interval` consecutive clean steps double it (torch.cuda.amp.GradScaler's policy)."""
+    An overflow halves the scale; `growth_interval` consecutive clean steps double it (torch.cuda.amp.GradScaler's policy).
+
+    Saturated f16 gradient stores (they clamp at +-65504 and would never show up as inf in the fp32 weight gradients) raise a
+    per-device flag word while a watch window is open.  Protocol of one optimiser step of one network (round 4, advisor
+    findings): begin_step() clears the flag; every GRADIENT pass of the step — the regularisers' inner autograd.grad calls
+    and the final backward() — runs inside `with scaler.watching():`; end_backward(bucket) snapshots the flag into this
+    scaler's own device scalar right after backward() (so launches of the OTHER network issued before a deferred update
+    cannot leak into it) and writes it as +inf into the bucket's flag slot, which rides along in the gradient exchange: every
+    rank then sees a non-finite bucket and all replicas skip the step and halve their scale together."""
 
     def __init__(self, device, init_scale=2.0 ** 12, growth_interval=1000, max_scale=2.0 ** 20):
         self.scale = torch.tensor(float(init_scale), device=device)
         self.inv_scale = torch.tensor(1.0 / float(init_scale), device=device)
         self.found_inf = torch.zeros((), device=device)
+        self.sat = torch.zeros((), device=device)  # this rank's "a gradient store saturated" snapshot of the current step
         self._good = torch.zeros((), device=device)
         self.growth_interval, self.max_scale = float(growth_interval), float(max_scale)
         self.skipped = torch.zeros((), device=device)  # number of skipped steps (read it after a synchronize)
 
+    def _hip(self):
+        return self.scale.is_cuda
+
+    def begin_step(self):
+        """Once per optimiser step, before its first gradient pass: clear the device's flag word (the window stays closed)."""
+        self.sat.zero_()
+        if self._hip():
+            from . import _lib
+            with torch.cuda.device(self.scale.device):
+                lib, st = _lib.load(), torch.cuda.current_stream().cuda_stream
+                _lib.check(lib.gif_f16_overflow_clear(st), "f16_overflow_clear")
+                _lib.check(lib.gif_f16_overflow_watch(0), "f16_overflow_watch")
+
+    @contextlib.contextmanager
+    def watching(self):
+        """f16 launches issued inside the block check their stores (forward passes outside it pay nothing)."""
+        if self._hip():
+            from . import _lib
+            _lib.check(_lib.load().gif_f16_overflow_watch(1), "f16_overflow_watch")
+        try:
+            yield
+        finally:
+            if self._hip():
+                from . import _lib
+                _lib.check(_lib.load().gif_f16_overflow_watch(0), "f16_overflow_watch")
+
     def begin_backward(self):
-        """Call right before backward(): clears the device's "an f16 gradient store saturated" flag (gif_f16_overflow_clear).
-        f16 stores clamp at +-65504, so an overflowing ACTIVATION gradient never shows up as inf in the fp32 weight gradients;
-        the kernels raise the flag instead and update() treats it like a non-finite gradient."""
-        from . import _lib
-        with torch.cuda.device(self.scale.device):
-            _lib.check(_lib.load().gif_f16_overflow_clear(torch.cuda.current_stream().cuda_stream), "f16_overflow_clear")
+        """Short form for a step whose only gradient pass is backward(): begin_step() + open the window; end_backward() or
+        update() closes it."""
+        self.begin_step()
+        if self._hip():
+            from . import _lib
+            _lib.check(_lib.load().gif_f16_overflow_watch(1), "f16_overflow_watch")
+
+    def _snapshot(self):
+        """sat |= the device's flag word (closes the window)."""
+        if self._hip():
+            from . import _lib
+            with torch.cuda.device(self.scale.device):
+                _lib.check(_lib.load().gif_f16_overflow_or_into(self.sat.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                           "f16_overflow_or_into")
+
+    @torch.no_grad()
+    def end_backward(self, bucket=None):
+        """Right after backward(), BEFORE the gradient exchange is enqueued: snapshot the flag; with a bucket, park it in the
+        bucket's flag slot as +inf (0 otherwise) so that the exchange spreads it to every rank."""
+        self._snapshot()
+        if bucket is not None:
+            bucket.flag_slot.copy_(torch.where(self.sat > 0, float("inf"), 0.0).reshape(1))
 
     @torch.no_grad()
     def update(self, flat):
-        """Call once per optimiser step BEFORE the Adam launch, with the (already exchanged) gradient bucket."""
-        from . import _lib
-        self.found_inf.copy_((~torch.isfinite(flat).all()).to(torch.float32))
-        with torch.cuda.device(self.scale.device):  # |= a saturated f16 gradient store since begin_backward()
-            _lib.check(_lib.load().gif_f16_overflow_or_into(self.found_inf.data_ptr(), torch.cuda.current_stream().cuda_stream),
-                       "f16_overflow_or_into")
+        """Call once per optimiser step BEFORE the Adam launch, with the (already exchanged) gradient bucket.  found_inf is a
+        function of the exchanged bucket alone (incl. its flag slot), i.e. identical on every rank; a caller that never called
+        end_backward() (single-process use without a bucket) still gets the local flag OR-ed in here."""
+        self._snapshot()
+        self.found_inf.copy_(torch.maximum((~torch.isfinite(flat).all()).to(torch.float32), (self.sat > 0).to(torch.float32)))
         bad = self.found_inf.clone()
         self.inv_scale.copy_(1.0 / self.scale)  # the scale the gradients in `flat` were produced with
         self.skipped.add_(bad)
@@ -339,6 +396,10 @@ class GifTrainer:
         requires_grad(D, True)
         self.d_bucket.zero()
         r1_step = bool(self.r1_every) and (i + 1) % self.r1_every == 0
+        sc = self.d_scaler
+        watch = sc.watching if sc is not None else contextlib.nullcontext
+        if sc is not None:
+            sc.begin_step()
         # the reference marks the real image as requiring grad on every iteration (train.py:135-136) but only uses the
         # gradient on R1 iterations; requesting it only then skips a dead dgrad of D's first layer otherwise
         real_image = real_image.detach().requires_grad_(r1_step)
@@ -347,8 +408,9 @@ class GifTrainer:
         if r1_step:
             # f16: the inner gradient (d scores / d image) is taken on scores pre-multiplied by a constant so that the
             # activation gradients of the first backward stay inside the f16 range; the result is divided back
-            real_loss = real_loss + losses.grad_penalty_loss([real_image], real_scores, step=None,
-                                                             grad_scale=(2.0 ** 10 if self.f16 else 1.0)).mean()
+            with watch():  # the inner gradient's f16 stores are gradient stores too (a clamped one falsifies the penalty)
+                real_loss = real_loss + losses.grad_penalty_loss([real_image], real_scores, step=None,
+                                                                 grad_scale=(2.0 ** 10 if self.f16 else 1.0)).mean()
         if fake is None:
             self._finish_g_update()  # G's exchange of the previous iteration ran under the D forward above
             with torch.no_grad():  # the reference detaches the fake image right after the forward (train.py:160)
@@ -356,9 +418,10 @@ class GifTrainer:
         fake_scores, _ = D([fake.detach()], condition=cond, step=self.res_step, alpha=self.alpha)
         fake_loss = F.softplus(fake_scores).mean()
         d_loss = real_loss + fake_loss
-        if self.d_scaler is not None:
-            self.d_scaler.begin_backward()
-        (d_loss if self.d_scaler is None else d_loss * self.d_scaler.scale).backward()
+        with watch():
+            (d_loss if sc is None else d_loss * sc.scale).backward()
+        if sc is not None:
+            sc.end_backward(self.d_bucket)  # before the exchange: this rank's saturation flag travels in the bucket
         if self.overlap_comm:
             self.d_bucket.all_reduce_mean(async_op=True)
             self._d_update_pending = True  # completed right before D is used again
@@ -375,6 +438,10 @@ class GifTrainer:
         requires_grad(D, False)
         self.g_bucket.zero()
         direct_reg = self.gen_reg_type == 'DIRECT_GRAD_REG'
+        sc = self.g_scaler
+        watch = sc.watching if sc is not None else contextlib.nullcontext
+        if sc is not None:
+            sc.begin_step()
         if direct_reg:
             cond = cond.detach().requires_grad_(True)
             fake = None  # the regulariser differentiates the images w.r.t. THIS condition tensor
@@ -384,18 +451,21 @@ class GifTrainer:
         pred, _ = D(fake, condition=cond.detach(), step=self.res_step, alpha=self.alpha)
         loss = F.softplus(-pred).mean()
         if self.pl_reg is not None:
-            loss = loss + 2 * self.pl_reg.path_length_reg(G, step=self.res_step, alpha=self.alpha,
-                                                          input_indices=input_indices, cond=cond)
+            with watch():  # (covers the regulariser's own generator forward as well: its stores are checked, harmlessly)
+                loss = loss + 2 * self.pl_reg.path_length_reg(G, step=self.res_step, alpha=self.alpha,
+                                                              input_indices=input_indices, cond=cond)
         elif direct_reg:
             # train.py:209-215: changes of the condition should change the image as little as possible.  The reference
             # adds the per-sample [B] penalty to the scalar loss and calls .backward() on the result, which only works
             # for batch 1; here the penalty is averaged over the batch (identical for batch 1).
-            loss = loss + 1e-8 * 8 * losses.grad_penalty_loss([cond], torch.pow(fake[-1], 2), step=None).mean()
+            with watch():
+                loss = loss + 1e-8 * 8 * losses.grad_penalty_loss([cond], torch.pow(fake[-1], 2), step=None).mean()
         if self.embedding_reg_weight:
             loss = loss + self.embedding_reg_weight * losses.l2_reg(G.z_to_w)
-        if self.g_scaler is not None:
-            self.g_scaler.begin_backward()
-        (loss if self.g_scaler is None else loss * self.g_scaler.scale).backward()
+        with watch():
+            (loss if sc is None else loss * sc.scale).backward()
+        if sc is not None:
+            sc.end_backward(self.g_bucket)
         self._g_update()
         requires_grad(G, False)
         return loss.detach()

@@ -38,6 +38,11 @@ int gif_abi_version(void);
  * stores (process-wide window): forward passes pay nothing. */
 int gif_f16_overflow_clear(gif_stream_t stream);
 int gif_f16_overflow_or_into(float* found_inf, gif_stream_t stream);
+/* ABI 3: open (1) / close (0) the window without touching the flag word, so that a host can keep SEVERAL gradient passes of one
+ * optimiser step inside it (the inner autograd.grad of R1 / the path-length regulariser, then backward()) and leave the forward
+ * passes in between outside: clear once per step, watch(1) .. watch(0) around every gradient pass, or_into right after the
+ * last one (loss_functions/losses.py:87-124 are the reference's regularisers). */
+int gif_f16_overflow_watch(int on);
 
 /* How the fp32 convolution contractions reach the matrix cores (process-wide; fp32 tensors in, fp32 tensors out either way):
  *   NATIVE : v_mfma_f32_32x32x2_f32 on the fp32 operands (157 TFLOP/s peak).

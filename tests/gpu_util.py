@@ -35,7 +35,7 @@ def assert_close(got, ref, tol, what=""):
     assert e <= tol, f"{what}: rel err {e:.3e} > {tol:.1e} (ref max {ref.abs().max().item():.3e})"
 
 
-def assert_grads_close(got, ref, names, tight, loose=5e-2, max_outlier_frac=0.25, l2_tol=None, what="grads"):
+def assert_grads_close(got, ref, names, tight, loose=5e-2, max_outlier_frac=0.10, l2_tol=None, what="grads"):
     """Whole-model gradients against the oracle's autograd.
 
     fp32 rounding leaves a handful of near-zero pre-activations on the other side of a (leaky) ReLU than in the oracle's own
@@ -43,7 +43,10 @@ def assert_grads_close(got, ref, names, tight, loose=5e-2, max_outlier_frac=0.25
     layer, |pre-activation| = 8e-7).  The backward mask of that element differs, which moves the gradients of the tensors fed
     by that layer by up to a few percent of their max — it says nothing about kernels or wiring, and every per-op test
     compares exactly-linear maps at 2e-5.  So: EVERY tensor within `loose`; all but `max_outlier_frac` of the tensors within
-    `tight`; and the relative L2 error over all parameters together within `l2_tol` (default 10 * tight).  A wrong operand,
+    `tight` (at most max(2, 10 %) of them: the 256x256 whole-model test shows 3 of D's 38 and 6 of G's 223 tensors between
+    3e-4 and 7e-4 — round 3 allowed 25 % and up to `loose` = 5e-2, under which a regression from a few marginal outliers to a
+    fifth of the model would have passed; that test now also passes loose=2e-3, three times its observed worst tensor); and
+    the relative L2 error over all parameters together within `l2_tol` (default 10 * tight).  A wrong operand,
     scale or missing term shows up as O(1) errors in whole groups of tensors and fails all three."""
     import torch
     errs, num, den = [], 0.0, 0.0
@@ -60,7 +63,8 @@ def assert_grads_close(got, ref, names, tight, loose=5e-2, max_outlier_frac=0.25
     worst = ", ".join(f"{k} {e:.2e}" for e, k in errs[:3])
     assert errs[0][0] <= loose, f"{what}: worst tensors {worst}"
     n_out = sum(1 for e, _ in errs if e > tight)
-    assert n_out <= max_outlier_frac * len(errs), f"{what}: {n_out} of {len(errs)} tensors above {tight:.0e}: {worst}"
+    limit = 0 if max_outlier_frac == 0 else max(2, max_outlier_frac * len(errs))
+    assert n_out <= limit, f"{what}: {n_out} of {len(errs)} tensors above {tight:.0e}: {worst}"
     l2 = (num / max(den, 1e-300)) ** 0.5
     l2_tol = 10 * tight if l2_tol is None else l2_tol
     assert l2 <= l2_tol, f"{what}: relative L2 error over all parameters {l2:.2e} > {l2_tol:.0e}"

@@ -27,7 +27,7 @@ def test_header_symbols_exported_and_bound():
         assert hasattr(lib, n), f"{n} declared in gif_hip.h but not exported by libgif_hip.so"
         assert n in _lib.PROTOTYPES, f"{n} has no ctypes prototype"
     assert sorted(_lib.PROTOTYPES) == names
-    assert lib.gif_abi_version() == 2
+    assert lib.gif_abi_version() == 3
 
 
 def test_argument_validation_without_gpu():

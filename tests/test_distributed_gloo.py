@@ -207,3 +207,91 @@ def test_attach_does_not_expose_stale_gradients_after_set_to_none():
     assert torch.equal(first.grad, torch.full_like(first, 2.0))
     for p in others:
         assert p.grad is not None and p.grad.abs().max().item() == 0.0, "stale gradient exposed"
+
+
+# ------------------------------------------------------------------------------------------------ bench.py launcher (round 4)
+def test_bench_self_launch_command_and_device_count_error():
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (the driver's command form) re-executes itself under
+    torch.distributed.run with one rank per GPU, and fails with a clear message — before spawning anything — when the node has
+    fewer than N GPUs (this container has none).  train.py:344-358 is the DataParallel wrapping this replaces."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    cmd = bench.launcher_command(8, ["--gpus", "8", "--steps", "20", "--warmup", "5"], 12345)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "12345"
+    i = cmd.index(os.path.join(root, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"], "the rank processes get the caller's arguments verbatim"
+    p0, p1 = bench.free_port(), bench.free_port()
+    assert 1024 < p0 < 65536 and 1024 < p1 < 65536
+    if torch.cuda.device_count() >= 2:
+        return  # (on a multi-GPU box the GPU tier runs the real thing: tests/test_gpu_round3.py)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert out.returncode != 0
+    assert "--gpus 2 but only" in out.stderr and "GPU(s) are visible" in out.stderr, out.stderr[-2000:]
+    assert "Traceback" not in out.stderr
+    # under a launcher whose rank count disagrees with --gpus: a message, not an assertion traceback
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300,
+                         env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), cwd=root)
+    assert out.returncode != 0 and "must agree" in out.stderr and "Traceback" not in out.stderr
+
+
+# ------------------------------------------------------------------------------------------------ loss scaler across ranks (round 4)
+def _worker_scaler(rank, world, port, q):
+    """A saturated f16 gradient store is a RANK-LOCAL event (advisor finding, round 3): it must reach every replica, or only
+    the rank that saw it skips its Adam step and halves its scale and the replicas diverge for good.  The flag travels as +inf
+    in the bucket's flag slot, inside the one gradient exchange."""
+    from gif_amd.train_step import DeviceLossScaler
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = _model()
+    bucket = FlatGradBucket(m.parameters())
+    sc = DeviceLossScaler(torch.device("cpu"), init_scale=1024.0)
+    g = torch.Generator().manual_seed(3)
+    x_all = torch.randn(4, 8, 8, generator=g)
+    log = []
+    for step in range(4):
+        x = x_all[step, rank * 4:(rank + 1) * 4]
+        bucket.zero()
+        sc.begin_step()
+        with sc.watching():
+            (torch.nn.functional.softplus(-m(x)).mean() * sc.scale).backward()
+        if step == 1 and rank == 1:
+            sc.sat.fill_(1.0)  # what gif_f16_overflow_or_into leaves behind when a store saturated on THIS rank only
+        sc.end_backward(bucket)
+        bucket.all_reduce_mean(async_op=(step % 2 == 1))
+        bucket.wait()
+        sc.update(bucket.flat)
+        with torch.no_grad():  # the Adam kernel's contract: nothing changes when found_inf is set, else un-scaled gradients
+            if sc.found_inf.item() == 0:
+                for p in m.parameters():
+                    if p.grad is not None:
+                        p.add_(p.grad * sc.inv_scale, alpha=-0.1)
+        grads_finite = all(torch.isfinite(p.grad).all().item() for p in m.parameters() if p.grad is not None)
+        log.append((sc.found_inf.item(), sc.scale.item(), sc.skipped.item(), grads_finite))
+    q.put((rank, log, torch.cat([p.detach().reshape(-1) for p in m.parameters()]).tolist()))
+    dist.destroy_process_group()
+
+
+def test_loss_scaler_saturation_flag_reaches_every_rank():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_scaler, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, log0, w0), (_, log1, w1) = res
+    assert log0 == log1, "found_inf / scale / skipped identical on both ranks at every step"
+    assert [e[0] for e in log0] == [0.0, 1.0, 0.0, 0.0], "only the step whose flag was raised on ONE rank is skipped — by both"
+    assert [e[1] for e in log0] == [1024.0, 512.0, 512.0, 512.0] and log0[-1][2] == 1.0
+    assert all(e[3] for e in log0), "the flag slot never leaks into a parameter's gradient view"
+    assert w0 == w1, "replicas stay bit-identical"

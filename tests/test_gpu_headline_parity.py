@@ -196,7 +196,7 @@ def test_full_backward_256_batch4_vs_oracle():
     g_grads_d = dict(zip(g_keys, torch.autograd.grad(g_loss_d, [g_named[k] for k in g_keys], allow_unused=True)))
     # every parameter gradient of both networks; tolerance policy: gpu_util.assert_grads_close (activation sign flips)
     for keys, got, ref, what in ((d_keys, d_grads_d, d_grads_r, "D"), (g_keys, g_grads_d, g_grads_r, "G")):
-        worst, n_out, l2 = assert_grads_close([got[k] for k in keys], [ref[k] for k in keys], keys, tight=3e-4,
+        worst, n_out, l2 = assert_grads_close([got[k] for k in keys], [ref[k] for k in keys], keys, tight=3e-4, loose=2e-3,
                                               what=f"{what} parameter gradients at 256x256, batch 4")
         print(f"{what}: worst tensor {worst:.2e}, {n_out} of {len(keys)} tensors above 3e-4, relative L2 over all parameters {l2:.2e}")
 
@@ -258,6 +258,40 @@ def test_config3_at_stated_size_vs_oracle():
     # gpu_util.assert_grads_close) move it by a fraction of a percent — measured 6e-3 on penalties of 5e-5; the batch-4 test
     # above holds the same quantity to 3e-4 on the direct kernels.
     assert_close(r1[sel.cuda()], r1_o, 2e-2, "R1 penalties of the group")
+    # The sign-flip explanation, demonstrated at THIS size (review item, round 3): the same batch with the Winograd kernels off
+    # (direct kernels only, the path of the batch-4 test) holds the penalties to the batch-4 bound, and the leaky-ReLU outputs of
+    # the two HIP forwards differ in sign at a counted handful of positions — the masks the penalty's gradient passes through.
+    from gif_amd import ops
+
+    def d_forward_recording_signs():
+        signs, hooks = [], []
+        for m in D.modules():
+            if type(m).__name__ == "ConvLayer":
+                hooks.append(m.register_forward_hook(lambda _m, _i, out: signs.append(torch.signbit(out.detach()))))
+        x = real.clone().requires_grad_(True)
+        sc = D([x], condition=cond)[0]
+        pen = losses.grad_penalty_loss([x], sc, step=None).detach()
+        for h in hooks:
+            h.remove()
+        return pen, signs
+
+    r1_w, signs_w = d_forward_recording_signs()
+    assert torch.equal(r1_w, r1), "the recorded pass repeats the one above (deterministic kernels)"
+    wino_was = ops.WINOGRAD
+    ops.WINOGRAD = False
+    try:
+        r1_d, signs_d = d_forward_recording_signs()
+    finally:
+        ops.WINOGRAD = wino_was
+    flips = sum(int((a != b).sum().item()) for a, b in zip(signs_w, signs_d))
+    total = sum(a.numel() for a in signs_w)
+    err_w, err_d = rel_err(r1[sel.cuda()], r1_o), rel_err(r1_d[sel.cuda()], r1_o)
+    print(f"R1 at batch 32 vs oracle: Winograd path {err_w:.2e}, direct kernels {err_d:.2e}; "
+          f"{flips} of {total} leaky-ReLU outputs of D differ in sign between the two HIP forwards")
+    assert_close(r1_d[sel.cuda()], r1_o, 3e-4, "R1 penalties of the group, Winograd kernels off")
+    assert len(signs_w) == len(signs_d) and total > 0
+    assert flips <= 1e-5 * total, f"{flips} sign flips of {total}: more than rounding of near-zero pre-activations explains"
+    assert err_w <= 3e-4 or flips > 0, "a Winograd-path deviation above the direct bound must come with flipped activations"
     d_expected = (F.softplus(-rs).mean() + r1.mean() + F.softplus(fs).mean()).item()
     # the training iteration itself (R1 iteration: i + 1 divisible by 16)
     tr = GifTrainer(G, D, G_ema, step=6, r1_every=16)

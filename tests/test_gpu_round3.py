@@ -323,9 +323,11 @@ def _run_bench(nproc, extra, port):
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(nproc), "--steps", "3", "--warmup", "1", "--res", "64",
+    # the driver's command form: no launcher around it, bench.py spawns its own ranks (bench.self_launch); `port` is unused
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(nproc), "--steps", "3", "--warmup", "1", "--res", "64",
            "--batch", "8", "--vocab", "64", "--r1-every", "2", "--no-cpu-baseline", "--no-prof", "--check-replicas"] + extra
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert out.returncode == 0, out.stderr[-3000:]
     return json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
@@ -333,7 +335,7 @@ def _run_bench(nproc, extra, port):
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs of one node (RCCL over xGMI); the round's boxes have one")
 def test_bench_two_ranks_on_rccl_replicas_identical_and_overlap_equals_in_place():
-    """bench.py under torch.distributed.run with two ranks on RCCL: the replicas stay bit-identical, RCCL reports two ranks, and
+    """`python bench.py --gpus 2` (self-launching two ranks on RCCL): the replicas stay bit-identical, RCCL reports two ranks, and
     the deferred (overlapped) exchange + optimiser schedule gives exactly the weights of the in-place schedule."""
     a = _run_bench(2, [], 29631)
     assert a["n_gpus"] == 2 and a["replicas"]["ranks"] == 2 and a["replicas"]["backend"] == "nccl"
