@@ -38,7 +38,7 @@ PROTOTYPES = {
     "gif_set_fp32_mfma_mode": (c_int, [c_int]),
     "gif_get_fp32_mfma_mode": (c_int, []),
     "gif_rasterize_workspace_bytes": (c_i64, [c_int, c_int, c_int, c_int]),
-    "gif_rasterize_assume_clean_workspace": (c_int, [c_int]),
+    "gif_rasterize_assume_clean_workspace": (c_int, [P, c_int]),
     "gif_rasterize_f32": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P]),
     "gif_rasterize_colors_f32": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P, P]),
     "gif_rasterize_f64": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P]),

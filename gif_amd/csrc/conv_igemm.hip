@@ -71,6 +71,7 @@ struct GatherParams {
     float* part_cs;
     float* part_dot;
     int part_row0;
+    int part_cap;              // partial-sum rows the workspace holds per buffer (stores beyond it are dropped, the host reports them)
     int no_split;              // keep the launch in ONE tile size (per-sample partial sums need uniform rows)
     unsigned* sat_flag;        // f16: "a store saturated" flag word of the device (common.h store4_flag), else NULL
     int out_f32;               // f16 kernels: the output tensor is fp32
@@ -199,9 +200,12 @@ __device__ __forceinline__ void conv_epilogue(const GatherParams& p, f32x16 (&ac
                 a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w;
                 b.x += b2.x; b.y += b2.y; b.z += b2.z; b.w += b2.w;
             }
-            const size_t prow = (size_t)(p.part_row0 + (m0 - p.m_begin) / BM) * p.Co + n;
-            if (p.part_cs) *reinterpret_cast<float4*>(p.part_cs + prow) = a;
-            if (p.part_dot) *reinterpret_cast<float4*>(p.part_dot + prow) = b;
+            const int prow_i = p.part_row0 + (m0 - p.m_begin) / BM;
+            const size_t prow = (size_t)prow_i * p.Co + n;
+            if (prow_i < p.part_cap) {  // never past the workspace: FusedSums::finish reports the overflow (tiles have >= 64 rows, so it cannot happen today)
+                if (p.part_cs) *reinterpret_cast<float4*>(p.part_cs + prow) = a;
+                if (p.part_dot) *reinterpret_cast<float4*>(p.part_dot + prow) = b;
+            }
         }
     }
 }
@@ -1153,6 +1157,7 @@ struct FusedSums {
         tmp = e->red_ws + 2 * cap * Co;
         p.part_cs = colsum ? part_cs : nullptr;
         p.part_dot = dot ? part_dot : nullptr;
+        p.part_cap = (int)cap;
         p.no_split = dot ? 1 : 0;
         (void)B;
         return 0;

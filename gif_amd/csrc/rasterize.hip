@@ -11,6 +11,8 @@
 // Arithmetic follows the reference operation by operation with FP contraction off, so results are
 // bit-identical to oracle/rasterize_ref.c.
 #include <atomic>
+#include <mutex>
+#include <unordered_set>
 
 #include "common.h"
 
@@ -366,8 +368,20 @@ raster_tiles(const T* __restrict__ fv, const T* __restrict__ fc, uint32_t* __res
 
 inline long pad2(long n) { return (n + 1) / 2 * 2; }  // keeps the list 8-byte aligned behind the counters
 
-// 1: the caller guarantees zeroed tile counters on entry (raster_tiles leaves them zero): no memset node per call
-std::atomic<int> g_clean_workspace{0};
+// Workspaces whose tile counters the caller guarantees to be zero on entry (raster_tiles hands them back zero): no memset node
+// per call for THESE pointers only (ABI 3: a property of the workspace, not of the process — another caller of the C API that
+// passes an unzeroed workspace, as the default contract allows, is not affected).  A failed call drops the registration.
+std::mutex g_clean_mu;
+std::unordered_set<const void*> g_clean_ws;
+
+bool workspace_is_clean(const void* ws) {
+    std::lock_guard<std::mutex> lk(g_clean_mu);
+    return g_clean_ws.count(ws) != 0;
+}
+void workspace_forget(const void* ws) {
+    std::lock_guard<std::mutex> lk(g_clean_mu);
+    g_clean_ws.erase(ws);
+}
 
 template <typename T>
 int run(const T* fv, const T* fc, T* depth, int32_t* tri, T* out3, int B, int F, int H, int W, void* workspace,
@@ -382,7 +396,7 @@ int run(const T* fv, const T* fc, T* depth, int32_t* tri, T* out3, int B, int F,
     hipStream_t s = gif::as_stream(stream);
     uint32_t* count = reinterpret_cast<uint32_t*>(workspace);
     uint32_t* list = count + pad2(B * nt);
-    if (!g_clean_workspace.load(std::memory_order_relaxed)) {
+    if (!workspace_is_clean(workspace)) {
         hipError_t me = hipMemsetAsync(count, 0, (size_t)B * nt * sizeof(uint32_t), s);
         if (me != hipSuccess) { gif::set_error("%s memset: %s", who, hipGetErrorString(me)); return (int)me; }
     }
@@ -390,15 +404,20 @@ int run(const T* fv, const T* fc, T* depth, int32_t* tri, T* out3, int B, int F,
     const dim3 grid((unsigned)(B * nt));
     if (fc) raster_tiles<T, true, kTileThreads><<<grid, kTileThreads, 0, s>>>(fv, fc, count, list, depth, tri, out3, F, H, W, tiles_x, tiles_y);
     else raster_tiles<T, false, kTileThreads><<<grid, kTileThreads, 0, s>>>(fv, nullptr, count, list, depth, tri, out3, F, H, W, tiles_x, tiles_y);
-    return gif::check_launch(who);
+    const int rc = gif::check_launch(who);
+    if (rc != 0) workspace_forget(workspace);  // the counters may be dirty: the next call through this pointer memsets again
+    return rc;
 }
 
 }  // namespace
 
 extern "C" {
 
-int gif_rasterize_assume_clean_workspace(int on) {
-    g_clean_workspace.store(on ? 1 : 0, std::memory_order_relaxed);
+int gif_rasterize_assume_clean_workspace(const void* workspace, int on) {
+    GIF_REQUIRE(workspace, "rasterize_assume_clean_workspace: null workspace");
+    std::lock_guard<std::mutex> lk(g_clean_mu);
+    if (on) g_clean_ws.insert(workspace);
+    else g_clean_ws.erase(workspace);
     return 0;
 }
 

@@ -591,22 +591,27 @@ def sqnorm_per_sample(g):
 
 
 # One zero-initialised rasteriser workspace per (device, stream, problem size), kept across calls: the tile kernel hands the
-# counters back zeroed, so the per-call memset node is switched off (gif_rasterize_assume_clean_workspace).  A failed call drops
-# its entry (the counters may be dirty).
+# counters back zeroed, so the per-call memset node is switched off for exactly these pointers
+# (gif_rasterize_assume_clean_workspace(ws, 1)).  A failed call drops its entry (the counters may be dirty).
 _raster_ws = {}
 _RASTER_WS_MAX = 8
 
 
+def _raster_ws_drop(lib, key):
+    ws = _raster_ws.pop(key, None)
+    if ws is not None:
+        lib.gif_rasterize_assume_clean_workspace(ws.data_ptr(), 0)  # before the memory can be handed to somebody else
+
+
 def _raster_workspace(lib, dev, B, F, h, w):
-    if not _raster_ws:
-        lib.gif_rasterize_assume_clean_workspace(1)
     key = (dev.index, torch.cuda.current_stream().cuda_stream, B, F, h, w)
     ws = _raster_ws.get(key)
     if ws is None:
         if len(_raster_ws) >= _RASTER_WS_MAX:
-            _raster_ws.pop(next(iter(_raster_ws)))
+            _raster_ws_drop(lib, next(iter(_raster_ws)))
         ws = torch.zeros((max(lib.gif_rasterize_workspace_bytes(B, F, h, w) // 8, 1),), device=dev, dtype=torch.int64)
         _raster_ws[key] = ws
+        _lib.check(lib.gif_rasterize_assume_clean_workspace(ws.data_ptr(), 1), "rasterize_assume_clean_workspace")
     return key, ws
 
 
@@ -625,7 +630,7 @@ def rasterize(face_vertices, depth, tri, out3, h, w, face_colors=None):
         rc = colors(face_vertices.data_ptr(), face_colors.data_ptr(), depth.data_ptr(), tri.data_ptr(), out3.data_ptr(), B, F,
                     h, w, ws.data_ptr(), _stream())
     if rc != 0:
-        _raster_ws.pop(key, None)
+        _raster_ws_drop(lib, key)  # (the library already forgot the pointer: its counters may be dirty)
     _lib.check(rc, "rasterize")
 
 

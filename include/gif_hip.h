@@ -93,9 +93,11 @@ int gif_pack_weight_f32x3_tapdense(const float* w, void* wp3, int R, int C, int 
  * ---------------------------------------------------------------------------------------------- */
 int64_t gif_rasterize_workspace_bytes(int B, int F, int H, int W);
 /* The tile counters at the head of the workspace (4 bytes per image and tile) are zeroed by a memset node at the start of every
- * call and handed back zero by the tile kernel.  A host that keeps ONE zero-initialised workspace per (stream, problem size)
- * and never shares it between concurrent calls may switch the memset off (process-wide): on != 0. */
-int gif_rasterize_assume_clean_workspace(int on);
+ * call and handed back zero by the tile kernel.  A host that keeps a zero-initialised workspace per (stream, problem size)
+ * and never shares it between concurrent calls may switch the memset off FOR THAT WORKSPACE POINTER (ABI 3; ABI 2 had a
+ * process-wide switch): on != 0 registers it, 0 forgets it (do that before the memory is freed); a call that fails forgets
+ * it as well.  Calls through any other pointer keep the memset. */
+int gif_rasterize_assume_clean_workspace(const void* workspace, int on);
 int gif_rasterize_f32(const float* face_vertices, float* depth, int32_t* tri, float* bary, int B, int F,
                       int H, int W, void* workspace, gif_stream_t stream);
 int gif_rasterize_colors_f32(const float* face_vertices, const float* face_colors, float* depth,
