@@ -77,6 +77,7 @@ struct GatherParams {
     int out_f32;               // f16 kernels: the output tensor is fp32
     int pair;                  // f16 kernels, Ci <= 32 (CP == 32): one 64-half K chunk = the channels of TWO taps (see glds_body)
     int dense;                 // bf16x3 kernels, 8 <= Ci < 32, 3x3: 16-byte chunks per tap (Ci / 4) of the tap-dense K order, else 0
+    int t2_tx, t2_ty;          // halo kernel: 16 x 16-pixel patches per row / column of the output sub-grid
 };
 
 // partial-sum rows handed out to the launches of one op (bulk + remainder launches, transposed-conv phases), and the tile height
@@ -96,14 +97,18 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // Epilogue shared by both kernels.  The accumulator tile is transposed through LDS (the staging buffers are free by
 // then) so that global I/O is row-wise float4: residual / out_scale / bias loads and the output store are 16 B per lane
 // and fully coalesced along the channel axis.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5).
-template <int BM, int BN, int LD, int MT, int NT, typename T = float, int THREADS = 256>
+// T2D (the halo kernel): the BM = 256 tile rows are a 16 x 16 patch of output pixels of ONE sample (row = 16 * ly + lx, patch
+// origin (t2_oy0, t2_ox0) of sample t2_b in the launch's output sub-grid) instead of BM consecutive GEMM rows; m0 = tile index * BM
+// only numbers the partial-sum rows.  LDS_FLOATS: floats of LDS the transposition may use (default: the staging buffers).
+template <int BM, int BN, int LD, int MT, int NT, typename T = float, int THREADS = 256, bool T2D = false, int LDS_FLOATS = 0>
 __device__ __forceinline__ void conv_epilogue(const GatherParams& p, f32x16 (&acc)[MT][NT], float* smem, int m0, int n0,
-                                              int wm0, int wn0, int tid, int li, int lh, int HWp) {
+                                              int wm0, int wn0, int tid, int li, int lh, int HWp, int t2_b = 0, int t2_oy0 = 0,
+                                              int t2_ox0 = 0) {
     const T* const res = static_cast<const T*>(p.residual);
     T* const yout = static_cast<T*>(p.y);
     constexpr int LDC = BN + 4;
     // the tile goes through LDS in EPI_CHUNKS row chunks so that it fits into the staging buffers' footprint
-    constexpr int STAGE_FLOATS = 2 * (BM + BN) * LD;
+    constexpr int STAGE_FLOATS = LDS_FLOATS ? LDS_FLOATS : 2 * (BM + BN) * LD;
     constexpr int EPI_CHUNKS = (BM * LDC <= STAGE_FLOATS) ? 1 : (BM / 2 * LDC <= STAGE_FLOATS) ? 2
                                : (BM / 4 * LDC <= STAGE_FLOATS) ? 4 : 8;
     constexpr int CR = BM / EPI_CHUNKS;  // rows per chunk
@@ -145,11 +150,18 @@ __device__ __forceinline__ void conv_epilogue(const GatherParams& p, f32x16 (&ac
 #pragma unroll 4
                 for (int it = 0; it < E_IT; ++it) {
                     const int row = e_row0 + it * EROWS;
-                    const int m = m0 + c * CR + row;
-                    if (m >= p.M) break;
-                    int b = m / HWp;
-                    int rr = m - b * HWp;
-                    int oy = rr / p.Wp, ox = rr - oy * p.Wp;
+                    int b, oy, ox;
+                    if constexpr (T2D) {
+                        const int r2 = c * CR + row;
+                        b = t2_b; oy = t2_oy0 + (r2 >> 4); ox = t2_ox0 + (r2 & 15);
+                        if (oy >= p.Hp || ox >= p.Wp) continue;  // patch overhangs the sub-grid
+                    } else {
+                        const int m = m0 + c * CR + row;
+                        if (m >= p.M) break;
+                        b = m / HWp;
+                        const int rr = m - b * HWp;
+                        oy = rr / p.Wp; ox = rr - oy * p.Wp;
+                    }
                     size_t o = (((size_t)b * p.Ho + (oy * p.os + p.ooy)) * p.Wo + (ox * p.os + p.oox)) * p.Co + n;
                     float4 v = *reinterpret_cast<const float4*>(Cs + row * LDC + e_c);
                     float4 xs = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -194,7 +206,7 @@ __device__ __forceinline__ void conv_epilogue(const GatherParams& p, f32x16 (&ac
         __syncthreads();
         if (tid < C4_ROW && n < p.Co) {
             float4 a = red[tid], b = red[THREADS + tid];
-#pragma unroll
+#pragma unroll 4  // (a full unroll of EROWS = 32 hoists 62 float4 loads: 248 VGPRs)
             for (int k = 1; k < EROWS; ++k) {
                 const float4 a2 = red[k * C4_ROW + tid], b2 = red[THREADS + k * C4_ROW + tid];
                 a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w;
@@ -823,6 +835,152 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_gather_mfma_glds_
     glds_body<T, BM, BN, WAVES_M, WAVES_N, SCALE, BK, X3>(mp.ph[k], b - begin, mp.wg_end[k] - begin);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// f16 "halo" kernel for the thin high-resolution layers (<= 64 contraction channels, <= 64 output channels: the 512^2 / 1024^2
+// blocks of BASELINE configs[4], stg2_generator.py:159-209 at step = 7, 8; the condition-noise convs and ToRGB at every size).
+// The gather kernel above fetches every input pixel once PER TAP through the vector-memory path (9 x 64 B per output pixel at
+// 32 channels, one 1-KiB LDS-DMA piece per two MFMAs): those layers ran at 0.08 of the f16 peak, bound by DMA issue.  Here a
+// workgroup owns a 16 x 16 patch of output pixels of one sample: the input patch + halo ((16 + nky - 1) x (16 + nkx - 1) pixels,
+// all channels) is staged in LDS ONCE by LDS-DMA (out-of-image pixels and channel padding read the zero page), and the taps are
+// formed by SHIFTED LDS reads — a tap moves every lane's pixel index by the same wave-uniform offset.  A pixel is CPP = CP / 8
+// 16-byte chunks; chunk c of pixel q sits at physical chunk (c + q / (16 / CPP)) % CPP, so the 16 pixels of a ds_read_b128 lane
+// group hit 16 distinct 16-byte slots whatever the tap shift (rule 21; applied on the SOURCE address of the DMA, whose LDS
+// destination is lane-linear).  The weights never touch LDS: every lane loads its B fragments (one output channel, 8 consecutive
+// input channels) of the next tap straight from the L2-resident packed tensor while the current tap computes.  Modulation
+// (ModulatedConv2d's s[b,ci], stylegan2_common_layers.py:311-320) multiplies the WEIGHT fragments — a patch belongs to one
+// sample, so this is the reference's per-sample weight modulation, done per wavefront in registers — demodulation stays in the
+// fp32 epilogue.  4 waves x (64 pixels x BN channels); v_mfma_f32_32x32x16_f16, fp32 accumulators; shared conv_epilogue (T2D).
+// The launch is HBM-shaped: 32 -> 32 channels at 1024^2 moves 64 B in + 64 B out per pixel for 18 KFLOP.
+// ------------------------------------------------------------------------------------------------------------------
+template <int BN, int CP>
+constexpr int halo_lds_floats() { return CP == 32 ? 5376 : 10496; }  // (18 * 18 * CPP chunks rounded up to 64) * 4 floats
+
+template <int BN, int CP>
+__global__ void __launch_bounds__(256, 3) conv_halo_f16(const GatherParams p) {
+    typedef gif::f16 T;
+    constexpr int TH = 16, TW = 16, BM = TH * TW;
+    constexpr int CPP = CP / 8;                   // 16-byte chunks per pixel
+    constexpr int CPP_SHIFT = CPP == 4 ? 2 : 3;
+    constexpr int PPS_SHIFT = CPP == 4 ? 2 : 1;   // q >> PPS_SHIFT = q / (16 / CPP): the swizzle advances once per 256 bytes
+    constexpr int KG = CP / 16, MT = 2, NT = BN / 32;
+    static_assert((CP == 32 || CP == 64) && (BN == 32 || BN == 64), "halo kernel configurations");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    T* const Xs = reinterpret_cast<T*>(smem);
+    const T* const px = static_cast<const T*>(p.x);
+    const T* const pw = static_cast<const T*>(p.wp);
+    const T* const pzero = static_cast<const T*>(p.zero);
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int tile = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int tpi = p.t2_tx * p.t2_ty;
+    const int b = tile / tpi, tr = tile - b * tpi;
+    const int tyi = tr / p.t2_tx, txi = tr - tyi * p.t2_tx;
+    const int oy0 = tyi * TH, ox0 = txi * TW;
+    const int dy_min = p.ddy > 0 ? p.dy0 : p.dy0 + (p.nky - 1) * p.ddy;
+    const int dx_min = p.ddx > 0 ? p.dx0 : p.dx0 + (p.nkx - 1) * p.ddx;
+    const int HWh = TW + p.nkx - 1;
+    const int nchunks = (TH + p.nky - 1) * HWh * CPP;
+
+    // ---- stage the input patch + halo (one pass, LDS-DMA)
+    {
+        const T* const xb = px + (size_t)b * p.Hi * p.Wi * p.Ci;
+        const int gy0 = oy0 + dy_min, gx0 = ox0 + dx_min;
+        for (int e0 = wave * 64; e0 < nchunks; e0 += 256) {  // wave-uniform
+            const int e = e0 + lane;
+            const int q = e >> CPP_SHIFT, cphys = e & (CPP - 1);
+            const int c = (cphys - (q >> PPS_SHIFT)) & (CPP - 1);
+            const int hy = q / HWh, hx = q - hy * HWh;
+            const int gy = gy0 + hy, gx = gx0 + hx;
+            const bool ok = e < nchunks && (unsigned)gy < (unsigned)p.Hi && (unsigned)gx < (unsigned)p.Wi && c * 8 < p.Ci;
+            const T* g = ok ? xb + ((size_t)gy * p.Wi + gx) * p.Ci + c * 8 : pzero;
+            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Xs + e0 * 8), 16, 0, 0);
+        }
+    }
+    // ---- per-sample modulation of the contraction channels, as f16 multipliers of the weight fragments
+    const bool has_scale = p.in_scale != nullptr;
+    gif::f16x8_t sreg[KG];
+    if (has_scale) {
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) {
+            const int ci = kg * 16 + lh * 8;
+            float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+            if (ci < p.Ci) {
+                s0 = *reinterpret_cast<const float4*>(p.in_scale + (size_t)b * p.Ci + ci);
+                s1 = *reinterpret_cast<const float4*>(p.in_scale + (size_t)b * p.Ci + ci + 4);
+            }
+            sreg[kg][0] = (T)s0.x; sreg[kg][1] = (T)s0.y; sreg[kg][2] = (T)s0.z; sreg[kg][3] = (T)s0.w;
+            sreg[kg][4] = (T)s1.x; sreg[kg][5] = (T)s1.y; sreg[kg][6] = (T)s1.z; sreg[kg][7] = (T)s1.w;
+        }
+    }
+    // B fragments of tap t: lane (li, lh) = output channel j * 32 + li, input channels 16 kg + 8 lh .. + 7
+    auto load_b = [&](int t, gif::f16x8_t (&bw)[KG][NT]) __attribute__((always_inline)) {
+        const int a = t / p.nkx, bb = t - a * p.nkx;
+        const int widx = (p.ky0 + a * p.kstep) * p.KW + p.kx0 + bb * p.kstep;
+        const T* wt = pw + ((size_t)widx * p.RP + li) * CP + lh * 8;
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                bw[kg][j] = *reinterpret_cast<const gif::f16x8_t*>(wt + (size_t)j * 32 * CP + kg * 16);
+            }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    int q0[MT];  // halo-patch pixel index of this lane's output pixel at tap offset (dy_min, dx_min)
+#pragma unroll
+    for (int i = 0; i < MT; ++i) q0[i] = (4 * wave + 2 * i + (li >> 4)) * HWh + (li & 15);
+
+    auto compute = [&](int t, gif::f16x8_t (&bw)[KG][NT]) __attribute__((always_inline)) {
+        const int a = t / p.nkx, bb = t - a * p.nkx;
+        const int off = (p.dy0 + a * p.ddy - dy_min) * HWh + (p.dx0 + bb * p.ddx - dx_min);  // wave-uniform tap shift
+        if (has_scale) {  // here, not behind the loads: the fragments were requested one tap ago
+#pragma unroll
+            for (int kg = 0; kg < KG; ++kg)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bw[kg][j] *= sreg[kg];
+        }
+        gif::f16x8_t av[KG][MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int q = q0[i] + off;
+            const int sw = q >> PPS_SHIFT;
+#pragma unroll
+            for (int kg = 0; kg < KG; ++kg)
+                av[kg][i] = *reinterpret_cast<const gif::f16x8_t*>(Xs + (((q << CPP_SHIFT) + ((kg * 2 + lh + sw) & (CPP - 1))) << 3));
+        }
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[kg][i], bw[kg][j], acc[i][j], 0, 0, 0);
+    };
+
+    gif::f16x8_t bw0[KG][NT], bw1[KG][NT];
+    load_b(0, bw0);
+    __syncthreads();  // the workgroup release waits for every wave's outstanding LDS-DMA
+    for (int t = 0; t < p.ntaps; t += 2) {
+        if (t + 1 < p.ntaps) load_b(t + 1, bw1);
+        compute(t, bw0);
+        if (t + 2 < p.ntaps) load_b(t + 2, bw0);
+        if (t + 1 < p.ntaps) compute(t + 1, bw1);
+    }
+    conv_epilogue<BM, BN, 8, MT, NT, T, 256, true, halo_lds_floats<BN, CP>()>(p, acc, smem, tile * BM, 0, wave * 64, 0, tid, li, lh, 0,
+                                                                             b, oy0, ox0);
+}
+
+
 struct TileCfg {
     int BM, BN, BK;
 };
@@ -971,6 +1129,44 @@ int launch_multi(GatherParams* ph, int nph, bool scale, hipStream_t s) {
     return scale ? launch_glds_multi<T, true>(ph, nph, s) : launch_glds_multi<T, false>(ph, nph, s);
 }
 
+// f16 halo kernel: launch configuration (tiles_n == 1: RP <= 64 is one N tile)
+template <int BN, int CP>
+int launch_halo_impl(GatherParams& p, hipStream_t s) {
+    static gif::LdsAttr attr;
+    p.t2_tx = gif::cdiv(p.Wp, 16);
+    p.t2_ty = gif::cdiv(p.Hp, 16);
+    p.tiles_m = p.B * p.t2_tx * p.t2_ty;
+    p.tiles_n = 1;
+    const size_t lds = (size_t)halo_lds_floats<BN, CP>() * sizeof(float);
+    auto kern = conv_halo_f16<BN, CP>;
+    attr.ensure(reinterpret_cast<const void*>(kern), lds);
+    p.zero = gif::zero_page16();
+    if (!p.zero) return -101;
+    p.part_row0 = t_part_rows;
+    t_part_rows += p.tiles_m;
+    t_last_bm = 256;
+    hipLaunchKernelGGL(kern, dim3((unsigned)p.tiles_m), dim3(256), lds, s, p);
+    return 0;
+}
+
+// Which f16 launches take the halo kernel: unit-stride gathers (forward stride 1, every data gradient incl. the output-parity
+// phases of a transposed convolution) over a tap grid of <= 3 x 3 with <= 64 contraction and <= 64 output channels, on a
+// sub-grid that fills at least one patch.  The modulation-gradient dot fusion needs whole patches (one partial row per patch,
+// Hp * Wp / 256 of them per sample).  GIF_F16_HALO=0: A/B knob (the gather kernel).
+inline bool halo_eligible(const GatherParams& p) {
+    const char* env = getenv("GIF_F16_HALO");  // read per launch: tests flip it inside one process
+    if ((env && atoi(env) == 0) || p.is != 1 || p.RP > 64 || p.CP > 64 || p.m_begin != 0) return false;
+    if (p.nky < 1 || p.nky > 3 || p.nkx < 1 || p.nkx > 3 || (p.ddy != 1 && p.ddy != -1) || (p.ddx != 1 && p.ddx != -1)) return false;
+    if (p.Hp < 16 || p.Wp < 16 || (long)p.B * gif::cdiv(p.Hp, 16) * gif::cdiv(p.Wp, 16) >= (1L << 23)) return false;
+    if (p.part_dot && (p.Hp % 16 || p.Wp % 16)) return false;
+    return true;
+}
+
+int launch_halo(GatherParams& p, hipStream_t s) {
+    if (p.RP <= 32) return p.CP <= 32 ? launch_halo_impl<32, 32>(p, s) : launch_halo_impl<32, 64>(p, s);
+    return p.CP <= 32 ? launch_halo_impl<64, 32>(p, s) : launch_halo_impl<64, 64>(p, s);
+}
+
 // GIF_CONV_VARIANT=1 forces the register-staged kernel everywhere (A/B benchmarking only)
 int conv_variant() {
     static int v = -1;
@@ -1004,6 +1200,7 @@ int launch(GatherParams& p, hipStream_t s) {
         return GIF_ENOSUP;
     }
     if constexpr (F16) {
+        if (halo_eligible(p) && launch_halo(p, s) == 0) return 0;
         if (c.BN == 64) return fail_f16(launch_glds<T, 128, 64, 2, 2>(p, s));
         // f16 MFMAs are 8x shorter than fp32 ones while an LDS-DMA piece costs the same to issue: on 128x128 tiles a wave issues
         // one 1-KiB piece per two MFMAs and the loop is bound by DMA issue + LDS traffic, not by the matrix pipe.  Layers with
@@ -1370,6 +1567,15 @@ int gif_conv2d_fwd_f32x3_tapdense(const float* big, const void* wp3, float* smal
 int gif_conv2d_bwd_data_f32x3_tapdense(const float* small, const void* wp3, float* big, const gif_conv_geom* g,
                                        const gif_conv_epilogue* e, gif_stream_t stream) {
     return conv2d_bwd_data_impl<float>(small, wp3, big, g, e, stream, "conv2d_bwd_data_f32x3_tapdense", true, true);
+}
+
+// would a FORWARD f16 convolution of this shape (activation channel counts, output grid Hs x Ws) run the halo kernel?
+int gif_conv2d_f16_halo_eligible(int cin, int cout, int KH, int KW, int stride, int Hs, int Ws) {
+    if (cin <= 0 || cout <= 0 || KH < 1 || KW < 1 || stride < 1 || Hs <= 0 || Ws <= 0) return 0;
+    GatherParams p{};
+    pack_dims<gif::f16>(cout, cin, &p.RP, &p.CP);
+    p.is = stride; p.nky = KH; p.nkx = KW; p.ddy = 1; p.ddx = 1; p.Hp = Hs; p.Wp = Ws; p.B = 1;
+    return halo_eligible(p) ? 1 : 0;
 }
 
 int gif_conv2d_fwd_f16(const void* big, const void* wp, void* small, const gif_conv_geom* g, const gif_conv_epilogue* e,

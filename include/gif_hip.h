@@ -399,6 +399,14 @@ int gif_prof_read(int family, double* ms, double* flops, int64_t* launches);
 int gif_conv2d_pack_dims_f16(int cout, int cin, int* RP, int* CP);
 int gif_pack_weight_f16(const float* w, void* wp, int R, int C, int KH, int KW, int RP, int CP, int64_t sr, int64_t sc,
                         int64_t sky, int64_t skx, float scale, gif_stream_t stream);
+/* ABI 3.  Thin high-resolution f16 layers (<= 64 contraction and <= 64 output channels, unit-stride gathers: stride-1 forward
+ * convolutions, every data gradient incl. the output-parity phases of a transposed convolution — the 512^2 / 1024^2 blocks of
+ * BASELINE configs[4], model/stg2_generator.py:159-209 at step 7 / 8) run the "halo" kernel inside gif_conv2d_fwd_f16 /
+ * gif_conv2d_bwd_data_f16: a workgroup stages the input patch of a 16 x 16-pixel output patch plus its halo in LDS once and forms
+ * the taps by shifted LDS reads (the gather kernel fetches every input pixel once per tap); per-sample modulation multiplies
+ * the weight fragments in registers.  Same contracts, same epilogue.  GIF_F16_HALO=0 (read per launch) keeps the gather kernel.
+ * The query answers for a FORWARD convolution with these activation channel counts on an Hs x Ws output grid. */
+int gif_conv2d_f16_halo_eligible(int cin, int cout, int KH, int KW, int stride, int Hs, int Ws);
 int gif_conv2d_fwd_f16(const void* big, const void* wp, void* small, const gif_conv_geom* g, const gif_conv_epilogue* e,
                        gif_stream_t stream);
 int gif_conv2d_bwd_data_f16(const void* small, const void* wp, void* big, const gif_conv_geom* g,

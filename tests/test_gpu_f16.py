@@ -202,7 +202,7 @@ def _build(res, vocab=16):
     return g, d
 
 
-@pytest.mark.parametrize("res,step,batch", [(32, 3, 4), (256, 6, 2)])
+@pytest.mark.parametrize("res,step,batch", [(32, 3, 4), (256, 6, 2), (1024, 8, 1)])  # 1024: BASELINE configs[4]'s stated size
 def test_f16_generator_and_discriminator_vs_fp32_oracle(res, step, batch):
     """Stated tolerance of the f16 path against the fp32 CPU oracle on identical fp32 weights: generator image
     L_inf <= 6 * 2^-11 * max|image| (2^-11 = half-precision unit round-off); D scores within 3e-2 of their magnitude scale.

@@ -1,0 +1,256 @@
+"""-m gpu: round-4 kernels and fixes.
+
+* f16 halo convolution (conv_igemm.hip: conv_halo_f16) — the thin high-resolution layers of BASELINE configs[4]
+  (stg2_generator.py:159-209 at step 7 / 8, stylegan2_common_layers.py:343-347): against an fp32 ATen-CPU computation on the
+  same f16-rounded operands, against the gather kernel it replaces (GIF_F16_HALO=0), with every epilogue form.
+* split-K forward / data-gradient launches of the low-resolution 512-channel layers (bf16x3).
+* loss-scaler window semantics, FlatAdam checkpoint load after loss-scaled steps (advisor findings of round 3)."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_util import assert_close, rel_err
+
+pytestmark = pytest.mark.gpu
+
+H16 = torch.float16
+TOL = 2e-3
+
+
+def pad8(c):
+    return (c + 7) // 8 * 8
+
+
+def dev16(x):
+    c = x.shape[1]
+    if pad8(c) != c:
+        x = F.pad(x, (0, 0, 0, 0, 0, pad8(c) - c))
+    return x.detach().cuda().to(H16).contiguous(memory_format=torch.channels_last)
+
+
+def r16(x):
+    return x.to(H16).float()
+
+
+def host(y, c=None):
+    y = y.detach().float()
+    if c is not None:
+        y = y[:, :c]
+    return y.cpu().contiguous()
+
+
+class halo:
+    """GIF_F16_HALO is read per launch: 0 keeps the gather kernel (the round-3 path)."""
+
+    def __init__(self, on):
+        self.on = on
+
+    def __enter__(self):
+        self.old = os.environ.get("GIF_F16_HALO")
+        os.environ["GIF_F16_HALO"] = "1" if self.on else "0"
+
+    def __exit__(self, *a):
+        if self.old is None:
+            os.environ.pop("GIF_F16_HALO", None)
+        else:
+            os.environ["GIF_F16_HALO"] = self.old
+
+
+HALO_CASES = [
+    # (B, Cin, Cout, K, stride, pad, H): forward AND data gradient are taken, whichever of them is halo-eligible runs it
+    (2, 32, 32, 3, 1, 1, 64),    # the 1024^2 block's layers (BN 32, CP 32)
+    (2, 64, 64, 3, 1, 1, 48),    # the 512^2 block's layers (BN 64, CP 64), 3 x 3 patches
+    (3, 64, 32, 3, 1, 1, 40),    # BN 32 / CP 64 forward, BN 64 / CP 32 data gradient; patches overhang (40 = 2.5 x 16)
+    (2, 24, 32, 3, 1, 1, 32),    # condition-noise conv 3: 24 channels = 3 real chunks + 1 zero chunk per pixel
+    (2, 12, 24, 3, 1, 1, 32),    # condition-noise conv 2 (16 / 24 padded channels)
+    (2, 6, 12, 3, 1, 1, 32),     # condition-noise conv 1 (8 / 16 padded channels)
+    (2, 32, 3, 1, 1, 0, 32),     # ToRGB at 32 channels: single tap, no halo; its data gradient has 8 contraction channels
+    (2, 9, 32, 1, 1, 0, 48),     # D's first layer at 1024^2: 1x1, 16 padded input channels
+    (2, 64, 32, 3, 2, 0, 33),    # data gradient = transposed stride 2: four output-parity phases of 4 / 2 / 2 / 1 taps, 17 / 16-pixel sub-grids
+    (2, 32, 64, 3, 2, 0, 65),    # (its forward is strided: gather kernel) data gradient 64 -> 32 on 33 / 32-pixel sub-grids
+    (1, 48, 40, 3, 1, 1, 16),    # ragged channel counts, exactly one patch
+    (5, 32, 32, 3, 1, 1, 17),    # one pixel more than a patch in both directions
+]
+
+
+@pytest.mark.parametrize("case", HALO_CASES)
+def test_f16_halo_conv_fwd_and_data_gradient(case):
+    from gif_amd import ops
+    B, Ci, Co, K, s, p, H = case
+    g = torch.Generator().manual_seed(11)
+    x = r16(torch.randn(B, Ci, H, H, generator=g))
+    w = torch.randn(Co, Ci, K, K, generator=g) / (Ci * K * K) ** 0.5
+    wq = r16(w)
+    spec = ops.ConvSpec(K, K, s, p)
+    ref = F.conv2d(x, wq, stride=s, padding=p)
+    Hs = ref.shape[2]
+    gy = r16(torch.randn(B, Co, Hs, Hs, generator=g))
+    refd = F.conv_transpose2d(gy, wq, stride=s, padding=p, output_padding=H - ((Hs - 1) * s + K - 2 * p))
+    out = {}
+    for on in (True, False):
+        with halo(on):
+            out[on] = (ops.conv_fwd(dev16(x), w.cuda(), spec), ops.conv_bwd_data(dev16(gy), w.cuda(), spec, (H, H)))
+    assert_close(host(out[True][0], Co), ref, TOL, f"halo conv_fwd {case}")
+    assert_close(host(out[True][1], Ci), refd, TOL, f"halo conv_bwd_data {case}")
+    if pad8(Co) != Co:
+        assert (host(out[True][0])[:, Co:] == 0).all(), "padded output channels must be zero"
+    # un-modulated launches: both kernels form exactly the same f16 products and fp32 sums up to the summation order
+    assert_close(out[True][0], out[False][0].float(), 1e-3, f"halo vs gather kernel, forward {case}")
+    assert_close(out[True][1], out[False][1].float(), 1e-3, f"halo vs gather kernel, data gradient {case}")
+
+
+def test_f16_halo_conv_modulation_and_epilogues():
+    """in_scale (weight-side in the halo kernel: w * s rounded to half, where the gather kernel rounds x * s), out_scale, bias,
+    residual, activation, fp32 output — on a ModulatedConv2d-shaped 32 -> 32 layer, a 64 -> 64 one, and the transposed
+    (up-sampling) form 64 -> 32."""
+    from gif_amd import ops
+    g = torch.Generator().manual_seed(12)
+    for (Ci, Co, H) in ((32, 32, 48), (64, 64, 32), (40, 56, 32)):
+        B = 3
+        x, w = r16(torch.randn(B, Ci, H, H, generator=g)), torch.randn(Co, Ci, 3, 3, generator=g) / (9 * Ci) ** 0.5
+        s, d = torch.rand(B, Ci, generator=g) + 0.5, torch.rand(B, Co, generator=g) + 0.5
+        res, bias = r16(torch.randn(B, Co, H, H, generator=g)), torch.randn(Co, generator=g)
+        # reference in fp32 on the exact operands: the only extra rounding of the halo path is half(w * s) per (sample, tap)
+        ref = F.conv2d(x * s[:, :, None, None], r16(w), padding=1) * d[:, :, None, None]
+        spec = ops.ConvSpec(3, 3, 1, 1)
+        with halo(True):
+            got = ops.conv_fwd(dev16(x), w.cuda(), spec, in_scale=F.pad(s, (0, pad8(Ci) - Ci)).cuda(),
+                               out_scale=F.pad(d, (0, pad8(Co) - Co)).cuda())
+        assert_close(host(got, Co), ref, TOL, f"halo modulated conv {Ci}->{Co}")
+        ref2 = 2 ** 0.5 * F.leaky_relu(ref + res + bias[None, :, None, None], 0.2)
+        with halo(True):
+            got2 = ops.conv_fwd(dev16(x), w.cuda(), spec, in_scale=F.pad(s, (0, pad8(Ci) - Ci)).cuda(),
+                                out_scale=F.pad(d, (0, pad8(Co) - Co)).cuda(), bias=F.pad(bias, (0, pad8(Co) - Co)).cuda(),
+                                residual=dev16(res), act=True)
+            got3 = ops.conv_fwd(dev16(x), w.cuda(), spec, bias=F.pad(bias, (0, pad8(Co) - Co)).cuda(), out_f32=True)
+        assert_close(host(got2, Co), ref2, TOL, f"halo fused epilogue {Ci}->{Co}")
+        assert got3.dtype == torch.float32
+        assert_close(host(got3, Co), F.conv2d(x, r16(w), padding=1) + bias[None, :, None, None], 5e-4, "halo fp32 output")
+    # transposed stride 2 with scales: the generator's up-sampling conv of the 1024^2 block (64 -> 32)
+    B, Ci, Co, H = 2, 64, 32, 32
+    x = r16(torch.randn(B, Ci, H, H, generator=g))
+    wt = torch.randn(Ci, Co, 3, 3, generator=g) / 24
+    s, d = torch.rand(B, Ci, generator=g) + 0.5, torch.rand(B, Co, generator=g) + 0.5
+    ref = F.conv_transpose2d(x * s[:, :, None, None], r16(wt), stride=2) * d[:, :, None, None]
+    with halo(True):
+        got = ops.conv_bwd_data(dev16(x), wt.cuda(), ops.ConvSpec(3, 3, 2, 0), (2 * H + 1, 2 * H + 1), in_scale=s.cuda(), out_scale=d.cuda())
+    assert_close(host(got), ref, TOL, "halo modulated transposed conv")
+
+
+def test_f16_halo_conv_gradient_producer_fusions():
+    """The gradient-producer epilogue (leaky-ReLU-backward mask, bias-gradient column sums, modulation-gradient dot product:
+    gif_conv_epilogue ABI 2) rides on the halo kernel's 16 x 16-pixel patches: one partial-sum row per patch."""
+    from gif_amd import ops
+    g = torch.Generator().manual_seed(13)
+    B, C, H = 3, 32, 64
+    w = torch.randn(C, C, 3, 3, generator=g) / 17
+    gy = r16(torch.randn(B, C, H, H, generator=g))
+    xprev = r16(torch.randn(B, C, H, H, generator=g))  # the consumer's saved input: mask and dot source
+    sc = torch.rand(B, C, generator=g) + 0.5
+    spec = ops.ConvSpec(3, 3, 1, 1)
+    contraction = F.conv_transpose2d(gy, r16(w), padding=1)
+    ref_dot = (contraction * xprev).sum(dim=(2, 3))
+    mask = torch.where(xprev > 0, torch.tensor(1.0), torch.tensor(0.2)) * 2 ** 0.5
+    ref_v = contraction * sc[:, :, None, None] * mask
+    res = {}
+    for on in (True, False):
+        with halo(on):
+            fuse = ops.GradFuse(mask_src=dev16(xprev), mask_slope=0.2, mask_gain=2 ** 0.5, want_colsum=True, dot_src=dev16(xprev))
+            v = ops.conv_bwd_data(dev16(gy), w.cuda(), spec, (H, H), out_scale=sc.cuda(), fuse=fuse)
+            res[on] = (v, fuse.colsum, fuse.dot)
+    v, cs, dot = res[True]
+    assert_close(host(v), ref_v, TOL, "halo fused data gradient")
+    assert_close(cs, ref_v.sum(dim=(0, 2, 3)), 1e-3, "halo fused column sums (fp32, before the store rounds)")
+    assert_close(dot, ref_dot, 1e-3, "halo fused modulation-gradient dot product")
+    assert_close(v, res[False][0].float(), 1e-3, "halo vs gather kernel")
+    assert_close(cs, res[False][1], 1e-4, "column sums: halo vs gather kernel")
+    assert_close(dot, res[False][2], 1e-4, "dot products: halo vs gather kernel")
+    # determinism: fixed-order reductions, no atomics
+    with halo(True):
+        fuse = ops.GradFuse(mask_src=dev16(xprev), mask_slope=0.2, mask_gain=2 ** 0.5, want_colsum=True, dot_src=dev16(xprev))
+        v2 = ops.conv_bwd_data(dev16(gy), w.cuda(), spec, (H, H), out_scale=sc.cuda(), fuse=fuse)
+    assert torch.equal(v2, v) and torch.equal(fuse.colsum, cs) and torch.equal(fuse.dot, dot)
+
+
+def test_f16_halo_kernel_is_the_one_that_runs():
+    """The halo path must not silently fall back: the profiled launch family of an eligible shape reports halo launches."""
+    from gif_amd import _lib
+    lib = _lib.load()
+    assert lib.gif_conv2d_f16_halo_eligible(32, 32, 3, 3, 1, 64, 64) == 1
+    assert lib.gif_conv2d_f16_halo_eligible(128, 128, 3, 3, 1, 64, 64) == 0, "> 64 channels stay on the gather kernel"
+    assert lib.gif_conv2d_f16_halo_eligible(32, 64, 3, 3, 2, 64, 64) == 0, "a strided FORWARD conv is a strided gather"
+    assert lib.gif_conv2d_f16_halo_eligible(32, 32, 3, 3, 1, 8, 8) == 0, "sub-grids smaller than a patch"
+    with halo(False):
+        assert lib.gif_conv2d_f16_halo_eligible(32, 32, 3, 3, 1, 64, 64) == 0
+
+
+# ------------------------------------------------------------------------------------------------ advisor findings of round 3
+def test_flat_adam_load_state_dict_after_loss_scaled_steps_resets_the_device_step():
+    from gif_amd.optim import FlatAdam
+    from gif_amd.train_step import FlatGradBucket
+    torch.manual_seed(0)
+    net = torch.nn.Linear(8, 4).cuda()
+    bucket = FlatGradBucket(net.parameters())
+    opt = FlatAdam(net.parameters(), lr=0.01, betas=(0.5, 0.9), bucket=bucket)
+    inv, found = torch.tensor(1.0, device="cuda"), torch.zeros((), device="cuda")
+    x = torch.randn(4, 8, device="cuda")
+    fresh = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in opt.state_dict().items() if k != "state"}
+    snap = None
+    for it in range(5):
+        bucket.zero()
+        net(x).pow(2).mean().backward()
+        opt.step(inv_grad_scale=inv, found_inf=found)
+        if it == 1:
+            import copy
+            snap = copy.deepcopy(opt.state_dict())
+    assert opt._step_dev is not None and opt._step_dev.item() == 5.0
+    opt.load_state_dict(snap)
+    assert opt._step_dev is None, "the stale device-side count must not survive a checkpoint load"
+    bucket.zero()
+    net(x).pow(2).mean().backward()
+    opt.step(inv_grad_scale=inv, found_inf=found)
+    assert opt._step_dev.item() == 3.0, "continues from the LOADED step (2), not from the stale device counter (5)"
+    assert float(next(iter(opt.state_dict()["state"].values()))["step"]) == 3.0
+
+
+def test_loss_scaler_window_covers_inner_gradients_and_ignores_forward_stores():
+    """begin_step() clears; only launches inside `watching()` check their f16 stores; end_backward() snapshots into THIS scaler, so
+    a saturating launch issued afterwards (the other network's pass before a deferred update) cannot leak into it."""
+    from gif_amd import ops
+    from gif_amd.train_step import DeviceLossScaler, FlatGradBucket
+    B, C, H = 2, 64, 16
+    w = (torch.randn(C, C, 3, 3) / 24).cuda()
+    spec = ops.ConvSpec(3, 3, 1, 1)
+    huge = (torch.randn(B, C, H, H) * 3e4).cuda().half().contiguous(memory_format=torch.channels_last)
+    small = torch.randn(B, C, H, H).cuda().half().contiguous(memory_format=torch.channels_last)
+    net = torch.nn.Linear(4, 4).cuda()
+    bucket = FlatGradBucket(net.parameters())
+
+    def run(inner_saturates, after_saturates, outside_saturates):
+        sc = DeviceLossScaler(torch.device("cuda"), init_scale=1024.0)
+        bucket.zero()
+        sc.begin_step()
+        if outside_saturates:  # a forward pass between the gradient passes: not watched
+            ops.conv_bwd_data(huge, w, spec, (H, H))
+        with sc.watching():    # the regulariser's inner gradient
+            ops.conv_bwd_data(huge if inner_saturates else small, w, spec, (H, H))
+        with sc.watching():    # backward()
+            ops.conv_bwd_data(small, w, spec, (H, H))
+        sc.end_backward(bucket)
+        if after_saturates:    # the OTHER network's launches before this network's deferred update
+            other = DeviceLossScaler(torch.device("cuda"), init_scale=1024.0)
+            other.begin_step()
+            with other.watching():
+                ops.conv_bwd_data(huge, w, spec, (H, H))
+            other.end_backward(None)
+            assert other.sat.item() == 1.0
+        sc.update(bucket.flat)
+        return sc.found_inf.item(), sc.scale.item()
+
+    assert run(False, False, False) == (0.0, 1024.0)
+    assert run(True, False, False) == (1.0, 512.0), "a clamped store in the inner gradient pass skips the step"
+    assert run(False, True, False) == (0.0, 1024.0), "launches after end_backward() belong to somebody else"
+    assert run(False, False, True) == (0.0, 1024.0), "stores outside the watch window are not gradient stores"
+    assert not torch.isfinite(bucket.flat).all() or bucket.flag_slot.item() == 0.0

@@ -1,0 +1,71 @@
+"""GPU probe: the f16 halo kernel vs the gather kernel (GIF_F16_HALO=0) on the thin layers of BASELINE configs[4] (1024^2, batch 8).
+Prints ms per launch and algorithmic TFLOP/s / GB/s per shape.  python tools/probes/f16_halo_bench.py [--batch 8]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from gif_amd import ops  # noqa: E402
+
+
+def timed(fn, n=10):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=8)
+    a = ap.parse_args()
+    B = a.batch
+    CL = torch.channels_last
+    # (what, direction, Cin_act, Cout, K, stride, pad, H of the op's INPUT, modulated)
+    shapes = [("G conv 32->32 @1024 (modulated)", "fwd", 32, 32, 3, 1, 1, 1024, True),
+              ("D conv1 32->32 @1024", "fwd", 32, 32, 3, 1, 1, 1024, False),
+              ("dgrad 32->32 @1024", "bwd", 32, 32, 3, 1, 1, 1024, False),
+              ("noise 24->32 @1024", "fwd", 24, 32, 3, 1, 1, 1024, False),
+              ("noise 16->24 @1024", "fwd", 16, 24, 3, 1, 1, 1024, False),
+              ("noise 8->16 @1024", "fwd", 8, 16, 3, 1, 1, 1024, False),
+              ("ToRGB 32->3 @1024 (modulated)", "fwd", 32, 3, 1, 1, 0, 1024, True),
+              ("D from-RGB 16->32 1x1 @1024", "fwd", 16, 32, 1, 1, 0, 1024, False),
+              ("G up-conv 64->32 512->1025 (transposed, modulated)", "bwd", 64, 32, 3, 2, 0, 512, True),
+              ("D conv2 dgrad 64->32 512->1025 (transposed)", "bwd", 64, 32, 3, 2, 0, 512, False),
+              ("G conv 64->64 @512 (modulated)", "fwd", 64, 64, 3, 1, 1, 512, True),
+              ("dgrad 64->64 @512", "bwd", 64, 64, 3, 1, 1, 512, False),
+              ("G up-conv 128->64 256->513 (transposed, modulated)", "bwd", 128, 64, 3, 2, 0, 256, True)]
+    print(f"batch {B}; ms per launch: halo / gather kernel; algorithmic TFLOP/s and GB/s (in + out once) of the halo launch")
+    for what, direction, ci, co, k, st, pad, H, mod in shapes:
+        spec = ops.ConvSpec(k, k, st, pad)
+        x = torch.randn(B, ci, H, H, device="cuda").half().contiguous(memory_format=CL)
+        if direction == "fwd":
+            w = (torch.randn(co, ci, k, k) / (ci * k * k) ** 0.5).cuda()
+            epi = dict(in_scale=torch.rand(B, ci, device="cuda") + 0.5, out_scale=torch.rand(B, ops.cpad(co, torch.float16), device="cuda") + 0.5) if mod else {}
+            fn = lambda: ops.conv_fwd(x, w, spec, **epi)  # noqa: E731
+            Ho = spec.small_hw(H, H)[0]
+            flops = 2.0 * B * Ho * Ho * k * k * ci * co
+        else:
+            w = (torch.randn(ci, co, k, k) / (ci * k * k) ** 0.5).cuda()  # forward conv co -> ci; its data gradient maps ci -> co
+            Ho = spec.big_hw(H, H)[0]
+            epi = dict(in_scale=torch.rand(B, ci, device="cuda") + 0.5, out_scale=torch.rand(B, ops.cpad(co, torch.float16), device="cuda") + 0.5) if mod else {}
+            fn = lambda: ops.conv_bwd_data(x, w, spec, (Ho, Ho), **epi)  # noqa: E731
+            flops = 2.0 * B * H * H * k * k * ci * co
+        byts = 2.0 * B * (H * H * ci + Ho * Ho * ops.cpad(co, torch.float16))
+        t = {}
+        for on in ("1", "0"):
+            os.environ["GIF_F16_HALO"] = on
+            t[on] = timed(fn)
+        os.environ.pop("GIF_F16_HALO")
+        print(f"{what:58s} {t['1']:8.3f} / {t['0']:8.3f} ms  x{t['0'] / t['1']:5.2f}   {flops / t['1'] / 1e9:7.1f} TFLOP/s  {byts / t['1'] / 1e6:7.0f} GB/s")
+
+
+if __name__ == "__main__":
+    main()
