@@ -845,8 +845,9 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_gather_mfma_glds_
 // formed by SHIFTED LDS reads — a tap moves every lane's pixel index by the same wave-uniform offset.  A pixel is CPP = CP / 8
 // 16-byte chunks; chunk c of pixel q sits at physical chunk (c + q / (16 / CPP)) % CPP, so the 16 pixels of a ds_read_b128 lane
 // group hit 16 distinct 16-byte slots whatever the tap shift (rule 21; applied on the SOURCE address of the DMA, whose LDS
-// destination is lane-linear).  The weights never touch LDS: every lane loads its B fragments (one output channel, 8 consecutive
-// input channels) of the next tap straight from the L2-resident packed tensor while the current tap computes.  Modulation
+// destination is lane-linear).  The launch's weight slices ([tap][BN][CP] halfs, <= 36 KB) are staged behind the patch by the
+// same DMA pass, so the tap loop is pure ds_read + MFMA with no memory latency inside (a first version loaded the B fragments of
+// the next tap from L2: every tap waited for them, 0.34 ms for 32 -> 32 channels at 1024^2 — r4 halo probe).  Modulation
 // (ModulatedConv2d's s[b,ci], stylegan2_common_layers.py:311-320) multiplies the WEIGHT fragments — a patch belongs to one
 // sample, so this is the reference's per-sample weight modulation, done per wavefront in registers — demodulation stays in the
 // fp32 epilogue.  4 waves x (64 pixels x BN channels); v_mfma_f32_32x32x16_f16, fp32 accumulators; shared conv_epilogue (T2D).
@@ -900,6 +901,21 @@ __global__ void __launch_bounds__(256, 3) conv_halo_f16(const GatherParams p) {
             __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Xs + e0 * 8), 16, 0, 0);
         }
     }
+    // ---- stage the launch's weight slices [tap][BN][CP] behind the patch (same swizzle: a row of CP halfs is a "pixel")
+    T* const Wsm = Xs + halo_lds_floats<BN, CP>() * 2;
+    {
+        const int wchunks = p.ntaps * BN * CPP;
+        for (int e0 = wave * 64; e0 < wchunks; e0 += 256) {  // wave-uniform; BN * CPP is a multiple of 64: no partial pieces
+            const int e = e0 + lane;
+            const int r = e >> CPP_SHIFT, cphys = e & (CPP - 1);
+            const int c = (cphys - (r >> PPS_SHIFT)) & (CPP - 1);
+            const int t = r / BN, n = r - t * BN;
+            const int a = t / p.nkx, bb = t - a * p.nkx;
+            const int widx = (p.ky0 + a * p.kstep) * p.KW + p.kx0 + bb * p.kstep;
+            const T* g = pw + ((size_t)widx * p.RP + n) * CP + c * 8;
+            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Wsm + e0 * 8), 16, 0, 0);
+        }
+    }
     // ---- per-sample modulation of the contraction channels, as f16 multipliers of the weight fragments
     const bool has_scale = p.in_scale != nullptr;
     gif::f16x8_t sreg[KG];
@@ -916,18 +932,6 @@ __global__ void __launch_bounds__(256, 3) conv_halo_f16(const GatherParams p) {
             sreg[kg][4] = (T)s1.x; sreg[kg][5] = (T)s1.y; sreg[kg][6] = (T)s1.z; sreg[kg][7] = (T)s1.w;
         }
     }
-    // B fragments of tap t: lane (li, lh) = output channel j * 32 + li, input channels 16 kg + 8 lh .. + 7
-    auto load_b = [&](int t, gif::f16x8_t (&bw)[KG][NT]) __attribute__((always_inline)) {
-        const int a = t / p.nkx, bb = t - a * p.nkx;
-        const int widx = (p.ky0 + a * p.kstep) * p.KW + p.kx0 + bb * p.kstep;
-        const T* wt = pw + ((size_t)widx * p.RP + li) * CP + lh * 8;
-#pragma unroll
-        for (int kg = 0; kg < KG; ++kg)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                bw[kg][j] = *reinterpret_cast<const gif::f16x8_t*>(wt + (size_t)j * 32 * CP + kg * 16);
-            }
-    };
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -940,16 +944,19 @@ __global__ void __launch_bounds__(256, 3) conv_halo_f16(const GatherParams p) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) q0[i] = (4 * wave + 2 * i + (li >> 4)) * HWh + (li & 15);
 
-    auto compute = [&](int t, gif::f16x8_t (&bw)[KG][NT]) __attribute__((always_inline)) {
+    __syncthreads();  // the workgroup release waits for every wave's outstanding LDS-DMA (patch and weights)
+    for (int t = 0; t < p.ntaps; ++t) {
         const int a = t / p.nkx, bb = t - a * p.nkx;
         const int off = (p.dy0 + a * p.ddy - dy_min) * HWh + (p.dx0 + bb * p.ddx - dx_min);  // wave-uniform tap shift
-        if (has_scale) {  // here, not behind the loads: the fragments were requested one tap ago
+        gif::f16x8_t av[KG][MT], bw[KG][NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {  // B fragments: lane (li, lh) = output channel j * 32 + li, input channels 16 kg + 8 lh .. + 7
+            const int r = t * BN + j * 32 + li;
+            const int sw = r >> PPS_SHIFT;
 #pragma unroll
             for (int kg = 0; kg < KG; ++kg)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) bw[kg][j] *= sreg[kg];
+                bw[kg][j] = *reinterpret_cast<const gif::f16x8_t*>(Wsm + (((r << CPP_SHIFT) + ((kg * 2 + lh + sw) & (CPP - 1))) << 3));
         }
-        gif::f16x8_t av[KG][MT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int q = q0[i] + off;
@@ -958,6 +965,12 @@ __global__ void __launch_bounds__(256, 3) conv_halo_f16(const GatherParams p) {
             for (int kg = 0; kg < KG; ++kg)
                 av[kg][i] = *reinterpret_cast<const gif::f16x8_t*>(Xs + (((q << CPP_SHIFT) + ((kg * 2 + lh + sw) & (CPP - 1))) << 3));
         }
+        if (has_scale) {
+#pragma unroll
+            for (int kg = 0; kg < KG; ++kg)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bw[kg][j] *= sreg[kg];
+        }
 #pragma unroll
         for (int kg = 0; kg < KG; ++kg)
 #pragma unroll
@@ -965,16 +978,6 @@ __global__ void __launch_bounds__(256, 3) conv_halo_f16(const GatherParams p) {
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[kg][i], bw[kg][j], acc[i][j], 0, 0, 0);
-    };
-
-    gif::f16x8_t bw0[KG][NT], bw1[KG][NT];
-    load_b(0, bw0);
-    __syncthreads();  // the workgroup release waits for every wave's outstanding LDS-DMA
-    for (int t = 0; t < p.ntaps; t += 2) {
-        if (t + 1 < p.ntaps) load_b(t + 1, bw1);
-        compute(t, bw0);
-        if (t + 2 < p.ntaps) load_b(t + 2, bw0);
-        if (t + 1 < p.ntaps) compute(t + 1, bw1);
     }
     conv_epilogue<BM, BN, 8, MT, NT, T, 256, true, halo_lds_floats<BN, CP>()>(p, acc, smem, tile * BM, 0, wave * 64, 0, tid, li, lh, 0,
                                                                              b, oy0, ox0);
@@ -1137,7 +1140,7 @@ int launch_halo_impl(GatherParams& p, hipStream_t s) {
     p.t2_ty = gif::cdiv(p.Hp, 16);
     p.tiles_m = p.B * p.t2_tx * p.t2_ty;
     p.tiles_n = 1;
-    const size_t lds = (size_t)halo_lds_floats<BN, CP>() * sizeof(float);
+    const size_t lds = (size_t)halo_lds_floats<BN, CP>() * sizeof(float) + (size_t)p.ntaps * BN * CP * 2;
     auto kern = conv_halo_f16<BN, CP>;
     attr.ensure(reinterpret_cast<const void*>(kern), lds);
     p.zero = gif::zero_page16();
@@ -1147,6 +1150,12 @@ int launch_halo_impl(GatherParams& p, hipStream_t s) {
     t_last_bm = 256;
     hipLaunchKernelGGL(kern, dim3((unsigned)p.tiles_m), dim3(256), lds, s, p);
     return 0;
+}
+
+// bytes of the weight slices a halo launch stages in LDS: [ntaps][BN][CP] halfs
+inline long halo_weight_bytes(const GatherParams& p) {
+    const int bn = p.RP <= 32 ? 32 : 64, cp = p.CP <= 32 ? 32 : 64;
+    return (long)p.ntaps * bn * cp * 2;
 }
 
 // Which f16 launches take the halo kernel: unit-stride gathers (forward stride 1, every data gradient incl. the output-parity
@@ -1159,6 +1168,7 @@ inline bool halo_eligible(const GatherParams& p) {
     if (p.nky < 1 || p.nky > 3 || p.nkx < 1 || p.nkx > 3 || (p.ddy != 1 && p.ddy != -1) || (p.ddx != 1 && p.ddx != -1)) return false;
     if (p.Hp < 16 || p.Wp < 16 || (long)p.B * gif::cdiv(p.Hp, 16) * gif::cdiv(p.Wp, 16) >= (1L << 23)) return false;
     if (p.part_dot && (p.Hp % 16 || p.Wp % 16)) return false;
+    if (halo_weight_bytes(p) > 36864) return false;  // 9 taps of 64 x 64 channels (72 KB) stay on the gather kernel
     return true;
 }
 
@@ -1574,7 +1584,7 @@ int gif_conv2d_f16_halo_eligible(int cin, int cout, int KH, int KW, int stride, 
     if (cin <= 0 || cout <= 0 || KH < 1 || KW < 1 || stride < 1 || Hs <= 0 || Ws <= 0) return 0;
     GatherParams p{};
     pack_dims<gif::f16>(cout, cin, &p.RP, &p.CP);
-    p.is = stride; p.nky = KH; p.nkx = KW; p.ddy = 1; p.ddx = 1; p.Hp = Hs; p.Wp = Ws; p.B = 1;
+    p.is = stride; p.nky = KH; p.nkx = KW; p.ntaps = KH * KW; p.ddy = 1; p.ddx = 1; p.Hp = Hs; p.Wp = Ws; p.B = 1;
     return halo_eligible(p) ? 1 : 0;
 }
 

@@ -192,6 +192,7 @@ class DeviceLossScaler:
         self.inv_scale = torch.tensor(1.0 / float(init_scale), device=device)
         self.found_inf = torch.zeros((), device=device)
         self.sat = torch.zeros((), device=device)  # this rank's "a gradient store saturated" snapshot of the current step
+        self._snapshotted = False
         self._good = torch.zeros((), device=device)
         self.growth_interval, self.max_scale = float(growth_interval), float(max_scale)
         self.skipped = torch.zeros((), device=device)  # number of skipped steps (read it after a synchronize)
@@ -202,6 +203,7 @@ class DeviceLossScaler:
     def begin_step(self):
         """Once per optimiser step, before its first gradient pass: clear the device's flag word (the window stays closed)."""
         self.sat.zero_()
+        self._snapshotted = False
         if self._hip():
             from . import _lib
             with torch.cuda.device(self.scale.device):
@@ -243,6 +245,7 @@ class DeviceLossScaler:
         """Right after backward(), BEFORE the gradient exchange is enqueued: snapshot the flag; with a bucket, park it in the
         bucket's flag slot as +inf (0 otherwise) so that the exchange spreads it to every rank."""
         self._snapshot()
+        self._snapshotted = True
         if bucket is not None:
             bucket.flag_slot.copy_(torch.where(self.sat > 0, float("inf"), 0.0).reshape(1))
 
@@ -250,8 +253,11 @@ class DeviceLossScaler:
     def update(self, flat):
         """Call once per optimiser step BEFORE the Adam launch, with the (already exchanged) gradient bucket.  found_inf is a
         function of the exchanged bucket alone (incl. its flag slot), i.e. identical on every rank; a caller that never called
-        end_backward() (single-process use without a bucket) still gets the local flag OR-ed in here."""
-        self._snapshot()
+        end_backward() (single-process use without a bucket) still gets the local flag OR-ed in here — but after
+        end_backward() the device's flag word belongs to whoever cleared it next (the other network's step)."""
+        if not self._snapshotted:
+            self._snapshot()
+        self._snapshotted = False
         self.found_inf.copy_(torch.maximum((~torch.isfinite(flat).all()).to(torch.float32), (self.sat > 0).to(torch.float32)))
         bad = self.found_inf.clone()
         self.inv_scale.copy_(1.0 / self.scale)  # the scale the gradients in `flat` were produced with

@@ -253,11 +253,11 @@ def test_config3_at_stated_size_vs_oracle():
     assert_close(fake[sel.cuda()], fake_o, 1e-4, "G images of the group")
     assert_close(fs[sel.cuda()], fs_o, 3e-4, "D(fake) scores of the group")
     assert_close(rs[sel.cuda()], rs_o.detach(), 3e-4, "D(real) scores of the group")
-    # R1 = 5 * ||d sum(scores) / d image||^2 is a sum of squares of a gradient that passes through every leaky-ReLU mask of
-    # D: the few activation sign flips between the batch-32 HIP forward (Winograd kernels) and the oracle's forward (see
-    # gpu_util.assert_grads_close) move it by a fraction of a percent — measured 6e-3 on penalties of 5e-5; the batch-4 test
-    # above holds the same quantity to 3e-4 on the direct kernels.
-    assert_close(r1[sel.cuda()], r1_o, 2e-2, "R1 penalties of the group")
+    # R1 = 5 * ||d sum(scores) / d image||^2 passes through every leaky-ReLU mask of D.  Round 3 held it to 2e-2 here on the
+    # strength of a sign-flip argument; measured in round 4 on this batch: 7.5e-6 on the Winograd path, 2.0e-5 on the direct
+    # kernels, 137 of 1.2e9 leaky-ReLU outputs on different sides between the two HIP forwards — so it is held to the batch-4
+    # test's 3e-4 on both paths.
+    assert_close(r1[sel.cuda()], r1_o, 3e-4, "R1 penalties of the group")
     # The sign-flip explanation, demonstrated at THIS size (review item, round 3): the same batch with the Winograd kernels off
     # (direct kernels only, the path of the batch-4 test) holds the penalties to the batch-4 bound, and the leaky-ReLU outputs of
     # the two HIP forwards differ in sign at a counted handful of positions — the masks the penalty's gradient passes through.
@@ -267,7 +267,8 @@ def test_config3_at_stated_size_vs_oracle():
         signs, hooks = [], []
         for m in D.modules():
             if type(m).__name__ == "ConvLayer":
-                hooks.append(m.register_forward_hook(lambda _m, _i, out: signs.append(torch.signbit(out.detach()))))
+                hooks.append(m.register_forward_hook(
+                    lambda _m, _i, out: signs.append(torch.signbit((out[0] if isinstance(out, (tuple, list)) else out).detach()))))
         x = real.clone().requires_grad_(True)
         sc = D([x], condition=cond)[0]
         pen = losses.grad_penalty_loss([x], sc, step=None).detach()
