@@ -78,6 +78,7 @@ struct GatherParams {
     int pair;                  // f16 kernels, Ci <= 32 (CP == 32): one 64-half K chunk = the channels of TWO taps (see glds_body)
     int dense;                 // bf16x3 kernels, 8 <= Ci < 32, 3x3: 16-byte chunks per tap (Ci / 4) of the tap-dense K order, else 0
     int t2_tx, t2_ty;          // halo kernel: 16 x 16-pixel patches per row / column of the output sub-grid
+    int halo_dbg;              // halo kernel: ablation bits of the probe (GIF_HALO_DBG; results are wrong when set)
 };
 
 // partial-sum rows handed out to the launches of one op (bulk + remainder launches, transposed-conv phases), and the tile height
@@ -843,7 +844,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_gather_mfma_glds_
 // workgroup owns a 16 x 16 patch of output pixels of one sample: the input patch + halo ((16 + nky - 1) x (16 + nkx - 1) pixels,
 // all channels) is staged in LDS ONCE by LDS-DMA (out-of-image pixels and channel padding read the zero page), and the taps are
 // formed by SHIFTED LDS reads — a tap moves every lane's pixel index by the same wave-uniform offset.  A pixel is CPP = CP / 8
-// 16-byte chunks; chunk c of pixel q sits at physical chunk (c + q / (16 / CPP)) % CPP, so the 16 pixels of a ds_read_b128 lane
+// 16-byte chunks; chunk c of pixel q sits at physical chunk c ^ (q / (16 / CPP)) % CPP, so the 16 pixels of a ds_read_b128 lane
 // group hit 16 distinct 16-byte slots whatever the tap shift (rule 21; applied on the SOURCE address of the DMA, whose LDS
 // destination is lane-linear).  The launch's weight slices ([tap][BN][CP] halfs, <= 36 KB) are staged behind the patch by the
 // same DMA pass, so the tap loop is pure ds_read + MFMA with no memory latency inside (a first version loaded the B fragments of
@@ -863,10 +864,13 @@ __global__ void __launch_bounds__(256, 3) conv_halo_f16(const GatherParams p) {
     constexpr int CPP = CP / 8;                   // 16-byte chunks per pixel
     constexpr int CPP_SHIFT = CPP == 4 ? 2 : 3;
     constexpr int PPS_SHIFT = CPP == 4 ? 2 : 1;   // q >> PPS_SHIFT = q / (16 / CPP): the swizzle advances once per 256 bytes
+    constexpr int SWM = CPP - 1;
     constexpr int KG = CP / 16, MT = 2, NT = BN / 32;
+    constexpr int HALO_HALFS = halo_lds_floats<BN, CP>() * 2;
     static_assert((CP == 32 || CP == 64) && (BN == 32 || BN == 64), "halo kernel configurations");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    T* const Xs = reinterpret_cast<T*>(smem);
+    T* const Xs = reinterpret_cast<T*>(smem);  // [HALO_HALFS] patch buffer (later the epilogue's transposition buffer), then the weight slices
+    T* const Wsm = Xs + HALO_HALFS;
     const T* const px = static_cast<const T*>(p.x);
     const T* const pw = static_cast<const T*>(p.wp);
     const T* const pzero = static_cast<const T*>(p.zero);
@@ -880,44 +884,64 @@ __global__ void __launch_bounds__(256, 3) conv_halo_f16(const GatherParams p) {
     const int tpi = p.t2_tx * p.t2_ty;
     const int b = tile / tpi, tr = tile - b * tpi;
     const int tyi = tr / p.t2_tx, txi = tr - tyi * p.t2_tx;
-    const int oy0 = tyi * TH, ox0 = txi * TW;
     const int dy_min = p.ddy > 0 ? p.dy0 : p.dy0 + (p.nky - 1) * p.ddy;
     const int dx_min = p.ddx > 0 ? p.dx0 : p.dx0 + (p.nkx - 1) * p.ddx;
     const int HWh = TW + p.nkx - 1;
     const int nchunks = (TH + p.nky - 1) * HWh * CPP;
+    const bool has_scale = p.in_scale != nullptr;
+    const int dbg = p.halo_dbg;  // ablation builds of the probe only (results are wrong): 1 no patch DMA, 2 no taps, 4 no stores
 
-    // ---- stage the input patch + halo (one pass, LDS-DMA)
-    {
+    // ---- stage the input patch + halo (one pass, LDS-DMA).  Lane's chunk e = 64 * wave + lane + 256 * it: its physical chunk e % CPP
+    // is the same in every pass; its pixel index q advances by 256 / CPP, i.e. (dqy, dqx) in the halo grid (no division per pass).
+    if (!(dbg & 1)) {
+        constexpr int QSTEP = 256 / CPP;
+        const int dqy = QSTEP / HWh, dqx = QSTEP - dqy * HWh;  // scalar
+        int q = (wave * 64 + lane) >> CPP_SHIFT;
+        int hy = q / HWh, hx = q - hy * HWh;
+        const int cphys = lane & SWM;
         const T* const xb = px + (size_t)b * p.Hi * p.Wi * p.Ci;
-        const int gy0 = oy0 + dy_min, gx0 = ox0 + dx_min;
+        const int gy0 = tyi * TH + dy_min, gx0 = txi * TW + dx_min;
         for (int e0 = wave * 64; e0 < nchunks; e0 += 256) {  // wave-uniform
-            const int e = e0 + lane;
-            const int q = e >> CPP_SHIFT, cphys = e & (CPP - 1);
-            const int c = (cphys - (q >> PPS_SHIFT)) & (CPP - 1);
-            const int hy = q / HWh, hx = q - hy * HWh;
+            const int c = cphys ^ ((q >> PPS_SHIFT) & SWM);
             const int gy = gy0 + hy, gx = gx0 + hx;
-            const bool ok = e < nchunks && (unsigned)gy < (unsigned)p.Hi && (unsigned)gx < (unsigned)p.Wi && c * 8 < p.Ci;
-            const T* g = ok ? xb + ((size_t)gy * p.Wi + gx) * p.Ci + c * 8 : pzero;
+            const bool ok = e0 + lane < nchunks && (unsigned)gy < (unsigned)p.Hi && (unsigned)gx < (unsigned)p.Wi && c * 8 < p.Ci;
+            const T* g = ok ? xb + ((gy * p.Wi + gx) * p.Ci + c * 8) : pzero;  // (32-bit offsets inside one sample: host check)
             __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Xs + e0 * 8), 16, 0, 0);
+            q += QSTEP;
+            hx += dqx; hy += dqy;
+            if (hx >= HWh) { hx -= HWh; ++hy; }
         }
     }
-    // ---- stage the launch's weight slices [tap][BN][CP] behind the patch (same swizzle: a row of CP halfs is a "pixel")
-    T* const Wsm = Xs + halo_lds_floats<BN, CP>() * 2;
+    // ---- stage the launch's weight slices [tap][BN][CP] behind the patch (same swizzle: a row of CP halfs is a "pixel"; tap
+    // slices start at multiples of 32 rows, so a row's swizzle term only depends on its channel n)
     {
-        const int wchunks = p.ntaps * BN * CPP;
-        for (int e0 = wave * 64; e0 < wchunks; e0 += 256) {  // wave-uniform; BN * CPP is a multiple of 64: no partial pieces
-            const int e = e0 + lane;
-            const int r = e >> CPP_SHIFT, cphys = e & (CPP - 1);
-            const int c = (cphys - (r >> PPS_SHIFT)) & (CPP - 1);
-            const int t = r / BN, n = r - t * BN;
-            const int a = t / p.nkx, bb = t - a * p.nkx;
-            const int widx = (p.ky0 + a * p.kstep) * p.KW + p.kx0 + bb * p.kstep;
-            const T* g = pw + ((size_t)widx * p.RP + n) * CP + c * 8;
-            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Wsm + e0 * 8), 16, 0, 0);
+        constexpr int WPT = BN * CPP;  // chunks per tap: 128 .. 512
+        const int cphys = lane & SWM;
+        if constexpr (WPT >= 256) {
+            const int n = (wave * 64 + lane) >> CPP_SHIFT;
+            const int c = cphys ^ ((n >> PPS_SHIFT) & SWM);
+            int ta = 0, tb = 0;
+            for (int t = 0; t < p.ntaps; ++t) {
+                const int widx = (p.ky0 + ta * p.kstep) * p.KW + p.kx0 + tb * p.kstep;
+                if (++tb == p.nkx) { tb = 0; ++ta; }
+                const T* const wt = pw + (size_t)widx * p.RP * CP;  // scalar
+#pragma unroll
+                for (int k = 0; k < WPT / 256; ++k)  // rows n + k * 256 / CPP: the same swizzle term
+                    __builtin_amdgcn_global_load_lds((gptr_t)(wt + (n + k * (256 / CPP)) * CP + c * 8),
+                                                     (lptr_t)(Wsm + (t * WPT + k * 256 + wave * 64) * 8), 16, 0, 0);
+            }
+        } else {  // 128 chunks per tap = two pieces: waves 0, 1 take the even taps, waves 2, 3 the odd ones
+            const int n = ((wave & 1) * 64 + lane) >> CPP_SHIFT;
+            const int c = cphys ^ ((n >> PPS_SHIFT) & SWM);
+            for (int t = wave >> 1; t < p.ntaps; t += 2) {  // wave-uniform
+                const int a = t / p.nkx, bb = t - a * p.nkx;
+                const int widx = (p.ky0 + a * p.kstep) * p.KW + p.kx0 + bb * p.kstep;
+                __builtin_amdgcn_global_load_lds((gptr_t)(pw + ((size_t)widx * p.RP + n) * CP + c * 8),
+                                                 (lptr_t)(Wsm + (t * WPT + (wave & 1) * 64) * 8), 16, 0, 0);
+            }
         }
     }
     // ---- per-sample modulation of the contraction channels, as f16 multipliers of the weight fragments
-    const bool has_scale = p.in_scale != nullptr;
     gif::f16x8_t sreg[KG];
     if (has_scale) {
 #pragma unroll
@@ -932,7 +956,19 @@ __global__ void __launch_bounds__(256, 3) conv_halo_f16(const GatherParams p) {
             sreg[kg][4] = (T)s1.x; sreg[kg][5] = (T)s1.y; sreg[kg][6] = (T)s1.z; sreg[kg][7] = (T)s1.w;
         }
     }
-
+    // lane-constant byte offsets: B fragment (j, kg) of tap 0, the chunk term of A fragment kg, the lane's pixel in the halo grid
+    int boff[NT][KG], ckg[KG], q0[MT];
+#pragma unroll
+    for (int kg = 0; kg < KG; ++kg) {
+        ckg[kg] = (kg * 2 + lh) << 4;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int r = j * 32 + li;
+            boff[j][kg] = ((r << CPP_SHIFT) + ((kg * 2 + lh) ^ ((r >> PPS_SHIFT) & SWM))) << 4;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) q0[i] = (4 * wave + 2 * i + (li >> 4)) * HWh + (li & 15);
     f32x16 acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -940,30 +976,26 @@ __global__ void __launch_bounds__(256, 3) conv_halo_f16(const GatherParams p) {
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    int q0[MT];  // halo-patch pixel index of this lane's output pixel at tap offset (dy_min, dx_min)
-#pragma unroll
-    for (int i = 0; i < MT; ++i) q0[i] = (4 * wave + 2 * i + (li >> 4)) * HWh + (li & 15);
 
+    const char* const Xb = reinterpret_cast<const char*>(Xs);
+    const char* Wb = reinterpret_cast<const char*>(Wsm);
     __syncthreads();  // the workgroup release waits for every wave's outstanding LDS-DMA (patch and weights)
-    for (int t = 0; t < p.ntaps; ++t) {
-        const int a = t / p.nkx, bb = t - a * p.nkx;
-        const int off = (p.dy0 + a * p.ddy - dy_min) * HWh + (p.dx0 + bb * p.ddx - dx_min);  // wave-uniform tap shift
+    int ta = 0, tb = 0;  // tap (row, column) of the grid, advanced without divisions
+    for (int t = 0; t < ((dbg & 2) ? 0 : p.ntaps); ++t) {
+        const int off = (p.dy0 + ta * p.ddy - dy_min) * HWh + (p.dx0 + tb * p.ddx - dx_min);  // wave-uniform tap shift
+        if (++tb == p.nkx) { tb = 0; ++ta; }
         gif::f16x8_t av[KG][MT], bw[KG][NT];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {  // B fragments: lane (li, lh) = output channel j * 32 + li, input channels 16 kg + 8 lh .. + 7
-            const int r = t * BN + j * 32 + li;
-            const int sw = r >> PPS_SHIFT;
+        for (int j = 0; j < NT; ++j)  // B fragments: lane (li, lh) = output channel j * 32 + li, input channels 16 kg + 8 lh .. + 7
 #pragma unroll
-            for (int kg = 0; kg < KG; ++kg)
-                bw[kg][j] = *reinterpret_cast<const gif::f16x8_t*>(Wsm + (((r << CPP_SHIFT) + ((kg * 2 + lh + sw) & (CPP - 1))) << 3));
-        }
+            for (int kg = 0; kg < KG; ++kg) bw[kg][j] = *reinterpret_cast<const gif::f16x8_t*>(Wb + boff[j][kg]);
+        Wb += BN * CP * 2;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int q = q0[i] + off;
-            const int sw = q >> PPS_SHIFT;
+            const int g16 = (q << (CPP_SHIFT + 4)) ^ ((q << (4 - PPS_SHIFT)) & (SWM << 4));
 #pragma unroll
-            for (int kg = 0; kg < KG; ++kg)
-                av[kg][i] = *reinterpret_cast<const gif::f16x8_t*>(Xs + (((q << CPP_SHIFT) + ((kg * 2 + lh + sw) & (CPP - 1))) << 3));
+            for (int kg = 0; kg < KG; ++kg) av[kg][i] = *reinterpret_cast<const gif::f16x8_t*>(Xb + (g16 ^ ckg[kg]));
         }
         if (has_scale) {
 #pragma unroll
@@ -979,10 +1011,10 @@ __global__ void __launch_bounds__(256, 3) conv_halo_f16(const GatherParams p) {
                 for (int j = 0; j < NT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[kg][i], bw[kg][j], acc[i][j], 0, 0, 0);
     }
+    if (dbg & 4) return;
     conv_epilogue<BM, BN, 8, MT, NT, T, 256, true, halo_lds_floats<BN, CP>()>(p, acc, smem, tile * BM, 0, wave * 64, 0, tid, li, lh, 0,
-                                                                             b, oy0, ox0);
+                                                                             b, tyi * TH, txi * TW);
 }
-
 
 struct TileCfg {
     int BM, BN, BK;
@@ -1142,6 +1174,7 @@ int launch_halo_impl(GatherParams& p, hipStream_t s) {
     p.tiles_n = 1;
     const size_t lds = (size_t)halo_lds_floats<BN, CP>() * sizeof(float) + (size_t)p.ntaps * BN * CP * 2;
     auto kern = conv_halo_f16<BN, CP>;
+    p.halo_dbg = getenv("GIF_HALO_DBG") ? atoi(getenv("GIF_HALO_DBG")) : 0;
     attr.ensure(reinterpret_cast<const void*>(kern), lds);
     p.zero = gif::zero_page16();
     if (!p.zero) return -101;

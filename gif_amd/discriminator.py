@@ -32,6 +32,9 @@ class Discriminator(nn.Module):
         self.convs = nn.Sequential(*convs)
         self.stddev_group = 4
         self.stddev_feat = 1
+        # > 1: the batch is that many independent calls stacked along dim 0 (GifTrainer runs D on [real; fake] in one pass):
+        # the minibatch-stddev statistic — the only cross-sample coupling — is taken inside each chunk, exactly as in separate calls
+        self.stddev_chunks = 1
         self.act_dtype = torch.float32  # see StyledGenerator.act_dtype
         self.final_conv = ConvLayer(in_channel + 1, channels[4], 3)
         self.final_linear = nn.Sequential(
@@ -56,9 +59,13 @@ class Discriminator(nn.Module):
             input = F.pad(input, (0, 0, 0, 0, 0, cp - c))
         out = self.convs(input.to(self.act_dtype).contiguous(memory_format=torch.channels_last))
         batch, channel, height, width = out.shape
-        group = min(batch, self.stddev_group)
         # [B,C,4,4] -> [B,cpad(C+1),4,4]: channel C is the group's mean stddev (wavefront-shuffle reduction in HIP)
-        out = GF.minibatch_stddev(out, group, cpad(channel + 1, out.dtype))
+        if self.stddev_chunks > 1:
+            assert batch % self.stddev_chunks == 0, (batch, self.stddev_chunks)
+            out = torch.cat([GF.minibatch_stddev(h, min(h.shape[0], self.stddev_group), cpad(channel + 1, out.dtype))
+                             for h in out.chunk(self.stddev_chunks, dim=0)], dim=0)
+        else:
+            out = GF.minibatch_stddev(out, min(batch, self.stddev_group), cpad(channel + 1, out.dtype))
         out = self.final_conv(out)
         out = out.reshape(batch, -1).float()  # logical NCHW order == the reference's view(batch, -1); the head is fp32
         out = self.final_linear(out)

@@ -362,3 +362,36 @@ def test_real_trainer_two_gloo_processes_on_cpu():
     assert err0 < 1e-5 and err1 < 1e-5, (err0, err1)
     assert g0 == g1 and d0 == d1 and m0 == m1, "replicas bit-identical after 2 iterations"
     assert all(np.isfinite(l0)) and all(np.isfinite(l1))
+
+
+def test_fused_discriminator_passes_equal_the_two_calls(cpu):
+    """GifTrainer.d_step runs D once on [real; fake] (minibatch-stddev per half) where train.py:142 / :169 call it twice: same
+    loss, same gradients (every D parameter receives one gradient instead of two that autograd adds), R1 iterations unchanged."""
+    import copy
+    from gif_amd.train_step import GifTrainer
+    torch.manual_seed(0)
+    G, G_ema, D = _build_g(), _build_g(), _build_d(16)
+    G_ema.load_state_dict(G.state_dict())
+    gen = torch.Generator().manual_seed(5)
+    real = torch.rand(8, 3, 16, 16, generator=gen) * 2 - 1
+    cond = torch.rand(8, 6, 16, 16, generator=gen) * 2 - 1
+    idx = torch.randint(0, 16, (8,), generator=gen)
+    out = {}
+    for fuse in (True, False):
+        g, ge, d = copy.deepcopy(G), copy.deepcopy(G_ema), copy.deepcopy(D)
+        tr = GifTrainer(g, d, ge, step=2, r1_every=2, fused_adam=False, fuse_d_passes=fuse)
+        calls = []
+        orig = d.forward
+        d.forward = lambda *a, _o=orig, **k: (calls.append(a[0][0].shape[0]), _o(*a, **k))[1]
+        loss0 = tr.d_step(0, real, cond, idx)
+        grads = [p.grad.clone() for p in d.parameters()]
+        n_plain = len(calls)
+        loss1 = tr.d_step(1, real, cond, idx)  # R1 iteration: separate calls in both modes
+        out[fuse] = (loss0.item(), grads, n_plain, len(calls) - n_plain, calls[:n_plain], loss1.item())
+    assert out[True][2] == 1 and out[True][4] == [16], "one D call over 2 x 8 samples"
+    assert out[False][2] == 2 and out[False][4] == [8, 8]
+    assert out[True][3] == 2 and out[False][3] == 2, "R1 iterations keep the two calls"
+    assert abs(out[True][0] - out[False][0]) < 1e-6 * max(1.0, abs(out[False][0]))
+    assert abs(out[True][5] - out[False][5]) < 1e-4 * max(1.0, abs(out[False][5]))
+    for a, b in zip(out[True][1], out[False][1]):
+        assert_close(a, b, 2e-5, "D gradients: fused pass vs two calls")
