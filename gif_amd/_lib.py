@@ -88,6 +88,10 @@ PROTOTYPES = {
     "gif_colsum_f32": (c_int, [P, P, P, c_i64, c_int, P]),
     "gif_mul_reduce_chunks": (c_int, [c_i64]),
     "gif_mul_reduce_f32": (c_int, [P, P, P, P, P, P, c_int, c_i64, c_int, P]),
+    "gif_pack_nhwc_f32": (c_int, [P, c_int, c_int, ctypes.POINTER(c_i64), P, c_int, c_int, ctypes.POINTER(c_i64), P, c_int, c_int, c_int, c_int, P]),
+    "gif_pack_nhwc_f16": (c_int, [P, c_int, c_int, ctypes.POINTER(c_i64), P, c_int, c_int, ctypes.POINTER(c_i64), P, c_int, c_int, c_int, c_int, P]),
+    "gif_unpack_nhwc_f32": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "gif_unpack_nhwc_f16": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "gif_bilinear_down_f32": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "gif_act_inv_mul_reduce_f32": (c_int, [P, P, P, P, P, P, c_int, c_i64, c_int, c_float, c_float, P]),
     "gif_mbstd_fwd_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),

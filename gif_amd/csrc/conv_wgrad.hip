@@ -734,6 +734,189 @@ inline bool small_wgrad_ok(const gif_conv_geom* g, bool scaled) {
            g->Cs <= 32 && g->Cb <= 16 && (long)g->B * g->Hs * g->Ws >= 65536;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// f16 "halo" weight gradient for the thin high-resolution layers (Cs <= 32, Cb <= 32, stride 1: the 1024^2 block of BASELINE
+// configs[4] and the condition-noise / ToRGB layers, model/stg2_generator.py:159-209, stylegan2_common_layers.py:388-431).
+// conv_wgrad_mfma above runs one workgroup per (pixel chunk, TAP): nine workgroups stream the same two activation chunks
+// through LDS-DMA and each gathers them again — 0.86 ms for 32 x 32 channels at 1024^2, batch 8 (0.18 ms of HBM traffic).
+// Here a PERSISTENT workgroup walks 16 x 16-pixel patches of one sample: the gy patch and the x patch + halo are staged in LDS
+// once (double buffered: the LDS-DMA of patch k + 1 runs under the MFMAs of patch k; nothing is stored per patch, so the loop
+// has no store latency in it), and all taps are formed from LDS: a K step is one patch row (16 pixels), the tap only shifts the
+// row / column of the x operand.  K = pixels is the slow axis of both tiles, so an operand fragment (8 consecutive pixels of
+// one channel) is gathered with eight 16-bit LDS reads as in the kernel above (lane = channel: a half wave reads 64
+// contiguous bytes of one pixel, conflict free); the gy fragment is gathered once per K step for all taps.
+// Each of the 4 waves owns every fourth patch row and all taps (9 accumulator tiles of 32 x 32 = 144 VGPRs); at the end the
+// waves' accumulators are reduced through LDS in a fixed order and the workgroup writes ONE split of the usual
+// [split][tap][RP][CP] workspace (nsplit = workgroups; deterministic, same unpack kernel).  Per-sample scales (modulated
+// layers) multiply the fragments: one scalar per lane, a patch belongs to one sample.
+// ------------------------------------------------------------------------------------------------------------------
+struct HaloWgradParams {
+    const void* sm;   // gy [B,H,W,Cs] f16
+    const void* bg;   // x  [B,H,W,Cb] f16 (same spatial size: stride 1, pad = (K - 1) / 2 or 0 for 1x1)
+    float* ws;        // [nsplit = gridDim.x][T][32][32]
+    const float* ss;  // [B,Cs] or null
+    const float* bs;  // [B,Cb] or null
+    int B, Hs, Ws, Hb, Wb, Cs, Cb, KH, KW, pad;
+    int tiles_x, tiles_y, ntiles;
+    const void* zero;
+};
+
+constexpr int kHwPatchHalfs = 256 * 32;        // gy patch: 16 x 16 pixels x 32 channels
+constexpr int kHwHaloHalfs = 5376 * 2;         // x patch + halo: 18 x 18 pixels x 32 channels, rounded up to whole DMA pieces
+constexpr int kHwBufHalfs = kHwPatchHalfs + kHwHaloHalfs;
+
+__global__ void __launch_bounds__(256, 2) conv_wgrad_halo_f16(const HaloWgradParams p) {
+    typedef gif::f16 T;
+    extern __shared__ __attribute__((aligned(16))) float hw_smem[];
+    T* const lds = reinterpret_cast<T*>(hw_smem);  // [2][kHwBufHalfs]
+    const T* const smb = static_cast<const T*>(p.sm);
+    const T* const bgb = static_cast<const T*>(p.bg);
+    const T* const pzero = static_cast<const T*>(p.zero);
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int tpi = p.tiles_x * p.tiles_y;
+    const int HWh = 16 + p.KW - 1;
+    const int nchunks_x = (16 + p.KH - 1) * HWh * 4;
+    const int T9 = p.KH * p.KW;
+
+    // chunk e = 64 * wave + lane + 256 * pass: channel chunk e % 4 is the same in every pass, the pixel advances by 64
+    const int c8 = (lane & 3) * 8;
+    const int q_first = (wave * 64 + lane) >> 2;
+    const int hy_first = q_first / HWh, hx_first = q_first - hy_first * HWh;
+    const int dqy = 64 / HWh, dqx = 64 - dqy * HWh;
+    auto issue_patch = [&](int tile, T* buf) __attribute__((always_inline)) {
+        const int b = tile / tpi, tr = tile - b * tpi;
+        const int ty = tr / p.tiles_x, tx = tr - ty * p.tiles_x;
+        const int oy0 = ty * 16, ox0 = tx * 16;
+        {   // gy patch: pixel q = 16 * ly + lx
+            const T* const gb = smb + (size_t)b * p.Hs * p.Ws * p.Cs;
+            int q = q_first;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int gy = oy0 + (q >> 4), gx = ox0 + (q & 15);
+                const bool ok = gy < p.Hs && gx < p.Ws && c8 < p.Cs;
+                const T* g = ok ? gb + ((gy * p.Ws + gx) * p.Cs + c8) : pzero;
+                __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(buf + (it * 256 + wave * 64) * 8), 16, 0, 0);
+                q += 64;
+            }
+        }
+        {   // x patch + halo: rows / columns shifted by -pad
+            const T* const xb = bgb + (size_t)b * p.Hb * p.Wb * p.Cb;
+            const int gy0 = oy0 - p.pad, gx0 = ox0 - p.pad;
+            int hy = hy_first, hx = hx_first;
+            T* const xbuf = buf + kHwPatchHalfs;
+            for (int e0 = wave * 64; e0 < nchunks_x; e0 += 256) {  // wave-uniform
+                const int gy = gy0 + hy, gx = gx0 + hx;
+                const bool ok = e0 + lane < nchunks_x && (unsigned)gy < (unsigned)p.Hb && (unsigned)gx < (unsigned)p.Wb && c8 < p.Cb;
+                const T* g = ok ? xb + ((gy * p.Wb + gx) * p.Cb + c8) : pzero;
+                __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(xbuf + e0 * 8), 16, 0, 0);
+                hx += dqx; hy += dqy;
+                if (hx >= HWh) { hx -= HWh; ++hy; }
+            }
+        }
+    };
+    auto load_scales = [&](int tile, float& sa, float& sb) __attribute__((always_inline)) {
+        const int b = tile / tpi;
+        sa = (p.ss && li < p.Cs) ? p.ss[(size_t)b * p.Cs + li] : 1.f;
+        sb = (p.bs && li < p.Cb) ? p.bs[(size_t)b * p.Cb + li] : 1.f;
+    };
+    const bool scaled = p.ss != nullptr || p.bs != nullptr;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int stride = (int)gridDim.x;
+    int tile = xcd_remap((int)blockIdx.x, stride);
+    float sa = 1.f, sb = 1.f, sa_n = 1.f, sb_n = 1.f;
+    if (tile < p.ntiles) {
+        issue_patch(tile, lds);
+        if (scaled) load_scales(tile, sa, sb);
+    }
+    int cur = 0;
+    for (; tile < p.ntiles; tile += stride) {
+        __syncthreads();  // patch `tile` landed (vmcnt(0) of every wave); everybody is done reading the other buffer
+        const int next = tile + stride;
+        if (next < p.ntiles) {
+            issue_patch(next, lds + (cur ^ 1) * kHwBufHalfs);
+            if (scaled) load_scales(next, sa_n, sb_n);
+        }
+        const T* const G = lds + cur * kHwBufHalfs;      // [256 px][32]
+        const T* const X = G + kHwPatchHalfs;             // [halo px][32]
+        const T fa = (T)sa, fb = (T)sb;
+#pragma unroll 1
+        for (int row = wave; row < 16; row += 4) {  // K step = one patch row: pixels 16 * row + 8 * lh + 0..7
+            gif::f16x8_t af;
+            const T* ga = G + (row * 16 + 8 * lh) * 32 + li;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) af[e] = ga[e * 32];
+            if (scaled) af *= fa;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                if (t < T9) {  // wave-uniform
+                    const int ky = t / p.KW, kx = t - ky * p.KW;
+                    const T* xa = X + ((row + ky) * HWh + 8 * lh + kx) * 32 + li;
+                    gif::f16x8_t bf;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bf[e] = xa[e * 32];
+                    if (scaled) bf *= fb;
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[t], 0, 0, 0);
+                }
+            }
+        }
+        sa = sa_n; sb = sb_n;
+        cur ^= 1;
+    }
+    // ---- fixed-order reduction of the four waves' accumulators through LDS (the patch buffers are free), then ONE split
+    __syncthreads();
+    float* const red = hw_smem;  // [2][9][1024] floats = 72 KB <= the two patch buffers (75.8 KB)
+    for (int h = 2; h >= 1; h >>= 1) {
+        if (wave >= h && wave < 2 * h) {
+            float* dst = red + (size_t)(wave - h) * 9 * 1024;
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dst[(t * 16 + r) * 64 + lane] = acc[t][r];
+        }
+        __syncthreads();
+        if (wave < h) {
+            const float* src = red + (size_t)wave * 9 * 1024;
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] += src[(t * 16 + r) * 64 + lane];
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+        // C/D layout of the 32x32 MFMA: column (cin) = lane & 31, row (cout) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+        float* out = p.ws + (size_t)blockIdx.x * T9 * 1024;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            if (t < T9) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) out[(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li] = acc[t][r];
+            }
+    }
+}
+
+// GIF_F16_HALO_WGRAD=0: A/B knob (the per-tap kernel).  Workgroups (= splits): two per CU, never more than patches.
+inline bool halo_wgrad_ok(const gif_conv_geom* g) {
+    static const int off = getenv("GIF_F16_HALO_WGRAD") ? atoi(getenv("GIF_F16_HALO_WGRAD")) == 0 : 0;
+    return !off && g->stride == 1 && g->Cs <= 32 && g->Cb <= 32 && g->KH <= 3 && g->KW <= 3 && g->Hs == g->Hb && g->Ws == g->Wb &&
+           g->KH == 2 * g->pad + 1 && g->KW == 2 * g->pad + 1 && g->Hs >= 16 && g->Ws >= 16 &&
+           (long)g->B * gif::cdiv(g->Hs, 16) * gif::cdiv(g->Ws, 16) >= 512;
+}
+inline int halo_wgrad_splits(const gif_conv_geom* g) {
+    const long patches = (long)g->B * gif::cdiv(g->Hs, 16) * gif::cdiv(g->Ws, 16);
+    return (int)(patches < 512 ? patches : 512);
+}
+
 // Winograd F(3x3,2x2) output transform fused with the split reduction: dW = A'^T dU A' with
 // A'^T = [1 1 1 0; 0 1 -1 0; 0 1 1 -1] (the F(3,2) matrix with the sign of the input transform's last row folded in,
 // because V was produced by the F(2,3) input transform whose last row is the negative of F(3,2)'s).
@@ -852,6 +1035,7 @@ int gif_conv2d_wgrad_dims_f16(int Cs, int Cb, int* RP, int* CP) {
 
 int gif_conv2d_wgrad_splits_f16(const gif_conv_geom* g) {
     if (!g || g->B <= 0) return 1;
+    if (halo_wgrad_ok(g)) return halo_wgrad_splits(g);  // conv_wgrad_halo_f16: one split per persistent workgroup
     int RP, CP;
     gif_conv2d_wgrad_dims_f16(g->Cs, g->Cb, &RP, &CP);
     const int t = wgrad_tile_f16(g->Cs, g->Cb);
@@ -883,6 +1067,23 @@ int gif_conv2d_wgrad_f16(const void* small, const void* big, float* ws, const fl
     gif_conv2d_wgrad_dims_f16(g->Cs, g->Cb, &p.RP, &p.CP);
     const int t = wgrad_tile_f16(g->Cs, g->Cb);
     p.Ntot = (long)g->B * g->Hs * g->Ws;
+    if (halo_wgrad_ok(g) && nsplit == halo_wgrad_splits(g) && p.RP == 32 && p.CP == 32) {
+        HaloWgradParams q{};
+        q.sm = small; q.bg = big; q.ws = ws; q.ss = small_scale; q.bs = big_scale;
+        q.B = g->B; q.Hs = g->Hs; q.Ws = g->Ws; q.Hb = g->Hb; q.Wb = g->Wb; q.Cs = g->Cs; q.Cb = g->Cb;
+        q.KH = g->KH; q.KW = g->KW; q.pad = g->pad;
+        q.tiles_x = gif::cdiv(g->Ws, 16); q.tiles_y = gif::cdiv(g->Hs, 16); q.ntiles = g->B * q.tiles_x * q.tiles_y;
+        q.zero = gif::zero_page16();
+        GIF_REQUIRE(q.zero, "conv2d_wgrad_f16: zero page lookup failed");
+        hipStream_t hs = gif::as_stream(stream);
+        gif::ProfScope prof(7, 2.0 * p.Ntot * (double)g->Cs * g->Cb * p.T, hs, (int)p.Ntot, g->Cs, g->Cb,
+                            p.T * 10 + g->stride + (small_scale || big_scale ? 100 : 0));
+        const size_t lds = (size_t)2 * kHwBufHalfs * sizeof(gif::f16);
+        static gif::LdsAttr attr;
+        attr.ensure(reinterpret_cast<const void*>(conv_wgrad_halo_f16), lds);
+        hipLaunchKernelGGL(conv_wgrad_halo_f16, dim3((unsigned)nsplit), dim3(256), lds, hs, q);
+        return gif::check_launch("conv2d_wgrad_f16(halo)");
+    }
     long chunk = (p.Ntot + nsplit - 1) / nsplit;
     p.chunk = (chunk + BKP_MAX - 1) / BKP_MAX * BKP_MAX;
     if (p.chunk < BKP_MAX) p.chunk = BKP_MAX;

@@ -778,6 +778,81 @@ int act_inv_mul_reduce_impl(const T* g, const T* y, const T* residual, const flo
 
 }  // namespace
 
+namespace {
+
+// ------------------------------------------------------------------------------------------------ input assembly (round 4)
+// Discriminator.forward (stg2_discriminator.py:48-53) concatenates image and condition along the channel axis; the NHWC
+// kernels want that tensor channel-padded (9 -> 12 / 16) and, in f16 mode, as halfs.  torch.cat + F.pad + .to() + .contiguous()
+// were 4 full-resolution passes (3.3 ms per iteration at 1024^2, batch 8: profiles/r4_aten_crumbs_f16_1024.txt); this is one:
+// one lane per pixel gathers the channels of up to two fp32 sources with arbitrary strides (NCHW: coalesced over the lanes per
+// channel) and writes the pixel's padded channel vector (consecutive lanes write consecutive 16 .. 64-byte pieces).
+struct PackSrc {
+    const float* p;
+    int C, c_off;
+    long sb, sc, sy, sx;  // element strides
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) pack_nhwc_kernel(PackSrc s0, PackSrc s1, T* __restrict__ dst, int H, int W, int Cp, long npix) {
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < npix; idx += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % W);
+        const long r = idx / W;
+        const int y = (int)(r % H);
+        const long b = r / H;
+        const float* b0 = s0.p + b * s0.sb + y * s0.sy + x * s0.sx;
+        const float* b1 = s1.p ? s1.p + b * s1.sb + y * s1.sy + x * s1.sx : nullptr;
+        T* out = dst + idx * Cp;
+        for (int c = 0; c < Cp; c += 4) {
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ch = c + k;
+                float t = 0.f;
+                if (ch >= s0.c_off && ch < s0.c_off + s0.C) t = b0[(ch - s0.c_off) * s0.sc];
+                else if (b1 && ch >= s1.c_off && ch < s1.c_off + s1.C) t = b1[(ch - s1.c_off) * s1.sc];
+                v[k] = t;
+            }
+            gif::store4(out + c, make_float4(v[0], v[1], v[2], v[3]));
+        }
+    }
+}
+
+// the adjoint w.r.t. one source: channels [c_off, c_off + C) of an NHWC tensor -> fp32 [B,H,W,C] (channels_last, unpadded)
+template <typename T>
+__global__ void __launch_bounds__(256) unpack_nhwc_kernel(const T* __restrict__ src, float* __restrict__ dst, int Cp, int c_off, int C,
+                                                          long npix) {
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < npix; idx += (long)gridDim.x * blockDim.x) {
+        const T* in = src + idx * Cp + c_off;
+        float* out = dst + idx * C;
+        for (int k = 0; k < C; ++k) out[k] = (float)in[k];
+    }
+}
+
+template <typename T>
+int pack_nhwc_impl(const float* src0, int C0, int off0, const int64_t* st0, const float* src1, int C1, int off1, const int64_t* st1,
+                   T* dst, int B, int H, int W, int Cp, gif_stream_t stream) {
+    GIF_REQUIRE(src0 && dst && st0 && B >= 0 && H > 0 && W > 0 && Cp > 0 && Cp % 4 == 0, "pack_nhwc: bad arguments (Cp=%d)", Cp);
+    GIF_REQUIRE(C0 > 0 && off0 >= 0 && off0 + C0 <= Cp, "pack_nhwc: source 0 channels [%d, %d) outside [0, %d)", off0, off0 + C0, Cp);
+    GIF_REQUIRE(!src1 || (st1 && C1 > 0 && off1 >= off0 + C0 && off1 + C1 <= Cp), "pack_nhwc: source 1 must follow source 0 inside Cp");
+    if (B == 0) return 0;
+    PackSrc s0{src0, C0, off0, st0[0], st0[1], st0[2], st0[3]};
+    PackSrc s1{src1, src1 ? C1 : 0, off1, src1 ? st1[0] : 0, src1 ? st1[1] : 0, src1 ? st1[2] : 0, src1 ? st1[3] : 0};
+    const long npix = (long)B * H * W;
+    pack_nhwc_kernel<T><<<ew_grid(npix), 256, 0, gif::as_stream(stream)>>>(s0, s1, dst, H, W, Cp, npix);
+    return gif::check_launch("pack_nhwc");
+}
+
+template <typename T>
+int unpack_nhwc_impl(const T* src, float* dst, int B, int H, int W, int Cp, int c_off, int C, gif_stream_t stream) {
+    GIF_REQUIRE(src && dst && B >= 0 && H > 0 && W > 0 && Cp > 0 && C > 0 && c_off >= 0 && c_off + C <= Cp, "unpack_nhwc: bad arguments");
+    if (B == 0) return 0;
+    const long npix = (long)B * H * W;
+    unpack_nhwc_kernel<T><<<ew_grid(npix), 256, 0, gif::as_stream(stream)>>>(src, dst, Cp, c_off, C, npix);
+    return gif::check_launch("unpack_nhwc");
+}
+
+}  // namespace
+
 extern "C" {
 
 int gif_upfirdn2d_f32(const float* x, const float* k, float* y, int B, int Hi, int Wi, int C, int Ho, int Wo, int up,
@@ -850,6 +925,21 @@ int gif_act_inv_mul_reduce_f16(const void* g, const void* y, const void* residua
     return act_inv_mul_reduce_impl<gif::f16>(static_cast<const gif::f16*>(g), static_cast<const gif::f16*>(y),
                                              static_cast<const gif::f16*>(residual), bias, out, partial, B, HW, C, slope, gain,
                                              stream);
+}
+
+int gif_pack_nhwc_f32(const float* src0, int C0, int off0, const int64_t* strides0, const float* src1, int C1, int off1,
+                      const int64_t* strides1, float* dst, int B, int H, int W, int Cp, gif_stream_t stream) {
+    return pack_nhwc_impl<float>(src0, C0, off0, strides0, src1, C1, off1, strides1, dst, B, H, W, Cp, stream);
+}
+int gif_pack_nhwc_f16(const float* src0, int C0, int off0, const int64_t* strides0, const float* src1, int C1, int off1,
+                      const int64_t* strides1, void* dst, int B, int H, int W, int Cp, gif_stream_t stream) {
+    return pack_nhwc_impl<gif::f16>(src0, C0, off0, strides0, src1, C1, off1, strides1, static_cast<gif::f16*>(dst), B, H, W, Cp, stream);
+}
+int gif_unpack_nhwc_f32(const float* src, float* dst, int B, int H, int W, int Cp, int c_off, int C, gif_stream_t stream) {
+    return unpack_nhwc_impl<float>(src, dst, B, H, W, Cp, c_off, C, stream);
+}
+int gif_unpack_nhwc_f16(const void* src, float* dst, int B, int H, int W, int Cp, int c_off, int C, gif_stream_t stream) {
+    return unpack_nhwc_impl<gif::f16>(static_cast<const gif::f16*>(src), dst, B, H, W, Cp, c_off, C, stream);
 }
 
 int gif_bilinear_down_f32(const float* x, float* y, int B, int R, int S, int C, int backward, gif_stream_t stream) {

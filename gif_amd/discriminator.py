@@ -51,13 +51,10 @@ class Discriminator(nn.Module):
     def forward(self, input, condition=None, step=0, alpha=0):
         if type(input) in (list, tuple):
             input = input[0]
-        if condition is not None:
-            input = torch.cat((input, condition), dim=1)
-        c = input.shape[1]
-        cp = cpad(c, self.act_dtype)
-        if cp != c:
-            input = F.pad(input, (0, 0, 0, 0, 0, cp - c))
-        out = self.convs(input.to(self.act_dtype).contiguous(memory_format=torch.channels_last))
+        # torch.cat((input, condition), 1) (reference :50-53) + channel padding (9 -> 12 / 16) + conversion to the activation
+        # dtype + NHWC layout: one HIP pass (round 3: four ATen passes, 3.3 ms per iteration at 1024^2)
+        c = input.shape[1] + (condition.shape[1] if condition is not None else 0)
+        out = self.convs(GF.pack_nhwc(input, condition, cpad(c, self.act_dtype), self.act_dtype))
         batch, channel, height, width = out.shape
         # [B,C,4,4] -> [B,cpad(C+1),4,4]: channel C is the group's mean stddev (wavefront-shuffle reduction in HIP)
         if self.stddev_chunks > 1:

@@ -609,6 +609,45 @@ class BilinearDownBwdFn(Function):  # linear map: its backward is the forward ag
         return BilinearDownFn.apply(ggx, S), None, None
 
 
+# --------------------------------------------------------------------------------------------------------
+# input assembly: cat + channel padding + dtype / layout conversion in one pass (stg2_discriminator.py:48-53)
+# --------------------------------------------------------------------------------------------------------
+class PackNhwcFn(Function):
+    """y [B,cp,H,W] (NHWC, `dtype`) = channels of a (at a_off) and b (at b_off, or None), zero elsewhere.  Linear: its backward
+    is UnpackNhwcFn per source, whose backward is PackNhwcFn again — differentiable to any order (R1 differentiates the
+    discriminator twice w.r.t. the image, train.py:148)."""
+
+    @staticmethod
+    def forward(ctx, a, b, a_off, b_off, cp, dtype):
+        ctx.cfg = (a_off, a.shape[1], b_off, None if b is None else b.shape[1])
+        return ops.pack_nhwc(a.float(), a_off, None if b is None else b.float(), b_off, cp, dtype)
+
+    @staticmethod
+    def backward(ctx, gy):
+        a_off, ca, b_off, cb = ctx.cfg
+        ga = UnpackNhwcFn.apply(gy, a_off, ca) if ctx.needs_input_grad[0] else None
+        gb = UnpackNhwcFn.apply(gy, b_off, cb) if (cb is not None and ctx.needs_input_grad[1]) else None
+        return ga, gb, None, None, None, None
+
+
+class UnpackNhwcFn(Function):
+    @staticmethod
+    def forward(ctx, g, c_off, C):
+        ctx.cfg = (c_off, g.shape[1], g.dtype)
+        return ops.unpack_nhwc(g, c_off, C)
+
+    @staticmethod
+    def backward(ctx, gg):
+        c_off, cp, dtype = ctx.cfg
+        return PackNhwcFn.apply(gg, None, c_off, 0, cp, dtype), None, None
+
+
+def pack_nhwc(a, b=None, cp=None, dtype=torch.float32):
+    """cat((a, b), 1) zero-padded to cp channels, as an NHWC tensor of `dtype` (b may be None)."""
+    ca = a.shape[1]
+    return PackNhwcFn.apply(a, b, 0, ca, cp, dtype)
+
+
 def bilinear_down(x, S):
     """F.interpolate(x, (S,S), 'bilinear', align_corners=False) for square inputs with R/S == 1 or even."""
     return BilinearDownFn.apply(x, S)

@@ -147,16 +147,15 @@ class StyledGenerator(nn.Module):
     def _condition_pyramid(self, cond, step):
         """noise[i] = bilinear resize of the condition to (4*2^i)^2 (reference :309-314), channel-padded NHWC; built in
         fp32, each level cast to the activation dtype."""
-        c = cond.shape[1]
-        cp = ops.cpad(c, self.act_dtype)
-        if cp != c:
-            cond = F.pad(cond.float(), (0, 0, 0, 0, 0, cp - c))
-        cond = cond.float().contiguous(memory_format=torch.channels_last)
+        # channel padding (6 -> 8) + NHWC layout in one pass (round 3: F.pad + .contiguous(), two full-resolution ATen passes)
+        cond = GF.pack_nhwc(cond, None, ops.cpad(cond.shape[1], self.act_dtype), torch.float32)
         levels = []
         H, W = cond.shape[2:]
         for i in range(step + 1):
             size = 4 * 2 ** i
-            if H == W and H % size == 0 and (H == size or (H // size) % 2 == 0):
+            if H == W and H == size:
+                levels.append(cond)  # the level at the condition's own resolution is the packed tensor itself
+            elif H == W and H % size == 0 and (H // size) % 2 == 0:
                 levels.append(GF.bilinear_down(cond, size))  # integer ratio: the taps are exact 0.5/0.5 (NHWC kernel)
             else:  # arbitrary ratio (e.g. a 2x2 dummy condition, non-square renders): the generic HIP resampler (csrc/resize.hip)
                 lvl = resize_image(cond, (size, size), 'bilinear')

@@ -542,6 +542,38 @@ def bilinear_down(x, S, backward_to=None):
     return y
 
 
+def _i64x4(t):
+    return (ctypes.c_int64 * 4)(*t.stride())
+
+
+@_device_guard
+def pack_nhwc(src0, off0, src1, off1, cp, dtype):
+    """[B,cp,H,W] NHWC tensor of `dtype` (fp32 / f16) with channels [off0, off0 + C0) = src0, [off1, off1 + C1) = src1 (or None),
+    zeros elsewhere — torch.cat + channel padding + conversion + layout change in one pass (include/gif_hip.h).  Sources: fp32,
+    logical [B,C,H,W], any strides."""
+    lib = _lib.load()
+    for t in (src0, src1):
+        if t is not None and (not t.is_cuda or t.dtype != torch.float32 or t.dim() != 4):
+            raise _lib.GifHipError("pack_nhwc needs 4-D fp32 device tensors (no CPU fallback)")
+    B, C0, H, W = src0.shape
+    if src1 is not None and (src1.shape[0], src1.shape[2], src1.shape[3]) != (B, H, W):
+        raise _lib.GifHipError(f"pack_nhwc: sources disagree: {tuple(src0.shape)} vs {tuple(src1.shape)}")
+    out = empty_nhwc(B, cp, H, W, src0.device, dtype)
+    _lib.check(_fn("pack_nhwc", dtype)(src0.data_ptr(), C0, off0, _i64x4(src0), _p(src1), 0 if src1 is None else src1.shape[1], off1,
+                                       None if src1 is None else _i64x4(src1), out.data_ptr(), B, H, W, cp, _stream()), "pack_nhwc")
+    return out
+
+
+@_device_guard
+def unpack_nhwc(g, c_off, C):
+    """Adjoint of pack_nhwc w.r.t. one source: channels [c_off, c_off + C) of the NHWC tensor g -> fp32 [B,C,H,W] (channels_last)."""
+    g = nhwc(g)
+    B, cp, H, W = g.shape
+    out = torch.empty((B, C, H, W), device=g.device, dtype=torch.float32, memory_format=CL)
+    _lib.check(_fn("unpack_nhwc", g.dtype)(g.data_ptr(), out.data_ptr(), B, H, W, cp, c_off, C, _stream()), "unpack_nhwc")
+    return out
+
+
 def act_inv_mul_reduce(g, y, residual, bias, slope, gain):
     """out[b,c] = sum_hw g * (act^-1(y) - residual - bias[c])  (see gif_hip.h)."""
     lib = _lib.load()

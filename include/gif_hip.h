@@ -301,6 +301,18 @@ int gif_mul_reduce_chunks(int64_t HW);
 int gif_mul_reduce_f32(const float* a, const float* b, const float* scale, float* scaled, float* out,
                        float* partial, int B, int64_t HW, int C, gif_stream_t stream);
 
+/* ABI 3.  Input assembly of the NHWC kernels in ONE pass — replaces torch.cat((image, condition), 1) of Discriminator.forward
+ * (stg2_discriminator.py:48-53) + channel padding + dtype / layout conversion: dst [B,H,W,Cp] (fp32 or f16) takes channels
+ * [off0, off0 + C0) from src0 and, if src1 != NULL, [off1, off1 + C1) from src1 (fp32, logical [B,C,H,W] with arbitrary element
+ * strides {batch, channel, row, column} — NCHW, channels-last and sliced views alike); every other channel is zero.
+ * gif_unpack_nhwc_* is the adjoint w.r.t. one source: channels [c_off, c_off + C) of src [B,H,W,Cp] -> fp32 dst [B,H,W,C]. */
+int gif_pack_nhwc_f32(const float* src0, int C0, int off0, const int64_t* strides0, const float* src1, int C1, int off1,
+                      const int64_t* strides1, float* dst, int B, int H, int W, int Cp, gif_stream_t stream);
+int gif_pack_nhwc_f16(const float* src0, int C0, int off0, const int64_t* strides0, const float* src1, int C1, int off1,
+                      const int64_t* strides1, void* dst, int B, int H, int W, int Cp, gif_stream_t stream);
+int gif_unpack_nhwc_f32(const float* src, float* dst, int B, int H, int W, int Cp, int c_off, int C, gif_stream_t stream);
+int gif_unpack_nhwc_f16(const void* src, float* dst, int B, int H, int W, int Cp, int c_off, int C, gif_stream_t stream);
+
 /* Condition pyramid level — replaces F.interpolate(cond, (S,S), 'bilinear', align_corners=False) of
  * StyledGenerator.forward (stg2_generator.py:309-314) for the integer ratios the model uses (R/S == 1 or even).
  * backward == 0: x [B,R,R,C] -> y [B,S,S,C];  backward != 0: x = grad [B,S,S,C] -> y = grad [B,R,R,C]. */

@@ -228,7 +228,20 @@ def demod_wgrad(w, g_wsq):
     return 2.0 * w * g_wsq[:, :, None, None]
 
 
-OPS = dict(weight_sq_sum=weight_sq_sum, style_demod=style_demod, style_demod_bwd_s=style_demod_bwd_s, style_demod_bwd_w=style_demod_bwd_w,
+def pack_nhwc(src0, off0, src1, off1, cp, dtype):
+    B, _, H, W = src0.shape
+    out = torch.zeros(B, cp, H, W, dtype=torch.float32)
+    out[:, off0:off0 + src0.shape[1]] = src0
+    if src1 is not None:
+        out[:, off1:off1 + src1.shape[1]] = src1
+    return out.to(dtype).contiguous(memory_format=CL)
+
+
+def unpack_nhwc(g, c_off, C):
+    return g[:, c_off:c_off + C].float().contiguous(memory_format=CL)
+
+
+OPS = dict(pack_nhwc=pack_nhwc, unpack_nhwc=unpack_nhwc, weight_sq_sum=weight_sq_sum, style_demod=style_demod, style_demod_bwd_s=style_demod_bwd_s, style_demod_bwd_w=style_demod_bwd_w,
            demod_wgrad=demod_wgrad, resize=resize, linear_nt=linear_nt, linear_nn=linear_nn, linear_tn=linear_tn, nhwc=nhwc, conv_fwd=conv_fwd, conv_bwd_data=conv_bwd_data, conv_wgrad=conv_wgrad, upfirdn2d=upfirdn2d,
            bias_act=bias_act, bias_act_bwd=bias_act_bwd, colsum=colsum, mul_reduce=mul_reduce,
            act_inv_mul_reduce=act_inv_mul_reduce, bilinear_down=bilinear_down, mbstd_fwd=mbstd_fwd, mbstd_bwd=mbstd_bwd,

@@ -254,3 +254,87 @@ def test_loss_scaler_window_covers_inner_gradients_and_ignores_forward_stores():
     assert run(False, True, False) == (0.0, 1024.0), "launches after end_backward() belong to somebody else"
     assert run(False, False, True) == (0.0, 1024.0), "stores outside the watch window are not gradient stores"
     assert not torch.isfinite(bucket.flat).all() or bucket.flag_slot.item() == 0.0
+
+
+# ------------------------------------------------------------------------------------------------ input assembly
+@pytest.mark.parametrize("dtype", [torch.float32, H16])
+def test_pack_nhwc_equals_cat_pad_convert_and_is_twice_differentiable(dtype):
+    """gif_pack_nhwc_*: torch.cat((image, condition), 1) + channel padding + conversion + NHWC in one pass
+    (stg2_discriminator.py:48-53), sources with NCHW, channels-last and sliced strides; gradients and the gradient of the
+    gradient (R1) against autograd through the ATen composition."""
+    from gif_amd import functional as GF
+    from gif_amd import ops
+    g = torch.Generator().manual_seed(21)
+    B, H, W = 3, 20, 24
+    img = torch.randn(B, 3, H, W, generator=g).cuda()
+    cond_full = torch.randn(B, 8, H, W, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    cond = cond_full[:, 1:7]  # a sliced channels-last view: 6 channels with foreign strides
+    cp = ops.cpad(9, dtype)
+    ref = F.pad(torch.cat((img, cond), 1), (0, 0, 0, 0, 0, cp - 9)).to(dtype)
+    got = ops.pack_nhwc(img, 0, cond, 3, cp, dtype)
+    assert got.dtype == dtype and got.is_contiguous(memory_format=torch.channels_last) and torch.equal(got, ref)
+    assert torch.equal(ops.pack_nhwc(img, 0, None, 0, ops.cpad(3, dtype), dtype)[:, :3], img.to(dtype))
+    assert torch.equal(ops.unpack_nhwc(got, 3, 6), ref[:, 3:9].float())
+    # autograd: first and second order through a nonlinearity downstream
+    a = img.clone().requires_grad_(True)
+    c = cond.clone().requires_grad_(True)
+    w = torch.randn(cp, H, W, generator=g).cuda()
+
+    def loss_of(y):
+        return (y.float() * w).pow(2).sum()
+
+    res = []
+    for fn in (lambda: GF.pack_nhwc(a, c, cp, dtype), lambda: F.pad(torch.cat((a, c), 1), (0, 0, 0, 0, 0, cp - 9)).to(dtype)):
+        ga, gc = torch.autograd.grad(loss_of(fn()), (a, c), create_graph=True)
+        (gga,) = torch.autograd.grad(ga.pow(2).sum() + gc.sum(), a)
+        res.append((ga.detach(), gc.detach(), gga))
+    tol = 1e-6 if dtype == torch.float32 else 2e-3
+    for x, y, what in zip(res[0], res[1], ("d/d image", "d/d condition", "second order d/d image")):
+        assert_close(x, y, tol, f"pack_nhwc {what} ({dtype})")
+
+
+# ------------------------------------------------------------------------------------------------ f16 halo weight gradient
+HALO_WGRAD_CASES = [
+    # (B, Cin, Cout, K, pad, H): >= 512 patches of 16 x 16 pixels, <= 32 channels on both sides
+    (2, 32, 32, 3, 1, 256),    # the 1024^2 block's layers
+    (4, 16, 24, 3, 1, 200),    # condition-noise conv 2, patches overhang (200 = 12.5 x 16)
+    (2, 6, 12, 3, 1, 256),     # condition-noise conv 1 (8 / 16 padded channels)
+    (2, 32, 3, 1, 0, 256),     # ToRGB-shaped 1x1: single tap, no halo
+    (9, 24, 32, 3, 1, 128),    # more workgroups' worth of samples than a workgroup walks in one stride
+]
+
+
+@pytest.mark.parametrize("case", HALO_WGRAD_CASES)
+def test_f16_halo_weight_gradient(case):
+    """conv_wgrad_halo_f16 (persistent workgroups over 16 x 16-pixel patches, all taps from one LDS patch) against autograd's
+    weight gradient on the same f16-rounded operands; fp32 result; deterministic."""
+    from gif_amd import _lib, ops
+    B, Ci, Co, K, pad, H = case
+    g = torch.Generator().manual_seed(31)
+    x = r16(torch.randn(B, Ci, H, H, generator=g))
+    gy = r16(torch.randn(B, Co, H, H, generator=g))
+    spec = ops.ConvSpec(K, K, 1, pad)
+    geom = _lib.ConvGeom(B, H, H, pad8(Ci), H, H, pad8(Co), K, K, 1, pad)
+    import ctypes
+    nsplit = _lib.load().gif_conv2d_wgrad_splits_f16(ctypes.byref(geom))
+    assert nsplit == min(512, B * ((H + 15) // 16) ** 2), "the halo kernel's split count = persistent workgroups"
+    wl = torch.zeros(Co, Ci, K, K, requires_grad=True)
+    (ref,) = torch.autograd.grad(F.conv2d(x, wl, padding=pad), wl, gy)
+    got = ops.conv_wgrad(dev16(gy), dev16(x), spec, Co, Ci)
+    assert got.dtype == torch.float32
+    assert_close(got, ref, 5e-4, f"f16 halo wgrad {case}")
+    assert torch.equal(got, ops.conv_wgrad(dev16(gy), dev16(x), spec, Co, Ci)), "fixed-order reductions"
+
+
+def test_f16_halo_weight_gradient_modulated():
+    """dW = sum (gy * d) (x) (x * s): per-sample scales multiply the f16 fragments (one scalar per lane; a patch is one sample)."""
+    from gif_amd import ops
+    g = torch.Generator().manual_seed(32)
+    B, C, H = 3, 32, 224
+    x, gy = r16(torch.randn(B, C, H, H, generator=g)), r16(torch.randn(B, C, H, H, generator=g))
+    s, d = torch.rand(B, C, generator=g) + 0.5, torch.rand(B, C, generator=g) + 0.5
+    xs, gyd = r16(x * r16(s)[:, :, None, None]), r16(gy * r16(d)[:, :, None, None])
+    wl = torch.zeros(C, C, 3, 3, requires_grad=True)
+    (ref,) = torch.autograd.grad(F.conv2d(xs, wl, padding=1), wl, gyd)
+    got = ops.conv_wgrad(dev16(gy), dev16(x), ops.ConvSpec(3, 3, 1, 1), C, C, small_scale=d.cuda(), big_scale=s.cuda())
+    assert_close(got, ref, 1e-3, "f16 modulated halo wgrad")

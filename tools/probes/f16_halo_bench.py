@@ -67,5 +67,22 @@ def main():
         print(f"{what:58s} {t['1']:8.3f} / {t['0']:8.3f} ms  x{t['0'] / t['1']:5.2f}   {flops / t['1'] / 1e9:7.1f} TFLOP/s  {byts / t['1'] / 1e6:7.0f} GB/s")
 
 
+def wgrads(B):
+    CL = torch.channels_last
+    print("weight gradients: ms per launch, halo kernel / per-tap kernel (GIF_F16_HALO_WGRAD is read once per process: run twice)")
+    for what, ci, co, k, pad, H in [("wgrad 32x32 3x3 @1024", 32, 32, 3, 1, 1024), ("wgrad 32x24 @1024", 24, 32, 3, 1, 1024),
+                                    ("wgrad 24x16 @1024", 16, 24, 3, 1, 1024), ("wgrad 16x8 @1024", 8, 16, 3, 1, 1024),
+                                    ("wgrad ToRGB 8x32 1x1 @1024", 32, 8, 1, 0, 1024), ("wgrad 24x16 @512", 16, 24, 3, 1, 512)]:
+        x = torch.randn(B, ci, H, H, device="cuda").half().contiguous(memory_format=CL)
+        gy = torch.randn(B, co, H, H, device="cuda").half().contiguous(memory_format=CL)
+        spec = ops.ConvSpec(k, k, 1, pad)
+        t = timed(lambda: ops.conv_wgrad(gy, x, spec, co, ci))
+        byts = 2.0 * B * H * H * (ci + co)
+        print(f"{what:40s} {t:8.3f} ms   {2.0 * B * H * H * k * k * ci * co / t / 1e9:7.1f} TFLOP/s  {byts / t / 1e6:7.0f} GB/s")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--wgrad":
+        wgrads(8)
+        sys.exit(0)
     main()
