@@ -765,6 +765,23 @@ constexpr int kHwPatchHalfs = 256 * 32;        // gy patch: 16 x 16 pixels x 32 
 constexpr int kHwHaloHalfs = 5376 * 2;         // x patch + halo: 18 x 18 pixels x 32 channels, rounded up to whole DMA pieces
 constexpr int kHwBufHalfs = kHwPatchHalfs + kHwHaloHalfs;
 
+// TR: operand fragments by two transposing LDS reads (ds_read_b64_tr_b16, gfx950) instead of eight 16-bit reads.  Semantics
+// (tools/probes/tr16_probe.hip): inside a 16-lane group, lane s supplies the address of an 8-byte chunk and receives element
+// s % 4 of the chunks of lanes 4 j + s / 4, j = 0..3.  Lane L of the group that owns channels 16 g .. 16 g + 15 therefore
+// supplies pixel k0 + L / 4, channels 16 g + 4 (L % 4) .. + 3, and lane s gets channel 16 g + s at pixels k0 .. k0 + 3.
+typedef __fp16 tr_h4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+__device__ __forceinline__ gif::f16x8_t halo_frag_tr(const gif::f16* base_lo) {
+    // base_lo: this lane's chunk of the first four pixels; the next four pixels are 4 * 32 halfs further
+    typedef __attribute__((address_space(3))) tr_h4* lp_t;
+    const tr_h4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lp_t)(base_lo));
+    const tr_h4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lp_t)(base_lo + 4 * 32));
+    gif::f16x8_t v;
+    v[0] = (gif::f16)lo[0]; v[1] = (gif::f16)lo[1]; v[2] = (gif::f16)lo[2]; v[3] = (gif::f16)lo[3];
+    v[4] = (gif::f16)hi[0]; v[5] = (gif::f16)hi[1]; v[6] = (gif::f16)hi[2]; v[7] = (gif::f16)hi[3];
+    return v;
+}
+
+template <bool TR>
 __global__ void __launch_bounds__(256, 2) conv_wgrad_halo_f16(const HaloWgradParams p) {
     typedef gif::f16 T;
     extern __shared__ __attribute__((aligned(16))) float hw_smem[];
@@ -824,6 +841,8 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_halo_f16(const HaloWgradPar
         sb = (p.bs && li < p.Cb) ? p.bs[(size_t)b * p.Cb + li] : 1.f;
     };
     const bool scaled = p.ss != nullptr || p.bs != nullptr;
+    // transposing reads: lane L = lane % 16 of channel group g = (lane >> 4) & 1 supplies pixel L / 4, channels 16 g + 4 (L % 4)
+    const int tr_px = (lane & 15) >> 2, tr_ch = ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
 
     f32x16 acc[9];
 #pragma unroll
@@ -852,18 +871,26 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_halo_f16(const HaloWgradPar
 #pragma unroll 1
         for (int row = wave; row < 16; row += 4) {  // K step = one patch row: pixels 16 * row + 8 * lh + 0..7
             gif::f16x8_t af;
-            const T* ga = G + (row * 16 + 8 * lh) * 32 + li;
+            if constexpr (TR) {
+                af = halo_frag_tr(G + (row * 16 + 8 * lh + tr_px) * 32 + tr_ch);
+            } else {
+                const T* ga = G + (row * 16 + 8 * lh) * 32 + li;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) af[e] = ga[e * 32];
+                for (int e = 0; e < 8; ++e) af[e] = ga[e * 32];
+            }
             if (scaled) af *= fa;
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 if (t < T9) {  // wave-uniform
                     const int ky = t / p.KW, kx = t - ky * p.KW;
-                    const T* xa = X + ((row + ky) * HWh + 8 * lh + kx) * 32 + li;
                     gif::f16x8_t bf;
+                    if constexpr (TR) {
+                        bf = halo_frag_tr(X + ((row + ky) * HWh + 8 * lh + kx + tr_px) * 32 + tr_ch);
+                    } else {
+                        const T* xa = X + ((row + ky) * HWh + 8 * lh + kx) * 32 + li;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) bf[e] = xa[e * 32];
+                        for (int e = 0; e < 8; ++e) bf[e] = xa[e * 32];
+                    }
                     if (scaled) bf *= fb;
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[t], 0, 0, 0);
                 }
@@ -1080,8 +1107,15 @@ int gif_conv2d_wgrad_f16(const void* small, const void* big, float* ws, const fl
                             p.T * 10 + g->stride + (small_scale || big_scale ? 100 : 0));
         const size_t lds = (size_t)2 * kHwBufHalfs * sizeof(gif::f16);
         static gif::LdsAttr attr;
-        attr.ensure(reinterpret_cast<const void*>(conv_wgrad_halo_f16), lds);
-        hipLaunchKernelGGL(conv_wgrad_halo_f16, dim3((unsigned)nsplit), dim3(256), lds, hs, q);
+        static const int tr_off = getenv("GIF_F16_HALO_WGRAD_TR") ? atoi(getenv("GIF_F16_HALO_WGRAD_TR")) == 0 : 0;  // A/B knob
+        if (tr_off) {
+            attr.ensure(reinterpret_cast<const void*>(conv_wgrad_halo_f16<false>), lds);
+            hipLaunchKernelGGL(conv_wgrad_halo_f16<false>, dim3((unsigned)nsplit), dim3(256), lds, hs, q);
+        } else {
+            static gif::LdsAttr attr_tr;
+            attr_tr.ensure(reinterpret_cast<const void*>(conv_wgrad_halo_f16<true>), lds);
+            hipLaunchKernelGGL(conv_wgrad_halo_f16<true>, dim3((unsigned)nsplit), dim3(256), lds, hs, q);
+        }
         return gif::check_launch("conv2d_wgrad_f16(halo)");
     }
     long chunk = (p.Ntot + nsplit - 1) / nsplit;

@@ -432,8 +432,17 @@ __global__ void __launch_bounds__(256) colsum_stage2(const float* __restrict__ p
     const int c = blockIdx.x * 64 + cl;
     float acc = 0.f;
     if (c < C) {
+        // 8 independent partial sums per lane (fixed assignment row -> slot, fixed final order): 8 loads in flight instead of one
+        // dependent L2 round trip per row — the launch is pure latency (r4: 215 launches, 3.3 ms per iteration at 1024^2)
         const float* pp = partial + (size_t)blockIdx.y * nblk * C + c;
-        for (int k = rl; k < nblk; k += 4) acc += pp[(size_t)k * C];
+        float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int k = rl;
+        for (; k + 28 < nblk; k += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) part[u] += pp[(size_t)(k + 4 * u) * C];
+        }
+        for (int u = 0; k < nblk; k += 4, ++u) part[u] += pp[(size_t)k * C];
+        acc = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
     }
     red[rl][cl] = acc;
     __syncthreads();
@@ -732,6 +741,11 @@ int reduce_partials(const float* partial, float* out, int Y, int nblk, int C, fl
         colsum_stage2<<<dim3(cdiv(C, 64), full), 256, 0, s>>>(partial, tmp, per, C);
         if (tail) colsum_stage2<<<dim3(cdiv(C, 64), 1), 256, 0, s>>>(partial + (size_t)full * per * C, tmp + (size_t)full * C, tail, C);
         colsum_stage2<<<dim3(cdiv(C, 64), 1), 256, 0, s>>>(tmp, out, full + (tail ? 1 : 0), C);
+    } else if (Y > 1 && nblk >= 1024 && nblk % 16 == 0 && (long)Y * 16 <= 4096) {
+        // per-sample sums over thousands of rows (the halo kernels' one row per 16 x 16 patch at 1024^2): Y blocks alone would
+        // crawl; 16 groups per sample first (groups of one sample are consecutive rows of tmp)
+        colsum_stage2<<<dim3(cdiv(C, 64), Y * 16), 256, 0, s>>>(partial, tmp, nblk / 16, C);
+        colsum_stage2<<<dim3(cdiv(C, 64), Y), 256, 0, s>>>(tmp, out, 16, C);
     } else {
         colsum_stage2<<<dim3(cdiv(C, 64), Y), 256, 0, s>>>(partial, out, nblk, C);
     }
