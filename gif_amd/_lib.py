@@ -23,8 +23,7 @@ class ConvEpilogue(ctypes.Structure):
     _fields_ = [("in_scale", P), ("out_scale", P), ("bias", P), ("residual", P),
                 ("act", ctypes.c_int32), ("slope", c_float), ("gain", c_float),
                 ("mask_src", P), ("mask_slope", c_float), ("mask_gain", c_float),
-                ("dot_src", P), ("dot", P), ("colsum", P), ("red_ws", P), ("out_f32", ctypes.c_int32),
-                ("splitk_ws", P), ("splitk_bytes", ctypes.c_int64)]
+                ("dot_src", P), ("dot", P), ("colsum", P), ("red_ws", P), ("out_f32", ctypes.c_int32)]
 
 
 GP, EP = ctypes.POINTER(ConvGeom), ctypes.POINTER(ConvEpilogue)

@@ -77,14 +77,6 @@ struct GatherParams {
     int out_f32;               // f16 kernels: the output tensor is fp32
     int pair;                  // f16 kernels, Ci <= 32 (CP == 32): one 64-half K chunk = the channels of TWO taps (see glds_body)
     int dense;                 // bf16x3 kernels, 8 <= Ci < 32, 3x3: 16-byte chunks per tap (Ci / 4) of the tap-dense K order, else 0
-    // split-K (bf16x3 kernels, launches that cannot fill the chip: the 4x4 .. 16x16 layers with 512 channels): the K steps are dealt
-    // to ksplit workgroups per output tile; each writes its accumulators to ks_ws, the LAST one to arrive (ks_cnt, self-resetting)
-    // sums all of them in split order — deterministic — and runs the epilogue
-    int ksplit;
-    float* ks_ws;
-    unsigned* ks_cnt;
-    long ks_bytes;             // bytes available behind ks_ws
-    int ks_cnt_n;              // counters available behind ks_cnt
     int t2_tx, t2_ty;          // halo kernel: 16 x 16-pixel patches per row / column of the output sub-grid
     int halo_dbg;              // halo kernel: ablation bits of the probe (GIF_HALO_DBG; results are wrong when set)
 };
@@ -455,16 +447,7 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
     const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
-    // split-K (X3 only): block = split * ntile + tile
-    int ksplit = 1, split = 0, ntile = nwg;
-    if constexpr (X3) {
-        if (p.ksplit > 1) {
-            ksplit = p.ksplit;
-            ntile = nwg / ksplit;
-            split = bid / ntile;
-        }
-    }
-    const int tile = xcd_remap(bid - split * ntile, ntile);
+    const int tile = xcd_remap(bid, nwg);
     const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
     const int m0 = p.m_begin + tm * BM, n0 = tn * BN;
     const int HWp = p.Hp * p.Wp;
@@ -522,19 +505,9 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
         }
         __syncthreads();
     }
-    int nsteps = dense_cpt ? (p.ntaps * dense_cpt + CH - 1) / CH : pair ? (p.ntaps + 1) / 2 : p.ntaps * (p.CP / BK);
+    const int nsteps = dense_cpt ? (p.ntaps * dense_cpt + CH - 1) / CH : pair ? (p.ntaps + 1) / 2 : p.ntaps * (p.CP / BK);
     int ld_a = 0, ld_b = 0, ld_kc = 0;
     int cmp_kc = 0;  // K-chunk of the step being computed (for the scale lookup)
-    if constexpr (X3) {
-        if (ksplit > 1) {  // this workgroup's K steps [s_begin, s_begin + nsteps) (host: every split gets at least one step)
-            const int per = (nsteps + ksplit - 1) / ksplit, s_begin = split * per;
-            nsteps = nsteps - s_begin < per ? nsteps - s_begin : per;
-            const int kch = p.CP / BK, tap = s_begin / kch;
-            ld_kc = cmp_kc = (s_begin - tap * kch) * BK;
-            ld_a = tap / p.nkx;
-            ld_b = tap - ld_a * p.nkx;
-        }
-    }
     // X3 weight DMA: block = wave + it * NWAVES covers rows (block % (BN/16)) * 16 + lane/4 of term block / (BN/16); this
     // lane's physical chunk lane%4 holds the logical chunk (lane%4) ^ ((lane/16)%4)  [(row>>2)&3 of a 16-aligned block]
     int b3_off[B3_IT];
@@ -838,46 +811,6 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
         mfma_group(g & 1);
     }
     }
-    if constexpr (X3) {
-        if (ksplit > 1) {
-            constexpr int ACC_N = MT * NT * 16;
-            float* const mine = p.ks_ws + ((size_t)split * ntile + tile) * (size_t)(ACC_N * THREADS) + tid;
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) mine[((i * NT + j) * 16 + r) * THREADS] = acc[i][j][r];
-            __threadfence();   // the partial tile is visible device-wide before the arrival is counted
-            __syncthreads();   // (also: every wave is done with the staging buffers)
-            unsigned* const flag = reinterpret_cast<unsigned*>(smem);
-            if (tid == 0) {
-                const unsigned prev = atomicAdd(p.ks_cnt + tile, 1u);
-                const bool last = prev == (unsigned)(ksplit - 1);
-                if (last) p.ks_cnt[tile] = 0;  // hand the counter back clean: no memset per launch
-                *flag = last ? 1u : 0u;
-            }
-            __syncthreads();
-            const bool last = *flag != 0;
-            if (!last) return;
-            __threadfence();
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-            for (int k = 0; k < ksplit; ++k) {  // fixed order, whatever the arrival order was
-                const float* src = p.ks_ws + ((size_t)k * ntile + tile) * (size_t)(ACC_N * THREADS) + tid;
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[i][j][r] += src[((i * NT + j) * 16 + r) * THREADS];
-            }
-        }
-    }
     conv_epilogue<BM, BN, 32, MT, NT, T, THREADS>(p, acc, smem, m0, n0, wm0, wn0, tid, li, lh, HWp);
 }
 
@@ -1134,32 +1067,12 @@ inline size_t scale_table(GatherParams& p) {
 template <int BM, int BN, bool X3>
 constexpr size_t stage_bytes() { return X3 ? (size_t)2 * BM * 128 + (size_t)2 * 3 * BN * 64 : (size_t)2 * (BM + BN) * 128; }
 
-// Split-K plan of one launch (GatherParams::ksplit): only the plain bf16x3 K order, only launches of fewer than kSplitMaxTiles
-// workgroups with at least 16 K steps; aims at ~768 workgroups, at least 8 steps per split, at most 16 splits; needs the
-// caller's workspace (gif_conv_epilogue::splitk_ws).  GIF_SPLITK=0: A/B knob; GIF_SPLITK_MAX_TILES: threshold.
-inline int plan_splitk(const GatherParams& p, int BM, int BN, long ws_off_bytes, int cnt_off) {
-    static const int off = getenv("GIF_SPLITK") ? atoi(getenv("GIF_SPLITK")) == 0 : 0;
-    static const int max_tiles = getenv("GIF_SPLITK_MAX_TILES") ? atoi(getenv("GIF_SPLITK_MAX_TILES")) : 384;
-    if (off || !p.x3 || p.dense || !p.ks_ws || !p.ks_cnt) return 1;
-    const long tiles = (long)gif::cdiv(p.M - p.m_begin, BM) * (p.RP / BN);
-    const int total = p.ntaps * (p.CP / 32);
-    if (tiles >= max_tiles || total < 16) return 1;
-    long ks = (768 + tiles - 1) / tiles;
-    if (ks > total / 8) ks = total / 8;
-    if (ks > 16) ks = 16;
-    while (ks > 1 && (ks - 1) * ((total + ks - 1) / ks) >= total) --ks;  // every split owns at least one step
-    while (ks > 1 && ws_off_bytes + ks * tiles * BM * BN * 4 > p.ks_bytes) --ks;
-    if (cnt_off + tiles > p.ks_cnt_n) return 1;
-    return ks < 1 ? 1 : (int)ks;
-}
-
 template <typename T, int BM, int BN, int WMv, int WNv, bool SCALE, bool X3 = false>
 int launch_glds_impl(GatherParams& p, hipStream_t s) {
     constexpr int BK = 128 / sizeof(T);  // 128-byte LDS rows
     static gif::LdsAttr attr;
     p.tiles_m = gif::cdiv(p.M - p.m_begin, BM);
     p.tiles_n = p.RP / BN;
-    p.ksplit = X3 ? plan_splitk(p, BM, BN, 0, 0) : 1;
     size_t lds = stage_bytes<BM, BN, X3>();
     p.stab_nb = 0;
     p.stab_stride = 0;
@@ -1173,7 +1086,7 @@ int launch_glds_impl(GatherParams& p, hipStream_t s) {
     p.part_row0 = t_part_rows;
     t_part_rows += p.tiles_m;
     t_last_bm = BM;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_m * p.tiles_n * p.ksplit)), dim3(64 * WMv * WNv), lds, s, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(64 * WMv * WNv), lds, s, p);
     return 0;
 }
 
@@ -1188,8 +1101,6 @@ int launch_glds_multi(GatherParams* ph, int nph, hipStream_t s) {
     MultiParams mp{};
     size_t lds_max = 0;
     int total = 0, rows = 0;
-    long ks_ws_off = 0;
-    int ks_cnt_off = 0;
     for (int i = 0; i < nph; ++i) {
         GatherParams& p = ph[i];
         p.tiles_m = gif::cdiv(p.M - p.m_begin, BM);
@@ -1200,22 +1111,10 @@ int launch_glds_multi(GatherParams* ph, int nph, hipStream_t s) {
         if (SCALE) lds += scale_table<T, BM>(p);
         if (lds > lds_max) lds_max = lds;
         p.zero = zero_page;
-        // split-K per phase: each phase owns its slice of the workspace and of the arrival counters
-        float* const ws0 = p.ks_ws;
-        unsigned* const cnt0 = p.ks_cnt;
-        p.ksplit = X3 ? plan_splitk(p, BM, BN, ks_ws_off, ks_cnt_off) : 1;
-        if (p.ksplit > 1) {
-            p.ks_ws = ws0 + ks_ws_off / 4;
-            p.ks_cnt = cnt0 + ks_cnt_off;
-            ks_ws_off += (long)p.ksplit * p.tiles_m * p.tiles_n * BM * BN * 4;
-            ks_cnt_off += p.tiles_m * p.tiles_n;
-        }
-        total += p.tiles_m * p.tiles_n * p.ksplit;
+        total += p.tiles_m * p.tiles_n;
         p.part_row0 = t_part_rows + rows;
         rows += p.tiles_m;
         mp.ph[i] = p;
-        p.ks_ws = ws0;
-        p.ks_cnt = cnt0;
         mp.wg_end[i] = total;
     }
     mp.nph = nph;
@@ -1463,15 +1362,6 @@ void fill_epilogue(GatherParams& p, const gif_conv_epilogue* e) {
     p.dot_src = e ? e->dot_src : nullptr;
     p.sat_flag = nullptr;
     p.out_f32 = e ? e->out_f32 : 0;
-    // split-K workspace: [16384 arrival counters (zero on entry, handed back zero)][partial accumulator tiles]
-    p.ksplit = 1;
-    p.ks_ws = nullptr; p.ks_cnt = nullptr; p.ks_bytes = 0; p.ks_cnt_n = 0;
-    if (e && e->splitk_ws && e->splitk_bytes > 65536) {
-        p.ks_cnt = static_cast<unsigned*>(e->splitk_ws);
-        p.ks_cnt_n = 16384;
-        p.ks_ws = reinterpret_cast<float*>(static_cast<char*>(e->splitk_ws) + 65536);
-        p.ks_bytes = e->splitk_bytes - 65536;
-    }
 }
 
 // tap-dense K order of the bf16x3 kernels (GatherParams::dense): 3x3 kernels over the full tap grid, contraction channels 8..28

@@ -132,28 +132,10 @@ def dot_fusable(H, W, dtype=torch.float32):
     return FUSE_GRAD and dtype in (torch.float32, torch.float16) and (H * W) % 1024 == 0
 
 
-# Split-K workspace of the bf16x3 direct kernels (gif_conv_epilogue::splitk_ws): one zero-initialised buffer per (device, stream),
-# 64 KB of arrival counters (the kernels hand them back zero) + 128 MB of partial accumulator tiles.
-SPLITK_BYTES = 65536 + (128 << 20)
-_splitk_ws = {}
-
-
-def _splitk_workspace(device):
-    key = (device.index, torch.cuda.current_stream().cuda_stream)
-    ws = _splitk_ws.get(key)
-    if ws is None:
-        ws = torch.zeros((SPLITK_BYTES,), device=device, dtype=torch.uint8)
-        _splitk_ws[key] = ws
-    return ws
-
-
 def _epilogue(in_scale=None, out_scale=None, bias=None, residual=None, act=False, slope=0.2, gain=2 ** 0.5, fuse=None,
-              out_bchw=None, dtype=torch.float32, out_f32=False, device=None):
+              out_bchw=None, dtype=torch.float32, out_f32=False):
     e = _lib.ConvEpilogue(_p(in_scale), _p(out_scale), _p(bias), _p(residual), 1 if act else 0, slope, gain)
     e.out_f32 = 1 if out_f32 else 0
-    if device is not None and dtype == torch.float32:
-        e.splitk_ws = _splitk_workspace(device).data_ptr()
-        e.splitk_bytes = SPLITK_BYTES
     if fuse is not None:
         B, C, H, W = out_bchw
         for t, what in ((fuse.mask_src, "mask_src"), (fuse.dot_src, "dot_src")):
@@ -365,7 +347,7 @@ def conv_fwd(big, w, spec: ConvSpec, wscale=1.0, keep_v=False, **epi):
     # out_f32 (f16 activations only): fp32 result, e.g. the RGB image of ToRGB
     out = empty_nhwc(B, Cs, Hs, Ws, big.device, torch.float32 if epi.get("out_f32") else dt)
     g = _geom(B, Hb, Wb, Cb, Hs, Ws, Cs, spec)
-    e = _epilogue(out_bchw=(B, Cs, Hs, Ws), dtype=dt, device=big.device if x3 else None, **epi)
+    e = _epilogue(out_bchw=(B, Cs, Hs, Ws), dtype=dt, **epi)
     fn = _lib.load().gif_conv2d_fwd_f32x3_tapdense if dense else _lib.load().gif_conv2d_fwd_f32x3 if x3 else _fn("conv2d_fwd", dt)
     _lib.check(fn(big.data_ptr(), wp.data_ptr(), out.data_ptr(), ctypes.byref(g), ctypes.byref(e), _stream()), "conv2d_fwd")
     return out
@@ -387,7 +369,7 @@ def conv_bwd_data(small, w, spec: ConvSpec, big_hw, wscale=1.0, **epi):
     wp = pack_weight(w, False, Cb, Cs, wscale, dt, x3=x3, tapdense=dense)
     out = empty_nhwc(B, Cb, Hb, Wb, small.device, dt)
     g = _geom(B, Hb, Wb, Cb, Hs, Ws, Cs, spec)
-    e = _epilogue(out_bchw=(B, Cb, Hb, Wb), dtype=dt, device=small.device if x3 else None, **epi)
+    e = _epilogue(out_bchw=(B, Cb, Hb, Wb), dtype=dt, **epi)
     fn = (_lib.load().gif_conv2d_bwd_data_f32x3_tapdense if dense else _lib.load().gif_conv2d_bwd_data_f32x3 if x3
           else _fn("conv2d_bwd_data", dt))
     _lib.check(fn(small.data_ptr(), wp.data_ptr(), out.data_ptr(), ctypes.byref(g), ctypes.byref(e), _stream()), "conv2d_bwd_data")

@@ -190,14 +190,6 @@ typedef struct {
     /* f16 entry points only: store the output as fp32 [B,Ho,Wo,Cout] instead of f16 (ToRGB in f16-activation mode: the running RGB
      * image reaches |v| ~ 8, where half precision resolves 3.9e-3 — the skip-connection sum is kept in fp32, it is 3 channels) */
     int32_t out_f32;
-    /* ---- ABI 3: split-K workspace of the bf16x3 direct kernels (optional).  Launches that cannot fill the chip — the 4x4 .. 16x16
-     * layers with 512 channels: 64 - 256 workgroups walking K = 4608 (stylegan2_common_layers.py:343-347 at step <= 2) — deal
-     * their K steps to up to 16 workgroups per output tile; every workgroup parks its fp32 accumulator tile here and the last one
-     * to arrive adds them up IN SPLIT ORDER (deterministic) and runs the epilogue.  Layout: 16384 uint32 arrival counters, zero
-     * on entry and handed back zero, then the partial tiles; one workspace per stream (launches on a stream are ordered).
-     * NULL / too small: the launch does not split. */
-    void* splitk_ws;
-    int64_t splitk_bytes;
 } gif_conv_epilogue;
 int64_t gif_conv_epilogue_ws_floats(int64_t out_rows, int cout);
 

@@ -3,7 +3,6 @@
 * f16 halo convolution (conv_igemm.hip: conv_halo_f16) — the thin high-resolution layers of BASELINE configs[4]
   (stg2_generator.py:159-209 at step 7 / 8, stylegan2_common_layers.py:343-347): against an fp32 ATen-CPU computation on the
   same f16-rounded operands, against the gather kernel it replaces (GIF_F16_HALO=0), with every epilogue form.
-* split-K forward / data-gradient launches of the low-resolution 512-channel layers (bf16x3).
 * loss-scaler window semantics, FlatAdam checkpoint load after loss-scaled steps (advisor findings of round 3)."""
 import os
 
