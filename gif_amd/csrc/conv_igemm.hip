@@ -101,7 +101,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // T2D (the halo kernel): the BM = 256 tile rows are a 16 x 16 patch of output pixels of ONE sample (row = 16 * ly + lx, patch
 // origin (t2_oy0, t2_ox0) of sample t2_b in the launch's output sub-grid) instead of BM consecutive GEMM rows; m0 = tile index * BM
 // only numbers the partial-sum rows.  LDS_FLOATS: floats of LDS the transposition may use (default: the staging buffers).
-template <int BM, int BN, int LD, int MT, int NT, typename T = float, int THREADS = 256, bool T2D = false, int LDS_FLOATS = 0>
+template <int BM, int BN, int LD, int MT, int NT, typename T = float, int THREADS = 256, bool T2D = false, int LDS_FLOATS = 0, int PFMAX = 4>
 __device__ __forceinline__ void conv_epilogue(const GatherParams& p, f32x16 (&acc)[MT][NT], float* smem, int m0, int n0,
                                               int wm0, int wn0, int tid, int li, int lh, int HWp, int t2_b = 0, int t2_oy0 = 0,
                                               int t2_ox0 = 0) {
@@ -146,53 +146,83 @@ __device__ __forceinline__ void conv_epilogue(const GatherParams& p, f32x16 (&ac
         if (n < p.Co) {
             // two copies of the row loop: the plain one carries none of the gradient-producer work (measured on the f16 step, whose
             // MFMA phase is 8x shorter: the extra branches and the running sums cost 2 % of the whole step when they ran always)
+            // The plain row loop, and the gradient-producer one.  In the latter the rows go in batches of PF: FIRST the mask / dot
+            // source loads of the whole batch, THEN the arithmetic and the stores — written as one loop, each row's load sits
+            // behind the previous row's store in program order (the compiler cannot prove that y does not alias the sources) and
+            // every row pays a full memory round trip on its own: the fused data gradient of 128 -> 128 channels at 256^2 took
+            // 0.39 ms longer than the plain one for an 85 us read (round 3: "unexplained").  Only these loads are batched and PF is
+            // 4: batching the residual / scale loads of the plain loop as well, 8 rows deep, cost 50-110 VGPRs per kernel and made
+            // the f16 step 15 % SLOWER (occupancy; r4l).
             auto rows = [&](auto fused_tag) __attribute__((always_inline)) {
                 constexpr bool FUSED = decltype(fused_tag)::value;
+                constexpr int PF = FUSED ? (E_IT < PFMAX ? E_IT : PFMAX) : 1;
+                static_assert(E_IT % PF == 0, "epilogue batches");
+                const bool two_src = FUSED && msk && dsrc && msk != dsrc;
 #pragma unroll 4
-                for (int it = 0; it < E_IT; ++it) {
-                    const int row = e_row0 + it * EROWS;
-                    int b, oy, ox;
-                    if constexpr (T2D) {
-                        const int r2 = c * CR + row;
-                        b = t2_b; oy = t2_oy0 + (r2 >> 4); ox = t2_ox0 + (r2 & 15);
-                        if (oy >= p.Hp || ox >= p.Wp) continue;  // patch overhangs the sub-grid
-                    } else {
-                        const int m = m0 + c * CR + row;
-                        if (m >= p.M) break;
-                        b = m / HWp;
-                        const int rr = m - b * HWp;
-                        oy = rr / p.Wp; ox = rr - oy * p.Wp;
-                    }
-                    size_t o = (((size_t)b * p.Ho + (oy * p.os + p.ooy)) * p.Wo + (ox * p.os + p.oox)) * p.Co + n;
-                    float4 v = *reinterpret_cast<const float4*>(Cs + row * LDC + e_c);
-                    float4 xs = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (FUSED && dsrc) {  // modulation gradient: sum_pixels contraction * x
-                        xs = gif::load4(dsrc + o);
-                        ds.x += v.x * xs.x; ds.y += v.y * xs.y; ds.z += v.z * xs.z; ds.w += v.w * xs.w;
-                    }
-                    if (p.out_scale) {
-                        float4 d = *reinterpret_cast<const float4*>(p.out_scale + (size_t)b * p.Co + n);
-                        v.x *= d.x; v.y *= d.y; v.z *= d.z; v.w *= d.w;
-                    }
-                    if (res) {
-                        float4 rv = gif::load4(res + o);
-                        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-                    }
-                    v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
-                    if (p.act) {
-                        v.x = (v.x > 0.f ? v.x : v.x * p.slope) * p.gain; v.y = (v.y > 0.f ? v.y : v.y * p.slope) * p.gain;
-                        v.z = (v.z > 0.f ? v.z : v.z * p.slope) * p.gain; v.w = (v.w > 0.f ? v.w : v.w * p.slope) * p.gain;
-                    }
-                    if (FUSED) {
-                        if (msk) {  // backward of the leaky ReLU that produced the tensor this gradient belongs to
-                            if (msk != dsrc) xs = gif::load4(msk + o);
-                            v.x *= p.mask_gain * (xs.x > 0.f ? 1.f : p.mask_slope); v.y *= p.mask_gain * (xs.y > 0.f ? 1.f : p.mask_slope);
-                            v.z *= p.mask_gain * (xs.z > 0.f ? 1.f : p.mask_slope); v.w *= p.mask_gain * (xs.w > 0.f ? 1.f : p.mask_slope);
+                for (int it0 = 0; it0 < E_IT; it0 += PF) {
+                    size_t off[PF];
+                    int bs[PF];
+                    bool ok[PF];
+                    float4 xa[PF], xb[PF];
+#pragma unroll
+                    for (int k = 0; k < PF; ++k) {
+                        const int row = e_row0 + (it0 + k) * EROWS;
+                        int b, oy, ox;
+                        if constexpr (T2D) {
+                            const int r2 = c * CR + row;
+                            b = t2_b; oy = t2_oy0 + (r2 >> 4); ox = t2_ox0 + (r2 & 15);
+                            ok[k] = oy < p.Hp && ox < p.Wp;  // else: the patch overhangs the sub-grid
+                        } else {
+                            const int m = m0 + c * CR + row;
+                            ok[k] = m < p.M;
+                            const int mm = ok[k] ? m : 0;
+                            b = mm / HWp;
+                            const int rr = mm - b * HWp;
+                            oy = rr / p.Wp; ox = rr - oy * p.Wp;
                         }
-                        cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
+                        bs[k] = b;
+                        off[k] = (((size_t)b * p.Ho + (oy * p.os + p.ooy)) * p.Wo + (ox * p.os + p.oox)) * p.Co + n;
+                        if constexpr (FUSED) {
+                            xa[k] = xb[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                            if (ok[k]) {
+                                if (dsrc) xa[k] = gif::load4(dsrc + off[k]);          // dot source (also the mask source if they coincide)
+                                else if (msk) xa[k] = gif::load4(msk + off[k]);        // mask source only
+                                if (two_src) xb[k] = gif::load4(msk + off[k]);         // distinct mask source
+                            }
+                        }
                     }
-                    if (sizeof(T) == 2 && p.out_f32) gif::store4(static_cast<float*>(p.y) + o, v);
-                    else gif::store4_flag(yout + o, v, p.sat_flag);
+#pragma unroll
+                    for (int k = 0; k < PF; ++k) {
+                        if (!ok[k]) continue;
+                        const int row = e_row0 + (it0 + k) * EROWS;
+                        float4 v = *reinterpret_cast<const float4*>(Cs + row * LDC + e_c);
+                        if (FUSED && dsrc) {  // modulation gradient: sum_pixels contraction * x
+                            ds.x += v.x * xa[k].x; ds.y += v.y * xa[k].y; ds.z += v.z * xa[k].z; ds.w += v.w * xa[k].w;
+                        }
+                        if (p.out_scale) {
+                            float4 d = *reinterpret_cast<const float4*>(p.out_scale + (size_t)bs[k] * p.Co + n);
+                            v.x *= d.x; v.y *= d.y; v.z *= d.z; v.w *= d.w;
+                        }
+                        if (res) {
+                            float4 rv = gif::load4(res + off[k]);
+                            v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                        }
+                        v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+                        if (p.act) {
+                            v.x = (v.x > 0.f ? v.x : v.x * p.slope) * p.gain; v.y = (v.y > 0.f ? v.y : v.y * p.slope) * p.gain;
+                            v.z = (v.z > 0.f ? v.z : v.z * p.slope) * p.gain; v.w = (v.w > 0.f ? v.w : v.w * p.slope) * p.gain;
+                        }
+                        if (FUSED) {
+                            if (msk) {  // backward of the leaky ReLU that produced the tensor this gradient belongs to
+                                const float4 xs = two_src ? xb[k] : xa[k];
+                                v.x *= p.mask_gain * (xs.x > 0.f ? 1.f : p.mask_slope); v.y *= p.mask_gain * (xs.y > 0.f ? 1.f : p.mask_slope);
+                                v.z *= p.mask_gain * (xs.z > 0.f ? 1.f : p.mask_slope); v.w *= p.mask_gain * (xs.w > 0.f ? 1.f : p.mask_slope);
+                            }
+                            cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
+                        }
+                        if (sizeof(T) == 2 && p.out_f32) gif::store4(static_cast<float*>(p.y) + off[k], v);
+                        else gif::store4_flag(yout + off[k], v, p.sat_flag);
+                    }
                 }
             };
             if (fused) rows(std::true_type{});
@@ -1012,8 +1042,7 @@ __global__ void __launch_bounds__(256, 3) conv_halo_f16(const GatherParams p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[kg][i], bw[kg][j], acc[i][j], 0, 0, 0);
     }
     if (dbg & 4) return;
-    conv_epilogue<BM, BN, 8, MT, NT, T, 256, true, halo_lds_floats<BN, CP>()>(p, acc, smem, tile * BM, 0, wave * 64, 0, tid, li, lh, 0,
-                                                                             b, tyi * TH, txi * TW);
+    conv_epilogue<BM, BN, 8, MT, NT, T, 256, true, halo_lds_floats<BN, CP>()>(p, acc, smem, tile * BM, 0, wave * 64, 0, tid, li, lh, 0, b, tyi * TH, txi * TW);
 }
 
 struct TileCfg {

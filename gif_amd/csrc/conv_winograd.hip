@@ -198,32 +198,60 @@ struct WinoParams {
     float* part_dot;
 };
 
-// the fused tail of both GEMM kernels' epilogues: modulation-gradient dot product, out_scale, residual, bias, activation,
-// leaky-ReLU-backward mask, running column sums
-template <bool FUSED>
-__device__ __forceinline__ f32x4 wino_epilogue_value(const WinoParams& p, f32x4 v, size_t off, int b, int n, const f32x4& bias4,
-                                                     f32x4& cs, f32x4& ds) {
-    f32x4 xs = (f32x4)(0.f);
-    if (FUSED && p.dot_src) {
-        xs = *reinterpret_cast<const f32x4*>(p.dot_src + off);
-        ds += v * xs;
-    }
-    if (p.out_scale) v *= *reinterpret_cast<const f32x4*>(p.out_scale + (size_t)b * p.Co + n);
-    if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + off);
-    v += bias4;
-    if (p.act) {
+// The row loop of both GEMM kernels' epilogues for one output position (oa, ob): modulation-gradient dot product, out_scale,
+// residual, bias, activation, leaky-ReLU-backward mask, running column sums.  Rows go in batches of PF: first every global load
+// of the batch, then the arithmetic and the stores — in one loop each row's loads would sit behind the previous row's store
+// (y may alias the sources as far as the compiler knows) and pay a full memory round trip on their own (conv_igemm.hip).
+template <bool FUSED, int E_IT, int EROWS, int LDC, int PF>
+__device__ __forceinline__ void wino_epilogue_rows(const WinoParams& p, const float* Cs, int m0, int e_row0, int e_c, int n, int oa, int ob,
+                                                   const f32x4& bias4, f32x4& cs, f32x4& ds) {
+    static_assert(E_IT % PF == 0, "epilogue batches");
+    const bool two_src = FUSED && p.mask_src && p.dot_src && p.mask_src != p.dot_src;
+#pragma unroll 1
+    for (int it0 = 0; it0 < E_IT; it0 += PF) {
+        size_t off[PF];
+        bool ok[PF];
+        f32x4 rv[PF], dv[PF], xa[PF], xb[PF];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (v[e] > 0.f ? v[e] : v[e] * p.slope) * p.gain;
-    }
-    if (FUSED) {
-        if (p.mask_src) {
-            if (p.mask_src != p.dot_src) xs = *reinterpret_cast<const f32x4*>(p.mask_src + off);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= p.mask_gain * (xs[e] > 0.f ? 1.f : p.mask_slope);
+        for (int k = 0; k < PF; ++k) {
+            const int m = m0 + e_row0 + (it0 + k) * EROWS;
+            ok[k] = m < p.ntiles;
+            const int mm = ok[k] ? m : 0;
+            const int tx = mm % p.TW, t2 = mm / p.TW;
+            const int ty = t2 % p.TH, b = t2 / p.TH;
+            off[k] = (((size_t)b * p.H + 2 * ty + oa) * p.W + 2 * tx + ob) * p.Co + n;
+            rv[k] = dv[k] = xa[k] = xb[k] = (f32x4)(0.f);
+            if (ok[k]) {
+                if (p.residual) rv[k] = *reinterpret_cast<const f32x4*>(p.residual + off[k]);
+                if (p.out_scale) dv[k] = *reinterpret_cast<const f32x4*>(p.out_scale + (size_t)b * p.Co + n);
+                if (FUSED && p.dot_src) xa[k] = *reinterpret_cast<const f32x4*>(p.dot_src + off[k]);
+                if (FUSED && p.mask_src && !p.dot_src) xa[k] = *reinterpret_cast<const f32x4*>(p.mask_src + off[k]);
+                if (two_src) xb[k] = *reinterpret_cast<const f32x4*>(p.mask_src + off[k]);
+            }
         }
-        cs += v;
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            if (!ok[k]) continue;
+            f32x4 v = *reinterpret_cast<const f32x4*>(Cs + (e_row0 + (it0 + k) * EROWS) * LDC + e_c);
+            if (FUSED && p.dot_src) ds += v * xa[k];
+            if (p.out_scale) v *= dv[k];
+            if (p.residual) v += rv[k];
+            v += bias4;
+            if (p.act) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (v[e] > 0.f ? v[e] : v[e] * p.slope) * p.gain;
+            }
+            if (FUSED) {
+                if (p.mask_src) {
+                    const f32x4 xs = two_src ? xb[k] : xa[k];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= p.mask_gain * (xs[e] > 0.f ? 1.f : p.mask_slope);
+                }
+                cs += v;
+            }
+            *reinterpret_cast<f32x4*>(p.y + off[k]) = v;
+        }
     }
-    return v;
 }
 
 // per-tile partial sums of one workgroup -> row `prow` of part_cs / part_dot (fixed order; smem is free by now)
@@ -435,20 +463,8 @@ __global__ void __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) wino_gemm_mfma(cons
             }
         __syncthreads();
         if (n < p.Co) {
-            const int oa = o >> 1, ob = o & 1;
-#pragma unroll 4
-            for (int it = 0; it < E_IT; ++it) {
-                const int row = e_row0 + it * EROWS;
-                const int m = m0 + row;
-                if (m >= p.ntiles) break;
-                int tx = m % p.TW;
-                int t2 = m / p.TW;
-                int ty = t2 % p.TH, b = t2 / p.TH;
-                size_t off = (((size_t)b * p.H + 2 * ty + oa) * p.W + 2 * tx + ob) * p.Co + n;
-                f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * LDC + e_c);
-                v = fused ? wino_epilogue_value<true>(p, v, off, b, n, bias4, cs, ds) : wino_epilogue_value<false>(p, v, off, b, n, bias4, cs, ds);
-                *reinterpret_cast<f32x4*>(p.y + off) = v;
-            }
+            if (fused) wino_epilogue_rows<true, E_IT, EROWS, LDC, (E_IT < 4 ? E_IT : 4)>(p, Cs, m0, e_row0, e_c, n, o >> 1, o & 1, bias4, cs, ds);
+            else wino_epilogue_rows<false, E_IT, EROWS, LDC, (E_IT < 4 ? E_IT : 4)>(p, Cs, m0, e_row0, e_c, n, o >> 1, o & 1, bias4, cs, ds);
         }
     }
     wino_write_partials<THREADS, C4_ROW, EROWS>(p, smem, tid, n, tm, cs, ds);
@@ -667,20 +683,8 @@ __global__ void __launch_bounds__(512, 1) wino_gemm_x3(const WinoParams p) {
             }
         __syncthreads();
         if (n < p.Co) {
-            const int oa = o >> 1, ob = o & 1;
-#pragma unroll 4
-            for (int it = 0; it < E_IT; ++it) {
-                const int row = e_row0 + it * EROWS;
-                const int m = m0 + row;
-                if (m >= p.ntiles) break;
-                int tx = m % p.TW;
-                int t2 = m / p.TW;
-                int ty = t2 % p.TH, b = t2 / p.TH;
-                size_t off = (((size_t)b * p.H + 2 * ty + oa) * p.W + 2 * tx + ob) * p.Co + n;
-                f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * LDC + e_c);
-                v = fused ? wino_epilogue_value<true>(p, v, off, b, n, bias4, cs, ds) : wino_epilogue_value<false>(p, v, off, b, n, bias4, cs, ds);
-                *reinterpret_cast<f32x4*>(p.y + off) = v;
-            }
+            if (fused) wino_epilogue_rows<true, E_IT, EROWS, LDC, (E_IT < 4 ? E_IT : 4)>(p, Cs, m0, e_row0, e_c, n, o >> 1, o & 1, bias4, cs, ds);
+            else wino_epilogue_rows<false, E_IT, EROWS, LDC, (E_IT < 4 ? E_IT : 4)>(p, Cs, m0, e_row0, e_c, n, o >> 1, o & 1, bias4, cs, ds);
         }
     }
     wino_write_partials<THREADS, C4_ROW, EROWS>(p, smem, tid, n, tm, cs, ds);
