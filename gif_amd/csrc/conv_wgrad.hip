@@ -1052,6 +1052,14 @@ static inline int wgrad_tile_f16(int Cs, int Cb) {
     return m <= 32 ? 32 : (m <= 64 ? 64 : 128);
 }
 
+// 256 x 256 tiles on 8 waves (wave tile 128 x 64) for the f16 weight gradients with multiples of 256 channels on both sides: half
+// the LDS-DMA pieces and 6 instead of 8 operand gathers per MFMA (the 128 x 128 loop is bound by both: DESIGN 3b).  GIF_F16_WGRAD256=0: A/B.
+static inline bool wgrad_tile256_f16(const gif_conv_geom* g, bool scaled) {
+    static const int off = getenv("GIF_F16_WGRAD256") ? atoi(getenv("GIF_F16_WGRAD256")) == 0 : 0;
+    (void)scaled;  // modulated launches too (the per-sample scale table of a 32-pixel stage is 2 KB per sample)
+    return !off && g->Cs % 256 == 0 && g->Cb % 256 == 0 && (long)g->B * g->Hs * g->Ws >= 16384 && ((long)g->Hs * g->Ws) % 32 == 0;
+}
+
 int gif_conv2d_wgrad_dims_f16(int Cs, int Cb, int* RP, int* CP) {
     GIF_REQUIRE(Cs > 0 && Cb > 0 && RP && CP, "wgrad_dims_f16: bad arguments");
     const int t = wgrad_tile_f16(Cs, Cb);
@@ -1065,10 +1073,11 @@ int gif_conv2d_wgrad_splits_f16(const gif_conv_geom* g) {
     if (halo_wgrad_ok(g)) return halo_wgrad_splits(g);  // conv_wgrad_halo_f16: one split per persistent workgroup
     int RP, CP;
     gif_conv2d_wgrad_dims_f16(g->Cs, g->Cb, &RP, &CP);
-    const int t = wgrad_tile_f16(g->Cs, g->Cb);
+    int t = wgrad_tile_f16(g->Cs, g->Cb);
+    if (wgrad_tile256_f16(g, false)) t = 256;
     long Ntot = (long)g->B * g->Hs * g->Ws;
     long tiles = (long)(RP / t) * (CP / t) * g->KH * g->KW;
-    long slots = t == 128 ? 1024 : 2048;  // resident workgroups: 4 per CU at 32 KB of LDS, more for the small tiles
+    long slots = t == 256 ? 512 : t == 128 ? 1024 : 2048;  // resident workgroups: 4 per CU at 32 KB of LDS, more for the small tiles
     long want = tiles >= slots ? 1 : slots / tiles;
     long max_by_work = (Ntot + 4 * BKP_MAX - 1) / (4 * BKP_MAX);
     long max_by_mem = (128L << 20) / ((long)g->KH * g->KW * RP * CP * 4);
@@ -1142,7 +1151,13 @@ int gif_conv2d_wgrad_f16(const void* small, const void* big, float* ws, const fl
         GIF_REQUIRE((size_t)p.stab_nb * 2 * tl * sizeof(float) <= 64 * 1024, "conv2d_wgrad_f16: scale table too large");
         GIF_REQUIRE(HWs % 16 == 0, "conv2d_wgrad_f16: modulated weight gradient needs Hs*Ws %% 16 == 0 (got %ld)", HWs);
     }
-    if (tl == 128) {
+    if (tl == 128 && wgrad_tile256_f16(g, scaled) && (!scaled || (size_t)p.stab_nb * 512 * sizeof(float) <= 32 * 1024)) {
+        p.tiles_q = p.CP / 256;
+        p.tiles_pq = (p.RP / 256) * p.tiles_q;
+        const dim3 g256((unsigned)(p.tiles_pq * p.T * nsplit));
+        if (!scaled) wgrad_launch<gif::f16, 256, 256, 2, 4, true, 32>(g256, 512, s, p);
+        else wgrad_launch<gif::f16, 256, 256, 2, 4, true, 32, true>(g256, 512, s, p);
+    } else if (tl == 128) {
         if (!scaled) wgrad_launch<gif::f16, 128, 128, 2, 2, true, 32>(grid, 256, s, p);
         else if (!st16) wgrad_launch<gif::f16, 128, 128, 2, 2, true, 32, true>(grid, 256, s, p);
         else wgrad_launch<gif::f16, 128, 128, 2, 2, true, 16, true>(grid, 256, s, p);

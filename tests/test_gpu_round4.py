@@ -337,3 +337,25 @@ def test_f16_halo_weight_gradient_modulated():
     (ref,) = torch.autograd.grad(F.conv2d(xs, wl, padding=1), wl, gyd)
     got = ops.conv_wgrad(dev16(gy), dev16(x), ops.ConvSpec(3, 3, 1, 1), C, C, small_scale=d.cuda(), big_scale=s.cuda())
     assert_close(got, ref, 1e-3, "f16 modulated halo wgrad")
+
+
+def test_f16_weight_gradient_256_tiles_plain_and_modulated():
+    """conv_wgrad_mfma<f16, 256, 256> (8 waves, wave tile 128 x 64): layers with multiples of 256 channels on both sides and >= 16384
+    reduction rows; plain and with per-sample scales (the scale table of a 256 x 256 tile)."""
+    from gif_amd import ops
+    g = torch.Generator().manual_seed(51)
+    for (B, Cs, Cb, K, s, p, H) in ((4, 256, 256, 3, 1, 1, 64), (2, 512, 256, 3, 2, 0, 257), (5, 256, 512, 1, 1, 0, 64)):
+        spec = ops.ConvSpec(K, K, s, p)
+        x = r16(torch.randn(B, Cb, H, H, generator=g))
+        hs = spec.small_hw(H, H)[0]
+        gy = r16(torch.randn(B, Cs, hs, hs, generator=g))
+        wl = torch.zeros(Cs, Cb, K, K, requires_grad=True)
+        (ref,) = torch.autograd.grad(F.conv2d(x, wl, stride=s, padding=p), wl, gy)
+        got = ops.conv_wgrad(dev16(gy), dev16(x), spec, Cs, Cb)
+        assert_close(got, ref, 5e-4, f"f16 wgrad on 256x256 tiles {(B, Cs, Cb, K, s, H)}")
+        if s == 1 and (hs * hs) % 32 == 0:
+            sc, d = torch.rand(B, Cb, generator=g) + 0.5, torch.rand(B, Cs, generator=g) + 0.5
+            xs, gyd = r16(x * r16(sc)[:, :, None, None]), r16(gy * r16(d)[:, :, None, None])
+            (refm,) = torch.autograd.grad(F.conv2d(xs, wl, stride=s, padding=p), wl, gyd)
+            gotm = ops.conv_wgrad(dev16(gy), dev16(x), spec, Cs, Cb, small_scale=d.cuda(), big_scale=sc.cuda())
+            assert_close(gotm, refm, 1e-3, f"f16 modulated wgrad on 256x256 tiles {(B, Cs, Cb, K, H)}")
