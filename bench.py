@@ -189,9 +189,11 @@ FAMILIES = {
     2: ("wino_gemm_mfma (Winograd F(2x2,3x3) fwd / dgrad GEMM + fused output transform and epilogue)", WINOGRAD_EXECUTED,
         "wino_gemm_mfma"),
     3: ("conv_wgrad_mfma in planes mode (Winograd F(3x3,2x2) weight-gradient GEMM)", WINOGRAD_EXECUTED, "conv_wgrad_mfma"),
-    6: ("conv_gather_mfma_glds<f16> (f16 fwd / dgrad / stride-2 / transposed conv, v_mfma_f32_32x32x16_f16)", 1.0,
+    6: ("conv_gather_mfma_glds<f16> + conv_halo_f16 (f16 fwd / dgrad / stride-2 / transposed conv, v_mfma_f32_32x32x16_f16; layers with "
+        "<= 64 contraction and output channels on the halo kernel: input patch + halo staged in LDS once, taps by shifted LDS reads)", 1.0,
         "conv_gather_mfma_glds_f16"),
-    7: ("conv_wgrad_mfma<f16> (f16 weight gradient, fp32 accumulation)", 1.0, "conv_wgrad_mfma_f16"),
+    7: ("conv_wgrad_mfma<f16> + conv_wgrad_halo_f16 (f16 weight gradient, fp32 accumulation; 256x256 tiles for multiples of 256 channels, "
+        "persistent halo kernel with transposing LDS reads for <= 32 channels)", 1.0, "conv_wgrad_mfma_f16"),
     8: ("conv_gather_mfma_glds<float, bf16x3> (fp32 direct fwd / dgrad / stride-2 / transposed conv on the bf16 matrix cores: exact "
         "3-way bf16 split of both operands, 6 v_mfma_f32_32x32x16_bf16 products per fp32 product, fp32 accumulation)", BF16X3_EXECUTED,
         "conv_gather_mfma_glds_x3"),
@@ -541,6 +543,8 @@ def main():
                        "algorithmic_tflop_per_image": fl_img / 1e12,
                        "grad_bucket_mb": {"G": trainer.g_bucket.flat.numel() * 4 / 1e6, "D": trainer.d_bucket.flat.numel() * 4 / 1e6},
                        "overlap_comm": bool(trainer.overlap_comm),
+                       "d_step_discriminator_passes": ("one pass over [real; fake] (minibatch-stddev per half; R1 iterations: two calls)"
+                                                       if trainer.fuse_d_passes else "two calls (train.py:142, :169)"),
                        "peak_hbm_allocated_gb": torch.cuda.max_memory_allocated() / 2 ** 30},
             "comm_exposed_ms": comm_ms / args.steps,
             "comm_note": ("one RCCL all-reduce (AVG) per optimiser step over each flat gradient bucket, enqueued right after the backward and "

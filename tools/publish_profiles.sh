@@ -4,10 +4,10 @@
 set -eu
 O=$1; C=$2; R=$3
 cp $O/pmc_traffic.json profiles/pmc_traffic.json
-for f in default default_12steps_no_r1_iteration one_generator_forward_NOT_headline no_tapdense native_fp32_mfma no_gradient_epilogue_fusions config2_batch16 config3_render_plreg f16_256 f16_1024; do
+for f in default default_12steps_no_r1_iteration one_generator_forward_NOT_headline two_discriminator_calls native_fp32_mfma no_gradient_epilogue_fusions config2_batch16 config3_render_plreg f16_256 f16_1024 f16_1024_no_halo_kernels f16_256_wgrad_128_tiles; do
   [ -s $O/bench_$f.json ] && cp $O/bench_$f.json profiles/${R}_bench_$f.json
 done
-for f in raster_bench.txt raster_bench.json f16_error_by_layer.txt x3_power_trace.txt; do [ -s $O/$f ] && cp $O/$f profiles/${R}_$f; done
+for f in raster_bench.txt raster_bench.json f16_error_by_layer.txt x3_power_trace.txt f16_halo_bench.txt f16_wgrad_per_tap_kernel.txt aten_crumbs_f32_256.txt aten_crumbs_f16_1024.txt; do [ -s $O/$f ] && cp $O/$f profiles/${R}_$f; done
 v=$(python -c "import json;d=json.load(open('$O/stats_bench.json'));print(f\"{d['value']:.1f} images/s, {d['ms_per_step']:.1f} ms/step\")")
 { echo "# rocprofv3 --kernel-trace --stats, round ${R#r} (commit $C, bf16x3 default): python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-prof"; echo
   echo "7 training iterations (5 timed + 2 warm-up) at 256x256, batch 32, fp32 tensors; summarised from the rocpd database by tools/rocpd_stats.py."
@@ -26,5 +26,14 @@ fi
 if [ -s $O/shapes_f16.csv ]; then
 { echo "# Per-launch-shape timings, f16 activations at 256x256, batch 32 (round ${R#r}, commit $C): family 6 = f16 conv fwd/dgrad, 7 = f16 wgrad; ALGORITHMIC TFLOP/s"; echo
   python tools/shape_table.py $O/shapes_f16.csv 8; } > profiles/${R}_conv_shapes_f16.md
+fi
+if [ -s $O/kernel_stats_f16_1024.md ]; then
+v=$(python -c "import json;d=json.load(open('$O/stats_bench_f16_1024.json'));print(f\"{d['value']:.1f} images/s, {d['ms_per_step']:.1f} ms/step\")")
+{ echo "# rocprofv3 --kernel-trace --stats, round ${R#r} (commit $C), BASELINE config 5: python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-prof --dtype f16 --res 1024 --batch 8"; echo
+  echo "7 training iterations at 1024x1024, batch 8, f16 activations; bench line of the profiled run: $v (profiler attached)"; echo; cat $O/kernel_stats_f16_1024.md; } > profiles/${R}_kernel_stats_f16_1024.md
+fi
+if [ -s $O/shapes_f16_1024.csv ]; then
+{ echo "# Per-launch-shape timings, f16 activations at 1024x1024, batch 8 (round ${R#r}, commit $C): family 6 = f16 conv fwd/dgrad (halo + gather kernels), 7 = f16 wgrad; ALGORITHMIC TFLOP/s"; echo
+  python tools/shape_table.py $O/shapes_f16_1024.csv 4; } > profiles/${R}_conv_shapes_f16_1024.md
 fi
 echo published $O at $C as $R
