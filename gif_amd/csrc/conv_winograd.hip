@@ -16,6 +16,7 @@
 //      LDS-transposed float4 epilogue, run once per output position (a,b) of the 2x2 tile.
 // HBM traffic: V is 4x the input (written once, read once); MFMA work is 4/9 of the direct convolution.
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.h"
 
@@ -91,6 +92,64 @@ __global__ void __launch_bounds__(256) wino_input_transform(const float* __restr
             *reinterpret_cast<f32x4*>(vout + (r * 4 + 1) * plane) = v1;
             *reinterpret_cast<f32x4*>(vout + (r * 4 + 2) * plane) = v2;
             *reinterpret_cast<f32x4*>(vout + (r * 4 + 3) * plane) = v3;
+        }
+    }
+}
+
+// Variant with vertical reuse (round 4, review item 6 "measure, don't argue"): the 4x4 patches of vertically adjacent tiles share two of
+// their four input rows; wino_input_transform fetches them again (PMC: 1.6x the ideal fetch, served by L2 / Infinity Cache).  Here
+// a lane walks TYB tiles down one tile column and keeps the two shared rows in registers: 8 instead of 16 float4 loads per tile.
+template <int TYB>
+__global__ void __launch_bounds__(256) wino_input_transform_rows(const float* __restrict__ x, const float* __restrict__ scale,
+                                                                 float* __restrict__ V, int B, int H, int W, int C, int CP,
+                                                                 long ntiles_pad) {
+    const int C4 = CP >> 2, TH = H >> 1, TW = W >> 1;
+    const int NYB = (TH + TYB - 1) / TYB;
+    const unsigned total = (unsigned)B * NYB * TW * C4;
+    const size_t plane = (size_t)ntiles_pad * CP;
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % (unsigned)C4);
+        unsigned r = idx / (unsigned)C4;
+        const int tx = (int)(r % (unsigned)TW);
+        r /= (unsigned)TW;
+        const int yb = (int)(r % (unsigned)NYB), b = (int)(r / (unsigned)NYB);
+        const int ty0 = yb * TYB, ty1 = min(ty0 + TYB, TH);
+        const bool pad = c4 * 4 >= C;
+        const float* xb = x + ((size_t)b * H * W) * C + c4 * 4;
+        f32x4 s = (f32x4)(1.f);
+        if (scale && !pad) s = *reinterpret_cast<const f32x4*>(scale + (size_t)b * C + c4 * 4);
+        auto load_row = [&](int iy, f32x4 (&d)[4]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int ix = 2 * tx - 1 + c;
+                const bool ok = !pad && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                d[c] = ok ? *reinterpret_cast<const f32x4*>(xb + ((size_t)iy * W + ix) * C) : (f32x4)(0.f);
+            }
+        };
+        f32x4 d[4][4];
+        load_row(2 * ty0 - 1, d[0]);
+        load_row(2 * ty0, d[1]);
+        for (int ty = ty0; ty < ty1; ++ty) {
+            load_row(2 * ty + 1, d[2]);
+            load_row(2 * ty + 2, d[3]);
+            float* vout = V + ((size_t)(b * TH + ty) * TW + tx) * CP + c4 * 4;
+            f32x4 t[4][4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                t[0][c] = d[0][c] - d[2][c];
+                t[1][c] = d[1][c] + d[2][c];
+                t[2][c] = d[2][c] - d[1][c];
+                t[3][c] = d[1][c] - d[3][c];
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                *reinterpret_cast<f32x4*>(vout + (rr * 4 + 0) * plane) = (t[rr][0] - t[rr][2]) * s;
+                *reinterpret_cast<f32x4*>(vout + (rr * 4 + 1) * plane) = (t[rr][1] + t[rr][2]) * s;
+                *reinterpret_cast<f32x4*>(vout + (rr * 4 + 2) * plane) = (t[rr][2] - t[rr][1]) * s;
+                *reinterpret_cast<f32x4*>(vout + (rr * 4 + 3) * plane) = (t[rr][1] - t[rr][3]) * s;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { d[0][c] = d[2][c]; d[1][c] = d[3][c]; }
         }
     }
 }
@@ -748,6 +807,21 @@ int winograd_input_transform(const float* x, const float* scale, float* V, int B
     long ntiles_pad;
     int CP;
     winograd_padded_dims(ntiles, C, &ntiles_pad, &CP);
+    // The vertical-reuse variant with 8 tiles per lane is the default (profiles/r4_wino_transform_rows.txt: 23.8 -> 23.0 ms/step, HBM bytes
+    // of the transform family 1.10x -> 1.065x the algorithmic count); GIF_WINO_XFORM=tile selects the one-patch-per-lane kernel,
+    // rows4 / rows16 the other depths (A/B).
+    static const int rows = [] {
+        const char* e = getenv("GIF_WINO_XFORM");
+        if (!e) return 8;
+        return !strncmp(e, "rows", 4) ? atoi(e + 4) : 0;
+    }();
+    if (rows == 4 || rows == 8 || rows == 16) {
+        const long lanes = (long)B * ((H / 2 + rows - 1) / rows) * (W / 2) * (CP / 4);
+        if (rows == 4) wino_input_transform_rows<4><<<transform_blocks(lanes), 256, 0, s>>>(x, scale, V, B, H, W, C, CP, ntiles_pad);
+        else if (rows == 8) wino_input_transform_rows<8><<<transform_blocks(lanes), 256, 0, s>>>(x, scale, V, B, H, W, C, CP, ntiles_pad);
+        else wino_input_transform_rows<16><<<transform_blocks(lanes), 256, 0, s>>>(x, scale, V, B, H, W, C, CP, ntiles_pad);
+        return check_launch("winograd_input_transform(rows)");
+    }
     wino_input_transform<<<transform_blocks(ntiles * (CP / 4)), 256, 0, s>>>(x, scale, V, B, H, W, C, CP, ntiles_pad);
     return check_launch("winograd_input_transform");
 }
