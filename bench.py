@@ -575,6 +575,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.res, res_step, args.cpu_batch, args.cpu_threads, args.cpu_timeout)
         print(json.dumps(out), flush=True)
     if use_dist:
+        dist.barrier()  # rank 0 does its side measurements above: the other ranks leave the process group together with it
         dist.destroy_process_group()
 
 
