@@ -26,6 +26,11 @@ class ConvEpilogue(ctypes.Structure):
                 ("dot_src", P), ("dot", P), ("colsum", P), ("red_ws", P), ("out_f32", ctypes.c_int32)]
 
 
+class LinearBankSeg(ctypes.Structure):
+    # one layer of the modulation bank (gif_linear_bank_seg, include/gif_hip.h)
+    _fields_ = [("w", P), ("bias", P), ("s", P), ("gs", P), ("gw", P), ("gbias", P), ("n", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
 GP, EP = ctypes.POINTER(ConvGeom), ctypes.POINTER(ConvEpilogue)
 
 # name -> (restype, argtypes); must list every symbol of include/gif_hip.h (tests/test_abi.py checks it)
@@ -114,6 +119,8 @@ PROTOTYPES = {
     "gif_linear_nt_f32": (c_int, [P, P, P, P] + [c_int] * 7 + [c_float, c_int, c_float, c_float, P]),
     "gif_linear_nn_f32": (c_int, [P, P, P] + [c_int] * 7 + [c_float, P]),
     "gif_linear_tn_f32": (c_int, [P, P, P] + [c_int] * 6 + [c_float, P]),
+    "gif_linear_bank_fwd_f32": (c_int, [P, c_int, c_int, c_int, ctypes.POINTER(LinearBankSeg), c_int, c_float, P]),
+    "gif_linear_bank_bwd_f32": (c_int, [P, c_int, c_int, c_int, ctypes.POINTER(LinearBankSeg), c_int, c_float, P, c_int, c_int, P]),
     "gif_weight_sq_sum_f32": (c_int, [P, P, c_int, c_int, c_int, P]),
     "gif_style_demod_f32": (c_int, [P, P, P] + [c_int] * 7 + [c_float, c_float, P]),
     "gif_style_demod_bwd_s_f32": (c_int, [P] * 6 + [c_int] * 7 + [c_float, P]),

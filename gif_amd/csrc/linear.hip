@@ -39,6 +39,7 @@ struct SkinnyParams {
     const float* E1;
     const float* E2;
     int lde;
+    float* colsum;    // TN: colsum[n] = sum_m A[m][n] (the bias gradient of a linear layer), written by the k-tile 0 wave of each n-tile
 };
 
 constexpr int SK_WAVES = 16;  // waves per workgroup = ways the reduction axis is split
@@ -74,11 +75,10 @@ __device__ __forceinline__ void reduce_store(const SkinnyParams& p, f32x16 acc, 
     }
 }
 
-__global__ void __launch_bounds__(64 * SK_WAVES) skinny_nt_kernel(const SkinnyParams p) {
-    __shared__ float red[SK_WAVES][16][64];
+__device__ __forceinline__ void skinny_nt_body(const SkinnyParams& p, int bx, int by, float (*red)[16][64]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+    const int n0 = bx * 32, m0 = by * 32;
     const bool a_ok = m0 + li < p.M, b_ok = n0 + li < p.N;
     const float* ap = p.A + (size_t)(a_ok ? m0 + li : 0) * p.lda + 4 * lh;
     const float* bp = p.B + (size_t)(b_ok ? n0 + li : 0) * p.ldb + 4 * lh;
@@ -103,6 +103,11 @@ __global__ void __launch_bounds__(64 * SK_WAVES) skinny_nt_kernel(const SkinnyPa
             for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][t], bv[u][t], acc, 0, 0, 0);
     }
     reduce_store(p, acc, red, wave, lane, m0, n0, p.M, p.N, p.cpad, true);
+}
+
+__global__ void __launch_bounds__(64 * SK_WAVES) skinny_nt_kernel(const SkinnyParams p) {
+    __shared__ float red[SK_WAVES][16][64];
+    skinny_nt_body(p, blockIdx.x, blockIdx.y, red);
 }
 
 __global__ void __launch_bounds__(64 * SK_WAVES) skinny_nn_kernel(const SkinnyParams p) {
@@ -142,11 +147,11 @@ __global__ void __launch_bounds__(64 * SK_WAVES) skinny_nn_kernel(const SkinnyPa
 }
 
 // one wave = one 32x32 tile of C[N][K]; the reduction axis (rows m) is short, no split
-__global__ void __launch_bounds__(256) skinny_tn_kernel(const SkinnyParams p) {
+__device__ __forceinline__ void skinny_tn_body(const SkinnyParams& p, int bx) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int tiles_k = (p.K + 31) / 32;
-    const int tile = blockIdx.x * 4 + wave;
+    const int tile = bx * 4 + wave;
     const int tn = tile / tiles_k, tk = tile - tn * tiles_k;
     const int n0 = tn * 32, k0 = tk * 32;
     if (n0 >= p.N) return;
@@ -158,6 +163,7 @@ __global__ void __launch_bounds__(256) skinny_tn_kernel(const SkinnyParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     constexpr int U = 8;
+    float asum = 0.f;  // this lane's half of colsum[n0 + li]: rows m = lh, lh + 2, ... in ascending order
     for (int m0 = 0; m0 < p.M; m0 += 2 * U) {
         float av[U], bv[U];
 #pragma unroll
@@ -170,15 +176,105 @@ __global__ void __launch_bounds__(256) skinny_tn_kernel(const SkinnyParams p) {
                 av[u] *= d * d * d;
             }
             if (p.b_sq) bv[u] *= bv[u];
+            asum += av[u];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+    }
+    if (p.colsum && tk == 0) {  // fixed order: even rows + odd rows
+        const float other = __shfl_xor(asum, 32);
+        if (lh == 0 && a_ok) p.colsum[n0 + li] = asum + other;
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = n0 + (r & 3) + 8 * (r >> 2) + 4 * lh, col = k0 + li;
         if (row < p.N && col < p.K) p.C[(size_t)row * p.ldc + col] = acc[r] * p.scale;
     }
+}
+
+__global__ void __launch_bounds__(256) skinny_tn_kernel(const SkinnyParams p) { skinny_tn_body(p, blockIdx.x); }
+
+// ---- the modulation bank: every ModulatedConv2d's EqualLinear of one generator pass (stylegan2_common_layers.py:311-313 —
+// StyledConv / ToRGB layers, all fed by the same w) as ONE launch forward and TWO backward.  Host-side segment table in the kernel
+// arguments; each segment is one layer's [n, K] weight with its own output / gradient pointers (no concatenated copies).
+constexpr int BANK_MAX = 40;
+struct BankSeg {
+    const float* w;     // [n][K], row stride K
+    const float* bias;  // [n] or NULL
+    float* s;           // forward: [M][n]
+    const float* gs;    // backward: [M][n]
+    float* gw;          // backward: [n][K] or NULL
+    float* gbias;       // backward: [n] or NULL
+    int n;
+    int blk_nt, blk_tn;  // first workgroup of this segment in the NT / TN launch
+    int chunk;           // first 8-wide chunk of this segment on the concatenated reduction axis of the NN launch
+};
+struct BankParams {
+    const float* x;  // [M][K] (ldx)
+    float* gx;       // backward: [M][gx_pad] (ldgx), columns K..gx_pad zero
+    int M, K, ldx, ldgx, gx_pad, nseg, nchunks;
+    float scale;
+    BankSeg seg[BANK_MAX];
+};
+
+__device__ __forceinline__ int bank_find(const BankParams& bp, int v, int BankSeg::*first) {
+    int l = 0;
+    while (l + 1 < bp.nseg && v >= bp.seg[l + 1].*first) ++l;
+    return l;
+}
+
+__global__ void __launch_bounds__(64 * SK_WAVES) linear_bank_nt_kernel(const BankParams bp) {
+    __shared__ float red[SK_WAVES][16][64];
+    const int l = bank_find(bp, blockIdx.x, &BankSeg::blk_nt);
+    const BankSeg& g = bp.seg[l];
+    SkinnyParams p{bp.x, g.w, g.s, g.bias, bp.M, g.n, bp.K, bp.ldx, bp.K, g.n, g.n, bp.scale, 0, 1.f, 1.f};
+    skinny_nt_body(p, blockIdx.x - g.blk_nt, blockIdx.y, red);
+}
+
+__global__ void __launch_bounds__(256) linear_bank_tn_kernel(const BankParams bp) {
+    const int l = bank_find(bp, blockIdx.x, &BankSeg::blk_tn);
+    const BankSeg& g = bp.seg[l];
+    SkinnyParams p{g.gs, bp.x, g.gw, nullptr, bp.M, g.n, bp.K, g.n, bp.ldx, bp.K, bp.K, bp.scale, 0, 1.f, 1.f};
+    p.colsum = g.gbias;
+    skinny_tn_body(p, blockIdx.x - g.blk_tn);
+}
+
+// gx[m][k] = scale * sum over all segments and their n of gs_l[m][n] * w_l[n][k]: skinny_nn over the concatenated reduction axis
+// (chunks of 8 in segment order, split over the 16 waves exactly as in skinny_nn_kernel: the summation order is fixed)
+__global__ void __launch_bounds__(64 * SK_WAVES) linear_bank_nn_kernel(const BankParams bp) {
+    __shared__ float red[SK_WAVES][16][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int k0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+    const bool a_ok = m0 + li < bp.M, b_ok = k0 + li < bp.K;
+    const int arow = a_ok ? m0 + li : 0, bcol = b_ok ? k0 + li : 0;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    constexpr int U = 4;
+    int l = 0;
+    for (int c0 = wave * U; c0 < bp.nchunks; c0 += SK_WAVES * U) {
+        f32x4 av[U];
+        float bv[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = c0 + u;
+            const bool ok = c < bp.nchunks;
+            while (l + 1 < bp.nseg && c >= bp.seg[l + 1].chunk) ++l;
+            const BankSeg& g = bp.seg[l];
+            const int n = 8 * (c - g.chunk) + 4 * lh;  // n % 8 == 0 per segment: a chunk never straddles two layers
+            av[u] = (ok && a_ok) ? *reinterpret_cast<const f32x4*>(g.gs + (size_t)arow * g.n + n) : (f32x4)(0.f);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bv[u][t] = (ok && b_ok) ? g.w[(size_t)(n + t) * bp.K + bcol] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][t], bv[u][t], acc, 0, 0, 0);
+    }
+    SkinnyParams p{};
+    p.C = bp.gx; p.ldc = bp.ldgx; p.scale = bp.scale; p.pad_value = 0.f;
+    reduce_store(p, acc, red, wave, lane, m0, k0, bp.M, bp.K, bp.gx_pad, false);
 }
 
 // wsq[co][ci] = sum_taps W[co][ci][t]^2 (the weight factor of the demodulation, :318) and its gradient back into the weight:
@@ -290,5 +386,62 @@ int gif_linear_tn_f32(const float* A, const float* B, float* C, int M, int N, in
     const int tiles = gif::cdiv(N, 32) * gif::cdiv(K, 32);
     skinny_tn_kernel<<<gif::cdiv(tiles, 4), 256, 0, gif::as_stream(stream)>>>(p);
     return gif::check_launch("linear_tn");
+}
+
+static int bank_fill(BankParams& bp, const gif_linear_bank_seg* segs, int nseg, bool backward, const char* what) {
+    GIF_REQUIRE(segs && nseg > 0 && nseg <= BANK_MAX, "%s: 1..%d segments per launch (got %d)", what, BANK_MAX, nseg);
+    int nt = 0, tn = 0, ch = 0;
+    for (int l = 0; l < nseg; ++l) {
+        const gif_linear_bank_seg& g = segs[l];
+        GIF_REQUIRE(g.w && g.n > 0 && g.n % 8 == 0 && ((uintptr_t)g.w & 15) == 0, "%s: segment %d needs a 16-byte aligned weight and n %% 8 == 0", what, l);
+        GIF_REQUIRE(backward ? (g.gs != nullptr && ((uintptr_t)g.gs & 15) == 0) : g.s != nullptr, "%s: segment %d has no %s", what, l,
+                    backward ? "16-byte aligned gs" : "output");
+        bp.seg[l] = BankSeg{g.w, g.bias, g.s, g.gs, g.gw, g.gbias, g.n, nt, tn, ch};
+        nt += gif::cdiv(g.n, 32);
+        tn += gif::cdiv(gif::cdiv(g.n, 32) * gif::cdiv(bp.K, 32), 4);
+        ch += g.n / 8;
+    }
+    bp.nseg = nseg; bp.nchunks = ch;
+    return 0;
+}
+
+// s_l[M][n_l] = scale * x[M][K] @ w_l[n_l][K]^T + bias_l  for every segment, one launch
+int gif_linear_bank_fwd_f32(const float* x, int M, int K, int ldx, const gif_linear_bank_seg* segs, int nseg, float scale,
+                            gif_stream_t stream) {
+    GIF_REQUIRE(x && M >= 0 && K > 0 && K % 4 == 0 && ldx % 4 == 0 && ldx >= K && ((uintptr_t)x & 15) == 0,
+                "linear_bank_fwd: x must be 16-byte aligned with K and ldx multiples of 4 floats");
+    BankParams bp{};
+    bp.x = x; bp.M = M; bp.K = K; bp.ldx = ldx; bp.scale = scale;
+    if (int rc = bank_fill(bp, segs, nseg, false, "linear_bank_fwd")) return rc;
+    if (M == 0) return 0;
+    const BankSeg& last = bp.seg[nseg - 1];
+    linear_bank_nt_kernel<<<dim3(last.blk_nt + gif::cdiv(last.n, 32), gif::cdiv(M, 32)), 64 * SK_WAVES, 0, gif::as_stream(stream)>>>(bp);
+    return gif::check_launch("linear_bank_fwd");
+}
+
+// gw_l[n_l][K] = scale * gs_l^T @ x,  gbias_l[n_l] = column sums of gs_l  (one launch; either pointer may be NULL in every segment
+// together);  gx[M][gx_pad] = scale * sum_l gs_l @ w_l  (second launch; gx may be NULL)
+int gif_linear_bank_bwd_f32(const float* x, int M, int K, int ldx, const gif_linear_bank_seg* segs, int nseg, float scale, float* gx,
+                            int ldgx, int gx_pad, gif_stream_t stream) {
+    GIF_REQUIRE(x && M >= 0 && K > 0 && ldx >= K, "linear_bank_bwd: bad arguments");
+    GIF_REQUIRE(!gx || (gx_pad >= K && ldgx >= gx_pad), "linear_bank_bwd: gx_pad / ldgx too small");
+    BankParams bp{};
+    bp.x = x; bp.gx = gx; bp.M = M; bp.K = K; bp.ldx = ldx; bp.ldgx = ldgx; bp.gx_pad = gx_pad; bp.scale = scale;
+    if (int rc = bank_fill(bp, segs, nseg, true, "linear_bank_bwd")) return rc;
+    int want_w = 0;
+    for (int l = 0; l < nseg; ++l) want_w += segs[l].gw != nullptr;
+    GIF_REQUIRE(want_w == 0 || want_w == nseg, "linear_bank_bwd: gw must be given for all segments or for none");
+    if (M == 0) return 0;
+    const BankSeg& last = bp.seg[nseg - 1];
+    if (want_w) {
+        const int blocks = last.blk_tn + gif::cdiv(gif::cdiv(last.n, 32) * gif::cdiv(K, 32), 4);
+        linear_bank_tn_kernel<<<blocks, 256, 0, gif::as_stream(stream)>>>(bp);
+        if (int rc = gif::check_launch("linear_bank_bwd (weights)")) return rc;
+    }
+    if (gx) {
+        linear_bank_nn_kernel<<<dim3(gif::cdiv(gx_pad, 32), gif::cdiv(M, 32)), 64 * SK_WAVES, 0, gif::as_stream(stream)>>>(bp);
+        return gif::check_launch("linear_bank_bwd (input)");
+    }
+    return 0;
 }
 }

@@ -383,6 +383,56 @@ def linear_bias_act(x, w, bias=None, scale=1.0, act=False, slope=0.2, gain=1.0, 
     return LinearBiasActFn.apply(x, w, bias, scale, bool(act), slope, gain, n_pad)
 
 
+class LinearBankFn(Function):
+    """(scale * x @ w_l^T + b_l for every layer l) in ONE launch; backward = one launch for all weight and bias gradients plus
+    one for the input gradient (ops.linear_bank_*).  While a backward is being recorded (the path-length regulariser
+    differentiates the modulation twice) the gradients are composed of the any-order pieces LinearNnFn / LinearTnFn instead."""
+
+    @staticmethod
+    def forward(ctx, x, scale, n, *wb):
+        ws, bs = wb[:n], wb[n:]
+        ctx.scale, ctx.n = scale, n
+        ctx.has_bias = [b is not None for b in bs]
+        ctx.save_for_backward(x, *ws)
+        return tuple(ops.linear_bank_fwd(x, ws, bs, scale))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        x, ws = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        n, scale = ctx.n, ctx.scale
+        live = [i for i in range(n) if gs[i] is not None]
+        need_x = ctx.needs_input_grad[0]
+        need_w = [ctx.needs_input_grad[3 + i] for i in range(n)]
+        need_b = [ctx.has_bias[i] and ctx.needs_input_grad[3 + n + i] for i in range(n)]
+        gx, gw, gb = None, [None] * n, [None] * n
+        if not live:
+            return (None, None, None) + tuple(gw) + tuple(gb)
+        if torch.is_grad_enabled():  # create_graph=True: stay differentiable
+            for i in live:
+                if need_x:
+                    t = LinearNnFn.apply(gs[i], ws[i], scale, x.shape[1])
+                    gx = t if gx is None else gx + t
+                if need_w[i]:
+                    gw[i] = LinearTnFn.apply(gs[i], x, scale, ws[i].shape[0], ws[i].shape[1])
+                if need_b[i]:
+                    gb[i] = gs[i].sum(0)
+        else:
+            want_w, want_b = any(need_w[i] for i in live), any(need_b[i] for i in live)
+            gx, gws, gbs = ops.linear_bank_bwd(x, [ws[i] for i in live], [gs[i] for i in live], scale, need_x, want_w, want_b,
+                                               x_cols=x.shape[1])
+            for j, i in enumerate(live):
+                if need_w[i]:
+                    gw[i] = gws[j]
+                if need_b[i]:
+                    gb[i] = gbs[j]
+        return (gx, None, None) + tuple(gw) + tuple(gb)
+
+
+def linear_bank(x, weights, biases, scale):
+    """[scale * x @ w^T + b for (w, b) in zip(weights, biases)] — x [M, K'], w [n, K] (n % 8 == 0), b [n] or None."""
+    return LinearBankFn.apply(x, float(scale), len(weights), *weights, *biases)
+
+
 # --------------------------------------------------------------------------------------------------------
 # style path of ModulatedConv2d (stylegan2_common_layers.py:311-320): demodulation d = rsqrt(scale^2 * s^2 @ wsq^T + eps)
 # --------------------------------------------------------------------------------------------------------

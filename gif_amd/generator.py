@@ -17,7 +17,7 @@ from torch.nn import functional as F
 from . import functional as GF
 from . import ops
 from .data import resize_image
-from .layers import StyledConv, ToRGB, get_w_frm_z
+from .layers import StyledConv, ToRGB, get_w_frm_z, modulation_bank
 
 
 class ConstantInput(nn.Module):
@@ -95,6 +95,13 @@ class Generator(nn.Module):
             inject_index = random.sample(list(range(step)), len(style) - 1)
         crossover = 0
         rgb = None
+        if len(style) < 2 and mixing_range == (-1, -1):
+            # one w for every layer: all modulation linears of this pass in one launch (layers.modulation_bank)
+            convs = []
+            for i in range(self.start_step, min(step, len(self.progression) - 1) + 1):
+                blk = self.progression[i]
+                convs += [blk.st_cv1.conv] + ([] if blk.one_conv_block else [blk.st_cv2.conv]) + [self.to_rgb[i].conv]
+            modulation_bank(convs, style[0])
         for i in range(self.start_step, len(self.progression)):
             if mixing_range == (-1, -1):
                 if crossover < len(inject_index) and i > inject_index[crossover]:

@@ -24,7 +24,18 @@ _SKINNY_MAX_ROWS = int(os.environ.get("GIF_SKINNY_MAX_ROWS", "512"))  # above: t
 def _pad_vec(v, n):
     """flat per-channel vector padded with zeros to n entries (for 3->4 channel RGB tensors)."""
     v = v.reshape(-1)
-    return v if v.numel() == n else F.pad(v, (0, n - v.numel()))
+    k = n - v.numel()
+    if k == 0:
+        return v
+    # cat with a cached zero tail: one launch forward, a view backward (F.pad: fill + copy forward, a copy backward)
+    key = (v.device, v.dtype, k)
+    tail = _ZERO_TAILS.get(key)
+    if tail is None:
+        tail = _ZERO_TAILS[key] = torch.zeros(k, device=v.device, dtype=v.dtype)
+    return torch.cat([v, tail])
+
+
+_ZERO_TAILS = {}
 
 
 class FusedLeakyReLU(nn.Module):
@@ -215,6 +226,8 @@ class ModulatedConv2d(nn.Module):
         return (f'{self.__class__.__name__}({self.in_channel}, {self.out_channel}, {self.kernel_size}, '
                 f'upsample={self.upsample}, downsample={self.downsample})')
 
+    _banked = None  # (style tensor, s) handed over by modulation_bank for the next call of scales()
+
     def scales(self, style, in_act=None, out_act=None):
         """(s [B, in_act], d [B, out_act] or None) in fp32, padded to the activations' channel counts (padded s lanes meet zero
         activations, padded d lanes are 1).  s: one skinny GEMM (EqualLinear); d: one more with the square / rsqrt in its operand
@@ -226,7 +239,10 @@ class ModulatedConv2d(nn.Module):
         if x.dtype != torch.float32:
             x = x.float()
         fast = x.shape[0] <= _SKINNY_MAX_ROWS and self.in_channel % 4 == 0 and in_act <= 1024 and mod.weight.shape[1] % 4 == 0
-        if fast:
+        banked, self._banked = self._banked, None
+        if banked is not None and banked[0] is style and in_act == self.in_channel and fast:
+            s = banked[1]  # computed with every other layer's modulation in one launch (modulation_bank below)
+        elif fast:
             bias = None if mod.bias is None else _pad_vec(mod.bias if mod.lr_mul == 1 else mod.bias * mod.lr_mul, in_act)
             s = GF.linear_bias_act(x, mod.weight, bias, mod.scale, False, 0.2, 1.0, in_act)  # columns >= in_channel: zero
         else:
@@ -236,9 +252,9 @@ class ModulatedConv2d(nn.Module):
         d = None
         if self.demodulate:
             if fast and out_act <= 1024:
-                d = GF.demodulation(s, self.weight[0], self.scale, self.eps, out_act)
+                d = GF.demodulation(s, self.weight.squeeze(0), self.scale, self.eps, out_act)
             else:
-                wsq = self.weight[0].pow(2).sum(dim=(2, 3))  # [Cout, Cin]
+                wsq = self.weight.squeeze(0).pow(2).sum(dim=(2, 3))  # [Cout, Cin]
                 cin, cout = self.in_channel, wsq.shape[0]
                 s2 = s[:, :cin].pow(2)
                 if pad4(cin) != cin:
@@ -258,7 +274,7 @@ class ModulatedConv2d(nn.Module):
         epilogues: same-resolution branch = one MFMA launch; up-sampling branch = conv_transpose + one FIR launch."""
         batch, in_act, height, width = input.shape
         s, d = self._padded_scales(style, in_act, input.dtype)
-        w = self.weight[0]
+        w = self.weight.squeeze(0)
         if self.upsample:
             out = GF.modulated_conv2d(input, w.transpose(0, 1), s, d, stride=2, pad=0, transposed=True,
                                       out_hw=(2 * height + self.kernel_size - 2, 2 * width + self.kernel_size - 2),
@@ -271,7 +287,7 @@ class ModulatedConv2d(nn.Module):
     def forward(self, input, style):
         batch, in_act, height, width = input.shape
         s, d = self._padded_scales(style, in_act, input.dtype)
-        w = self.weight[0]  # [Cout, Cin, k, k]
+        w = self.weight.squeeze(0)  # [Cout, Cin, k, k]
         if self.upsample:
             # conv_transpose2d(x, W^T, stride 2): underlying forward conv maps Cout -> Cin, so canonical = W^T view
             out = GF.modulated_conv2d(input, w.transpose(0, 1), s, d, stride=2, pad=0, transposed=True,
@@ -283,6 +299,30 @@ class ModulatedConv2d(nn.Module):
         else:
             out = GF.modulated_conv2d(input, w, s, d, stride=1, pad=self.padding, wscale=self.scale, out_f32=self.out_fp32)
         return out
+
+
+_STYLE_BANK = os.environ.get("GIF_STYLE_BANK", "1") != "0"
+
+
+def modulation_bank(convs, style):
+    """The modulation linears of `convs` (ModulatedConv2d layers about to be called with the same `style`) as ONE launch
+    (GF.linear_bank; reference: one EqualLinear call per layer, stylegan2_common_layers.py:311-313).  Each layer picks its s up in
+    its next scales() call; layers the bank does not take (odd widths, a different style tensor) compute their own as before."""
+    if not _STYLE_BANK or len(convs) < 2:
+        return
+    x = style.reshape(-1, style.shape[-1])
+    mods = [c.modulation for c in convs]
+    m0 = mods[0]
+    same = all(m.scale == m0.scale and m.lr_mul == 1 and m.bias is not None and m.activation is None and
+               m.weight.shape[1] == m0.weight.shape[1] for m in mods)
+    if not same or x.dtype != torch.float32 or x.shape[0] > _SKINNY_MAX_ROWS or any(c.in_channel > 1024 for c in convs):
+        return
+    weights = [m.weight for m in mods]
+    if not GF.ops.linear_bank_ok(x, weights):
+        return
+    outs = GF.linear_bank(x, weights, [m.bias for m in mods], m0.scale)
+    for c, o in zip(convs, outs):
+        c._banked = (style, o)
 
 
 class NoiseInjection(nn.Module):

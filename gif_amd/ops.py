@@ -748,6 +748,77 @@ def linear_nt(a, b, bias=None, scale=1.0, act=False, slope=0.2, gain=1.0, n_pad=
     return c
 
 
+LINEAR_BANK_MAX = 40  # segments per launch (kernel-argument table, csrc/linear.hip)
+
+
+def linear_bank_ok(x, weights):
+    """The modulation bank takes fp32 [n, K] weights with n % 8 == 0 over one [M, K'] input (K % 4 == 0)."""
+    K = weights[0].shape[1]
+    return (0 < len(weights) <= LINEAR_BANK_MAX and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] >= K and K % 4 == 0
+            and all(w.dim() == 2 and w.shape[1] == K and w.shape[0] % 8 == 0 and w.dtype == torch.float32 for w in weights))
+
+
+def _bank_segs(weights):
+    segs = (_lib.LinearBankSeg * len(weights))()
+    keep = []
+    for g, w in zip(segs, weights):
+        w = _mat(w, "linear_bank")
+        assert w.stride(0) == w.shape[1], "linear_bank: weight rows must be contiguous"
+        keep.append(w)
+        g.w, g.n = w.data_ptr(), w.shape[0]
+    return segs, keep
+
+
+def linear_bank_fwd(x, weights, biases, scale):
+    """[scale * x @ w_l^T + b_l for l]: ONE launch for all layers (gif_linear_bank_fwd_f32)."""
+    lib = _lib.load()
+    x = _mat(x, "linear_bank_fwd")
+    M, K = x.shape[0], weights[0].shape[1]
+    segs, keep = _bank_segs(weights)
+    outs = []
+    for g, w, b in zip(segs, weights, biases):
+        o = torch.empty((M, w.shape[0]), device=x.device, dtype=torch.float32)
+        if b is not None:
+            assert b.dtype == torch.float32 and b.numel() == w.shape[0] and b.is_contiguous()
+            g.bias = b.data_ptr()
+        g.s = o.data_ptr()
+        outs.append(o)
+    _lib.check(lib.gif_linear_bank_fwd_f32(x.data_ptr(), M, K, x.stride(0), segs, len(weights), float(scale), _stream()), "linear_bank_fwd")
+    return outs
+
+
+def linear_bank_bwd(x, weights, grads, scale, want_x, want_w, want_b, x_cols=None):
+    """(gx [M, x_cols] or None, [gw_l] or None, [gb_l] or None) of linear_bank_fwd for the per-layer output gradients `grads`:
+    one launch for all weight / bias gradients, one for gx (gif_linear_bank_bwd_f32)."""
+    lib = _lib.load()
+    x = _mat(x, "linear_bank_bwd")
+    M, K = x.shape[0], weights[0].shape[1]
+    segs, keep = _bank_segs(weights)
+    gws = gbs = None
+    if want_w:
+        gws = [torch.empty_like(w, memory_format=torch.contiguous_format) for w in weights]
+    if want_b:
+        gbs = [torch.empty((w.shape[0],), device=x.device, dtype=torch.float32) for w in weights]
+    if want_b and not want_w:  # the column sums ride on the weight-gradient launch
+        gws = [torch.empty_like(w, memory_format=torch.contiguous_format) for w in weights]
+    for i, (g, w, gs) in enumerate(zip(segs, weights, grads)):
+        gs = gs.contiguous()
+        assert gs.shape == (M, w.shape[0]) and gs.dtype == torch.float32, (gs.shape, gs.dtype)
+        keep.append(gs)
+        g.gs = gs.data_ptr()
+        if gws is not None:
+            g.gw = gws[i].data_ptr()
+        if gbs is not None:
+            g.gbias = gbs[i].data_ptr()
+    gx = None
+    x_cols = K if x_cols is None else x_cols
+    if want_x:
+        gx = torch.empty((M, x_cols), device=x.device, dtype=torch.float32)
+    _lib.check(lib.gif_linear_bank_bwd_f32(x.data_ptr(), M, K, x.stride(0), segs, len(weights), float(scale), _p(gx),
+                                           x_cols, x_cols, _stream()), "linear_bank_bwd")
+    return gx, (gws if want_w else None), gbs
+
+
 def linear_nn(a, b, scale=1.0, n_valid=None, k_pad=None):
     """[M, k_pad] = scale * a[M, :n_valid] @ b[n_valid, K]; columns K..k_pad are zero."""
     lib = _lib.load()

@@ -455,6 +455,30 @@ int gif_linear_nn_f32(const float* A, const float* B, float* C, int M, int N, in
 int gif_linear_tn_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, float scale,
                       gif_stream_t stream);
 
+/* The modulation bank: the EqualLinear of every ModulatedConv2d of one generator pass (stylegan2_common_layers.py:285-286 declares
+ * it, :311-313 applies it; StyledConv :434-462 and ToRGB :465-490 hand every layer the same w at `len(style) < 2`,
+ * stylegan2_common_layers.py Generator.forward) as one launch forward and two backward instead of one / two per layer.
+ * `segs` is a HOST array (copied into the kernel arguments, at most 40 segments per call); each segment is one layer's weight
+ * [n][K] (contiguous rows, n % 8 == 0) with its own output and gradient pointers — nothing is concatenated.
+ *   fwd: s_l[M][n_l]  = scale * x[M][K] . w_l^T + bias_l                    (bias may be NULL)
+ *   bwd: gw_l[n_l][K] = scale * gs_l^T . x,  gbias_l[n_l] = sum_m gs_l[m][:]  (gw for all segments or none; gbias may be NULL)
+ *        gx[M][0:K]   = scale * sum_l gs_l . w_l, columns [K, gx_pad) zero   (gx may be NULL)
+ * Deterministic: fixed summation order (segments in table order on the reduction axis of gx).  (ABI 3) */
+typedef struct gif_linear_bank_seg {
+    const float* w;
+    const float* bias;
+    float* s;
+    const float* gs;
+    float* gw;
+    float* gbias;
+    int n;
+    int reserved;
+} gif_linear_bank_seg;
+int gif_linear_bank_fwd_f32(const float* x, int M, int K, int ldx, const gif_linear_bank_seg* segs, int nseg, float scale,
+                            gif_stream_t stream);
+int gif_linear_bank_bwd_f32(const float* x, int M, int K, int ldx, const gif_linear_bank_seg* segs, int nseg, float scale, float* gx,
+                            int ldgx, int gx_pad, gif_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Fused Adam (+ EMA generator) over the flat gradient bucket — replaces torch.optim.Adam.step() (train.py:173, :243;
  * Adam(lr, betas=(0, 0.99**r)): no weight decay, no amsgrad) and generic_utils.accumulate (my_utils/generic_utils.py:63-76)

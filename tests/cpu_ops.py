@@ -241,7 +241,21 @@ def unpack_nhwc(g, c_off, C):
     return g[:, c_off:c_off + C].float().contiguous(memory_format=CL)
 
 
-OPS = dict(pack_nhwc=pack_nhwc, unpack_nhwc=unpack_nhwc, weight_sq_sum=weight_sq_sum, style_demod=style_demod, style_demod_bwd_s=style_demod_bwd_s, style_demod_bwd_w=style_demod_bwd_w,
+def linear_bank_fwd(x, weights, biases, scale):
+    K = weights[0].shape[1]
+    return [scale * (x[:, :K] @ w.t()) + (0 if b is None else b) for w, b in zip(weights, biases)]
+
+
+def linear_bank_bwd(x, weights, grads, scale, want_x, want_w, want_b, x_cols=None):
+    K = weights[0].shape[1]
+    x_cols = K if x_cols is None else x_cols
+    gx = F.pad(scale * sum(g @ w for g, w in zip(grads, weights)), (0, x_cols - K)) if want_x else None
+    gws = [scale * (g.t() @ x[:, :K]) for g in grads] if want_w else None
+    gbs = [g.sum(0) for g in grads] if want_b else None
+    return gx, gws, gbs
+
+
+OPS = dict(linear_bank_fwd=linear_bank_fwd, linear_bank_bwd=linear_bank_bwd, pack_nhwc=pack_nhwc, unpack_nhwc=unpack_nhwc, weight_sq_sum=weight_sq_sum, style_demod=style_demod, style_demod_bwd_s=style_demod_bwd_s, style_demod_bwd_w=style_demod_bwd_w,
            demod_wgrad=demod_wgrad, resize=resize, linear_nt=linear_nt, linear_nn=linear_nn, linear_tn=linear_tn, nhwc=nhwc, conv_fwd=conv_fwd, conv_bwd_data=conv_bwd_data, conv_wgrad=conv_wgrad, upfirdn2d=upfirdn2d,
            bias_act=bias_act, bias_act_bwd=bias_act_bwd, colsum=colsum, mul_reduce=mul_reduce,
            act_inv_mul_reduce=act_inv_mul_reduce, bilinear_down=bilinear_down, mbstd_fwd=mbstd_fwd, mbstd_bwd=mbstd_bwd,

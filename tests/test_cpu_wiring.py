@@ -395,3 +395,40 @@ def test_fused_discriminator_passes_equal_the_two_calls(cpu):
     assert abs(out[True][5] - out[False][5]) < 1e-4 * max(1.0, abs(out[False][5]))
     for a, b in zip(out[True][1], out[False][1]):
         assert_close(a, b, 2e-5, "D gradients: fused pass vs two calls")
+
+
+def test_modulation_bank_is_one_call_and_equals_the_per_layer_linears(cpu, monkeypatch):
+    """Generator.forward hands every ModulatedConv2d the same w (len(style) < 2): their EqualLinears run as ONE LinearBankFn call
+    (reference: one call per layer, stylegan2_common_layers.py:311-313) — same image, same parameter gradients; two styles
+    (mixing) fall back to the per-layer path."""
+    from gif_amd import functional as GF, layers
+    torch.manual_seed(0)
+    g = _build_g()
+    _seeded(g, 9)
+    gen = torch.Generator().manual_seed(3)
+    cond = torch.rand(2, 6, 16, 16, generator=gen) * 2 - 1
+    idx = torch.tensor([1, 7])
+    calls = []
+    orig = GF.ops.linear_bank_fwd
+    monkeypatch.setattr(GF.ops, "linear_bank_fwd", lambda x, ws, bs, sc: (calls.append(len(ws)), orig(x, ws, bs, sc))[1])
+    out = {}
+    for bank in (True, False):
+        monkeypatch.setattr(layers, "_STYLE_BANK", bank)
+        g.zero_grad(set_to_none=True)
+        img = g(cond, None, step=2, alpha=1, input_indices=idx)[-1]
+        img.pow(2).mean().backward()
+        out[bank] = (img.detach().clone(), {k: p.grad.clone() for k, p in g.named_parameters() if p.grad is not None})
+    assert calls == [8], calls  # 4x4: conv + ToRGB, 8x8 and 16x16: two convs + ToRGB each
+    assert_close(out[True][0], out[False][0], 1e-6, "image: bank vs per-layer modulation")
+    assert out[True][1].keys() == out[False][1].keys()
+    for k in out[False][1]:
+        assert_close(out[True][1][k], out[False][1][k], 2e-5, f"grad {k}: bank vs per-layer modulation")
+    assert all(c.conv._banked is None for c in g.generator.to_rgb), "every banked s was consumed"
+    # two styles: no bank
+    monkeypatch.setattr(layers, "_STYLE_BANK", True)
+    calls.clear()
+    styles = [torch.randn(2, 512, generator=gen), torch.randn(2, 512, generator=gen)]
+    noise = g._condition_pyramid(cond, 2) if hasattr(g, "_condition_pyramid") else None
+    if noise is not None:
+        g.generator(styles, None, noise, step=2, alpha=1)
+        assert calls == []

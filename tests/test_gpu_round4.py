@@ -359,3 +359,89 @@ def test_f16_weight_gradient_256_tiles_plain_and_modulated():
             (refm,) = torch.autograd.grad(F.conv2d(xs, wl, stride=s, padding=p), wl, gyd)
             gotm = ops.conv_wgrad(dev16(gy), dev16(x), spec, Cs, Cb, small_scale=d.cuda(), big_scale=sc.cuda())
             assert_close(gotm, refm, 1e-3, f"f16 modulated wgrad on 256x256 tiles {(B, Cs, Cb, K, H)}")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# modulation bank (csrc/linear.hip: linear_bank_*): every ModulatedConv2d's EqualLinear of a generator pass in one launch
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,widths", [(32, [512, 512, 256, 128, 64]), (5, [16, 24, 32, 8, 512]), (1, [64]), (40, [128] * 27),
+                                      (32, [512] * 13 + [256, 256, 128, 128, 64, 64, 32, 32, 16, 16] + [512] * 4 + [256, 128, 64, 32, 16])])
+def test_linear_bank_kernels_vs_fp64(M, widths):
+    """forward (one launch), weight + bias gradients (one launch), input gradient over the concatenated reduction axis (one
+    launch) against float64 on the host; bit-identical across two runs (fixed summation order)."""
+    from gif_amd import ops
+    g = torch.Generator().manual_seed(M * 100 + len(widths))
+    K, scale = 512, 1.0 / 512 ** 0.5
+    x = torch.randn(M, K, generator=g)
+    ws = [torch.randn(n, K, generator=g) for n in widths]
+    bs = [torch.randn(n, generator=g) if i % 3 else None for i, n in enumerate(widths)]
+    gs = [torch.randn(M, n, generator=g) for n in widths]
+    xd, wd, bd, gd = x.cuda(), [w.cuda() for w in ws], [None if b is None else b.cuda() for b in bs], [t.cuda() for t in gs]
+    assert ops.linear_bank_ok(xd, wd)
+    outs = ops.linear_bank_fwd(xd, wd, bd, scale)
+    outs2 = ops.linear_bank_fwd(xd, wd, bd, scale)
+    for i, (o, o2, w, b) in enumerate(zip(outs, outs2, ws, bs)):
+        ref = scale * (x.double() @ w.double().t()) + (0 if b is None else b.double())
+        assert_close(o, ref.float(), 2e-6, f"bank forward, layer {i} (n={widths[i]})")
+        assert torch.equal(o, o2)
+        assert_close(o, ops.linear_nt(xd, wd[i], bd[i], scale), 1e-6, f"bank vs per-layer kernel, layer {i}")
+    gx, gws, gbs = ops.linear_bank_bwd(xd, wd, gd, scale, True, True, True)
+    gx2, gws2, gbs2 = ops.linear_bank_bwd(xd, wd, gd, scale, True, True, True)
+    ref_gx = scale * sum(t.double() @ w.double() for t, w in zip(gs, ws))
+    assert_close(gx, ref_gx.float(), 3e-6, "bank input gradient")
+    assert torch.equal(gx, gx2)
+    for i, (t, w) in enumerate(zip(gs, ws)):
+        assert_close(gws[i], (scale * (t.double().t() @ x.double())).float(), 2e-6, f"bank weight gradient {i}")
+        assert_close(gbs[i], t.double().sum(0).float(), 2e-6, f"bank bias gradient {i}")
+        assert torch.equal(gws[i], gws2[i]) and torch.equal(gbs[i], gbs2[i])
+    # subsets of the outputs: gx only / weights only
+    gx3, w3, b3 = ops.linear_bank_bwd(xd, wd, gd, scale, True, False, False)
+    assert w3 is None and b3 is None and torch.equal(gx3, gx)
+    gx4, w4, b4 = ops.linear_bank_bwd(xd, wd, gd, scale, False, True, False)
+    assert gx4 is None and b4 is None and all(torch.equal(a, b) for a, b in zip(w4, gws))
+
+
+def test_linear_bank_rejects_what_it_cannot_take():
+    from gif_amd import ops, _lib
+    x = torch.randn(4, 512, device="cuda")
+    assert not ops.linear_bank_ok(x, [torch.randn(12, 512, device="cuda")])          # n % 8
+    assert not ops.linear_bank_ok(x, [torch.randn(16, 512, device="cuda")] * 41)     # table size
+    assert not ops.linear_bank_ok(x.half(), [torch.randn(16, 512, device="cuda")])
+    with pytest.raises(_lib.GifHipError):
+        ops.linear_bank_fwd(x, [torch.randn(12, 512, device="cuda")], [None], 1.0)
+
+
+def test_generator_modulation_bank_vs_per_layer_launches(monkeypatch):
+    """The whole generator with the bank on / off (GIF_STYLE_BANK): same image and gradients to fp32 rounding, recorded
+    (create_graph) backward included; 15 modulation launches become 1 forward (+2 backward)."""
+    import contextlib, io
+    from gif_amd import layers, ops
+    from gif_amd.generator import StyledGenerator
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        G = StyledGenerator(embedding_vocab_size=16, rendered_flame_ascondition=True, normal_maps_as_cond=True).cuda()
+    gen = torch.Generator().manual_seed(1)
+    cond = (torch.rand(4, 6, 64, 64, generator=gen) * 2 - 1).cuda()
+    idx = torch.randint(0, 16, (4,), generator=gen).cuda()
+    out = {}
+    for bank in (True, False):
+        monkeypatch.setattr(layers, "_STYLE_BANK", bank)
+        G.zero_grad(set_to_none=True)
+        img = G(cond, None, step=4, alpha=1, input_indices=idx)[-1]
+        img.pow(2).mean().backward()
+        grads = {k: p.grad.clone() for k, p in G.named_parameters() if p.grad is not None}
+        # recorded backward (path-length form): d/dparams of |d img / d w|^2
+        w = torch.randn(4, 512, device="cuda", generator=torch.Generator(device="cuda").manual_seed(2)).requires_grad_(True)
+        img2 = G.generator([w], None, G._condition_pyramid(cond, 4), step=4, alpha=1)[-1]
+        (gw,) = torch.autograd.grad(img2.sum(), w, create_graph=True)
+        pen = gw.pow(2).sum()
+        pgr = torch.autograd.grad(pen, [p for p in G.generator.parameters()], allow_unused=True)
+        out[bank] = (img.detach(), grads, gw.detach(), pgr)
+    assert_close(out[True][0], out[False][0], 1e-5, "image")
+    for k in out[False][1]:
+        assert_close(out[True][1][k], out[False][1][k], 2e-4, f"grad {k}")
+    assert_close(out[True][2], out[False][2], 1e-4, "d img / d w")
+    for a, b in zip(out[True][3], out[False][3]):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert_close(a, b, 5e-4, "second-order parameter gradient")
