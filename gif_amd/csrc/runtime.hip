@@ -155,7 +155,8 @@ int gif_f16_overflow_watch(int on) {
 }
 
 // 2: gif_conv_epilogue gradient-producer fusions, rasteriser workspace (B, F, H, W)
-// 3: gif_f16_overflow_watch, gif_pack_nhwc / gif_unpack_nhwc, gif_conv2d_f16_halo_eligible (f16 halo kernels), rasteriser clean-workspace per pointer
+// 3: gif_f16_overflow_watch, gif_pack_nhwc / gif_unpack_nhwc, gif_conv2d_f16_halo_eligible (f16 halo kernels), rasteriser clean-workspace per pointer,
+//    gif_linear_bank_fwd / _bwd (modulation bank)
 int gif_abi_version(void) { return 3; }
 
 int gif_set_fp32_mfma_mode(int mode) {
