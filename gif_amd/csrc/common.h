@@ -6,6 +6,12 @@
 
 #include "gif_hip.h"
 
+// Timing probe only (tools/probes/x3_three_products.sh): -DGIF_X3_FIRST_TERM=3 builds the bf16x3 kernels with the three smallest
+// of their six products left out — WRONG numerics (16-bit products), the upper bound of what a two-piece split could buy.
+#ifndef GIF_X3_FIRST_TERM
+#define GIF_X3_FIRST_TERM 0
+#endif
+
 namespace gif {
 
 void set_error(const char* fmt, ...);

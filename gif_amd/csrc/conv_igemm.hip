@@ -720,7 +720,7 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
             constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
             int n = 0, piece = 0;
 #pragma unroll
-            for (int t = 0; t < 6; ++t)
+            for (int t = GIF_X3_FIRST_TERM; t < 6; ++t)
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll

@@ -277,7 +277,7 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const 
                 // smallest terms first; mid*lo, lo*mid, lo*lo (<= 2^-23 of the product) are not formed
                 constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-                for (int t6 = 0; t6 < 6; ++t6)
+                for (int t6 = GIF_X3_FIRST_TERM; t6 < 6; ++t6)
 #pragma unroll
                     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -418,7 +418,7 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const 
             constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
             int n = 0, piece = 0;
 #pragma unroll
-            for (int t6 = 0; t6 < 6; ++t6)
+            for (int t6 = GIF_X3_FIRST_TERM; t6 < 6; ++t6)
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll

@@ -647,17 +647,17 @@ __global__ void __launch_bounds__(512, 1) wino_gemm_x3(const WinoParams p) {
     auto group = [&](int slot, int rbuf, int nq) __attribute__((always_inline)) {
         read_a(rbuf, nq);
         __builtin_amdgcn_sched_barrier(0);
-        mma(slot, 0, 2);  // hi * lo
+        if (GIF_X3_FIRST_TERM == 0) mma(slot, 0, 2);  // hi * lo
         if (!(DBG & 4)) read_b(rbuf, nq, 2);
         __builtin_amdgcn_sched_barrier(0);
-        mma(slot, 1, 1);  // mid * mid
+        if (GIF_X3_FIRST_TERM == 0) mma(slot, 1, 1);  // mid * mid
         if (!(DBG & 2)) split_piece(slot ^ 1, 0);
         __builtin_amdgcn_sched_barrier(0);
         mma(slot, 0, 1);  // hi * mid
         if (!(DBG & 4)) read_b(rbuf, nq, 1);
         if (!(DBG & 2)) split_piece(slot ^ 1, 1);
         __builtin_amdgcn_sched_barrier(0);
-        mma(slot, 2, 0);  // lo * hi
+        if (GIF_X3_FIRST_TERM == 0) mma(slot, 2, 0);  // lo * hi
         if (!(DBG & 2)) split_piece(slot ^ 1, 2);
         __builtin_amdgcn_sched_barrier(0);
         mma(slot, 1, 0);  // mid * hi
