@@ -30,6 +30,20 @@
 
 #include "common.h"
 
+#ifdef GIF_X3_TIMING_PROBE
+// tools/probes/x3_sync_probe.sh: cycles the waves of the bf16x3 direct kernel spend at the mid-stage sync (own DMA wait, barrier), cycles in the K loop, waves
+__device__ unsigned long long g_x3_probe[4];
+extern "C" int gif_debug_x3_probe_read(unsigned long long* out4, int reset) {
+    hipDeviceSynchronize();
+    if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_x3_probe), 32) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[4] = {0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_x3_probe), z, 32) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -441,6 +455,22 @@ __global__ void __launch_bounds__(256) conv_gather_mfma(const GatherParams p) {
 //        16-byte chunks are XOR-swizzled with (row >> 2) & 3, so a B operand is one ds_read_b128 and costs no VALU.
 //        Six v_mfma_f32_32x32x16_bf16 per tile pair and 16 k-values.  On this chip VALU work does NOT hide under the MFMAs
 //        of the same SIMD (measured: time ~ MFMA + VALU), so the split work per MFMA is what bounds the kernel.
+// raw buffer descriptor (stride 0, num_records 2^32 - 1) + LDS-DMA through it: `buffer_load_dwordx4 v, s[rsrc], s_off offen lds`.
+// (The builtins exist in the device pass only; the host pass of this translation unit sees empty stand-ins.)
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t buf_rsrc_t;
+__device__ __forceinline__ buf_rsrc_t make_buf_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0xFFFFFFFFu, 0x00020000);
+}
+__device__ __forceinline__ void buf_load_lds16(buf_rsrc_t r, __attribute__((address_space(3))) void* lds, unsigned voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds, 16, (int)voff, soff, 0, 0);
+}
+#else
+struct buf_rsrc_t {};
+__device__ __forceinline__ buf_rsrc_t make_buf_rsrc(const void*) { return {}; }
+__device__ __forceinline__ void buf_load_lds16(buf_rsrc_t, __attribute__((address_space(3))) void*, unsigned, int) {}
+#endif
+
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool SCALE, int BK, bool X3 = false>
 __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, const int nwg) {
     constexpr bool F16 = sizeof(T) == 2;
@@ -467,7 +497,6 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
     T* As = reinterpret_cast<T*>(smem);  // [2][BM][LD]
     T* Bs = As + 2 * BM * LD;            // [2][BN][LD]
     unsigned short* const B3 = reinterpret_cast<unsigned short*>(Bs);  // X3: [2][3][BN][32] bf16
-    const unsigned short* const pw3 = static_cast<const unsigned short*>(p.wp);
     const T* const px = static_cast<const T*>(p.x);
     const T* const pw = static_cast<const T*>(p.wp);
     const T* const pzero = static_cast<const T*>(p.zero);
@@ -501,6 +530,18 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
 
     int a_iy0[A_IT], a_ix0[A_IT], a_base[A_IT];
     unsigned row_ok = 0;
+    // X3: the activation DMA is `buffer_load_dwordx4 ... offen lds` — per lane and row ONE byte offset (loop invariant) and ONE bit per
+    // tap saying whether that tap's pixel exists; the tap's offset travels in the instruction's SGPR offset and a lane whose pixel is
+    // padding sends an out-of-range offset (the buffer unit then writes zeros into LDS: tools/probes/buffer_lds_oob_probe.hip).  Per
+    // step that is 3 VALU per DMA instruction instead of the ~10 of the bounds checks + 64-bit address + zero-page select below, and
+    // the matrix pipe does not run while a SIMD issues VALU (profiles/r4_pmc_x3.md).  Needs < 2^30 input elements and <= 32 taps.
+    constexpr bool BUF = X3 || F16;  // (the native fp32 kernel keeps 64-bit addresses: it is the entry point for tensors of any size)
+    unsigned a_voff[A_IT], a_mask[A_IT];
+    int min_off = 0;  // most negative tap offset (elements): folded into the buffer base so that the SGPR offsets are >= 0
+    if constexpr (BUF) {
+        const int dyl = p.dy0 + (p.nky - 1) * p.ddy, dxl = p.dx0 + (p.nkx - 1) * p.ddx;
+        min_off = (min(p.dy0, dyl) * p.Wi + min(p.dx0, dxl)) * p.Ci;
+    }
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
         int m = m0 + t_row + it * RPP;
@@ -509,10 +550,24 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
         int b = mm / HWp;
         int r = mm - b * HWp;
         int oy = r / p.Wp, ox = r - oy * p.Wp;
-        a_iy0[it] = oy * p.is;
-        a_ix0[it] = ox * p.is;
-        a_base[it] = ((b * p.Hi + a_iy0[it]) * p.Wi + a_ix0[it]) * p.Ci + src_c4;
-        row_ok |= (ok ? 1u : 0u) << it;
+        if constexpr (BUF) {
+            const int iy0 = oy * p.is, ix0 = ox * p.is;
+            a_voff[it] = (unsigned)(((b * p.Hi + iy0) * p.Wi + ix0) * p.Ci + src_c4) * (unsigned)sizeof(T);
+            if (pair && src_c4 >= p.Ci) ok = false;  // pair mode (one K chunk per tap pair): lanes past the last channel never load
+            unsigned mk = 0;
+            for (int ta = 0; ta < p.nky; ++ta)
+                for (int tb = 0; tb < p.nkx; ++tb) {
+                    const bool v = ok && (unsigned)(iy0 + p.dy0 + ta * p.ddy) < (unsigned)p.Hi &&
+                                   (unsigned)(ix0 + p.dx0 + tb * p.ddx) < (unsigned)p.Wi;
+                    mk |= (v ? 1u : 0u) << (ta * p.nkx + tb);
+                }
+            a_mask[it] = mk;
+        } else {
+            a_iy0[it] = oy * p.is;
+            a_ix0[it] = ox * p.is;
+            a_base[it] = ((b * p.Hi + a_iy0[it]) * p.Wi + a_ix0[it]) * p.Ci + src_c4;
+            row_ok |= (ok ? 1u : 0u) << it;
+        }
     }
     // Modulated convs: the DMA cannot scale data in flight, so the per-sample input scales s[b, 0:Ci) of the (few)
     // samples this tile touches are parked in an LDS table and multiplied into the A fragments after the operand read
@@ -551,31 +606,37 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
     }
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
+    // X3: raw buffer descriptors (stride 0, num_records = 2^32 - 1: validity is the lane's own out-of-range offset)
+    const buf_rsrc_t rs_a = make_buf_rsrc(px + (BUF ? min_off : 0));
+    const buf_rsrc_t rs_b = make_buf_rsrc(p.wp);
+    // f16 weight tile: this lane's byte offset inside a tap's [RP][CP] slice (rows it * RPP further down go through the SGPR offset)
+    const unsigned b_voff = (b_lane_ok && !(pair && src_c4 >= p.Ci)) ? (unsigned)((n0 + t_row) * p.CP + src_c4) * (unsigned)sizeof(T) : 0xFFFFFFFFu;
 
     // pair mode: taps (ld_a, ld_b) and its successor, chosen per lane
     auto issue_pair = [&](int buf) __attribute__((always_inline)) {
         int a1 = ld_a, b1 = ld_b + 1;
         if (b1 == p.nkx) { b1 = 0; ++a1; }
-        const int ta = pair_hi ? a1 : ld_a, tb = pair_hi ? b1 : ld_b;
-        const bool tap_ok = ta < p.nky && src_c4 < p.Ci;
-        const int dy = p.dy0 + ta * p.ddy, dx = p.dx0 + tb * p.ddx;
-        const int widx = (p.ky0 + ta * p.kstep) * p.KW + p.kx0 + tb * p.kstep;
-        const int tap_off = (dy * p.Wi + dx) * p.Ci;
+        // both taps' offsets are wave-uniform (SALU); a lane picks its own by one select
+        const int off0 = ((p.dy0 + ld_a * p.ddy) * p.Wi + p.dx0 + ld_b * p.ddx) * p.Ci - min_off;
+        const int off1 = ((p.dy0 + a1 * p.ddy) * p.Wi + p.dx0 + b1 * p.ddx) * p.Ci - min_off;
+        const int w0 = ((p.ky0 + ld_a * p.kstep) * p.KW + p.kx0 + ld_b * p.kstep) * p.RP * p.CP;
+        const int w1 = ((p.ky0 + a1 * p.kstep) * p.KW + p.kx0 + b1 * p.kstep) * p.RP * p.CP;
+        const unsigned t_lane = (unsigned)(ld_a * p.nkx + ld_b) + (pair_hi ? 1u : 0u);
+        const unsigned tap_bytes = (unsigned)(pair_hi ? off1 : off0) * (unsigned)sizeof(T);
+        const unsigned w_bytes = (unsigned)(pair_hi ? w1 : w0) * (unsigned)sizeof(T);
+        const unsigned past = t_lane < (unsigned)p.ntaps ? 0u : 0xFFFFFFFFu;  // upper half of the last odd tap's chunk
         T* Ad = As + buf * BM * LD + wave * RPW * LD;
         T* Bd = Bs + buf * BN * LD + wave * RPW * LD;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
-            bool ok = ((row_ok >> it) & 1u) && tap_ok && (unsigned)(a_iy0[it] + dy) < (unsigned)p.Hi &&
-                      (unsigned)(a_ix0[it] + dx) < (unsigned)p.Wi;
-            const T* g = ok ? px + (a_base[it] + tap_off) : pzero;
-            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Ad + it * RPP * LD), 16, 0, 0);
+            const unsigned voff = (a_voff[it] + tap_bytes) | (__builtin_amdgcn_ubfe(a_mask[it], t_lane, 1u) - 1u);
+            buf_load_lds16(rs_a, (lptr_t)(Ad + it * RPP * LD), voff, 0);
         }
-        const T* wt = pw + ((size_t)widx * p.RP + n0 + t_row) * p.CP + src_c4;
         if (BN % RPP == 0 || wave * RPW < BN) {
+            const unsigned voff = (b_voff + w_bytes) | past | (b_voff == 0xFFFFFFFFu ? 0xFFFFFFFFu : 0u);
 #pragma unroll
             for (int it = 0; it < B_IT; ++it)
-                __builtin_amdgcn_global_load_lds((gptr_t)((b_lane_ok && tap_ok) ? wt + (size_t)it * RPP * p.CP : pzero),
-                                                 (lptr_t)(Bd + it * RPP * LD), 16, 0, 0);
+                buf_load_lds16(rs_b, (lptr_t)(Bd + it * RPP * LD), voff, it * RPP * p.CP * (int)sizeof(T));
         }
 #pragma unroll
         for (int k = 0; k < 2; ++k)
@@ -588,23 +649,20 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
             const int t = (q * ((65536 + dense_cpt - 1) / dense_cpt)) >> 16;  // q / cpt (exact for q < 128)
             const int ch = (q - t * dense_cpt) * EPC;
             const int ta = (t * 11) >> 5, tb = t - 3 * ta;  // 3x3 tap grid: t / 3, t % 3 (t < 12)
-            const bool tap_ok = t < p.ntaps;
             const int dy = p.dy0 + ta * p.ddy, dx = p.dx0 + tb * p.ddx;
-            const int tap_off = (dy * p.Wi + dx) * p.Ci + ch;
+            const unsigned tap_bytes = (unsigned)((dy * p.Wi + dx) * p.Ci + ch - min_off) * 4u;  // this LANE's tap (garbage past the last tap: masked)
             T* Ad = As + buf * BM * LD + wave * RPW * LD;
 #pragma unroll
             for (int it = 0; it < A_IT; ++it) {
-                bool ok = ((row_ok >> it) & 1u) && tap_ok && (unsigned)(a_iy0[it] + dy) < (unsigned)p.Hi &&
-                          (unsigned)(a_ix0[it] + dx) < (unsigned)p.Wi;
-                const T* g = ok ? px + (a_base[it] + tap_off) : pzero;
-                __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Ad + it * RPP * LD), 16, 0, 0);
+                const unsigned voff = (a_voff[it] + tap_bytes) | (__builtin_amdgcn_ubfe(a_mask[it], (unsigned)t, 1u) - 1u);
+                buf_load_lds16(rs_a, (lptr_t)(Ad + it * RPP * LD), voff, 0);
             }
-            const unsigned short* wt = pw3 + (size_t)ld_step * 3 * p.RP * p.CP;
+            const int so_b = ld_step * 3 * p.RP * p.CP * 2;
 #pragma unroll
             for (int it = 0; it < B3_IT; ++it) {
                 const int blk = wave + it * NWAVES;  // wave-uniform
                 if (B3_BLK % NWAVES == 0 || blk < B3_BLK)
-                    __builtin_amdgcn_global_load_lds((gptr_t)(wt + b3_off[it]), (lptr_t)(B3 + (buf * B3_BLK + blk) * 512), 16, 0, 0);
+                    buf_load_lds16(rs_b, (lptr_t)(B3 + (buf * B3_BLK + blk) * 512), (unsigned)(b3_off[it] * 2), so_b);
             }
             ++ld_step;
         }
@@ -623,22 +681,45 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
         const bool ch_ok = kc + src_c4 < p.Ci;
         T* Ad = As + buf * BM * LD + wave * RPW * LD;  // wave-uniform; lane l lands at +l*16 bytes
         T* Bd = Bs + buf * BN * LD + wave * RPW * LD;
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            bool ok = ((row_ok >> it) & 1u) && ch_ok && (unsigned)(a_iy0[it] + dy) < (unsigned)p.Hi &&
-                      (unsigned)(a_ix0[it] + dx) < (unsigned)p.Wi;
-            const T* g = ok ? px + (a_base[it] + tap_off) : pzero;
-            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Ad + it * RPP * LD), 16, 0, 0);
-        }
         if constexpr (X3) {
-            const unsigned short* wt = pw3 + (size_t)widx * 3 * p.RP * p.CP + kc;
+            const unsigned t_cur = (unsigned)(ld_a * p.nkx + ld_b);            // wave-uniform
+            const int so_a = (tap_off - min_off) * 4;                            // >= 0, wave-uniform
+            const unsigned ch_or = ch_ok ? 0u : 0xFFFFFFFFu;
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) {
+                const unsigned voff = a_voff[it] | (__builtin_amdgcn_ubfe(a_mask[it], t_cur, 1u) - 1u) | ch_or;
+                buf_load_lds16(rs_a, (lptr_t)(Ad + it * RPP * LD), voff, so_a);
+            }
+            const int so_b = (widx * 3 * p.RP * p.CP + kc) * 2;
 #pragma unroll
             for (int it = 0; it < B3_IT; ++it) {
                 const int blk = wave + it * NWAVES;  // wave-uniform
                 if (B3_BLK % NWAVES == 0 || blk < B3_BLK)
-                    __builtin_amdgcn_global_load_lds((gptr_t)(wt + b3_off[it]), (lptr_t)(B3 + (buf * B3_BLK + blk) * 512), 16, 0, 0);
+                    buf_load_lds16(rs_b, (lptr_t)(B3 + (buf * B3_BLK + blk) * 512), (unsigned)(b3_off[it] * 2), so_b);
+            }
+        } else if constexpr (F16) {
+            const unsigned t_cur = (unsigned)(ld_a * p.nkx + ld_b);
+            const int so_a = (tap_off - min_off) * (int)sizeof(T);
+            const unsigned ch_or = ch_ok ? 0u : 0xFFFFFFFFu;
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) {
+                const unsigned voff = a_voff[it] | (__builtin_amdgcn_ubfe(a_mask[it], t_cur, 1u) - 1u) | ch_or;
+                buf_load_lds16(rs_a, (lptr_t)(Ad + it * RPP * LD), voff, so_a);
+            }
+            if (BN % RPP == 0 || wave * RPW < BN) {  // wave-uniform: waves beyond the B tile issue nothing
+                const int so_b = (widx * p.RP * p.CP + kc) * (int)sizeof(T);
+#pragma unroll
+                for (int it = 0; it < B_IT; ++it)
+                    buf_load_lds16(rs_b, (lptr_t)(Bd + it * RPP * LD), b_voff, so_b + it * RPP * p.CP * (int)sizeof(T));
             }
         } else {
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) {
+                bool ok = ((row_ok >> it) & 1u) && ch_ok && (unsigned)(a_iy0[it] + dy) < (unsigned)p.Hi &&
+                          (unsigned)(a_ix0[it] + dx) < (unsigned)p.Wi;
+                const T* g = ok ? px + (a_base[it] + tap_off) : pzero;
+                __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Ad + it * RPP * LD), 16, 0, 0);
+            }
             const T* wt = pw + ((size_t)widx * p.RP + n0 + t_row) * p.CP + kc + src_c4;
             if (BN % RPP == 0 || wave * RPW < BN) {  // wave-uniform: waves beyond the B tile issue nothing
 #pragma unroll
@@ -746,6 +827,10 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
         read_raw(0, 0, 0, 0);
 #pragma unroll
         for (int k = 0; k < NP; ++k) split_piece(0, k);
+#ifdef GIF_X3_TIMING_PROBE
+        long long probe_sync = 0, probe_wait = 0;
+        const long long probe_t0 = clock64();
+#endif
         for (int step = 0; step + 1 < nsteps; ++step) {
             issue(cur ^ 1);
             __builtin_amdgcn_sched_barrier(0);
@@ -755,7 +840,18 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
                 __builtin_amdgcn_sched_barrier(0);
                 group(g & 1, (g + 1) & 1);
             }
+#ifdef GIF_X3_TIMING_PROBE
+            {   // time parked at the mid-stage sync, split into the wave's own DMA wait and the barrier
+                const long long ta = clock64();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const long long tb = clock64();
+                __syncthreads();
+                probe_wait += tb - ta;
+                probe_sync += clock64() - tb;
+            }
+#else
             __syncthreads();
+#endif
             cmp_kc = next_kc(cmp_kc);
             cur ^= 1;
             read_raw(cur, 0, cmp_kc, 0);
@@ -770,6 +866,14 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
             }
             group(g & 1, g + 1 < KG ? (g + 1) & 1 : -1);
         }
+#ifdef GIF_X3_TIMING_PROBE
+        if (lane == 0) {
+            atomicAdd(&g_x3_probe[0], (unsigned long long)probe_wait);
+            atomicAdd(&g_x3_probe[1], (unsigned long long)probe_sync);
+            atomicAdd(&g_x3_probe[2], (unsigned long long)(clock64() - probe_t0));
+            atomicAdd(&g_x3_probe[3], 1ull);
+        }
+#endif
     } else {
     frag_t av[2][MT], bv[2][NT];
     auto frag_read = [&](int buf, int kk, int slot, int kc) __attribute__((always_inline)) {
@@ -1255,6 +1359,11 @@ int launch(GatherParams& p, hipStream_t s) {
     if (p.M <= 0 || p.ntaps <= 0) return 0;
     if ((long)p.B * p.Hi * p.Wi * p.Ci >= (1L << 31) || (long)p.B * p.Ho * p.Wo * p.Co >= (1L << 31)) {
         gif::set_error("conv: tensors of >= 2^31 elements are not supported (32-bit offsets)");
+        return GIF_ENOSUP;
+    }
+    if ((p.x3 || F16) && ((long)p.B * p.Hi * p.Wi * p.Ci * (long)sizeof(T) > (1L << 32) - (1L << 26) || p.nky * p.nkx > 32)) {
+        gif::set_error("conv (%s): the buffer-addressed activation DMA takes < 4 GiB of input and <= 32 taps (%ld elements, %d taps)%s",
+                       F16 ? "f16" : "bf16x3", (long)p.B * p.Hi * p.Wi * p.Ci, p.nky * p.nkx, F16 ? "" : ": use the _f32 entry point");
         return GIF_ENOSUP;
     }
     TileCfg c = pick_cfg<T>(p.Co, p.Ci);
