@@ -196,8 +196,17 @@ X3_TAPDENSE = os.environ.get("GIF_X3_TAPDENSE", "1") != "0"  # tap-dense K order
 X3_MIN_CIN = int(os.environ.get("GIF_X3_MIN_CIN", "24"))  # gif_conv2d_x3_eligible: >= 24 (one zero-padded 32-float K chunk)
 
 
-def x3_conv(dtype, cin_act: int) -> bool:
-    """fp32 conv fwd/dgrad with `cin_act` contraction channels runs on the bf16x3 kernels (mode + eligibility)."""
+X3_MAX_INPUT_BYTES = (1 << 32) - (1 << 26)  # the bf16x3 / f16 kernels address their input through 32-bit buffer offsets (conv_igemm.hip)
+X3_MAX_TAPS = 32
+
+
+def x3_conv(dtype, cin_act: int, src=None, spec=None) -> bool:
+    """fp32 conv fwd/dgrad with `cin_act` contraction channels runs on the bf16x3 kernels (mode + eligibility).  Launches the
+    buffer-addressed DMA does not take (>= 4 GiB of input, more than 32 taps) stay on the native fp32 kernel."""
+    if src is not None and src.numel() * src.element_size() > X3_MAX_INPUT_BYTES:
+        return False
+    if spec is not None and spec.KH * spec.KW > X3_MAX_TAPS:
+        return False
     return dtype == torch.float32 and cin_act >= X3_MIN_CIN and get_fp32_mfma_mode() == "bf16x3"
 
 
@@ -341,8 +350,8 @@ def conv_fwd(big, w, spec: ConvSpec, wscale=1.0, keep_v=False, **epi):
         return conv3x3_winograd(big, w, True, Cs, wscale, keep_v=keep_v, **epi)
     if keep_v:
         return conv_fwd(big, w, spec, wscale, **epi), None
-    x3 = x3_conv(dt, Cb)
-    dense = x3_tapdense(dt, Cb, spec, False, epi, Cs)
+    x3 = x3_conv(dt, Cb, big, spec)
+    dense = x3_tapdense(dt, Cb, spec, False, epi, Cs) and big.numel() * 4 <= X3_MAX_INPUT_BYTES
     wp = pack_weight(w, True, Cs, Cb, wscale, dt, x3=x3, tapdense=dense)
     # out_f32 (f16 activations only): fp32 result, e.g. the RGB image of ToRGB
     out = empty_nhwc(B, Cs, Hs, Ws, big.device, torch.float32 if epi.get("out_f32") else dt)
@@ -364,8 +373,8 @@ def conv_bwd_data(small, w, spec: ConvSpec, big_hw, wscale=1.0, **epi):
     _epi_check(small, epi)
     if (Hb, Wb) == (Hs, Ws) and winograd_eligible(spec, B, Hs, Ws, Cs, Cb, dtype=dt):
         return conv3x3_winograd(small, w, False, Cb, wscale, **epi)
-    x3 = x3_conv(dt, Cs)
-    dense = x3_tapdense(dt, Cs, spec, True, epi, Cb)
+    x3 = x3_conv(dt, Cs, small, spec)
+    dense = x3_tapdense(dt, Cs, spec, True, epi, Cb) and small.numel() * 4 <= X3_MAX_INPUT_BYTES
     wp = pack_weight(w, False, Cb, Cs, wscale, dt, x3=x3, tapdense=dense)
     out = empty_nhwc(B, Cb, Hb, Wb, small.device, dt)
     g = _geom(B, Hb, Wb, Cb, Hs, Ws, Cs, spec)
