@@ -553,7 +553,6 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
         if constexpr (BUF) {
             const int iy0 = oy * p.is, ix0 = ox * p.is;
             a_voff[it] = (unsigned)(((b * p.Hi + iy0) * p.Wi + ix0) * p.Ci + src_c4) * (unsigned)sizeof(T);
-            if (pair && src_c4 >= p.Ci) ok = false;  // pair mode (one K chunk per tap pair): lanes past the last channel never load
             unsigned mk = 0;
             for (int ta = 0; ta < p.nky; ++ta)
                 for (int tb = 0; tb < p.nkx; ++tb) {
@@ -562,11 +561,12 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
                     mk |= (v ? 1u : 0u) << (ta * p.nkx + tb);
                 }
             a_mask[it] = mk;
-        } else {
+        }
+        if constexpr (!BUF || F16) {  // native fp32 kernel; f16: the tap-pair mode below (per-lane taps through the buffer unit measured 9 % slower)
             a_iy0[it] = oy * p.is;
             a_ix0[it] = ox * p.is;
             a_base[it] = ((b * p.Hi + a_iy0[it]) * p.Wi + a_ix0[it]) * p.Ci + src_c4;
-            row_ok |= (ok ? 1u : 0u) << it;
+            row_ok |= ((m < p.M) ? 1u : 0u) << it;
         }
     }
     // Modulated convs: the DMA cannot scale data in flight, so the per-sample input scales s[b, 0:Ci) of the (few)
@@ -610,33 +610,32 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
     const buf_rsrc_t rs_a = make_buf_rsrc(px + (BUF ? min_off : 0));
     const buf_rsrc_t rs_b = make_buf_rsrc(p.wp);
     // f16 weight tile: this lane's byte offset inside a tap's [RP][CP] slice (rows it * RPP further down go through the SGPR offset)
-    const unsigned b_voff = (b_lane_ok && !(pair && src_c4 >= p.Ci)) ? (unsigned)((n0 + t_row) * p.CP + src_c4) * (unsigned)sizeof(T) : 0xFFFFFFFFu;
+    const unsigned b_voff = b_lane_ok ? (unsigned)((n0 + t_row) * p.CP + src_c4) * (unsigned)sizeof(T) : 0xFFFFFFFFu;
 
     // pair mode: taps (ld_a, ld_b) and its successor, chosen per lane
     auto issue_pair = [&](int buf) __attribute__((always_inline)) {
         int a1 = ld_a, b1 = ld_b + 1;
         if (b1 == p.nkx) { b1 = 0; ++a1; }
-        // both taps' offsets are wave-uniform (SALU); a lane picks its own by one select
-        const int off0 = ((p.dy0 + ld_a * p.ddy) * p.Wi + p.dx0 + ld_b * p.ddx) * p.Ci - min_off;
-        const int off1 = ((p.dy0 + a1 * p.ddy) * p.Wi + p.dx0 + b1 * p.ddx) * p.Ci - min_off;
-        const int w0 = ((p.ky0 + ld_a * p.kstep) * p.KW + p.kx0 + ld_b * p.kstep) * p.RP * p.CP;
-        const int w1 = ((p.ky0 + a1 * p.kstep) * p.KW + p.kx0 + b1 * p.kstep) * p.RP * p.CP;
-        const unsigned t_lane = (unsigned)(ld_a * p.nkx + ld_b) + (pair_hi ? 1u : 0u);
-        const unsigned tap_bytes = (unsigned)(pair_hi ? off1 : off0) * (unsigned)sizeof(T);
-        const unsigned w_bytes = (unsigned)(pair_hi ? w1 : w0) * (unsigned)sizeof(T);
-        const unsigned past = t_lane < (unsigned)p.ntaps ? 0u : 0xFFFFFFFFu;  // upper half of the last odd tap's chunk
+        const int ta = pair_hi ? a1 : ld_a, tb = pair_hi ? b1 : ld_b;
+        const bool tap_ok = ta < p.nky && src_c4 < p.Ci;
+        const int dy = p.dy0 + ta * p.ddy, dx = p.dx0 + tb * p.ddx;
+        const int widx = (p.ky0 + ta * p.kstep) * p.KW + p.kx0 + tb * p.kstep;
+        const int tap_off = (dy * p.Wi + dx) * p.Ci;
         T* Ad = As + buf * BM * LD + wave * RPW * LD;
         T* Bd = Bs + buf * BN * LD + wave * RPW * LD;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
-            const unsigned voff = (a_voff[it] + tap_bytes) | (__builtin_amdgcn_ubfe(a_mask[it], t_lane, 1u) - 1u);
-            buf_load_lds16(rs_a, (lptr_t)(Ad + it * RPP * LD), voff, 0);
+            bool ok = ((row_ok >> it) & 1u) && tap_ok && (unsigned)(a_iy0[it] + dy) < (unsigned)p.Hi &&
+                      (unsigned)(a_ix0[it] + dx) < (unsigned)p.Wi;
+            const T* g = ok ? px + (a_base[it] + tap_off) : pzero;
+            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Ad + it * RPP * LD), 16, 0, 0);
         }
+        const T* wt = pw + ((size_t)widx * p.RP + n0 + t_row) * p.CP + src_c4;
         if (BN % RPP == 0 || wave * RPW < BN) {
-            const unsigned voff = (b_voff + w_bytes) | past | (b_voff == 0xFFFFFFFFu ? 0xFFFFFFFFu : 0u);
 #pragma unroll
             for (int it = 0; it < B_IT; ++it)
-                buf_load_lds16(rs_b, (lptr_t)(Bd + it * RPP * LD), voff, it * RPP * p.CP * (int)sizeof(T));
+                __builtin_amdgcn_global_load_lds((gptr_t)((b_lane_ok && tap_ok) ? wt + (size_t)it * RPP * p.CP : pzero),
+                                                 (lptr_t)(Bd + it * RPP * LD), 16, 0, 0);
         }
 #pragma unroll
         for (int k = 0; k < 2; ++k)

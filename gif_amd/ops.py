@@ -197,15 +197,12 @@ X3_MIN_CIN = int(os.environ.get("GIF_X3_MIN_CIN", "24"))  # gif_conv2d_x3_eligib
 
 
 X3_MAX_INPUT_BYTES = (1 << 32) - (1 << 26)  # the bf16x3 / f16 kernels address their input through 32-bit buffer offsets (conv_igemm.hip)
-X3_MAX_TAPS = 32
 
 
 def x3_conv(dtype, cin_act: int, src=None, spec=None) -> bool:
     """fp32 conv fwd/dgrad with `cin_act` contraction channels runs on the bf16x3 kernels (mode + eligibility).  Launches the
-    buffer-addressed DMA does not take (>= 4 GiB of input, more than 32 taps) stay on the native fp32 kernel."""
+    buffer-addressed DMA does not take (>= 4 GiB of input) stay on the native fp32 kernel."""
     if src is not None and src.numel() * src.element_size() > X3_MAX_INPUT_BYTES:
-        return False
-    if spec is not None and spec.KH * spec.KW > X3_MAX_TAPS:
         return False
     return dtype == torch.float32 and cin_act >= X3_MIN_CIN and get_fp32_mfma_mode() == "bf16x3"
 
