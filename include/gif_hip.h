@@ -61,10 +61,7 @@ int gif_get_fp32_mfma_mode(void);
  * The mode above is only the default a host should honour; the kernels are selected by the entry point.
  * Weights are pre-split once per optimiser step: gif_pack_weight_f32x3 writes wp3[tap][3][RP][CP] bf16 (hi, mid, lo planes;
  * RP/CP from gif_conv2d_pack_dims_x3; 6 bytes per padded element).  Activations are split inside the kernels after the LDS
- * read.  Layers with fewer than 24 input channels stay on the native kernels (gif_conv2d_x3_eligible() == 0).
- * Size limit (round 4): the bf16x3 and the f16 direct kernels address the tensor they gather from through 32-bit buffer offsets
- * (`buffer_load ... lds`, padding = an out-of-range lane offset): that tensor must be smaller than 4 GiB - 64 MiB (GIF_ENOSUP
- * otherwise; the _f32 entry points keep 64-bit addresses and take up to 2^31 - 1 elements). */
+ * read.  Layers with fewer than 24 input channels stay on the native kernels (gif_conv2d_x3_eligible() == 0). */
 int gif_conv2d_x3_eligible(int cout, int cin);
 int gif_conv2d_pack_dims_x3(int cout, int cin, int* RP, int* CP); /* like gif_conv2d_pack_dims; CP a multiple of 32 */
 int gif_pack_weight_f32x3(const float* w, void* wp3, int R, int C, int KH, int KW, int RP, int CP, int64_t sr, int64_t sc,
