@@ -155,4 +155,48 @@ __device__ __forceinline__ void split_pair_scalar(const float a0, const float a1
     lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{s0, s1}, bf16x2_t));
 }
 
+// ---- f16x2 ("h2"): fp32 contractions as THREE f16 MFMA products under per-row power-of-two scales ---------------
+// x * 2^e = hi + lo, hi = rne_f16(x * 2^e), lo = rne_f16(x * 2^e - hi): 11 + 11 significand bits while lo stays in f16's normal
+// range, an absolute floor of 2^-25 (half the f16 denormal quantum: v_mfma_f32_32x32x16_f16 keeps denormal inputs on gfx950,
+// tools/probes/f16x2_hw_probe.hip) below it.  a * b ~ hi*hi + hi*lo + lo*hi (the dropped lo*lo is <= 2^-22 of the product), fp32
+// accumulation, result * 2^-(e_a + e_b).  The exponent e belongs to a ROW of the GEMM (it factors out of the dot product):
+//   weights: one exponent per packed row, chosen by the packing kernel (row maximum -> [2^14, 2^15));
+//   activations: a RUNNING exponent per row inside the kernel: a new row maximum is scaled into [2^13, 2^14) and the row's
+//   accumulators are multiplied by the (exact) power of two; later elements may grow 4x before the next rescale.
+// Guard ("window"): every 16-element K group of every operand row must lie within 2^-kH2Window of the row maximum (all-zero groups
+// excepted) — then the group's largest element carries >= 22 bits.  A launch that sees a narrower group raises its gate word and
+// is recomputed by the bf16x3 kernel (gated relaunch: the bf16x3 launch that follows returns at once unless the gate is raised).
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+constexpr int kH2Target = 13;        // activations: a new row maximum lands in [2^13, 2^14)
+constexpr int kH2TargetW = 14;       // weights (static): the row maximum lands in [2^14, 2^15)
+constexpr float kH2Limit = 65472.f;  // rescale before |x| * 2^e reaches the f16 overflow threshold (65520)
+constexpr int kH2Window = 14;        // activations: exponent-field distance (row maximum, smallest non-zero group maximum) allowed
+constexpr int kH2WindowW = 16;       // weights: one binade more headroom comes from the tighter scaling target
+// exponent e with m * 2^e in [2^target, 2^(target+1)), clamped to what a float scale factor can hold
+__device__ __host__ __forceinline__ int h2_exp_for(unsigned m_bits, int target) {
+    const int e = target + 127 - (int)((m_bits >> 23) & 0xffu);
+    return e > 126 ? 126 : (e < -126 ? -126 : e);
+}
+__device__ __forceinline__ float h2_pow2(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }  // -126 <= e <= 127
+// one pair of floats -> the packed {x1, x0} f16 dwords of the two terms (6 VALU: pk_mul, cvt_pk, 2 cvt, pk_fma / 2 sub, cvt_pk)
+__device__ __forceinline__ void split_pair_h2(const float a0, const float a1, const float sc, unsigned& hi, unsigned& lo) {
+    const float x0 = a0 * sc, x1 = a1 * sc;
+    const f16x2_t h = __builtin_convertvector(f32x2_t{x0, x1}, f16x2_t);
+    const float r0 = x0 - (float)h[0], r1 = x1 - (float)h[1];  // exact: the rounding residual of an fp32 value fits fp32
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{r0, r1}, f16x2_t));
+}
+// header of an f16x2 weight packing: int32 exponents of the RP rows, then kH2HdrExtra ints (the first one is the "a 16-element
+// group of some row is narrower than the window" flag); the f16 planes follow.
+constexpr int kH2HdrExtra = 32;
+inline size_t h2_header_bytes(int RP) { return (size_t)(RP + kH2HdrExtra) * sizeof(int); }
+// gate words of the guarded launches (runtime.hip): a ring of device words and a generation counter — a kernel raises a gate with
+// atomicMax(gate, gen), the fallback launch runs iff *gate == gen; a word is reused 65536 launches later under a larger gen.
+struct H2Gate {
+    unsigned* word;
+    unsigned gen;
+};
+H2Gate h2_next_gate();        // {NULL, 0} when the guard is switched off (GIF_H2_GUARD=0)
+unsigned* h2_stats_words();   // [0] fallback launches taken, [1] guarded launches flagged by the weight packing
+
 }  // namespace gif

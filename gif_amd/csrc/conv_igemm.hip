@@ -76,7 +76,11 @@ struct GatherParams {
     int stab_nb, stab_stride;  // LDS table of per-sample input scales (LDS-DMA kernel): samples per tile, row stride
     const void* zero;          // 16 zero bytes in HBM: source of the LDS-DMA lanes that fall outside the tensor
     int m_begin;               // first GEMM row of this launch (a launch may cover only rows [m_begin, M))
-    int x3;                    // fp32 only: wp is the pre-split bf16x3 packing, run the bf16 matrix-core kernels
+    int x3;                    // fp32 only: 1 = wp is the pre-split bf16x3 packing, run the bf16 matrix-core kernels; 2 = f16x2 packing (planes only)
+    const int* wexp;           // f16x2: exponents of the packed weight rows (the packing's header)
+    unsigned* gate;            // f16x2: word the kernel raises (atomicMax with gate_gen) when a K group leaves the precision window;
+    unsigned gate_gen;         //        bf16x3 launch with a gate: the guarded fallback — it runs iff *gate == gate_gen
+    unsigned* h2_stats;        // [0] += 1 by a fallback launch that runs
     // gradient-producer fusions (gif_conv_epilogue ABI 2, see gif_hip.h): mask of the leaky ReLU this gradient flows into, and
     // per-tile partial sums (row part_row0 + tile_m of part_cs / part_dot, [rows][Co]) of the stored values / of contraction * dot_src
     const void* mask_src;
@@ -471,7 +475,7 @@ __device__ __forceinline__ buf_rsrc_t make_buf_rsrc(const void*) { return {}; }
 __device__ __forceinline__ void buf_load_lds16(buf_rsrc_t, __attribute__((address_space(3))) void*, unsigned, int) {}
 #endif
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool SCALE, int BK, bool X3 = false>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool SCALE, int BK, int X3 = 0>
 __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, const int nwg) {
     constexpr bool F16 = sizeof(T) == 2;
     static_assert(!X3 || !F16, "the split path is an fp32 mode");
@@ -489,14 +493,24 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
     constexpr int A_IT = BM / RPP, B_IT = (BN + RPP - 1) / RPP;
     static_assert((NWAVES == 4 || NWAVES == 8) && BM % RPP == 0 && (X3 || BN % RPP == 0 || BN < RPP), "tile config");
     static_assert(BK * sizeof(T) == 128, "only 128-byte rows are validated (a 64-byte-row variant measured 8-10 % slower)");
-    // X3: pre-split weight tiles, [2][3][BN][32] bf16 in 1-KiB DMA blocks of 16 rows
-    constexpr int B3_BLK = 3 * BN / 16;                      // blocks per stage
+    // X3: pre-split weight tiles, [2][NPL][BN][32] 16-bit elements in 1-KiB DMA blocks of 16 rows; NPL = 3 bf16 planes (hi, mid, lo
+    // of bf16x3) or 2 f16 planes (hi, lo of f16x2 — H2, common.h)
+    constexpr bool H2 = X3 == 2;
+    constexpr int NPL = H2 ? 2 : 3;
+    constexpr int B3_BLK = NPL * BN / 16;                    // blocks per stage
     constexpr int B3_IT = (B3_BLK + NWAVES - 1) / NWAVES;    // blocks per wave and stage
 
+    if constexpr (X3 == 1) {
+        // guarded fallback of an f16x2 launch (common.h): nothing to do unless that launch (or the weight packing) raised the gate
+        if (p.gate) {
+            if (*p.gate != p.gate_gen) return;
+            if (bid == 0 && threadIdx.x == 0 && p.h2_stats) atomicAdd(p.h2_stats, 1u);
+        }
+    }
     extern __shared__ __attribute__((aligned(16))) float smem[];
     T* As = reinterpret_cast<T*>(smem);  // [2][BM][LD]
     T* Bs = As + 2 * BM * LD;            // [2][BN][LD]
-    unsigned short* const B3 = reinterpret_cast<unsigned short*>(Bs);  // X3: [2][3][BN][32] bf16
+    unsigned short* const B3 = reinterpret_cast<unsigned short*>(Bs);  // X3: [2][NPL][BN][32] bf16 / f16
     const T* const px = static_cast<const T*>(p.x);
     const T* const pw = static_cast<const T*>(p.wp);
     const T* const pzero = static_cast<const T*>(p.zero);
@@ -524,7 +538,7 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
     // (Ci = 8) zero padding.  Instead K runs densely over (tap, channel): 16-byte chunk q = 8 * step + lane chunk belongs to tap
     // q / (Ci/4), channels 4 * (q % (Ci/4)).. — each DMA lane fetches its own tap's pixel; the weights are packed in the same order
     // (gif_pack_weight_f32x3_tapdense).  9 taps of 24 channels = 7 steps instead of 9, of 12 channels = 4, of 8 channels = 3.
-    const int dense_cpt = X3 ? p.dense : 0;
+    const int dense_cpt = X3 == 1 ? p.dense : 0;
     const int src_c4 = dense_cpt ? 0 : (pair ? (lchunk & (CH / 2 - 1)) : lchunk) * EPC;
     const bool b_lane_ok = (BN % RPP == 0) || t_row < BN;
 
@@ -573,7 +587,7 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
     // samples this tile touches are parked in an LDS table and multiplied into the A fragments after the operand read
     // ("weight modulation" applied on the activation side; algebraically identical).  Filled BEFORE the first DMA so no
     // ordinary global load is outstanding while DMAs are in flight (hipcc would drain them with vmcnt(0)).
-    T* Stab = X3 ? reinterpret_cast<T*>(B3 + 2 * 3 * BN * 32) : As + 2 * (BM + BN) * LD;  // [stab_nb][stab_stride], row tails zeroed
+    T* Stab = X3 ? reinterpret_cast<T*>(B3 + 2 * NPL * BN * 32) : As + 2 * (BM + BN) * LD;  // [stab_nb][stab_stride], row tails zeroed
     int s_row[MT];
     if (SCALE) {
         const int b_first = m0 / HWp;
@@ -643,7 +657,7 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
     };
     int ld_step = 0;
     auto issue_dense = [&](int buf) __attribute__((always_inline)) {
-        if constexpr (X3) {
+        if constexpr (X3 == 1) {
             const int q = ld_step * CH + lchunk;
             const int t = (q * ((65536 + dense_cpt - 1) / dense_cpt)) >> 16;  // q / cpt (exact for q < 128)
             const int ch = (q - t * dense_cpt) * EPC;
@@ -656,7 +670,7 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
                 const unsigned voff = (a_voff[it] + tap_bytes) | (__builtin_amdgcn_ubfe(a_mask[it], (unsigned)t, 1u) - 1u);
                 buf_load_lds16(rs_a, (lptr_t)(Ad + it * RPP * LD), voff, 0);
             }
-            const int so_b = ld_step * 3 * p.RP * p.CP * 2;
+            const int so_b = ld_step * NPL * p.RP * p.CP * 2;
 #pragma unroll
             for (int it = 0; it < B3_IT; ++it) {
                 const int blk = wave + it * NWAVES;  // wave-uniform
@@ -670,7 +684,7 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
         if constexpr (F16 && !X3) {
             if (pair) { issue_pair(buf); return; }
         }
-        if constexpr (X3) {
+        if constexpr (X3 == 1) {
             if (dense_cpt) { issue_dense(buf); return; }
         }
         const int dy = p.dy0 + ld_a * p.ddy, dx = p.dx0 + ld_b * p.ddx;
@@ -689,7 +703,7 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
                 const unsigned voff = a_voff[it] | (__builtin_amdgcn_ubfe(a_mask[it], t_cur, 1u) - 1u) | ch_or;
                 buf_load_lds16(rs_a, (lptr_t)(Ad + it * RPP * LD), voff, so_a);
             }
-            const int so_b = (widx * 3 * p.RP * p.CP + kc) * 2;
+            const int so_b = (widx * NPL * p.RP * p.CP + kc) * 2;
 #pragma unroll
             for (int it = 0; it < B3_IT; ++it) {
                 const int blk = wave + it * NWAVES;  // wave-uniform
@@ -749,14 +763,32 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
     auto next_kc = [&](int kc) { return (kc + BK >= p.CP) ? 0 : kc + BK; };
     int cur = 0;
     if constexpr (X3) {
-        // ---- bf16x3 schedule.  A k-group is 16 k-values: two 16-byte fragments per 32-row tile and lane.  Software
-        // pipeline, per group: [LDS reads of the NEXT group's fp32 fragments] then the 6*MT*NT bf16 MFMAs of THIS group's
-        // split operands with the split of the next group's fragments (44 VALU per fragment pair) interleaved between
-        // them — the matrix pipe and the VALU are separate, and the in-order wave only overlaps them when the instruction
-        // stream alternates (sched_group_barrier pins the pattern).
-        gif::u32x4_t sa[2][3][MT], sb[2][3][NT];  // [slot][hi, mid, lo][tile]: 8 packed bf16 each
-        f32x4 ra[MT][2], rs[MT][2];              // raw A fragments (and modulation scales) of the group being split
-        const int b3_sw = (li >> 2) & 3;         // (row >> 2) & 3 of every weight row this lane reads
+        // ---- bf16x3 / f16x2 schedule.  A k-group is 16 k-values: two 16-byte fragments per 32-row tile and lane.  Software
+        // pipeline, per group: [LDS reads of the NEXT group's fp32 fragments] then the NPROD*MT*NT MFMAs of THIS group's
+        // split operands with the split of the next group's fragments interleaved between them — the matrix pipe and the VALU
+        // are separate, and the in-order wave only overlaps them when the instruction stream alternates (sched_barrier pins it).
+        // bf16x3: 6 products, 11 VALU per pair of floats.  f16x2 (H2): 3 products, 6 VALU per pair + the running row scale:
+        // per group and tile the maximum |a| of the lane's 8 floats (both lane halves exchange theirs: they feed the same row),
+        // compared with the largest magnitude the row's current exponent can hold; in the rare case that a row outgrows it the
+        // new exponent takes effect for the fragments split from here on and the row's accumulators are multiplied by the exact
+        // power of two once the MFMAs of the group in flight have issued (`rescale`).
+        gif::u32x4_t sa[2][NPL][MT], sb[2][NPL][NT];  // [slot][term][tile]: 8 packed bf16 / f16 each
+        f32x4 ra[MT][2], rs[MT][2];                  // raw A fragments (and modulation scales) of the group being split
+        const int b3_sw = (li >> 2) & 3;             // (row >> 2) & 3 of every weight row this lane reads
+        // f16x2 row state (lane li and li + 32 hold the same values): exponent, its float 2^e, the largest |a| it can take, the
+        // pending exponent change, and the guard's statistics (row maximum, smallest non-zero group maximum as bits - 1)
+        int h_ex[MT], h_dl[MT];
+        float h_sc[MT], h_lim[MT], h_max[MT];
+        unsigned h_gmin[MT];
+        bool h_need = false;  // wave-uniform: some row of this wave changed its exponent in the last `track`
+        if constexpr (H2) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                h_ex[i] = 126; h_dl[i] = 0;
+                h_sc[i] = gif::h2_pow2(126); h_lim[i] = gif::kH2Limit * gif::h2_pow2(-126);
+                h_max[i] = 0.f; h_gmin[i] = 0xFFFFFFFFu;
+            }
+        }
         // LDS reads of group q of stage `buf`: raw fp32 A fragments (split later, piecewise) and the pre-split B operands
         auto read_raw = [&](int buf, int q, int kc, int slot) __attribute__((always_inline)) {
             const T* Ab = As + buf * BM * LD + (wm0 + li) * LD;
@@ -774,56 +806,123 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
                         rs[i][u] = *reinterpret_cast<const f32x4*>(Stab + s_row[i] - lh * EPC + kc + lc * EPC);
                 }
             }
-            const unsigned short* Bb = B3 + buf * 3 * BN * 32 + (wn0 + li) * 32 + (((q * 2 + lh) ^ b3_sw) << 3);
+            const unsigned short* Bb = B3 + buf * NPL * BN * 32 + (wn0 + li) * 32 + (((q * 2 + lh) ^ b3_sw) << 3);
 #pragma unroll
-            for (int t = 0; t < 3; ++t)
+            for (int t = 0; t < NPL; ++t)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
                     sb[slot][t][j] = *reinterpret_cast<const gif::u32x4_t*>(Bb + (t * BN + j * 32) * 32);
         };
-        // piece k of the split of one group: one pair of floats -> one packed dword of each term (11 VALU, +2 modulated)
+        // f16x2: modulation multiply, group maximum, exponent decision of the raw fragments just read
+        auto track = [&]() __attribute__((always_inline)) {
+            if constexpr (H2) {
+                h_need = false;
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    if (SCALE) { ra[i][0] *= rs[i][0]; ra[i][1] *= rs[i][1]; }
+                    float m = fmaxf(fmaxf(fabsf(ra[i][0][0]), fabsf(ra[i][0][1])), fabsf(ra[i][0][2]));
+                    m = fmaxf(fmaxf(m, fabsf(ra[i][0][3])), fabsf(ra[i][1][0]));
+                    m = fmaxf(fmaxf(m, fabsf(ra[i][1][1])), fabsf(ra[i][1][2]));
+                    m = fmaxf(m, fabsf(ra[i][1][3]));
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+                    m = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));  // the row's 16 k-values of this group
+                    h_max[i] = fmaxf(h_max[i], m);
+                    h_gmin[i] = min(h_gmin[i], __float_as_uint(m) - 1u);          // an all-zero group (0 - 1 = 0xffffffff) never wins
+                    h_dl[i] = 0;
+                    if (__builtin_amdgcn_ballot_w64(m > h_lim[i]) != 0) {          // wave-uniform, rare after a row's first groups
+                        if (m > h_lim[i]) {
+                            const int ne = gif::h2_exp_for(__float_as_uint(m), gif::kH2Target);
+                            h_dl[i] = ne - h_ex[i];
+                            h_ex[i] = ne;
+                            h_sc[i] = gif::h2_pow2(ne);
+                            h_lim[i] = ldexpf(gif::kH2Limit, -ne);
+                        }
+                        h_need = true;
+                    }
+                }
+            }
+        };
+        // f16x2: rows whose exponent changed: acc *= 2^(e' - e), exact.  Accumulator register r of a 32x32 tile holds row
+        // (r & 3) + 8 (r >> 2) + 4 lh, whose exponent change lives in lane `row`.
+        auto rescale = [&]() __attribute__((always_inline)) {
+            if constexpr (H2) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int d = __builtin_amdgcn_ds_bpermute(((r & 3) + 8 * (r >> 2) + 4 * lh) * 4, h_dl[i]);
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) acc[i][j][r] = ldexpf(acc[i][j][r], d);
+                    }
+            }
+        };
+        // piece k of the split of one group: one pair of floats -> one packed dword of each term (bf16x3: 11 VALU, +2 modulated;
+        // f16x2: 6)
         constexpr int NP = MT * 4;
         auto split_piece = [&](int slot, int k) __attribute__((always_inline)) {
             const int f = k / 4, e = k % 4;  // A tile, dword of the packed operand
             float a0 = ra[f][e / 2][(e % 2) * 2], a1 = ra[f][e / 2][(e % 2) * 2 + 1];
-            if (SCALE) { a0 *= rs[f][e / 2][(e % 2) * 2]; a1 *= rs[f][e / 2][(e % 2) * 2 + 1]; }
-            unsigned h, m, l;
-            gif::split_pair_scalar(a0, a1, h, m, l);
-            sa[slot][0][f][e] = h; sa[slot][1][f][e] = m; sa[slot][2][f][e] = l;
+            if constexpr (H2) {
+                unsigned h, l;
+                gif::split_pair_h2(a0, a1, h_sc[f], h, l);
+                sa[slot][0][f][e] = h; sa[slot][1][f][e] = l;
+            } else {
+                if (SCALE) { a0 *= rs[f][e / 2][(e % 2) * 2]; a1 *= rs[f][e / 2][(e % 2) * 2 + 1]; }
+                unsigned h, m, l;
+                gif::split_pair_scalar(a0, a1, h, m, l);
+                sa[slot][0][f][e] = h; sa[slot][1][f][e] = m; sa[slot][2][f][e] = l;
+            }
         };
-        // The 6*MT*NT MFMAs of the group in `slot` (smallest terms first; lo*mid, mid*lo, lo*lo <= 2^-23 of the product are
-        // not formed; term-major: consecutive MFMAs write different accumulators), with the split of the next group
-        // (-> slot `nslot`, or nothing if nslot < 0) placed piecewise between them.  sched_barrier(0) after every MFMA and
-        // every piece: the compiler keeps exactly this interleave (sched_group_barrier's VALU class also matches MFMAs).
-        constexpr int LEAD = 6;  // MFMAs ahead of the first piece: they cover the LDS latency of the raw reads
+        // The NPROD*MT*NT MFMAs of the group in `slot` (smallest terms first; bf16x3: lo*mid, mid*lo, lo*lo <= 2^-23 of the
+        // product are not formed, f16x2: lo*lo <= 2^-22; term-major: consecutive MFMAs write different accumulators), with the
+        // preparation of the next group (-> slot `nslot`, or nothing if nslot < 0) placed piecewise between them.
+        // sched_barrier(0) after every MFMA and every piece: the compiler keeps exactly this interleave (sched_group_barrier's
+        // VALU class also matches MFMAs).
+        constexpr int NPROD = H2 ? 3 : 6;
+        constexpr int LEAD = H2 ? 4 : 6;  // MFMAs ahead of the first piece: they cover the LDS latency of the raw reads
         auto group = [&](int slot, int nslot) __attribute__((always_inline)) {
-            constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
-            int n = 0, piece = 0;
+            constexpr int TA6[6] = {2, 0, 1, 1, 0, 0}, TB6[6] = {0, 2, 1, 0, 1, 0};
+            constexpr int TA3[3] = {1, 0, 0}, TB3[3] = {0, 1, 0};
+            int n = 0, piece = H2 ? -1 : 0;  // piece -1: the tracking step of f16x2
 #pragma unroll
-            for (int t = GIF_X3_FIRST_TERM; t < 6; ++t)
+            for (int t = (H2 ? 0 : GIF_X3_FIRST_TERM); t < NPROD; ++t)
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NT; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gif::bf16x8_t, sa[slot][TA[t]][i]),
-                                                                            __builtin_bit_cast(gif::bf16x8_t, sb[slot][TB[t]][j]),
-                                                                            acc[i][j], 0, 0, 0);
+                        if constexpr (H2)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gif::f16x8_t, sa[slot][TA3[t]][i]),
+                                                                               __builtin_bit_cast(gif::f16x8_t, sb[slot][TB3[t]][j]),
+                                                                               acc[i][j], 0, 0, 0);
+                        else
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gif::bf16x8_t, sa[slot][TA6[t]][i]),
+                                                                                __builtin_bit_cast(gif::bf16x8_t, sb[slot][TB6[t]][j]),
+                                                                                acc[i][j], 0, 0, 0);
                         __builtin_amdgcn_sched_barrier(0);
                         ++n;
                         if (nslot >= 0 && n >= LEAD && piece < NP) {
-                            split_piece(nslot, piece++);
+                            if (piece < 0) track();
+                            else split_piece(nslot, piece);
+                            ++piece;
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
             if (nslot >= 0) {
 #pragma unroll
-                for (; piece < NP; ++piece) split_piece(nslot, piece);
+                for (; piece < NP; ++piece) {
+                    if (piece < 0) track();
+                    else split_piece(nslot, piece);
+                }
+                if constexpr (H2) {
+                    if (h_need) rescale();
+                }
             }
         };
-        static_assert(KG == 2, "bf16x3: 32 floats per K chunk");
+        static_assert(KG == 2, "bf16x3 / f16x2: 32 floats per K chunk");
         issue(0);
         __syncthreads();
         read_raw(0, 0, 0, 0);
+        track();  // (f16x2: first exponents; the accumulators are still zero)
 #pragma unroll
         for (int k = 0; k < NP; ++k) split_piece(0, k);
 #ifdef GIF_X3_TIMING_PROBE
@@ -873,6 +972,30 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
             atomicAdd(&g_x3_probe[3], 1ull);
         }
 #endif
+        if constexpr (H2) {
+            // guard: a row one of whose 16-element K groups lies more than 2^kH2Window below the row maximum (the group's values no
+            // longer carry 22 bits) raises the launch's gate: the bf16x3 launch that follows recomputes the op (common.h)
+            bool wide = false;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                wide |= (int)(__float_as_uint(h_max[i]) >> 23) - (int)((h_gmin[i] + 1u) >> 23) > gif::kH2Window;
+            if (p.gate) {
+                if (__builtin_amdgcn_ballot_w64(wide) != 0 && lane == 0) atomicMax(p.gate, p.gate_gen);
+                if (tile == 0 && tid == 0 && p.wexp[p.RP] != 0) atomicMax(p.gate, p.gate_gen);  // flagged by the weight packing
+            }
+            // back to the operands' own scale: acc[row][col] *= 2^-(e_row + e_col)
+            int wex[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) wex[j] = p.wexp[n0 + wn0 + j * 32 + li];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int er = __builtin_amdgcn_ds_bpermute(((r & 3) + 8 * (r >> 2) + 4 * lh) * 4, h_ex[i]);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j][r] = ldexpf(acc[i][j][r], -(er + wex[j]));
+                }
+        }
     } else {
     frag_t av[2][MT], bv[2][NT];
     auto frag_read = [&](int buf, int kk, int slot, int kc) __attribute__((always_inline)) {
@@ -947,7 +1070,7 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
     conv_epilogue<BM, BN, 32, MT, NT, T, THREADS>(p, acc, smem, m0, n0, wm0, wn0, tid, li, lh, HWp);
 }
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool SCALE, int BK, bool X3 = false>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool SCALE, int BK, int X3 = 0>
 __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_gather_mfma_glds(const GatherParams p) {
     glds_body<T, BM, BN, WAVES_M, WAVES_N, SCALE, BK, X3>(p, (int)blockIdx.x, (int)gridDim.x);
 }
@@ -960,7 +1083,7 @@ struct MultiParams {
     int nph;
 };
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool SCALE, int BK, bool X3 = false>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool SCALE, int BK, int X3 = 0>
 __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_gather_mfma_glds_multi(const MultiParams mp) {
     const int b = (int)blockIdx.x;
     int k = 0;
@@ -1196,10 +1319,10 @@ inline size_t scale_table(GatherParams& p) {
 }
 
 // LDS bytes of the double-buffered operand tiles: 128-byte rows; X3: the weight tile is three 64-byte-row bf16 tiles
-template <int BM, int BN, bool X3>
-constexpr size_t stage_bytes() { return X3 ? (size_t)2 * BM * 128 + (size_t)2 * 3 * BN * 64 : (size_t)2 * (BM + BN) * 128; }
+template <int BM, int BN, int X3>
+constexpr size_t stage_bytes() { return X3 ? (size_t)2 * BM * 128 + (size_t)2 * (X3 == 2 ? 2 : 3) * BN * 64 : (size_t)2 * (BM + BN) * 128; }
 
-template <typename T, int BM, int BN, int WMv, int WNv, bool SCALE, bool X3 = false>
+template <typename T, int BM, int BN, int WMv, int WNv, bool SCALE, int X3 = 0>
 int launch_glds_impl(GatherParams& p, hipStream_t s) {
     constexpr int BK = 128 / sizeof(T);  // 128-byte LDS rows
     static gif::LdsAttr attr;
@@ -1224,7 +1347,7 @@ int launch_glds_impl(GatherParams& p, hipStream_t s) {
 
 // all phases in one launch (64x64 tiles for the low-resolution layers, 256x128 / 8 waves for the big bf16x3 ones: one grid
 // instead of up to eight launches with a partly filled last round each); returns -100 if the configuration does not fit
-template <typename T, bool SCALE, bool X3 = false, int BM = 64, int BN = 64, int WMv = 2, int WNv = 2>
+template <typename T, bool SCALE, int X3 = 0, int BM = 64, int BN = 64, int WMv = 2, int WNv = 2>
 int launch_glds_multi(GatherParams* ph, int nph, hipStream_t s) {
     constexpr int BK = 128 / sizeof(T);
     static gif::LdsAttr attr;
@@ -1262,9 +1385,15 @@ int launch_glds_multi(GatherParams* ph, int nph, hipStream_t s) {
 template <typename T, int BM, int BN, int WMv, int WNv>
 int launch_glds(GatherParams& p, hipStream_t s) {
     if constexpr (sizeof(T) == 4) {
+        if constexpr (WNv == 1 || (BM == 64 && BN == 64)) {  // the wave layouts the f16x2 kernels are built for
+            if (p.x3 == 2)
+                return p.in_scale ? launch_glds_impl<T, BM, BN, WMv, WNv, true, 2>(p, s)
+                                  : launch_glds_impl<T, BM, BN, WMv, WNv, false, 2>(p, s);
+        }
+        if (p.x3 == 2) return -102;
         if (p.x3)
-            return p.in_scale ? launch_glds_impl<T, BM, BN, WMv, WNv, true, true>(p, s)
-                              : launch_glds_impl<T, BM, BN, WMv, WNv, false, true>(p, s);
+            return p.in_scale ? launch_glds_impl<T, BM, BN, WMv, WNv, true, 1>(p, s)
+                              : launch_glds_impl<T, BM, BN, WMv, WNv, false, 1>(p, s);
     }
     return p.in_scale ? launch_glds_impl<T, BM, BN, WMv, WNv, true>(p, s)
                       : launch_glds_impl<T, BM, BN, WMv, WNv, false>(p, s);
@@ -1275,7 +1404,7 @@ int launch_glds(GatherParams& p, hipStream_t s) {
 template <typename T>
 int launch_big_x3(GatherParams& p, hipStream_t s) {
     static const int layout = getenv("GIF_X3_WAVES") ? atoi(getenv("GIF_X3_WAVES")) : 81;
-    return layout == 42 ? launch_glds<T, 256, 128, 4, 2>(p, s) : launch_glds<T, 256, 128, 8, 1>(p, s);
+    return (layout == 42 && p.x3 == 1) ? launch_glds<T, 256, 128, 4, 2>(p, s) : launch_glds<T, 256, 128, 8, 1>(p, s);
 }
 
 // 128x128 tile: 2 x 2 waves of 64 x 64; bf16x3: 4 x 1 waves of 32 x 128 (one activation fragment to split per 24 MFMAs)
@@ -1283,7 +1412,7 @@ template <typename T>
 int launch_128(GatherParams& p, hipStream_t s) {
     if constexpr (sizeof(T) == 4) {
         static const int layout = getenv("GIF_X3_WAVES") ? atoi(getenv("GIF_X3_WAVES")) : 81;
-        if (p.x3 && layout != 42) return launch_glds<T, 128, 128, 4, 1>(p, s);
+        if (p.x3 == 2 || (p.x3 && layout != 42)) return launch_glds<T, 128, 128, 4, 1>(p, s);
     }
     return launch_glds<T, 128, 128, 2, 2>(p, s);
 }
@@ -1291,7 +1420,8 @@ int launch_128(GatherParams& p, hipStream_t s) {
 template <typename T>
 int launch_multi(GatherParams* ph, int nph, bool scale, hipStream_t s) {
     if constexpr (sizeof(T) == 4) {
-        if (ph[0].x3) return scale ? launch_glds_multi<T, true, true>(ph, nph, s) : launch_glds_multi<T, false, true>(ph, nph, s);
+        if (ph[0].x3 == 2) return scale ? launch_glds_multi<T, true, 2>(ph, nph, s) : launch_glds_multi<T, false, 2>(ph, nph, s);
+        if (ph[0].x3) return scale ? launch_glds_multi<T, true, 1>(ph, nph, s) : launch_glds_multi<T, false, 1>(ph, nph, s);
     }
     return scale ? launch_glds_multi<T, true>(ph, nph, s) : launch_glds_multi<T, false>(ph, nph, s);
 }
@@ -1564,6 +1694,24 @@ void pack_dims(int cout, int cin, int* RP, int* CP, bool x3 = false) {
     if (sizeof(T) == 2 && cin <= 32) *CP = 32;  // "pair" mode of the f16 kernel: two taps per 64-half K chunk (GatherParams::pair)
 }
 
+// f16x2 launches: the packing is [header: RP row exponents + flag][planes]; the launch gets a fresh gate word (common.h)
+inline void h2_operands(GatherParams& p, const void* wp2, const void* wp_fallback) {
+    p.wexp = static_cast<const int*>(wp2);
+    p.wp = static_cast<const char*>(wp2) + gif::h2_header_bytes(p.RP);
+    p.gate = nullptr; p.gate_gen = 0; p.h2_stats = nullptr;
+    if (wp_fallback) {
+        const gif::H2Gate gt = gif::h2_next_gate();
+        p.gate = gt.word; p.gate_gen = gt.gen;
+        p.h2_stats = gif::h2_stats_words();
+    }
+}
+// the same parameters for the guarded bf16x3 launch
+inline void h2_to_fallback(GatherParams& p, const void* wp3) {
+    p.x3 = 1;
+    p.wp = wp3;
+    p.wexp = nullptr;
+}
+
 template <typename T>
 int check_channels(const gif_conv_geom* g, const char* who) {
     if (sizeof(T) == 2)
@@ -1573,13 +1721,13 @@ int check_channels(const gif_conv_geom* g, const char* who) {
 
 template <typename T>
 int conv2d_fwd_impl(const void* big, const void* wp, void* small, const gif_conv_geom* g, const gif_conv_epilogue* e,
-                    gif_stream_t stream, const char* who, bool x3 = false, bool dense = false) {
+                    gif_stream_t stream, const char* who, int x3 = 0, bool dense = false, const void* wp_fallback = nullptr) {
     if (int rc = check_geom(g, who)) return rc;
     if (int rc = check_channels<T>(g, who)) return rc;
     if (g->B == 0) return 0;
     GIF_REQUIRE(big && wp && small, "%s: null pointer", who);
     GatherParams p{};
-    p.x = big; p.wp = wp; p.y = small; p.x3 = x3 ? 1 : 0;
+    p.x = big; p.wp = wp; p.y = small; p.x3 = x3;
     fill_epilogue(p, e);
     if (sizeof(T) == 2) p.sat_flag = gif::f16_sat_flag();
     p.B = g->B; p.Hi = g->Hb; p.Wi = g->Wb; p.Ci = g->Cb;
@@ -1588,12 +1736,13 @@ int conv2d_fwd_impl(const void* big, const void* wp, void* small, const gif_conv
     p.nky = g->KH; p.nkx = g->KW; p.ntaps = g->KH * g->KW;
     p.dy0 = -g->pad; p.ddy = 1; p.dx0 = -g->pad; p.ddx = 1;
     p.ky0 = 0; p.kx0 = 0; p.kstep = 1; p.KW = g->KW;
-    pack_dims<T>(p.Co, p.Ci, &p.RP, &p.CP, x3);
+    pack_dims<T>(p.Co, p.Ci, &p.RP, &p.CP, x3 != 0);
     p.pair = (sizeof(T) == 2 && p.CP == 32) ? 1 : 0;
     if (dense) {
         if (int rc = check_tapdense(g, e, g->Cb, false, who)) return rc;
         p.dense = g->Cb / 4;
     }
+    if (x3 == 2) h2_operands(p, wp, wp_fallback);
     p.M = p.B * p.Hp * p.Wp;
     double flops = 2.0 * p.M * (double)p.Co * p.Ci * p.ntaps;
     const int fam = sizeof(T) == 2 ? 6 : dense ? 12 : x3 ? 8 : (p.Ci >= 32 ? 0 : 5);
@@ -1601,26 +1750,32 @@ int conv2d_fwd_impl(const void* big, const void* wp, void* small, const gif_conv
     if (int rc = sums.begin(p, e, p.M, p.Co, p.B, (long)p.Hp * p.Wp, true, who)) return rc;
     gif::ProfScope prof(fam, flops, gif::as_stream(stream), p.M, p.Co, p.Ci, p.ntaps * 10 + g->stride);
     if (int rc = launch<T>(p, gif::as_stream(stream))) return rc;
+    if (x3 == 2 && p.gate && wp_fallback) {  // guarded fallback: the same op on the bf16x3 kernels, a no-op unless the gate was raised
+        h2_to_fallback(p, wp_fallback);
+        t_part_rows = 0;
+        if (int rc = launch<T>(p, gif::as_stream(stream))) return rc;
+    }
     if (int rc = sums.finish(p.Co, p.B, (long)p.Hp * p.Wp, gif::as_stream(stream), who)) return rc;
     return gif::check_launch(who);
 }
 
 template <typename T>
 int conv2d_bwd_data_impl(const void* small, const void* wp, void* big, const gif_conv_geom* g, const gif_conv_epilogue* e,
-                         gif_stream_t stream, const char* who, bool x3 = false, bool dense = false) {
+                         gif_stream_t stream, const char* who, int x3 = 0, bool dense = false, const void* wp_fallback = nullptr) {
     if (int rc = check_geom(g, who)) return rc;
     if (int rc = check_channels<T>(g, who)) return rc;
     if (g->B == 0) return 0;
     GIF_REQUIRE(small && wp && big, "%s: null pointer", who);
     hipStream_t s = gif::as_stream(stream);
     GatherParams base{};
-    base.x = small; base.wp = wp; base.y = big; base.x3 = x3 ? 1 : 0;
+    base.x = small; base.wp = wp; base.y = big; base.x3 = x3;
     fill_epilogue(base, e);
     if (sizeof(T) == 2) base.sat_flag = gif::f16_sat_flag();
     base.B = g->B; base.Hi = g->Hs; base.Wi = g->Ws; base.Ci = g->Cs;
     base.Ho = g->Hb; base.Wo = g->Wb; base.Co = g->Cb;
-    pack_dims<T>(base.Co, base.Ci, &base.RP, &base.CP, x3);
+    pack_dims<T>(base.Co, base.Ci, &base.RP, &base.CP, x3 != 0);
     base.pair = (sizeof(T) == 2 && base.CP == 32) ? 1 : 0;
+    if (x3 == 2) h2_operands(base, wp, wp_fallback);
     if (dense) {
         if (int rc = check_tapdense(g, e, g->Cs, true, who)) return rc;
         base.dense = g->Cs / 4;
@@ -1662,33 +1817,44 @@ int conv2d_bwd_data_impl(const void* small, const void* wp, void* big, const gif
         const int fam = sizeof(T) == 2 ? 6 : dense ? 12 : x3 ? 8 : (base.Ci >= 32 ? 0 : 5);
         gif::ProfScope prof(fam, flops, s, g->B * g->Hb * g->Wb, base.Co, base.Ci, -(g->KH * g->KW * 10 + g->stride));
         // small transposed convs: every phase alone would sit on the 64x64-tile path with a partly filled chip
-        bool merged = false;
-        if (nph > 1 && conv_variant() == 0) {
-            TileCfg c = pick_cfg<T>(base.Co, base.Ci);
-            if (x3) c.BK = 32;
-            bool small_all = c.BN == 128 && (sizeof(T) == 2 || c.BK == 32);
-            for (int i = 0; i < nph && small_all; ++i)
-                small_all = (long)gif::cdiv(ph[i].M, 128) * (ph[i].RP / 128) < 384 &&
-                            (long)ph[i].B * ph[i].Hi * ph[i].Wi * ph[i].Ci < (1L << 31) &&
-                            (long)ph[i].B * ph[i].Ho * ph[i].Wo * ph[i].Co < (1L << 31);
-            if (small_all)
-                merged = launch_multi<T>(ph, nph, base.in_scale != nullptr, s) == 0;
-            if constexpr (sizeof(T) == 4) {
-                // big bf16x3 transposed convs: every phase would run 256x128 tiles on its own (bulk + remainder launch each)
-                static const int big_multi_off = getenv("GIF_X3_MULTI_BIG") ? atoi(getenv("GIF_X3_MULTI_BIG")) == 0 : 0;
-                bool big_all = x3 && !small_all && !big_multi_off && c.BN == 128;
-                for (int i = 0; i < nph && big_all; ++i)
-                    big_all = (long)gif::cdiv(ph[i].M, 256) * (ph[i].RP / 128) >= 512 &&
-                              (long)ph[i].B * ph[i].Hi * ph[i].Wi * ph[i].Ci < (1L << 31) &&
-                              (long)ph[i].B * ph[i].Ho * ph[i].Wo * ph[i].Co < (1L << 31);
-                if (big_all)
-                    merged = (base.in_scale ? launch_glds_multi<T, true, true, 256, 128, 8, 1>(ph, nph, s)
-                                            : launch_glds_multi<T, false, true, 256, 128, 8, 1>(ph, nph, s)) == 0;
+        auto run_phases = [&]() -> int {
+            bool merged = false;
+            if (nph > 1 && conv_variant() == 0) {
+                TileCfg c = pick_cfg<T>(base.Co, base.Ci);
+                if (x3) c.BK = 32;
+                bool small_all = c.BN == 128 && (sizeof(T) == 2 || c.BK == 32);
+                for (int i = 0; i < nph && small_all; ++i)
+                    small_all = (long)gif::cdiv(ph[i].M, 128) * (ph[i].RP / 128) < 384 &&
+                                (long)ph[i].B * ph[i].Hi * ph[i].Wi * ph[i].Ci < (1L << 31) &&
+                                (long)ph[i].B * ph[i].Ho * ph[i].Wo * ph[i].Co < (1L << 31);
+                if (small_all)
+                    merged = launch_multi<T>(ph, nph, base.in_scale != nullptr, s) == 0;
+                if constexpr (sizeof(T) == 4) {
+                    // big bf16x3 / f16x2 transposed convs: every phase would run 256x128 tiles on its own (bulk + remainder launch each)
+                    static const int big_multi_off = getenv("GIF_X3_MULTI_BIG") ? atoi(getenv("GIF_X3_MULTI_BIG")) == 0 : 0;
+                    bool big_all = x3 && !small_all && !big_multi_off && c.BN == 128;
+                    for (int i = 0; i < nph && big_all; ++i)
+                        big_all = (long)gif::cdiv(ph[i].M, 256) * (ph[i].RP / 128) >= 512 &&
+                                  (long)ph[i].B * ph[i].Hi * ph[i].Wi * ph[i].Ci < (1L << 31) &&
+                                  (long)ph[i].B * ph[i].Ho * ph[i].Wo * ph[i].Co < (1L << 31);
+                    if (big_all)
+                        merged = (ph[0].x3 == 2 ? (base.in_scale ? launch_glds_multi<T, true, 2, 256, 128, 8, 1>(ph, nph, s)
+                                                                 : launch_glds_multi<T, false, 2, 256, 128, 8, 1>(ph, nph, s))
+                                                : (base.in_scale ? launch_glds_multi<T, true, 1, 256, 128, 8, 1>(ph, nph, s)
+                                                                 : launch_glds_multi<T, false, 1, 256, 128, 8, 1>(ph, nph, s))) == 0;
+                }
             }
+            if (!merged)
+                for (int i = 0; i < nph; ++i)
+                    if (int rc = launch<T>(ph[i], s)) return rc;
+            return 0;
+        };
+        if (int rc = run_phases()) return rc;
+        if (x3 == 2 && base.gate && wp_fallback) {  // guarded fallback on the bf16x3 kernels (a no-op unless the gate was raised)
+            for (int i = 0; i < nph; ++i) h2_to_fallback(ph[i], wp_fallback);
+            t_part_rows = 0;
+            if (int rc = run_phases()) return rc;
         }
-        if (!merged)
-            for (int i = 0; i < nph; ++i)
-                if (int rc = launch<T>(ph[i], s)) return rc;
         if (int rc = sums.finish(base.Co, g->B, (long)g->Hb * g->Wb, s, who)) return rc;
     }
     return gif::check_launch(who);
@@ -1731,22 +1897,32 @@ int gif_conv2d_pack_dims_x3(int cout, int cin, int* RP, int* CP) {
 
 int gif_conv2d_fwd_f32x3(const float* big, const void* wp3, float* small, const gif_conv_geom* g, const gif_conv_epilogue* e,
                          gif_stream_t stream) {
-    return conv2d_fwd_impl<float>(big, wp3, small, g, e, stream, "conv2d_fwd_f32x3", true);
+    return conv2d_fwd_impl<float>(big, wp3, small, g, e, stream, "conv2d_fwd_f32x3", 1);
 }
 
 int gif_conv2d_bwd_data_f32x3(const float* small, const void* wp3, float* big, const gif_conv_geom* g,
                               const gif_conv_epilogue* e, gif_stream_t stream) {
-    return conv2d_bwd_data_impl<float>(small, wp3, big, g, e, stream, "conv2d_bwd_data_f32x3", true);
+    return conv2d_bwd_data_impl<float>(small, wp3, big, g, e, stream, "conv2d_bwd_data_f32x3", 1);
+}
+
+int gif_conv2d_fwd_f32h2(const float* big, const void* wp2, const void* wp3, float* small, const gif_conv_geom* g,
+                         const gif_conv_epilogue* e, gif_stream_t stream) {
+    return conv2d_fwd_impl<float>(big, wp2, small, g, e, stream, "conv2d_fwd_f32h2", 2, false, wp3);
+}
+
+int gif_conv2d_bwd_data_f32h2(const float* small, const void* wp2, const void* wp3, float* big, const gif_conv_geom* g,
+                              const gif_conv_epilogue* e, gif_stream_t stream) {
+    return conv2d_bwd_data_impl<float>(small, wp2, big, g, e, stream, "conv2d_bwd_data_f32h2", 2, false, wp3);
 }
 
 int gif_conv2d_fwd_f32x3_tapdense(const float* big, const void* wp3, float* small, const gif_conv_geom* g,
                                   const gif_conv_epilogue* e, gif_stream_t stream) {
-    return conv2d_fwd_impl<float>(big, wp3, small, g, e, stream, "conv2d_fwd_f32x3_tapdense", true, true);
+    return conv2d_fwd_impl<float>(big, wp3, small, g, e, stream, "conv2d_fwd_f32x3_tapdense", 1, true);
 }
 
 int gif_conv2d_bwd_data_f32x3_tapdense(const float* small, const void* wp3, float* big, const gif_conv_geom* g,
                                        const gif_conv_epilogue* e, gif_stream_t stream) {
-    return conv2d_bwd_data_impl<float>(small, wp3, big, g, e, stream, "conv2d_bwd_data_f32x3_tapdense", true, true);
+    return conv2d_bwd_data_impl<float>(small, wp3, big, g, e, stream, "conv2d_bwd_data_f32x3_tapdense", 1, true);
 }
 
 // would a FORWARD f16 convolution of this shape (activation channel counts, output grid Hs x Ws) run the halo kernel?

@@ -16,6 +16,11 @@ static thread_local char g_err[512] = "";
 __device__ __attribute__((aligned(16))) float g_zero_page[4];
 __device__ unsigned g_f16_sat_flag;
 
+// f16x2 guard (common.h): gate words of the guarded launches and the fallback statistics
+constexpr unsigned kH2GateRing = 65536;
+__device__ unsigned g_h2_gates[kH2GateRing];
+__device__ unsigned g_h2_stats[4];
+
 __global__ void f16_flag_or_into(const unsigned* flag, float* found_inf) {
     if (*flag) *found_inf = 1.f;
 }
@@ -57,6 +62,36 @@ unsigned* f16_sat_flag_word() {
 }
 
 unsigned* f16_sat_flag() { return g_f16_watch.load(std::memory_order_relaxed) ? f16_sat_flag_word() : nullptr; }
+
+static unsigned* h2_symbol(const void* sym, unsigned* (&cache)[kMaxDevices]) {
+    static std::mutex mu;
+    const int d = current_device();
+    std::lock_guard<std::mutex> lk(mu);
+    if (!cache[d]) {
+        void* ptr = nullptr;
+        if (hipGetSymbolAddress(&ptr, sym) != hipSuccess) return nullptr;
+        cache[d] = static_cast<unsigned*>(ptr);
+    }
+    return cache[d];
+}
+
+unsigned* h2_stats_words() {
+    static unsigned* cache[kMaxDevices] = {};
+    return h2_symbol(HIP_SYMBOL(g_h2_stats), cache);
+}
+
+H2Gate h2_next_gate() {
+    static unsigned* cache[kMaxDevices] = {};
+    static std::atomic<unsigned long long> next[kMaxDevices];
+    static const bool off = getenv("GIF_H2_GUARD") && atoi(getenv("GIF_H2_GUARD")) == 0;
+    if (off) return {nullptr, 0};
+    unsigned* ring = h2_symbol(HIP_SYMBOL(g_h2_gates), cache);
+    if (!ring) return {nullptr, 0};
+    const unsigned long long n = next[current_device()].fetch_add(1, std::memory_order_relaxed);
+    // the words start at zero, generations at 1; a word's generation only grows (atomicMax), so a stale raise of an earlier
+    // launch on the same word never equals a later launch's generation
+    return {ring + (n % kH2GateRing), (unsigned)(n / kH2GateRing) + 1u};
+}
 
 void LdsAttr::ensure(const void* kernel, size_t bytes) {
     static std::mutex mu;
@@ -116,8 +151,10 @@ int fp32_mfma_mode() {
     int m = g_fp32_mode.load(std::memory_order_relaxed);
     if (m >= 0) return m;
     const char* e = getenv("GIF_FP32_MFMA");
-    m = GIF_FP32_MFMA_BF16X3;
+    m = GIF_FP32_MFMA_F16X2;
     if (e && (!strcmp(e, "native") || !strcmp(e, "0"))) m = GIF_FP32_MFMA_NATIVE;
+    if (e && (!strcmp(e, "bf16x3") || !strcmp(e, "1"))) m = GIF_FP32_MFMA_BF16X3;
+    if (e && (!strcmp(e, "f16x2") || !strcmp(e, "2"))) m = GIF_FP32_MFMA_F16X2;
     g_fp32_mode.store(m, std::memory_order_relaxed);
     return m;
 }
@@ -157,10 +194,11 @@ int gif_f16_overflow_watch(int on) {
 // 2: gif_conv_epilogue gradient-producer fusions, rasteriser workspace (B, F, H, W)
 // 3: gif_f16_overflow_watch, gif_pack_nhwc / gif_unpack_nhwc, gif_conv2d_f16_halo_eligible (f16 halo kernels), rasteriser clean-workspace per pointer,
 //    gif_linear_bank_fwd / _bwd (modulation bank)
-int gif_abi_version(void) { return 3; }
+// 4: f16x2 contraction mode (GIF_FP32_MFMA_F16X2, gif_pack_weight_f32h2, gif_conv2d_*_f32h2, gif_h2_fallback_stats)
+int gif_abi_version(void) { return 4; }
 
 int gif_set_fp32_mfma_mode(int mode) {
-    if (mode != GIF_FP32_MFMA_NATIVE && mode != GIF_FP32_MFMA_BF16X3) {
+    if (mode != GIF_FP32_MFMA_NATIVE && mode != GIF_FP32_MFMA_BF16X3 && mode != GIF_FP32_MFMA_F16X2) {
         gif::set_error("set_fp32_mfma_mode: unknown mode %d", mode);
         return GIF_EINVAL;
     }
@@ -169,6 +207,21 @@ int gif_set_fp32_mfma_mode(int mode) {
 }
 
 int gif_get_fp32_mfma_mode(void) { return gif::fp32_mfma_mode(); }
+
+/* f16x2 guard statistics of the current device since the last reset: out[0] = guarded launches that took the bf16x3 fallback.
+ * Synchronises the device. */
+int gif_h2_fallback_stats(uint64_t* out2, int reset) {
+    unsigned* st = gif::h2_stats_words();
+    GIF_REQUIRE(st && out2, "h2_fallback_stats: null pointer");
+    unsigned h[4] = {0, 0, 0, 0};
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(h, st, sizeof(h), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && reset) e = hipMemset(st, 0, sizeof(h));
+    if (e != hipSuccess) { gif::set_error("h2_fallback_stats: %s", hipGetErrorString(e)); return (int)e; }
+    out2[0] = h[0];
+    out2[1] = h[1];
+    return 0;
+}
 
 int gif_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(gif::g_prof_mu);

@@ -204,7 +204,20 @@ def x3_conv(dtype, cin_act: int, src=None, spec=None) -> bool:
     buffer-addressed DMA does not take (>= 4 GiB of input) stay on the native fp32 kernel."""
     if src is not None and src.numel() * src.element_size() > X3_MAX_INPUT_BYTES:
         return False
-    return dtype == torch.float32 and cin_act >= X3_MIN_CIN and get_fp32_mfma_mode() == "bf16x3"
+    return dtype == torch.float32 and cin_act >= X3_MIN_CIN and split_mode()
+
+
+def split_mode() -> bool:
+    """The fp32 contractions run on the 16-bit matrix cores (bf16x3, or f16x2 with bf16x3 for the layers f16x2 does not take)."""
+    return get_fp32_mfma_mode() in ("bf16x3", "f16x2")
+
+
+H2_CONV = os.environ.get("GIF_H2_CONV", "1") != "0"    # f16x2 mode: direct fwd / dgrad kernels (A/B knobs per kernel family)
+
+
+def h2_conv(x3: bool, dense: bool) -> bool:
+    """This bf16x3-eligible direct launch runs the f16x2 kernels (three f16 products under per-row scales, guarded bf16x3 fallback)."""
+    return bool(x3) and not dense and H2_CONV and get_fp32_mfma_mode() == "f16x2"
 
 
 def x3_tapdense(dtype, cin_act: int, spec, transposed: bool, epi, cout_act: int = 64) -> bool:
@@ -214,14 +227,14 @@ def x3_tapdense(dtype, cin_act: int, spec, transposed: bool, epi, cout_act: int 
     before the mode existed): 24 -> 128 3.62 vs 4.08 ms per step, 12 -> 24 0.88 vs 1.15 (native kernel); but 8 -> 12 0.76 vs 0.66
     (native) and 24 -> 12 0.79 vs 0.67 (padded bf16x3): with <= 32 output channels the launch is bound by its gathers, which the
     dense order scatters over two pixels per 128-byte row — those two keep their old kernels."""
-    if not (X3_TAPDENSE and dtype == torch.float32 and get_fp32_mfma_mode() == "bf16x3" and 8 <= cin_act < 32 and cin_act % 4 == 0
+    if not (X3_TAPDENSE and dtype == torch.float32 and split_mode() and 8 <= cin_act < 32 and cin_act % 4 == 0
             and (spec.KH, spec.KW) == (3, 3) and not (transposed and spec.stride != 1) and epi.get("in_scale") is None):
         return False
     return cin_act >= 12 and (cout_act > 32 or cin_act < X3_MIN_CIN)
 
 
 def pack_weight(w: torch.Tensor, rows_are_out: bool, cout_act: int, cin_act: int, scale: float = 1.0, dtype=torch.float32, x3=False,
-                tapdense=False):
+                tapdense=False, h2=False):
     """Pack a canonical forward-conv weight view w[O,I,KH,KW] (any strides) into [T][RP][CP] of `dtype` (fp32 or f16), or
     (x3=True) into the pre-split bf16x3 operand [T][3][RP][CP] (bf16) of the gif_conv2d_*_f32x3 entry points.
 
@@ -238,7 +251,7 @@ def pack_weight(w: torch.Tensor, rows_are_out: bool, cout_act: int, cin_act: int
 
     def build():
         RP, CP = ctypes.c_int(), ctypes.c_int()
-        dims = lib.gif_conv2d_pack_dims_x3 if (x3 or tapdense) else (lib.gif_conv2d_pack_dims_f16 if f16 else lib.gif_conv2d_pack_dims)
+        dims = lib.gif_conv2d_pack_dims_x3 if (x3 or tapdense or h2) else (lib.gif_conv2d_pack_dims_f16 if f16 else lib.gif_conv2d_pack_dims)
         _lib.check(dims(cout_act, cin_act, ctypes.byref(RP), ctypes.byref(CP)), "pack_dims")
         if tapdense:
             steps = lib.gif_conv2d_x3_tapdense_steps(cin_act, KH, KW)
@@ -246,7 +259,10 @@ def pack_weight(w: torch.Tensor, rows_are_out: bool, cout_act: int, cin_act: int
             _lib.check(lib.gif_pack_weight_f32x3_tapdense(w.data_ptr(), wp.data_ptr(), R, C, cin_act, KH, KW, RP.value, sr, sc, sky, skx,
                                                           float(scale), _stream()), "pack_weight_tapdense")
             return wp
-        if x3:
+        if h2:  # f16x2 packing: [row exponents + flag][tap][2][RP][CP] f16, an opaque byte buffer
+            wp = torch.empty((lib.gif_pack_weight_f32h2_bytes(KH, KW, RP.value, CP.value),), device=w.device, dtype=torch.uint8)
+            fn = lib.gif_pack_weight_f32h2
+        elif x3:
             wp = torch.empty((KH * KW, 3, RP.value, CP.value), device=w.device, dtype=torch.bfloat16)
             fn = lib.gif_pack_weight_f32x3
         else:
@@ -256,7 +272,7 @@ def pack_weight(w: torch.Tensor, rows_are_out: bool, cout_act: int, cin_act: int
                    "pack_weight")
         return wp
 
-    return _cached_weight_op(w, ("pack", rows_are_out, cout_act, cin_act, float(scale), dtype, bool(x3), bool(tapdense)), build)
+    return _cached_weight_op(w, ("pack", rows_are_out, cout_act, cin_act, float(scale), dtype, bool(x3), bool(tapdense), bool(h2)), build)
 
 
 # Winograd F(2x2,3x3) dispatch for stride-1 / pad-1 3x3 convs (conv_winograd.hip).  GIF_WINOGRAD=0 forces the direct
@@ -297,7 +313,7 @@ def conv3x3_winograd(x, w, rows_are_out: bool, cout_act: int, wscale=1.0, keep_v
     assert R <= cout_act and Cc <= C, (R, cout_act, Cc, C)
 
     # bf16x3: the GEMM's 128-wide N tile wants full tiles; other channel counts stay on the native GEMM (GIF_WINO_X3=0: A/B)
-    x3 = WINOGRAD_X3 and get_fp32_mfma_mode() == "bf16x3" and cout_act % 128 == 0
+    x3 = WINOGRAD_X3 and split_mode() and cout_act % 128 == 0
 
     def build():
         RP, CP = ctypes.c_int(), ctypes.c_int()
@@ -354,6 +370,11 @@ def conv_fwd(big, w, spec: ConvSpec, wscale=1.0, keep_v=False, **epi):
     out = empty_nhwc(B, Cs, Hs, Ws, big.device, torch.float32 if epi.get("out_f32") else dt)
     g = _geom(B, Hb, Wb, Cb, Hs, Ws, Cs, spec)
     e = _epilogue(out_bchw=(B, Cs, Hs, Ws), dtype=dt, **epi)
+    if h2_conv(x3, dense):  # f16x2 kernels + the bf16x3 packing for their guarded fallback
+        wp2 = pack_weight(w, True, Cs, Cb, wscale, dt, h2=True)
+        _lib.check(_lib.load().gif_conv2d_fwd_f32h2(big.data_ptr(), wp2.data_ptr(), wp.data_ptr(), out.data_ptr(), ctypes.byref(g),
+                                                    ctypes.byref(e), _stream()), "conv2d_fwd_f32h2")
+        return out
     fn = _lib.load().gif_conv2d_fwd_f32x3_tapdense if dense else _lib.load().gif_conv2d_fwd_f32x3 if x3 else _fn("conv2d_fwd", dt)
     _lib.check(fn(big.data_ptr(), wp.data_ptr(), out.data_ptr(), ctypes.byref(g), ctypes.byref(e), _stream()), "conv2d_fwd")
     return out
@@ -376,6 +397,11 @@ def conv_bwd_data(small, w, spec: ConvSpec, big_hw, wscale=1.0, **epi):
     out = empty_nhwc(B, Cb, Hb, Wb, small.device, dt)
     g = _geom(B, Hb, Wb, Cb, Hs, Ws, Cs, spec)
     e = _epilogue(out_bchw=(B, Cb, Hb, Wb), dtype=dt, **epi)
+    if h2_conv(x3, dense):
+        wp2 = pack_weight(w, False, Cb, Cs, wscale, dt, h2=True)
+        _lib.check(_lib.load().gif_conv2d_bwd_data_f32h2(small.data_ptr(), wp2.data_ptr(), wp.data_ptr(), out.data_ptr(), ctypes.byref(g),
+                                                         ctypes.byref(e), _stream()), "conv2d_bwd_data_f32h2")
+        return out
     fn = (_lib.load().gif_conv2d_bwd_data_f32x3_tapdense if dense else _lib.load().gif_conv2d_bwd_data_f32x3 if x3
           else _fn("conv2d_bwd_data", dt))
     _lib.check(fn(small.data_ptr(), wp.data_ptr(), out.data_ptr(), ctypes.byref(g), ctypes.byref(e), _stream()), "conv2d_bwd_data")
@@ -406,7 +432,7 @@ def conv3x3_winograd_wgrad(small, big, O, I, wscale=1.0, small_scale=None, big_s
     V = big_v if big_v is not None else torch.empty((nv,), device=dev, dtype=torch.float32)
     Mg = torch.empty((lib.gif_winograd_workspace_floats(B, H, W, Cs),), device=dev, dtype=torch.float32)
     ws = torch.empty((nsplit, 16, RP.value, CP.value), device=dev, dtype=torch.float32)
-    fn = lib.gif_conv3x3_winograd_wgrad_f32x3 if get_fp32_mfma_mode() == "bf16x3" else lib.gif_conv3x3_winograd_wgrad_f32
+    fn = lib.gif_conv3x3_winograd_wgrad_f32x3 if split_mode() else lib.gif_conv3x3_winograd_wgrad_f32
     _lib.check(fn(None if big_v is not None else big.data_ptr(), small.data_ptr(), V.data_ptr(), Mg.data_ptr(), ws.data_ptr(),
                                                   _p(small_scale), _p(big_scale), B, H, W, Cs, Cb, nsplit, _stream()),
                "conv3x3_winograd_wgrad")
@@ -439,7 +465,7 @@ def conv_wgrad(small, big, spec: ConvSpec, O, I, wscale=1.0, small_scale=None, b
     nsplit = splits(ctypes.byref(g))
     T = spec.KH * spec.KW
     ws = torch.empty((nsplit, T, RP.value, CP.value), device=small.device, dtype=torch.float32)
-    fn = lib.gif_conv2d_wgrad_f32x3 if (not f16 and get_fp32_mfma_mode() == "bf16x3") else _fn("conv2d_wgrad", dt)
+    fn = lib.gif_conv2d_wgrad_f32x3 if (not f16 and split_mode()) else _fn("conv2d_wgrad", dt)
     _lib.check(fn(small.data_ptr(), big.data_ptr(), ws.data_ptr(), _p(small_scale), _p(big_scale), ctypes.byref(g), nsplit, _stream()),
                "conv2d_wgrad")
     dw = torch.empty((O, I, spec.KH, spec.KW), device=small.device, dtype=torch.float32)
@@ -929,7 +955,7 @@ for _name in ("linear_nt", "linear_nn", "linear_tn", "weight_sq_sum", "style_dem
 del _name
 
 
-FP32_MFMA_MODES = {"native": 0, "bf16x3": 1}
+FP32_MFMA_MODES = {"native": 0, "bf16x3": 1, "f16x2": 2}
 
 
 def set_fp32_mfma_mode(mode):
@@ -950,6 +976,13 @@ def get_fp32_mfma_mode() -> str:
         m = _lib.load().gif_get_fp32_mfma_mode()
         _fp32_mode_cache = {v: k for k, v in FP32_MFMA_MODES.items()}[m]
     return _fp32_mode_cache
+
+
+def h2_fallback_stats(reset=False):
+    """(guarded f16x2 launches that took the bf16x3 fallback,) on the current device since the last reset.  Synchronises."""
+    out = (ctypes.c_uint64 * 2)()
+    _lib.check(_lib.load().gif_h2_fallback_stats(out, 1 if reset else 0), "h2_fallback_stats")
+    return int(out[0])
 
 
 def prof_enable(on: bool):

@@ -52,9 +52,24 @@ int gif_f16_overflow_watch(int on);
  *            peak => 417 TFLOP/s of fp32-equivalent work).  Each bf16*bf16 product is exact in fp32; the three dropped cross
  *            terms are <= 2^-23 |a*b| (typically 2^-25: below one fp32 product rounding).  Measured error against an fp64
  *            convolution: equal to or below the native fp32 MFMA path (tools/probes/x3_probe.py).
- *            Default: the GIF_FP32_MFMA environment variable ("native" / "bf16x3"), else BF16X3. */
+ *   F16X2  : (ABI 4) every operand element is scaled by a power of two 2^e that belongs to its ROW of the GEMM (output pixel /
+ *            output channel: it factors out of the dot product) and split into two f16 terms x*2^e = hi + lo (11 + 11 significand
+ *            bits); a*b is accumulated in fp32 from the THREE products hi*hi, hi*lo, lo*hi on v_mfma_f32_32x32x16_f16 (2.5 PFLOP/s
+ *            peak => 833 TFLOP/s of fp32-equivalent work) and the result is multiplied by 2^-(e_a + e_b).  The dropped lo*lo is
+ *            <= 2^-22 |a*b|.  Weight rows get their exponent from the packing kernel; activation rows carry a RUNNING exponent
+ *            inside the kernel (a new row maximum is scaled into [2^13, 2^14); when a row outgrows its exponent its fp32
+ *            accumulators are multiplied by the exact power of two).  Precision contract: every 16-element K group of every
+ *            operand row is represented to >= 22 bits relative to the group's own maximum, provided the group's maximum lies
+ *            within 2^14 (activations) / 2^16 (weights) of the row maximum; a launch that meets a narrower (non-zero) group
+ *            raises a device-side gate and the op is recomputed by the BF16X3 kernels in the same stream ("guarded fallback":
+ *            the bf16x3 launch that follows every f16x2 launch returns at once unless the gate is raised; no host
+ *            synchronisation; gif_h2_fallback_stats counts the fallbacks taken; GIF_H2_GUARD=0 removes the guard).
+ *            Measured error against an fp64 convolution: 1.0-1.3 x the native fp32 MFMA path (tests/test_gpu_f16x2.py).
+ *            Layers the f16x2 kernels do not take (tap-dense thin layers, Winograd GEMMs not built for it) run BF16X3.
+ *            Default: the GIF_FP32_MFMA environment variable ("native" / "bf16x3" / "f16x2"), else F16X2. */
 #define GIF_FP32_MFMA_NATIVE 0
 #define GIF_FP32_MFMA_BF16X3 1
+#define GIF_FP32_MFMA_F16X2 2
 int gif_set_fp32_mfma_mode(int mode);
 int gif_get_fp32_mfma_mode(void);
 /* The bf16x3 entry points (fp32 activations in and out, exactly like their _f32 namesakes; stylegan2_common_layers.py:330-345).
@@ -67,6 +82,16 @@ int gif_conv2d_pack_dims_x3(int cout, int cin, int* RP, int* CP); /* like gif_co
 int gif_pack_weight_f32x3(const float* w, void* wp3, int R, int C, int KH, int KW, int RP, int CP, int64_t sr, int64_t sc,
                           int64_t sky, int64_t skx, float scale, gif_stream_t stream);
 /* gif_conv2d_fwd_f32x3 / gif_conv2d_bwd_data_f32x3: declared next to their _f32 namesakes below */
+/* The f16x2 entry points (ABI 4).  gif_pack_weight_f32h2 writes wp2 = [RP + 32 int32: the rows' exponents, then a flag word the
+ * packing sets when a 16-channel group of some row falls out of the precision window][tap][2][RP][CP] f16 (hi, lo planes of
+ * scale * w * 2^e_row; RP/CP from gif_conv2d_pack_dims_x3; gif_pack_weight_f32h2_bytes of device memory).  The convolution entry
+ * points take BOTH packings of the same weights: wp2 for the f16x2 kernels and wp3 (gif_pack_weight_f32x3) for the guarded
+ * fallback; wp3 == NULL runs unguarded.  Eligibility as for bf16x3 (gif_conv2d_x3_eligible; no tap-dense variant). */
+int64_t gif_pack_weight_f32h2_bytes(int KH, int KW, int RP, int CP);
+int gif_pack_weight_f32h2(const float* w, void* wp2, int R, int C, int KH, int KW, int RP, int CP, int64_t sr, int64_t sc,
+                          int64_t sky, int64_t skx, float scale, gif_stream_t stream);
+/* out2[0] = guarded launches that took the bf16x3 fallback on the current device since the last reset (synchronises the device) */
+int gif_h2_fallback_stats(uint64_t* out2, int reset);
 /* Tap-dense K order for 3x3 layers with 8 <= cin_act < 32 contraction channels (the condition-noise convs 6->12->24 and the 24->C
  * layers that inject their result, stylegan2_common_layers.py:217-246): K runs over (tap, channel) without padding every tap to a
  * 32-float chunk — 9 taps of 24 channels take 7 K steps instead of 9, of 12 channels 4, of 8 channels 3.
@@ -205,6 +230,10 @@ int gif_conv2d_bwd_data_f32(const float* small, const float* wp, float* big, con
 int gif_conv2d_fwd_f32x3(const float* big, const void* wp3, float* small, const gif_conv_geom* g, const gif_conv_epilogue* e,
                          gif_stream_t stream);
 int gif_conv2d_bwd_data_f32x3(const float* small, const void* wp3, float* big, const gif_conv_geom* g,
+                              const gif_conv_epilogue* e, gif_stream_t stream);
+int gif_conv2d_fwd_f32h2(const float* big, const void* wp2, const void* wp3, float* small, const gif_conv_geom* g,
+                         const gif_conv_epilogue* e, gif_stream_t stream);
+int gif_conv2d_bwd_data_f32h2(const float* small, const void* wp2, const void* wp3, float* big, const gif_conv_geom* g,
                               const gif_conv_epilogue* e, gif_stream_t stream);
 int gif_conv2d_fwd_f32x3_tapdense(const float* big, const void* wp3, float* small, const gif_conv_geom* g,
                                   const gif_conv_epilogue* e, gif_stream_t stream);
