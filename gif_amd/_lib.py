@@ -74,6 +74,7 @@ PROTOTYPES = {
     "gif_conv2d_wgrad_splits": (c_int, [GP]),
     "gif_conv2d_wgrad_f32": (c_int, [P, P, P, P, P, GP, c_int, P]),
     "gif_conv2d_wgrad_f32x3": (c_int, [P, P, P, P, P, GP, c_int, P]),
+    "gif_conv2d_wgrad_f32h2": (c_int, [P, P, P, P, P, GP, c_int, P]),
     "gif_unpack_wgrad_f32": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_float, P]),
     "gif_winograd_pack_dims": (c_int, [c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "gif_winograd_pack_dims_x3": (c_int, [c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
@@ -85,6 +86,7 @@ PROTOTYPES = {
     "gif_conv3x3_winograd_wgrad_splits": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "gif_conv3x3_winograd_wgrad_f32": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "gif_conv3x3_winograd_wgrad_f32x3": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "gif_conv3x3_winograd_wgrad_f32h2": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "gif_winograd_unpack_wgrad_f32": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_float, P]),
     "gif_texture_pair_loss_partials": (c_int, [c_i64]),
     "gif_texture_pair_loss_f32": (c_int, [P, P, P, P, P, P, P, c_int, c_i64, P]),

@@ -829,14 +829,13 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
                     h_max[i] = fmaxf(h_max[i], m);
                     h_gmin[i] = min(h_gmin[i], __float_as_uint(m) - 1u);          // an all-zero group (0 - 1 = 0xffffffff) never wins
                     h_dl[i] = 0;
-                    if (__builtin_amdgcn_ballot_w64(m > h_lim[i]) != 0) {          // wave-uniform, rare after a row's first groups
-                        if (m > h_lim[i]) {
-                            const int ne = gif::h2_exp_for(__float_as_uint(m), gif::kH2Target);
-                            h_dl[i] = ne - h_ex[i];
-                            h_ex[i] = ne;
-                            h_sc[i] = gif::h2_pow2(ne);
-                            h_lim[i] = ldexpf(gif::kH2Limit, -ne);
-                        }
+                    if (__builtin_amdgcn_ballot_w64(m > h_lim[i]) != 0) {          // wave-uniform (scalar branch), rare after a row's first groups
+                        // per-lane update by selects: no EXEC manipulation anywhere near the MFMA stream
+                        const int ne = m > h_lim[i] ? gif::h2_exp_for(__float_as_uint(m), gif::kH2Target) : h_ex[i];
+                        h_dl[i] = ne - h_ex[i];
+                        h_ex[i] = ne;
+                        h_sc[i] = gif::h2_pow2(ne);
+                        h_lim[i] = ldexpf(gif::kH2Limit, -ne);
                         h_need = true;
                     }
                 }
@@ -1071,7 +1070,9 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
 }
 
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool SCALE, int BK, int X3 = 0>
-__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_gather_mfma_glds(const GatherParams p) {
+// (f16x2 on 4 waves: min. 2 workgroups per CU = a 256-register budget, so that the accumulators stay in architectural VGPRs for
+// the VALU rescale path — see conv_wgrad.hip)
+__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, (X3 == 2 && WAVES_M * WAVES_N == 4) ? 2 : 1) conv_gather_mfma_glds(const GatherParams p) {
     glds_body<T, BM, BN, WAVES_M, WAVES_N, SCALE, BK, X3>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 
@@ -1084,7 +1085,7 @@ struct MultiParams {
 };
 
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool SCALE, int BK, int X3 = 0>
-__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_gather_mfma_glds_multi(const MultiParams mp) {
+__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, (X3 == 2 && WAVES_M * WAVES_N == 4) ? 2 : 1) conv_gather_mfma_glds_multi(const MultiParams mp) {
     const int b = (int)blockIdx.x;
     int k = 0;
     while (k + 1 < mp.nph && b >= mp.wg_end[k]) ++k;  // wave-uniform

@@ -35,6 +35,11 @@ struct WgradParams {
     const void* zero;   // 16 zero bytes in HBM (source of out-of-range LDS-DMA lanes), passed as an argument
     // "planes" mode (Winograd wgrad): tap t has no spatial shift but its own operand planes sm + t*sm_plane, bg + t*bg_plane
     long sm_plane, bg_plane;
+    // f16x2 (common.h "h2"): gate word the kernel raises when a K group leaves the precision window; bf16x3 launch WITH a gate:
+    // the guarded fallback, runs iff *gate == gate_gen
+    unsigned* gate;
+    unsigned gate_gen;
+    unsigned* h2_stats;
 };
 
 // XCD-aware, bijective block remap: XCD k (= blockIdx % 8 by dispatch order) gets a contiguous range of logical ids.
@@ -59,10 +64,25 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // consecutive pixels of its channel per operand tile (eight ds_read_b32, conflict free), then splits the 8 floats into the
 // three bf16x8 terms; six v_mfma_f32_32x32x16_bf16 per tile pair and 16 pixels.  Both operands are activations, so neither can
 // be pre-split; the split (36 VALU per fragment) overlaps with the MFMAs of the other resident waves.
-template <typename T, int BP, int BQ, int WAVES_P, int WAVES_Q, bool GLDS, int BKP, bool TAB = false, bool X3 = false>
-__global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const WgradParams p) {
+// X3 = 2 ("f16x2", common.h): the same tiles, v_mfma_f32_32x32x16_f16 on two f16 terms per operand under per-CHANNEL power-of-two
+// scales (a row of either operand is a channel, K runs over pixels): both operands carry a running exponent per lane, three products.
+template <typename T, int BP, int BQ, int WAVES_P, int WAVES_Q, bool GLDS, int BKP, bool TAB = false, int X3 = 0>
+// (f16x2, 4 waves: "at least 2 workgroups per CU" caps the budget at 256 registers, which makes hipcc keep the accumulators in
+// architectural VGPRs — the rare rescale path multiplies them with VALU instructions; from AGPRs that costs 64 temporaries and the
+// kernel would no longer fit two waves per SIMD)
+#ifndef GIF_H2_WG_DBG
+#define GIF_H2_WG_DBG 0
+#endif
+__global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q, ((X3 == 2 && WAVES_P * WAVES_Q == 4 && !(GIF_H2_WG_DBG & 2)) || (X3 == 1 && (GIF_H2_WG_DBG & 16) && WAVES_P * WAVES_Q == 4)) ? 2 : 1) conv_wgrad_mfma(const WgradParams p) {
     constexpr bool F16 = sizeof(T) == 2;
+    if constexpr (X3 == 1) {
+        if (p.gate) {  // guarded fallback of an f16x2 launch: nothing to do unless that launch raised the gate
+            if (*p.gate != p.gate_gen) return;
+            if (blockIdx.x == 0 && threadIdx.x == 0 && p.h2_stats) atomicAdd(p.h2_stats, 1u);
+        }
+    }
     static_assert(!X3 || (!F16 && GLDS && BKP % 16 == 0), "bf16x3: fp32 tiles through the LDS-DMA path, 16-pixel K steps");
+    static_assert(X3 != 2 || BKP == 32, "f16x2: the software-pipelined 32-pixel stages only");
     constexpr int EPC = 16 / sizeof(T);  // elements per 16-byte chunk
     constexpr int THREADS = 64 * WAVES_P * WAVES_Q;
     constexpr int WPt = BP / WAVES_P, WQt = BQ / WAVES_Q;
@@ -230,7 +250,7 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     auto compute = [&](int buf) __attribute__((always_inline)) {
-        if constexpr (X3) {
+        if constexpr (X3 == 1) {
             float psv[MT], qsv[NT];
             if (TAB) {
                 const float* row = Stab + tab_row * (BP + BQ);
@@ -368,13 +388,30 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const 
     };
 
     if constexpr (X3 && BKP == 32) {
-        // ---- bf16x3, software-pipelined (two 16-pixel groups per stage; same schedule as conv_gather_mfma_glds' X3 path):
+        // ---- bf16x3 / f16x2, software-pipelined (two 16-pixel groups per stage; same schedule as conv_gather_mfma_glds' X3 path):
         //   DMA(stage+1) | MFMAs(g0) + read & split g1 | barrier | MFMAs(g1) + read & split g0 of stage+1
-        // The split of the NEXT group (16 pieces of 9 VALU, +2 with per-sample scales) sits piecewise between the 24 MFMAs of
-        // the current one; sched_barrier(0) pins the interleave.
-        gif::u32x4_t sa[2][3][MT], sb[2][3][NT];  // [slot][hi, mid, lo][tile]
-        float ra[MT][8], rb[NT][8];               // raw fragments of the group being split
-        float psv[MT], qsv[NT];                   // per-sample scales of the stage being split (TAB)
+        // The split of the NEXT group ((MT + NT) * 4 pieces: bf16x3 11 VALU each, +2 with per-sample scales; f16x2 6 VALU + the
+        // running exponents) sits piecewise between the MFMAs of the current one; sched_barrier(0) pins the interleave.
+        constexpr bool H2 = X3 == 2;
+        constexpr int NPL = H2 ? 2 : 3;
+        constexpr int NF = MT + NT;                   // operand fragments per group: P tiles, then Q tiles
+        gif::u32x4_t sa[2][NPL][MT], sb[2][NPL][NT];  // [slot][term][tile]
+        float ra[MT][8], rb[NT][8];                   // raw fragments of the group being split
+        float psv[MT], qsv[NT];                       // per-sample scales of the stage being split (TAB)
+        // f16x2 state per fragment (channel = lane li of the tile; lanes li and li + 32 agree): exponent, 2^e, the largest |v| it
+        // holds, pending exponent change, the guard's statistics (channel maximum, smallest non-zero group maximum as bits - 1)
+        int h_ex[NF], h_dl[NF];
+        float h_sc[NF], h_lim[NF], h_max[NF];
+        unsigned h_gmin[NF];
+        bool h_need = false;
+        if constexpr (H2) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                h_ex[f] = 126; h_dl[f] = 0;
+                h_sc[f] = gif::h2_pow2(126); h_lim[f] = gif::kH2Limit * gif::h2_pow2(-126);
+                h_max[f] = 0.f; h_gmin[f] = 0xFFFFFFFFu;
+            }
+        }
         auto scales = [&]() __attribute__((always_inline)) {
             if (TAB) {
                 const float* row = Stab + tab_row * (BP + BQ);
@@ -397,45 +434,131 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const 
 #pragma unroll
                 for (int e = 0; e < 8; ++e) rb[j][e] = Qs[buf][k0 + e][wq0 + j * 32 + li];
         };
-        constexpr int NPC = (MT + NT) * 4;
-        auto split_piece = [&](int slot, int k) __attribute__((always_inline)) {
-            const int f = k / 4, e = k % 4;
-            unsigned h, m, l;
-            if (f < MT) {
-                float x0 = ra[f][2 * e], x1 = ra[f][2 * e + 1];
-                if (TAB) { x0 *= psv[f]; x1 *= psv[f]; }
-                gif::split_pair_scalar(x0, x1, h, m, l);
-                sa[slot][0][f][e] = h; sa[slot][1][f][e] = m; sa[slot][2][f][e] = l;
-            } else {
-                float x0 = rb[f - MT][2 * e], x1 = rb[f - MT][2 * e + 1];
-                if (TAB) { x0 *= qsv[f - MT]; x1 *= qsv[f - MT]; }
-                gif::split_pair_scalar(x0, x1, h, m, l);
-                sb[slot][0][f - MT][e] = h; sb[slot][1][f - MT][e] = m; sb[slot][2][f - MT][e] = l;
+        // f16x2: per-sample scale, group maximum and exponent decision of fragment f of the raw group just read
+        auto track = [&](int f) __attribute__((always_inline)) {
+#if GIF_H2_WG_DBG & 32
+            if (f >= 0) { h_sc[f] = 1024.f; h_ex[f] = 10; return; }  // debug: fixed scale, no tracking instructions at all
+#endif
+            if constexpr (H2) {
+                float* v = f < MT ? ra[f] : rb[f - MT];
+                if (TAB) {
+                    const float sv = f < MT ? psv[f] : qsv[f - MT];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= sv;
+                }
+                float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fabsf(v[2]));
+                m = fmaxf(fmaxf(m, fabsf(v[3])), fabsf(v[4]));
+                m = fmaxf(fmaxf(m, fabsf(v[5])), fabsf(v[6]));
+                m = fmaxf(m, fabsf(v[7]));
+#if !(GIF_H2_WG_DBG & 64)
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+                m = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));  // the channel's 16 pixels of this group
+#endif
+#if GIF_H2_WG_DBG & 128
+                m = fmaxf(m, __shfl_xor(m, 32));
+#endif
+                h_max[f] = fmaxf(h_max[f], m);
+                h_gmin[f] = min(h_gmin[f], __float_as_uint(m) - 1u);
+                h_dl[f] = 0;
+                if (__builtin_amdgcn_ballot_w64(m > h_lim[f]) != 0) {  // wave-uniform (scalar branch), rare after a channel's first groups
+                    // per-lane update by selects: no EXEC manipulation anywhere near the MFMA stream
+                    const int ne = m > h_lim[f] ? gif::h2_exp_for(__float_as_uint(m), gif::kH2Target) : h_ex[f];
+                    h_dl[f] = ne - h_ex[f];
+                    h_ex[f] = ne;
+                    h_sc[f] = gif::h2_pow2(ne);
+                    h_lim[f] = ldexpf(gif::kH2Limit, -ne);
+                    h_need = true;
+                }
             }
         };
-        constexpr int LEAD = 6;  // MFMAs ahead of the first piece: they cover the latency of the 32 ds_read_b32 (issued as 20 ds_read2)
-        auto group = [&](int slot, int nslot) __attribute__((always_inline)) {
-            constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
-            int n = 0, piece = 0;
+        // f16x2: acc[i][j][r] *= 2^(change of its P row + change of its Q column); the row (r & 3) + 8 (r >> 2) + 4 lh of P tile i
+        // lives in lane `row`, the column of Q tile j is this lane's own
+        auto rescale = [&]() __attribute__((always_inline)) {
+            if constexpr (H2) {
 #pragma unroll
-            for (int t6 = GIF_X3_FIRST_TERM; t6 < 6; ++t6)
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int d = __builtin_amdgcn_ds_bpermute(((r & 3) + 8 * (r >> 2) + 4 * lh) * 4, h_dl[i]);
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) acc[i][j][r] = ldexpf(acc[i][j][r], d + h_dl[MT + j]);
+                    }
+            }
+        };
+        constexpr int NPC = NF * 4;
+        auto split_piece = [&](int slot, int k) __attribute__((always_inline)) {
+            const int f = k / 4, e = k % 4;
+            if constexpr (H2) {
+                unsigned h, l;
+                if (f < MT) {
+                    gif::split_pair_h2(ra[f][2 * e], ra[f][2 * e + 1], h_sc[f], h, l);
+                    sa[slot][0][f][e] = h; sa[slot][1][f][e] = l;
+                } else {
+                    gif::split_pair_h2(rb[f - MT][2 * e], rb[f - MT][2 * e + 1], h_sc[f], h, l);
+                    sb[slot][0][f - MT][e] = h; sb[slot][1][f - MT][e] = l;
+                }
+            } else {
+                unsigned h, m, l;
+                if (f < MT) {
+                    float x0 = ra[f][2 * e], x1 = ra[f][2 * e + 1];
+                    if (TAB) { x0 *= psv[f]; x1 *= psv[f]; }
+                    gif::split_pair_scalar(x0, x1, h, m, l);
+                    sa[slot][0][f][e] = h; sa[slot][1][f][e] = m; sa[slot][2][f][e] = l;
+                } else {
+                    float x0 = rb[f - MT][2 * e], x1 = rb[f - MT][2 * e + 1];
+                    if (TAB) { x0 *= qsv[f - MT]; x1 *= qsv[f - MT]; }
+                    gif::split_pair_scalar(x0, x1, h, m, l);
+                    sb[slot][0][f - MT][e] = h; sb[slot][1][f - MT][e] = m; sb[slot][2][f - MT][e] = l;
+                }
+            }
+        };
+        // preparation step `q` of the next group: f16x2 runs a fragment's tracking step right before its four split pieces
+        constexpr int NSTEP = H2 ? NF * 5 : NPC;
+        auto prep = [&](int nslot, int q) __attribute__((always_inline)) {
+            if constexpr (H2) {
+                if (q % 5 == 0) track(q / 5);
+                else split_piece(nslot, (q / 5) * 4 + q % 5 - 1);
+            } else {
+                split_piece(nslot, q);
+            }
+        };
+        constexpr int NPROD = H2 ? 3 : 6;
+        constexpr int LEAD = (H2 && !(GIF_H2_WG_DBG & 1)) ? 3 : 6;  // MFMAs ahead of the first piece: they cover the latency of the 32 ds_read_b32 (issued as 20 ds_read2)
+        auto group = [&](int slot, int nslot) __attribute__((always_inline)) {
+            constexpr int TA6[6] = {2, 0, 1, 1, 0, 0}, TB6[6] = {0, 2, 1, 0, 1, 0};
+            constexpr int TA3[3] = {1, 0, 0}, TB3[3] = {0, 1, 0};
+            int n = 0, q = 0;
+            if constexpr (H2) h_need = false;
+#pragma unroll
+            for (int t6 = (H2 ? 0 : GIF_X3_FIRST_TERM); t6 < NPROD; ++t6)
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NT; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gif::bf16x8_t, sa[slot][TA[t6]][i]),
-                                                                            __builtin_bit_cast(gif::bf16x8_t, sb[slot][TB[t6]][j]),
-                                                                            acc[i][j], 0, 0, 0);
+                        if constexpr (H2)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gif::f16x8_t, sa[slot][TA3[t6]][i]),
+                                                                               __builtin_bit_cast(gif::f16x8_t, sb[slot][TB3[t6]][j]),
+                                                                               acc[i][j], 0, 0, 0);
+                        else
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gif::bf16x8_t, sa[slot][TA6[t6]][i]),
+                                                                                __builtin_bit_cast(gif::bf16x8_t, sb[slot][TB6[t6]][j]),
+                                                                                acc[i][j], 0, 0, 0);
                         __builtin_amdgcn_sched_barrier(0);
                         ++n;
-                        if (nslot >= 0 && n >= LEAD && piece < NPC) {
-                            split_piece(nslot, piece++);
+                        // f16x2 has half the MFMAs to hide twice the steps under: two steps per MFMA slot
+                        if (nslot >= 0 && n >= LEAD) {
+#pragma unroll
+                            for (int rep2 = 0; rep2 < ((H2 && !(GIF_H2_WG_DBG & 1)) ? 2 : 1); ++rep2)
+                                if (q < NSTEP) prep(nslot, q++);
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
             if (nslot >= 0) {
 #pragma unroll
-                for (; piece < NPC; ++piece) split_piece(nslot, piece);
+                for (; q < NSTEP; ++q) prep(nslot, q);
+                if constexpr (H2) {
+                    if (h_need && !(GIF_H2_WG_DBG & 4)) rescale();
+                }
             }
         };
         if (n_begin < n_end) {
@@ -444,7 +567,7 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const 
             scales();
             read_raw(0, 0);
 #pragma unroll
-            for (int k = 0; k < NPC; ++k) split_piece(0, k);
+            for (int q = 0; q < NSTEP; ++q) prep(0, q);  // (f16x2: first exponents; the accumulators are still zero)
             int cur = 0;
             for (int n0 = n_begin; n0 + BKP < n_end; n0 += BKP) {
                 load_global(cur ^ 1);  // stage n0 + BKP: its buffer was last read before the previous stage's barrier
@@ -463,6 +586,25 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const 
             __builtin_amdgcn_sched_barrier(0);
             group(0, 1);
             group(1, -1);
+        }
+        if constexpr (H2) {
+            bool wide = false;
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+                wide |= (int)(__float_as_uint(h_max[f]) >> 23) - (int)((h_gmin[f] + 1u) >> 23) > gif::kH2Window;
+            if (p.gate && __builtin_amdgcn_ballot_w64(wide) != 0 && lane == 0) atomicMax(p.gate, p.gate_gen);
+#if GIF_H2_WG_DBG & 8
+#pragma unroll
+            for (int z = 0; z < 16; ++z) asm volatile("s_nop 15");
+#endif
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int er = __builtin_amdgcn_ds_bpermute(((r & 3) + 8 * (r >> 2) + 4 * lh) * 4, h_ex[i]);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j][r] = ldexpf(acc[i][j][r], -(er + h_ex[MT + j]));
+                }
         }
     } else if (n_begin < n_end) {
         load_global(0);
@@ -495,10 +637,11 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q) conv_wgrad_mfma(const 
         }
 }
 
-template <typename T, int BP, int BQ, int WP_, int WQ_, bool GLDS, int BKP, bool TAB = false, bool X3 = false>
+template <typename T, int BP, int BQ, int WP_, int WQ_, bool GLDS, int BKP, bool TAB = false, int X3 = 0>
 void wgrad_launch(dim3 grid, int threads, hipStream_t s, const WgradParams& p) {
     static gif::LdsAttr attr;
-    const size_t lds = (size_t)2 * BKP * (BP + BQ) * sizeof(T) + (size_t)(TAB ? p.stab_nb * (BP + BQ) : 0) * sizeof(float);
+    static const size_t lds_pad = getenv("GIF_WG_LDS_PAD") ? (size_t)atoi(getenv("GIF_WG_LDS_PAD")) : 0;  // debug: forces one workgroup per CU
+    const size_t lds = (size_t)2 * BKP * (BP + BQ) * sizeof(T) + (size_t)(TAB ? p.stab_nb * (BP + BQ) : 0) * sizeof(float) + lds_pad;
     auto kern = conv_wgrad_mfma<T, BP, BQ, WP_, WQ_, GLDS, BKP, TAB, X3>;
     attr.ensure(reinterpret_cast<const void*>(kern), lds);
     hipLaunchKernelGGL(kern, grid, dim3(threads), lds, s, p);
@@ -1268,8 +1411,10 @@ int gif_conv2d_wgrad_splits(const gif_conv_geom* g) {
     return (int)n;
 }
 
+// x3: 0 native fp32 MFMA, 1 bf16x3, 2 f16x2 with the guarded bf16x3 fallback (launch shapes f16x2 is not built for run bf16x3)
 static int conv2d_wgrad_f32_impl(const float* small, const float* big, float* ws, const float* small_scale,
-                                 const float* big_scale, const gif_conv_geom* g, int nsplit, gif_stream_t stream, bool x3) {
+                                 const float* big_scale, const gif_conv_geom* g, int nsplit, gif_stream_t stream, int x3_mode) {
+    bool x3 = x3_mode != 0;
     GIF_REQUIRE(g && small && big && ws && nsplit >= 1, "conv2d_wgrad: bad arguments");
     GIF_REQUIRE(g->Cb % 4 == 0 && g->Cs % 4 == 0, "conv2d_wgrad: channels must be multiples of 4");
     GIF_REQUIRE(g->KH >= 1 && g->KH <= 3 && g->KW >= 1 && g->KW <= 3 && (g->stride == 1 || g->stride == 2),
@@ -1328,20 +1473,31 @@ static int conv2d_wgrad_f32_impl(const float* small, const float* big, float* ws
     else wgrad_launch<float, BP_, BQ_, WP_, WQ_, false, 32>(grid, TH_, s, p)
         const bool tab = (small_scale || big_scale) && (variant != 1 || x3) && tab_fits;
         static const int x3_simple = getenv("GIF_X3_WGRAD_SIMPLE") ? atoi(getenv("GIF_X3_WGRAD_SIMPLE")) : 0;  // A/B: 16-pixel stages, no pipeline
-        if (x3_thin) {
+        // f16x2: the software-pipelined 32-pixel-stage instantiations; the launch is followed by its guarded bf16x3 twin
+        const bool h2 = x3 && x3_mode == 2 && !x3_simple && (x3_thin || !tab || HWs % 32 == 0);
+        if (h2) {
+            const gif::H2Gate gt = gif::h2_next_gate();
+            p.gate = gt.word; p.gate_gen = gt.gen; p.h2_stats = gif::h2_stats_words();
+            if (x3_thin) wgrad_launch<float, 128, 32, 2, 1, true, 32, false, 2>(grid, 128, s, p);
+            else if (tab) wgrad_launch<float, 128, 128, 2, 2, true, 32, true, 2>(grid, 256, s, p);
+            else wgrad_launch<float, 128, 128, 2, 2, true, 32, false, 2>(grid, 256, s, p);
+        }
+        if (h2 && !p.gate) {
+            // unguarded (GIF_H2_GUARD=0): done
+        } else if (x3_thin) {
             // two waves of 64x32: 3 fragment splits per 12 MFMAs (four waves of 32x32: 2 per 6 — GIF_X3_WGRAD_THIN=4 for the A/B:
             // 128x24 at 256^2 76 -> 80 TFLOP/s, 256x24 at 128^2 70 -> 78, 512x24 at 64^2 80 -> 82)
             static const int thin4 = getenv("GIF_X3_WGRAD_THIN") ? atoi(getenv("GIF_X3_WGRAD_THIN")) == 4 : 0;
-            if (thin4) wgrad_launch<float, 128, 32, 4, 1, true, 32, false, true>(grid, 256, s, p);
-            else wgrad_launch<float, 128, 32, 2, 1, true, 32, false, true>(grid, 128, s, p);
+            if (thin4) wgrad_launch<float, 128, 32, 4, 1, true, 32, false, 1>(grid, 256, s, p);
+            else wgrad_launch<float, 128, 32, 2, 1, true, 32, false, 1>(grid, 128, s, p);
         } else if (x3 && tab && HWs % 32 == 0 && !x3_simple) {
-            wgrad_launch<float, 128, 128, 2, 2, true, 32, true, true>(grid, 256, s, p);
+            wgrad_launch<float, 128, 128, 2, 2, true, 32, true, 1>(grid, 256, s, p);
         } else if (x3 && tab) {
-            wgrad_launch<float, 128, 128, 2, 2, true, 16, true, true>(grid, 256, s, p);
+            wgrad_launch<float, 128, 128, 2, 2, true, 16, true, 1>(grid, 256, s, p);
         } else if (x3 && !x3_simple) {
-            wgrad_launch<float, 128, 128, 2, 2, true, 32, false, true>(grid, 256, s, p);
+            wgrad_launch<float, 128, 128, 2, 2, true, 32, false, 1>(grid, 256, s, p);
         } else if (x3) {
-            wgrad_launch<float, 128, 128, 2, 2, true, 16, false, true>(grid, 256, s, p);
+            wgrad_launch<float, 128, 128, 2, 2, true, 16, false, 1>(grid, 256, s, p);
         } else if (big_tile) {
             wgrad_launch<float, 256, 128, 2, 2, true, 16>(grid, 256, s, p);
         } else if (bp == 128 && bq == 128 && tab) {
@@ -1361,12 +1517,18 @@ static int conv2d_wgrad_f32_impl(const float* small, const float* big, float* ws
 
 int gif_conv2d_wgrad_f32(const float* small, const float* big, float* ws, const float* small_scale,
                          const float* big_scale, const gif_conv_geom* g, int nsplit, gif_stream_t stream) {
-    return conv2d_wgrad_f32_impl(small, big, ws, small_scale, big_scale, g, nsplit, stream, false);
+    return conv2d_wgrad_f32_impl(small, big, ws, small_scale, big_scale, g, nsplit, stream, 0);
 }
 
 int gif_conv2d_wgrad_f32x3(const float* small, const float* big, float* ws, const float* small_scale,
                            const float* big_scale, const gif_conv_geom* g, int nsplit, gif_stream_t stream) {
-    return conv2d_wgrad_f32_impl(small, big, ws, small_scale, big_scale, g, nsplit, stream, true);
+    return conv2d_wgrad_f32_impl(small, big, ws, small_scale, big_scale, g, nsplit, stream, 1);
+}
+
+/* f16x2 (ABI 4): same contract; the f16x2 launch is followed by its guarded bf16x3 twin (a no-op unless the gate was raised) */
+int gif_conv2d_wgrad_f32h2(const float* small, const float* big, float* ws, const float* small_scale,
+                           const float* big_scale, const gif_conv_geom* g, int nsplit, gif_stream_t stream) {
+    return conv2d_wgrad_f32_impl(small, big, ws, small_scale, big_scale, g, nsplit, stream, 2);
 }
 
 int gif_unpack_wgrad_f32(const float* ws, float* dw, int nsplit, int R, int C, int KH, int KW, int RP, int CP,
@@ -1399,7 +1561,8 @@ int gif_conv3x3_winograd_wgrad_splits(int B, int H, int W, int Cs, int Cb) {
 
 static int conv3x3_winograd_wgrad_impl(const float* x, const float* gy, float* V, float* Mg, float* ws,
                                        const float* small_scale, const float* big_scale, int B, int H, int W, int Cs, int Cb,
-                                       int nsplit, gif_stream_t stream, bool x3) {
+                                       int nsplit, gif_stream_t stream, int x3_mode) {
+    bool x3 = x3_mode != 0;
     GIF_REQUIRE(gy && V && Mg && ws && nsplit >= 1, "winograd_wgrad: bad arguments");  // x == NULL: V is already filled
     GIF_REQUIRE(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "winograd_wgrad: bad dims (H, W must be even)");
     GIF_REQUIRE(Cs > 0 && Cb > 0 && Cs % 4 == 0 && Cb % 4 == 0, "winograd_wgrad: channels must be multiples of 4");
@@ -1440,8 +1603,15 @@ static int conv3x3_winograd_wgrad_impl(const float* x, const float* gy, float* V
     p.zero = gif::zero_page16();
     GIF_REQUIRE(p.zero, "winograd_wgrad: zero page lookup failed");
     static const int x3_simple = getenv("GIF_X3_WGRAD_SIMPLE") ? atoi(getenv("GIF_X3_WGRAD_SIMPLE")) : 0;
-    if (x3 && !x3_simple) wgrad_launch<float, 128, 128, 2, 2, true, 32, false, true>(grid, 256, s, p);
-    else if (x3) wgrad_launch<float, 128, 128, 2, 2, true, 16, false, true>(grid, 256, s, p);
+    const bool h2 = x3 && x3_mode == 2 && !x3_simple;
+    if (h2) {
+        const gif::H2Gate gt = gif::h2_next_gate();
+        p.gate = gt.word; p.gate_gen = gt.gen; p.h2_stats = gif::h2_stats_words();
+        wgrad_launch<float, 128, 128, 2, 2, true, 32, false, 2>(grid, 256, s, p);
+    }
+    if (h2 && !p.gate) {}
+    else if (x3 && !x3_simple) wgrad_launch<float, 128, 128, 2, 2, true, 32, false, 1>(grid, 256, s, p);
+    else if (x3) wgrad_launch<float, 128, 128, 2, 2, true, 16, false, 1>(grid, 256, s, p);
     else if (big) wgrad_launch<float, 256, 128, 2, 2, true, 16>(grid, 256, s, p);
     else if (bp == 128 && bq == 128) wgrad_launch<float, 128, 128, 2, 2, true, 16>(grid, 256, s, p);
     else if (bp == 128 && bq == 32) wgrad_launch<float, 128, 32, 4, 1, true, 32>(grid, 256, s, p);
@@ -1453,13 +1623,19 @@ static int conv3x3_winograd_wgrad_impl(const float* x, const float* gy, float* V
 int gif_conv3x3_winograd_wgrad_f32(const float* x, const float* gy, float* V, float* Mg, float* ws,
                                    const float* small_scale, const float* big_scale, int B, int H, int W, int Cs, int Cb,
                                    int nsplit, gif_stream_t stream) {
-    return conv3x3_winograd_wgrad_impl(x, gy, V, Mg, ws, small_scale, big_scale, B, H, W, Cs, Cb, nsplit, stream, false);
+    return conv3x3_winograd_wgrad_impl(x, gy, V, Mg, ws, small_scale, big_scale, B, H, W, Cs, Cb, nsplit, stream, 0);
 }
 
 int gif_conv3x3_winograd_wgrad_f32x3(const float* x, const float* gy, float* V, float* Mg, float* ws,
                                      const float* small_scale, const float* big_scale, int B, int H, int W, int Cs, int Cb,
                                      int nsplit, gif_stream_t stream) {
-    return conv3x3_winograd_wgrad_impl(x, gy, V, Mg, ws, small_scale, big_scale, B, H, W, Cs, Cb, nsplit, stream, true);
+    return conv3x3_winograd_wgrad_impl(x, gy, V, Mg, ws, small_scale, big_scale, B, H, W, Cs, Cb, nsplit, stream, 1);
+}
+
+int gif_conv3x3_winograd_wgrad_f32h2(const float* x, const float* gy, float* V, float* Mg, float* ws,
+                                     const float* small_scale, const float* big_scale, int B, int H, int W, int Cs, int Cb,
+                                     int nsplit, gif_stream_t stream) {
+    return conv3x3_winograd_wgrad_impl(x, gy, V, Mg, ws, small_scale, big_scale, B, H, W, Cs, Cb, nsplit, stream, 2);
 }
 
 int gif_winograd_unpack_wgrad_f32(const float* ws, float* dw, int nsplit, int R, int C, int RP, int CP, int64_t sr,

@@ -213,6 +213,12 @@ def split_mode() -> bool:
 
 
 H2_CONV = os.environ.get("GIF_H2_CONV", "1") != "0"    # f16x2 mode: direct fwd / dgrad kernels (A/B knobs per kernel family)
+# f16x2 weight-gradient kernels (direct and Winograd plane GEMMs): OFF — the 128 x 128 instantiation returns wrong sums when two of its
+# workgroups share a CU (correct with one; tools/probes/h2_wgrad_debug.py), cause not found yet; weight gradients stay on bf16x3
+H2_WGRAD = os.environ.get("GIF_H2_WGRAD", "0") != "0"
+
+
+H2_GUARD = True  # False: f16x2 launches run without their guarded bf16x3 twin (tests only: shows what the guard protects against)
 
 
 def h2_conv(x3: bool, dense: bool) -> bool:
@@ -372,7 +378,7 @@ def conv_fwd(big, w, spec: ConvSpec, wscale=1.0, keep_v=False, **epi):
     e = _epilogue(out_bchw=(B, Cs, Hs, Ws), dtype=dt, **epi)
     if h2_conv(x3, dense):  # f16x2 kernels + the bf16x3 packing for their guarded fallback
         wp2 = pack_weight(w, True, Cs, Cb, wscale, dt, h2=True)
-        _lib.check(_lib.load().gif_conv2d_fwd_f32h2(big.data_ptr(), wp2.data_ptr(), wp.data_ptr(), out.data_ptr(), ctypes.byref(g),
+        _lib.check(_lib.load().gif_conv2d_fwd_f32h2(big.data_ptr(), wp2.data_ptr(), wp.data_ptr() if H2_GUARD else None, out.data_ptr(), ctypes.byref(g),
                                                     ctypes.byref(e), _stream()), "conv2d_fwd_f32h2")
         return out
     fn = _lib.load().gif_conv2d_fwd_f32x3_tapdense if dense else _lib.load().gif_conv2d_fwd_f32x3 if x3 else _fn("conv2d_fwd", dt)
@@ -399,7 +405,7 @@ def conv_bwd_data(small, w, spec: ConvSpec, big_hw, wscale=1.0, **epi):
     e = _epilogue(out_bchw=(B, Cb, Hb, Wb), dtype=dt, **epi)
     if h2_conv(x3, dense):
         wp2 = pack_weight(w, False, Cb, Cs, wscale, dt, h2=True)
-        _lib.check(_lib.load().gif_conv2d_bwd_data_f32h2(small.data_ptr(), wp2.data_ptr(), wp.data_ptr(), out.data_ptr(), ctypes.byref(g),
+        _lib.check(_lib.load().gif_conv2d_bwd_data_f32h2(small.data_ptr(), wp2.data_ptr(), wp.data_ptr() if H2_GUARD else None, out.data_ptr(), ctypes.byref(g),
                                                          ctypes.byref(e), _stream()), "conv2d_bwd_data_f32h2")
         return out
     fn = (_lib.load().gif_conv2d_bwd_data_f32x3_tapdense if dense else _lib.load().gif_conv2d_bwd_data_f32x3 if x3
@@ -432,7 +438,8 @@ def conv3x3_winograd_wgrad(small, big, O, I, wscale=1.0, small_scale=None, big_s
     V = big_v if big_v is not None else torch.empty((nv,), device=dev, dtype=torch.float32)
     Mg = torch.empty((lib.gif_winograd_workspace_floats(B, H, W, Cs),), device=dev, dtype=torch.float32)
     ws = torch.empty((nsplit, 16, RP.value, CP.value), device=dev, dtype=torch.float32)
-    fn = lib.gif_conv3x3_winograd_wgrad_f32x3 if split_mode() else lib.gif_conv3x3_winograd_wgrad_f32
+    fn = (lib.gif_conv3x3_winograd_wgrad_f32h2 if (H2_WGRAD and get_fp32_mfma_mode() == "f16x2") else
+          lib.gif_conv3x3_winograd_wgrad_f32x3 if split_mode() else lib.gif_conv3x3_winograd_wgrad_f32)
     _lib.check(fn(None if big_v is not None else big.data_ptr(), small.data_ptr(), V.data_ptr(), Mg.data_ptr(), ws.data_ptr(),
                                                   _p(small_scale), _p(big_scale), B, H, W, Cs, Cb, nsplit, _stream()),
                "conv3x3_winograd_wgrad")
@@ -465,7 +472,8 @@ def conv_wgrad(small, big, spec: ConvSpec, O, I, wscale=1.0, small_scale=None, b
     nsplit = splits(ctypes.byref(g))
     T = spec.KH * spec.KW
     ws = torch.empty((nsplit, T, RP.value, CP.value), device=small.device, dtype=torch.float32)
-    fn = lib.gif_conv2d_wgrad_f32x3 if (not f16 and split_mode()) else _fn("conv2d_wgrad", dt)
+    fn = (lib.gif_conv2d_wgrad_f32h2 if (not f16 and H2_WGRAD and get_fp32_mfma_mode() == "f16x2") else
+          lib.gif_conv2d_wgrad_f32x3 if (not f16 and split_mode()) else _fn("conv2d_wgrad", dt))
     _lib.check(fn(small.data_ptr(), big.data_ptr(), ws.data_ptr(), _p(small_scale), _p(big_scale), ctypes.byref(g), nsplit, _stream()),
                "conv2d_wgrad")
     dw = torch.empty((O, I, spec.KH, spec.KW), device=small.device, dtype=torch.float32)

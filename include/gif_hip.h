@@ -249,6 +249,9 @@ int gif_conv2d_wgrad_f32(const float* small, const float* big, float* ws, const 
 /* same contract (operands, workspace, splits) on the bf16x3 kernels; layers with a <= 32-channel side run the native kernel */
 int gif_conv2d_wgrad_f32x3(const float* small, const float* big, float* ws, const float* small_scale,
                            const float* big_scale, const gif_conv_geom* g, int nsplit, gif_stream_t stream);
+/* same contract on the f16x2 kernels (ABI 4; both operands carry a running per-channel exponent) with the guarded bf16x3 fallback */
+int gif_conv2d_wgrad_f32h2(const float* small, const float* big, float* ws, const float* small_scale,
+                           const float* big_scale, const gif_conv_geom* g, int nsplit, gif_stream_t stream);
 /* dw[r*sr + c*sc + ky*sky + kx*skx] = scale * sum_s ws[s][t][r][c]   (inverse of gif_pack_weight_f32) */
 int gif_unpack_wgrad_f32(const float* ws, float* dw, int nsplit, int R, int C, int KH, int KW, int RP, int CP,
                          int64_t sr, int64_t sc, int64_t sky, int64_t skx, float scale, gif_stream_t stream);
@@ -295,6 +298,9 @@ int gif_conv3x3_winograd_wgrad_f32(const float* x, const float* gy, float* V, fl
 int gif_conv3x3_winograd_wgrad_f32x3(const float* x, const float* gy, float* V, float* Mg, float* ws,
                                      const float* small_scale, const float* big_scale, int B, int H, int W, int Cs,
                                      int Cb, int nsplit, gif_stream_t stream);
+int gif_conv3x3_winograd_wgrad_f32h2(const float* x, const float* gy, float* V, float* Mg, float* ws,
+                                     const float* small_scale, const float* big_scale, int B, int H, int W, int Cs,
+                                     int Cb, int nsplit, gif_stream_t stream);  /* ABI 4: plane GEMMs on the f16x2 kernel + guarded fallback */
 int gif_winograd_unpack_wgrad_f32(const float* ws, float* dw, int nsplit, int R, int C, int RP, int CP, int64_t sr,
                                   int64_t sc, int64_t sky, int64_t skx, float scale, gif_stream_t stream);
 

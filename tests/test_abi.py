@@ -27,7 +27,7 @@ def test_header_symbols_exported_and_bound():
         assert hasattr(lib, n), f"{n} declared in gif_hip.h but not exported by libgif_hip.so"
         assert n in _lib.PROTOTYPES, f"{n} has no ctypes prototype"
     assert sorted(_lib.PROTOTYPES) == names
-    assert lib.gif_abi_version() == 3
+    assert lib.gif_abi_version() == 4  # 4: the f16x2 contraction mode (round 5)
 
 
 def test_argument_validation_without_gpu():
@@ -49,18 +49,21 @@ def test_argument_validation_without_gpu():
 
 
 def test_fp32_mfma_mode_api_without_gpu():
-    """include/gif_hip.h: process-wide numerics mode of the fp32 contractions; default bf16x3 unless GIF_FP32_MFMA says otherwise."""
+    """include/gif_hip.h: process-wide numerics mode of the fp32 contractions; default f16x2 unless GIF_FP32_MFMA says otherwise."""
     import os
     from gif_amd import ops
     lib = _lib.load()
     before = lib.gif_get_fp32_mfma_mode()
-    if os.environ.get("GIF_FP32_MFMA") in (None, "bf16x3"):
-        assert before in (0, 1)  # (an earlier test of this process may have switched it)
+    if os.environ.get("GIF_FP32_MFMA") in (None, "bf16x3", "f16x2"):
+        assert before in (0, 1, 2)  # (an earlier test of this process may have switched it)
     try:
         assert lib.gif_set_fp32_mfma_mode(0) == 0 and lib.gif_get_fp32_mfma_mode() == 0
         ops.set_fp32_mfma_mode("bf16x3")
         assert ops.get_fp32_mfma_mode() == "bf16x3" and lib.gif_get_fp32_mfma_mode() == 1
+        ops.set_fp32_mfma_mode("f16x2")
+        assert ops.get_fp32_mfma_mode() == "f16x2" and lib.gif_get_fp32_mfma_mode() == 2 and ops.split_mode()
         assert lib.gif_set_fp32_mfma_mode(5) == -1 and b"unknown mode" in lib.gif_last_error()
+        assert lib.gif_pack_weight_f32h2_bytes(3, 3, 128, 128) == (128 + 32) * 4 + 9 * 2 * 128 * 128 * 2
     finally:
         lib.gif_set_fp32_mfma_mode(before)
         ops._fp32_mode_cache = None
@@ -75,7 +78,7 @@ def test_fp32_mfma_mode_api_without_gpu():
     # (the dispatch itself is narrower: measured per shape, ops.x3_tapdense)
     spec = ops.ConvSpec(3, 3, 1, 1)
     ops._fp32_mode_cache = None
-    if ops.get_fp32_mfma_mode() == "bf16x3":
+    if ops.split_mode():  # (bf16x3, and f16x2: its thin layers keep the tap-dense bf16x3 kernels)
         import torch
         assert ops.x3_tapdense(torch.float32, 24, spec, False, {}, 128) and ops.x3_tapdense(torch.float32, 12, spec, True, {}, 24)
         assert not ops.x3_tapdense(torch.float32, 24, spec, True, {}, 12) and not ops.x3_tapdense(torch.float32, 8, spec, False, {}, 12)

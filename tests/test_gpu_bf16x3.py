@@ -28,7 +28,7 @@ def _restore_mode():
 def test_mode_api():
     from gif_amd import _lib, ops
     lib = _lib.load()
-    assert ops.get_fp32_mfma_mode() in ("native", "bf16x3")
+    assert ops.get_fp32_mfma_mode() in ("native", "bf16x3", "f16x2")  # (f16x2, round 5: tests/test_gpu_f16x2.py)
     ops.set_fp32_mfma_mode("native")
     assert lib.gif_get_fp32_mfma_mode() == 0 and ops.get_fp32_mfma_mode() == "native"
     ops.set_fp32_mfma_mode("bf16x3")

@@ -125,6 +125,16 @@ FUSE_CASES = [
     (4, 128, 64, 3, 2, 0, 65, "dgrad", False, "bf16x3"),    # transposed stride 2: four phases (mask + colsum only)
     (4, 512, 512, 3, 2, 0, 9, "dgrad", False, "bf16x3"),    # transposed stride 2, phases merged into one launch
     (32, 256, 128, 3, 2, 0, 129, "dgrad", False, "bf16x3"), # transposed stride 2, bulk + remainder launches per phase
+    # the same direct launches on the f16x2 kernels (round 5: the descaled accumulators go through the shared epilogue)
+    (8, 128, 128, 3, 1, 1, 128, "dgrad", False, "f16x2"),   # 256x128 tiles (8 waves)
+    (8, 128, 128, 3, 1, 1, 96, "dgrad", False, "f16x2"),    # 128x128 tiles (4 waves, two workgroups per CU)
+    (4, 256, 256, 3, 1, 1, 32, "dgrad", False, "f16x2"),    # 64x64 tiles
+    (32, 512, 512, 3, 1, 1, 32, "dgrad", False, "f16x2"),   # 128x64 tiles
+    (4, 128, 24, 3, 1, 1, 64, "dgrad", False, "f16x2"),     # 256x32 tiles
+    (4, 128, 64, 3, 2, 0, 65, "fwd", False, "f16x2"),       # stride-2 forward
+    (4, 128, 64, 3, 2, 0, 65, "dgrad", False, "f16x2"),     # transposed stride 2: four phases
+    (4, 512, 512, 3, 2, 0, 9, "dgrad", False, "f16x2"),     # phases merged into one launch
+    (32, 256, 128, 3, 2, 0, 129, "dgrad", False, "f16x2"),  # big phases merged / bulk + remainder
 ]
 
 

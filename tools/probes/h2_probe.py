@@ -83,7 +83,58 @@ def main():
             line += f"  {mode} {err(y, ref):.2e} finite={bool(torch.isfinite(y).all())}"
         print(line, "fallbacks", ops.h2_fallback_stats(reset=True))
 
+    # weight gradients (direct, modulated, thin, Winograd plane GEMMs)
+    for (B, ci, co, k, s_, p_, h, wino) in [(4, 128, 128, 3, 1, 1, 64, False), (4, 128, 256, 3, 2, 0, 65, False), (4, 24, 128, 3, 1, 1, 64, False),
+                                          (2, 256, 256, 1, 1, 0, 32, False), (4, 128, 128, 3, 1, 1, 64, True), (2, 256, 512, 3, 1, 1, 32, True),
+                                          (3, 160, 96, 3, 1, 1, 20, False)]:
+        torch.manual_seed(B + ci + co + h)
+        ops.WINOGRAD = wino
+        ops.WINOGRAD_MIN_TILES, ops.WINOGRAD_WGRAD_MIN_TILES = (1, 1) if wino else (8192, 2048)
+        spec = ops.ConvSpec(k, k, s_, p_)
+        x = torch.randn(B, ci, h, h, device=dev).contiguous(memory_format=torch.channels_last)
+        hs, ws_ = spec.small_hw(h, h)
+        gy = torch.randn(B, co, hs, ws_, device=dev).contiguous(memory_format=torch.channels_last)
+        sc, sd = torch.rand(B, ci, device=dev) + 0.5, torch.rand(B, co, device=dev) + 0.5
+        wd = torch.zeros(co, ci, k, k, device=dev, dtype=torch.float64, requires_grad=True)
+        (ref,) = torch.autograd.grad(F.conv2d(x.double(), wd, stride=s_, padding=p_), wd, gy.double())
+        wd2 = torch.zeros(co, ci, k, k, device=dev, dtype=torch.float64, requires_grad=True)
+        (ref_s,) = torch.autograd.grad(F.conv2d(x.double() * sc.double()[:, :, None, None], wd2, stride=s_, padding=p_), wd2,
+                                       gy.double() * sd.double()[:, :, None, None])
+        line = f"wgrad {(B, ci, co, k, s_, h, 'wino' if wino else 'direct')}:"
+        for mode in ("native", "bf16x3", "f16x2"):
+            ops.set_fp32_mfma_mode(mode)
+            n0 = ops.prof_winograd_calls()
+            e0 = err(ops.conv_wgrad(gy, x, spec, co, ci), ref)
+            e1 = err(ops.conv_wgrad(gy, x, spec, co, ci, small_scale=sd, big_scale=sc), ref_s)
+            line += f"  {mode} {e0:.2e} scaled {e1:.2e}" + (" (wino)" if ops.prof_winograd_calls() > n0 else "")
+        print(line, " fallbacks", ops.h2_fallback_stats(reset=True), flush=True)
+    ops.WINOGRAD = False
+    ops.WINOGRAD_MIN_TILES, ops.WINOGRAD_WGRAD_MIN_TILES = 8192, 2048
+
     if "--time" in sys.argv:
+        for (B, ci, co, k, s_, p_, h, wino) in [(32, 128, 256, 3, 2, 0, 257, False), (32, 256, 512, 3, 2, 0, 129, False), (32, 24, 128, 3, 1, 1, 256, False),
+                                              (32, 128, 128, 3, 1, 1, 256, True), (32, 256, 256, 3, 1, 1, 128, True), (32, 512, 512, 3, 1, 1, 64, True)]:
+            ops.WINOGRAD = wino
+            spec = ops.ConvSpec(k, k, s_, p_)
+            x = torch.randn(B, ci, h, h, device=dev).contiguous(memory_format=torch.channels_last)
+            hs, ws_ = spec.small_hw(h, h)
+            gy = torch.randn(B, co, hs, ws_, device=dev).contiguous(memory_format=torch.channels_last)
+            flops = 2.0 * B * hs * ws_ * k * k * ci * co
+            line = f"wgrad {(B, ci, co, k, s_, h, 'wino' if wino else 'direct')}:"
+            for mode in ("bf16x3", "f16x2"):
+                ops.set_fp32_mfma_mode(mode)
+                for _ in range(3):
+                    ops.conv_wgrad(gy, x, spec, co, ci)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    ops.conv_wgrad(gy, x, spec, co, ci)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / 10
+                line += f"  {mode} {dt * 1e3:.3f} ms {flops / dt / 1e12:.0f} TF"
+            print(line, flush=True)
+        ops.WINOGRAD = False
+
         shapes = [(32, 128, 256, 3, 2, 0, 257, "fwd"), (32, 128, 256, 3, 2, 0, 257, "dgrad"), (32, 128, 128, 3, 1, 1, 256, "fwd"),
                   (32, 256, 256, 3, 1, 1, 128, "fwd"), (32, 512, 512, 3, 1, 1, 16, "fwd"), (32, 128, 24, 3, 1, 1, 256, "fwd"),
                   (32, 256, 512, 3, 2, 0, 129, "dgrad"), (32, 512, 512, 3, 2, 0, 65, "fwd")]
