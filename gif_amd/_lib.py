@@ -83,6 +83,9 @@ PROTOTYPES = {
     "gif_winograd_weight_f32x3": (c_int, [P, P, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_int, c_float, P]),
     "gif_conv3x3_winograd_f32": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, EP, P]),
     "gif_conv3x3_winograd_f32x3": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, EP, P]),
+    "gif_winograd_weight_f32h2_bytes": (c_i64, [c_int, c_int]),
+    "gif_winograd_weight_f32h2": (c_int, [P, P, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_int, c_float, P]),
+    "gif_conv3x3_winograd_f32h2": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, EP, P]),
     "gif_conv3x3_winograd_wgrad_splits": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "gif_conv3x3_winograd_wgrad_f32": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "gif_conv3x3_winograd_wgrad_f32x3": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),

@@ -186,10 +186,9 @@ __device__ __forceinline__ void split_pair_h2(const float a0, const float a1, co
     hi = __builtin_bit_cast(unsigned, h);
     lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{r0, r1}, f16x2_t));
 }
-// header of an f16x2 weight packing: int32 exponents of the RP rows, then kH2HdrExtra ints (the first one is the "a 16-element
-// group of some row is narrower than the window" flag); the f16 planes follow.
-constexpr int kH2HdrExtra = 32;
-inline size_t h2_header_bytes(int RP) { return (size_t)(RP + kH2HdrExtra) * sizeof(int); }
+// header of an f16x2 weight packing: int32 exponents of the RP rows, then RP int32 row flags ("a 16-element K group of this row
+// lies outside the window": launches that use the row take the bf16x3 fallback); the f16 planes follow.
+inline size_t h2_header_bytes(int RP) { return (size_t)2 * RP * sizeof(int); }
 // gate words of the guarded launches (runtime.hip): a ring of device words and a generation counter — a kernel raises a gate with
 // atomicMax(gate, gen), the fallback launch runs iff *gate == gen; a word is reused 65536 launches later under a larger gen.
 struct H2Gate {

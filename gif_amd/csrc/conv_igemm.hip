@@ -979,8 +979,9 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
             for (int i = 0; i < MT; ++i)
                 wide |= (int)(__float_as_uint(h_max[i]) >> 23) - (int)((h_gmin[i] + 1u) >> 23) > gif::kH2Window;
             if (p.gate) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) wide |= p.wexp[p.RP + n0 + wn0 + j * 32 + li] != 0;  // rows flagged by the weight packing
                 if (__builtin_amdgcn_ballot_w64(wide) != 0 && lane == 0) atomicMax(p.gate, p.gate_gen);
-                if (tile == 0 && tid == 0 && p.wexp[p.RP] != 0) atomicMax(p.gate, p.gate_gen);  // flagged by the weight packing
             }
             // back to the operands' own scale: acc[row][col] *= 2^-(e_row + e_col)
             int wex[NT];

@@ -726,15 +726,18 @@ __global__ void pack_weight_x3_dense_kernel(const float* __restrict__ w, unsigne
     o[2 * plane] = (unsigned short)(l & 0xffffu);
 }
 
-// f16x2 packing (common.h "h2"): one workgroup per packed row.  Header exps[r] = the row's exponent e (row maximum over all taps and
-// channels of scale * w lands in [2^14, 2^15)); planes wp2[t][2][RP][CP] (f16 bits) = hi / lo of scale * w * 2^e.  A 16-channel K
-// group (the kernels' k-groups: 16 consecutive padded channels of one tap) whose maximum lies more than 2^kH2WindowW below the row
-// maximum sets the header's flag word: its values no longer carry 22 bits, launches with this packing take the bf16x3 fallback.
+// f16x2 packing (common.h "h2"): one workgroup per packed row.  Header hdr[r] = the row's exponent e (row maximum over all taps and
+// channels of scale * w lands in [2^14, 2^15)), hdr[RP + r] = the row's flag; planes wp2[t][2][RP][CP] (f16 bits) = hi / lo of
+// scale * w * 2^e.  A 16-channel K group (the kernels' k-groups: 16 consecutive padded channels of one tap) whose maximum lies more
+// than 2^kH2WindowW below the row maximum sets the flag: its values no longer carry 22 bits, launches using the row take the bf16x3
+// fallback.
 __global__ void __launch_bounds__(256) pack_weight_h2_kernel(const float* __restrict__ w, int* __restrict__ hdr, unsigned short* __restrict__ planes,
                                                              int R, int C, int KH, int KW, int RP, int CP, long sr, long sc, long sky, long skx,
                                                              float scale) {
     __shared__ float red[256];
+    __shared__ int s_flag;
     const int r = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) s_flag = 0;
     const int gpt = CP / 16, ngroups = KH * KW * gpt;  // 16-channel groups per tap / per row
     auto value = [&](int t, int c) -> float {
         const int ky = t / KW, kx = t - ky * KW;
@@ -755,7 +758,6 @@ __global__ void __launch_bounds__(256) pack_weight_h2_kernel(const float* __rest
     const float rowmax = red[0];
     const int e = gif::h2_exp_for(__float_as_uint(rowmax), gif::kH2TargetW);
     const float sc2 = gif::h2_pow2(e);
-    if (tid == 0) hdr[r] = e;
     const size_t plane = (size_t)RP * CP;
     bool narrow = false;
     for (int g = tid; g < ngroups; g += 256) {
@@ -773,7 +775,12 @@ __global__ void __launch_bounds__(256) pack_weight_h2_kernel(const float* __rest
         }
         if (gm > 0.f && (int)(__float_as_uint(rowmax) >> 23) - (int)(__float_as_uint(gm) >> 23) > gif::kH2WindowW) narrow = true;
     }
-    if (narrow) atomicOr(reinterpret_cast<unsigned*>(hdr + RP), 1u);
+    if (narrow) atomicOr(&s_flag, 1);
+    __syncthreads();
+    if (tid == 0) {
+        hdr[r] = e;
+        hdr[RP + r] = s_flag;
+    }
 }
 
 __global__ void unpack_wgrad_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit, int R, int C,
@@ -1210,7 +1217,7 @@ int gif_pack_weight_f32x3(const float* w, void* wp3, int R, int C, int KH, int K
     return gif::check_launch("pack_weight_f32x3");
 }
 
-/* f16x2 packing: [RP + 32 int32: row exponents, flag][tap][2][RP][CP] f16 — gif_pack_weight_f32h2_bytes of device memory */
+/* f16x2 packing: [RP int32 row exponents][RP int32 row flags][tap][2][RP][CP] f16 — gif_pack_weight_f32h2_bytes of device memory */
 int64_t gif_pack_weight_f32h2_bytes(int KH, int KW, int RP, int CP) {
     if (KH <= 0 || KW <= 0 || RP <= 0 || CP <= 0) return 0;
     return (int64_t)gif::h2_header_bytes(RP) + (int64_t)KH * KW * 2 * RP * CP * 2;
@@ -1221,8 +1228,6 @@ int gif_pack_weight_f32h2(const float* w, void* wp2, int R, int C, int KH, int K
     GIF_REQUIRE(w && wp2 && R > 0 && C > 0 && RP >= R && CP >= C && KH > 0 && KW > 0 && RP % 32 == 0 && CP % 32 == 0,
                 "pack_weight_f32h2: bad arguments");
     int* hdr = static_cast<int*>(wp2);
-    hipError_t me = hipMemsetAsync(hdr + RP, 0, gif::kH2HdrExtra * sizeof(int), gif::as_stream(stream));
-    if (me != hipSuccess) { gif::set_error("pack_weight_f32h2 memset: %s", hipGetErrorString(me)); return (int)me; }
     unsigned short* planes = reinterpret_cast<unsigned short*>(static_cast<char*>(wp2) + gif::h2_header_bytes(RP));
     pack_weight_h2_kernel<<<RP, 256, 0, gif::as_stream(stream)>>>(w, hdr, planes, R, C, KH, KW, RP, CP, sr, sc, sky, skx, scale);
     return gif::check_launch("pack_weight_f32h2");

@@ -255,6 +255,12 @@ struct WinoParams {
     float mask_slope, mask_gain;
     float* part_cs;
     float* part_dot;
+    // f16x2 (common.h "h2"): U = the f16 planes, uexp = their header ([RP] row exponents, then [RP] row flags); gate: raised by the
+    // f16x2 GEMM when a K group leaves the precision window; wino_gemm_x3 WITH a gate is the guarded fallback (runs iff *gate == gate_gen)
+    const int* uexp;
+    unsigned* gate;
+    unsigned gate_gen;
+    unsigned* h2_stats;
 };
 
 // The row loop of both GEMM kernels' epilogues for one output position (oa, ob): modulation-gradient dot product, out_scale,
@@ -544,6 +550,10 @@ __global__ void __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) wino_gemm_mfma(cons
 // Block BM x BN = 128 x 128 (4 x 2 waves; default) or 256 x 64 (8 x 1 waves: every V fragment is split by exactly one wave).
 template <int DBG = 0, int BM = 256, int BN = 64>
 __global__ void __launch_bounds__(512, 1) wino_gemm_x3(const WinoParams p) {
+    if (p.gate) {  // guarded fallback of an f16x2 launch: nothing to do unless that launch raised the gate
+        if (*p.gate != p.gate_gen) return;
+        if (blockIdx.x == 0 && threadIdx.x == 0 && p.h2_stats) atomicAdd(p.h2_stats, 1u);
+    }
     constexpr int THREADS = 512, PROWS = THREADS / 8;
     constexpr int LD = WBK, CH = WBK / 4, RB = 64 / WBK, RPW = 64 / CH;
     constexpr int NT = 2, WAVES_N = BN / 64;
@@ -747,6 +757,350 @@ __global__ void __launch_bounds__(512, 1) wino_gemm_x3(const WinoParams p) {
         }
     }
     wino_write_partials<THREADS, C4_ROW, EROWS>(p, smem, tid, n, tm, cs, ds);
+}
+
+// ------------------------------------------------------------------------------------------------ f16x2 GEMM (round 5)
+// The same GEMM + fused output transform on v_mfma_f32_32x32x16_f16 with THREE products per fp32 product (common.h "h2").
+// V stays fp32 in HBM and LDS (the weight gradient reuses it); a V fragment is split into two f16 terms under the RUNNING exponent of
+// its row (= Winograd tile), which persists over all 16 positions: the four 2x2-output accumulators then all live in ONE scale per
+// row and are brought back to fp32's own scale once, in the epilogue (a per-position exponent would cost 32 ldexp + 16 lane
+// exchanges per position: a quarter of a 128-channel position's MFMA time).  When a row outgrows its exponent the position
+// accumulator AND the four output accumulators of that row are multiplied by the exact power of two (160 registers, rare).
+// U2 = gif_winograd_weight_f32h2: [16][2][RP][CP] f16 planes of G g G^T * 2^e_row, one exponent per output channel over all positions.
+// Block 128 x 128, 8 waves as 4 (M) x 2 (N), wave tile 32 tiles x 64 couts, 3-stage ring: 48 KB of fp32 V + 48 KB of f16 planes.
+template <int BM = 128, int BN = 128>
+__global__ void __launch_bounds__(512, 1) wino_gemm_h2(const WinoParams p) {
+    constexpr int THREADS = 512, PROWS = THREADS / 8;
+    constexpr int LD = WBK, CH = WBK / 4, RB = 64 / WBK, RPW = 64 / CH;
+    constexpr int NT = 2, WAVES_N = BN / 64;
+    static_assert(BM == 128 && BN == 128, "8 waves of 32 tiles x 64 couts as 4 x 2");
+    constexpr int A_IT = BM / PROWS;        // 2
+    constexpr int B2_BLK = 2 * BN / 16;     // 16 one-KiB blocks (16 rows x 64 B) per stage
+    constexpr int B2_IT = B2_BLK / 8;       // 2 per wave
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                                                                    // [NSTAGE][BM][LD] fp32
+    unsigned short* B2 = reinterpret_cast<unsigned short*>(smem + WNSTAGE * BM * LD);   // [NSTAGE][2][BN][32] f16
+    const unsigned short* const U2 = reinterpret_cast<const unsigned short*>(p.U);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm0 = (wave / WAVES_N) * 32, wn0 = (wave % WAVES_N) * 64;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int t_row = tid / CH;
+    const int src_c4 = ((tid % CH) ^ ((t_row / RB) % CH)) * 4;
+    const int fsw = (li / RB) % CH;
+    const int b2_sw = (li >> 2) & 3;
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+
+    const unsigned a_off = (unsigned)(m0 + t_row) * (unsigned)p.CP + (unsigned)src_c4;
+    const size_t pass_stride = (size_t)PROWS * p.CP;
+    const size_t planeV = (size_t)p.ntiles_pad * p.CP, planeU = (size_t)p.RP * p.CP;  // planeU: one TERM plane of one position
+    unsigned b2_off[B2_IT];
+#pragma unroll
+    for (int it = 0; it < B2_IT; ++it) {
+        const int blk = wave + it * 8;
+        const int term = blk / (BN / 16), r = (blk % (BN / 16)) * 16 + (lane >> 2);
+        b2_off[it] = (unsigned)((size_t)term * planeU + (size_t)(n0 + r) * p.CP + (((lane & 3) ^ ((lane >> 4) & 3)) << 3));
+    }
+    const int kchunks = p.CP / WBK;
+    const int nsteps = 16 * kchunks;
+    const float* vptr = p.V;
+    const unsigned short* uptr = U2;
+    int ld_kc = 0;
+
+    auto issue = [&](int buf) __attribute__((always_inline)) {
+        float* Ad = As + buf * BM * LD + wave * RPW * LD;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it)
+            __builtin_amdgcn_global_load_lds((gptr_t)((vptr + it * pass_stride) + a_off), (lptr_t)(Ad + it * PROWS * LD), 16, 0, 0);
+#pragma unroll
+        for (int it = 0; it < B2_IT; ++it)
+            __builtin_amdgcn_global_load_lds((gptr_t)(uptr + b2_off[it]), (lptr_t)(B2 + (buf * B2_BLK + wave + it * 8) * 512), 16, 0, 0);
+        vptr += WBK;
+        uptr += WBK;
+        ld_kc += WBK;
+        if (ld_kc >= p.CP) {  // next position: same rows of the next plane (U2: skip the two term planes)
+            ld_kc = 0;
+            vptr += planeV - p.CP;
+            uptr += 2 * planeU - p.CP;
+        }
+    };
+
+    f32x16 acc[NT];
+    f32x16 yo[4][NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc[j][r] = 0.f;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) yo[o][j][r] = 0.f;
+        }
+
+    gif::u32x4_t sa[2][2];   // [slot][hi, lo] of the V fragment
+    gif::u32x4_t sb[2][NT];  // [hi, lo][cout tile]
+    f32x4 ra[2];             // raw V fragments of the group being split
+    // running exponent of this lane's row (lanes li and li + 32 agree) and the guard's statistics (common.h)
+    int h_ex = 126, h_dl = 0;
+    float h_sc = gif::h2_pow2(126), h_lim = gif::kH2Limit * gif::h2_pow2(-126), h_max = 0.f;
+    unsigned h_gmin = 0xFFFFFFFFu;
+    bool h_need = false;
+
+    auto read_a = [&](int buf, int q) __attribute__((always_inline)) {
+        const float* Ab = As + buf * BM * LD + (wm0 + li) * LD;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) ra[u] = *reinterpret_cast<const f32x4*>(Ab + (((q * 4 + lh * 2 + u) ^ fsw) << 2));
+    };
+    auto read_b = [&](int buf, int q, int t) __attribute__((always_inline)) {
+        const unsigned short* Bb = B2 + (buf * 2 + t) * BN * 32 + (wn0 + li) * 32 + (((q * 2 + lh) ^ b2_sw) << 3);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) sb[t][j] = *reinterpret_cast<const gif::u32x4_t*>(Bb + j * 32 * 32);
+    };
+    auto track = [&]() __attribute__((always_inline)) {
+        float m = fmaxf(fmaxf(fabsf(ra[0][0]), fabsf(ra[0][1])), fabsf(ra[0][2]));
+        m = fmaxf(fmaxf(m, fabsf(ra[0][3])), fabsf(ra[1][0]));
+        m = fmaxf(fmaxf(m, fabsf(ra[1][1])), fabsf(ra[1][2]));
+        m = fmaxf(m, fabsf(ra[1][3]));
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+        m = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        h_max = fmaxf(h_max, m);
+        h_gmin = min(h_gmin, __float_as_uint(m) - 1u);
+        h_dl = 0;
+        h_need = false;
+        if (__builtin_amdgcn_ballot_w64(m > h_lim) != 0) {  // wave-uniform, rare
+            const int ne = m > h_lim ? gif::h2_exp_for(__float_as_uint(m), gif::kH2Target) : h_ex;
+            h_dl = ne - h_ex;
+            h_ex = ne;
+            h_sc = gif::h2_pow2(ne);
+            h_lim = ldexpf(gif::kH2Limit, -ne);
+            h_need = true;
+        }
+    };
+    // rows whose exponent changed: the position accumulator and the four output accumulators *= 2^(e' - e) (exact)
+    auto rescale = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d = __builtin_amdgcn_ds_bpermute(((r & 3) + 8 * (r >> 2) + 4 * lh) * 4, h_dl);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                acc[j][r] = ldexpf(acc[j][r], d);
+#pragma unroll
+                for (int o = 0; o < 4; ++o) yo[o][j][r] = ldexpf(yo[o][j][r], d);
+            }
+        }
+    };
+    auto split_piece = [&](int slot, int e) __attribute__((always_inline)) {
+        unsigned h, l;
+        gif::split_pair_h2(ra[e / 2][(e % 2) * 2], ra[e / 2][(e % 2) * 2 + 1], h_sc, h, l);
+        sa[slot][0][e] = h; sa[slot][1][e] = l;
+    };
+    auto mma = [&](int slot, int ta, int tb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gif::f16x8_t, sa[slot][ta]),
+                                                            __builtin_bit_cast(gif::f16x8_t, sb[tb][j]), acc[j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // one 16-k group: the 6 MFMAs of (slot) + operand preparation of the next group (V fragments of (rbuf, nq) -> slot ^ 1, weights)
+    auto group = [&](int slot, int rbuf, int nq) __attribute__((always_inline)) {
+        read_a(rbuf, nq);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(slot, 1, 0);  // lo * hi
+        track();
+        __builtin_amdgcn_sched_barrier(0);
+        split_piece(slot ^ 1, 0);
+        split_piece(slot ^ 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(slot, 0, 1);  // hi * lo
+        read_b(rbuf, nq, 1);
+        split_piece(slot ^ 1, 2);
+        split_piece(slot ^ 1, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(slot, 0, 0);  // hi * hi
+        read_b(rbuf, nq, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (h_need) rescale();
+    };
+    auto fold = [&](int pos) __attribute__((always_inline)) {
+        const int xi = pos >> 2, nu = pos & 3;
+        float cf[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) cf[o] = wino_coef(o >> 1, xi) * wino_coef(o & 1, nu);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            if (cf[o] != 0.f) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) yo[o][j] += cf[o] * acc[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = (f32x16)(0.f);
+    };
+
+    // DMA instructions per stage and wave: 2 (V) + 2 (planes): the newest stage stays in flight
+    auto wait_newest_in_flight = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); };
+    issue(0);
+    issue(1);  // nsteps >= 16
+    wait_newest_in_flight();
+    __builtin_amdgcn_s_barrier();
+    read_a(0, 0);
+    read_b(0, 0, 0);
+    read_b(0, 0, 1);
+    track();  // first exponents (the accumulators are zero)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split_piece(0, e);
+
+    int cur = 0, kc_in_pos = 0, pos = 0;
+    for (int step = 0; step < nsteps; ++step) {
+        if (step + 2 < nsteps) issue(cur >= 1 ? cur - 1 : 2);  // (cur + 2) % 3: last read before the previous stage's barrier
+        __builtin_amdgcn_sched_barrier(0);
+        group(0, cur, 1);
+        if (step + 2 < nsteps) wait_newest_in_flight();
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        cur = cur == 2 ? 0 : cur + 1;
+        group(1, cur, 0);  // (after the last stage this prepares operands nobody uses: the reads stay inside the ring)
+        if (++kc_in_pos == kchunks) {
+            fold(pos);
+            kc_in_pos = 0;
+            ++pos;
+        }
+    }
+
+    // guard (common.h): a 16-element K group more than 2^kH2Window below its row's maximum raises the launch's gate; so does a
+    // weight row the packing flagged
+    {
+        // (the tracking step after the last stage looked at ring data nobody uses: its statistics may only widen the window check,
+        // never narrow it — a spurious fallback at worst; rows >= ntiles are padding and may hold anything: same remark)
+        bool wide = m0 + wm0 + li < p.ntiles && (int)(__float_as_uint(h_max) >> 23) - (int)((h_gmin + 1u) >> 23) > gif::kH2Window;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wide |= p.uexp[p.RP + n0 + wn0 + j * 32 + li] != 0;
+        if (p.gate && __builtin_amdgcn_ballot_w64(wide) != 0 && lane == 0) atomicMax(p.gate, p.gate_gen);
+    }
+    // back to fp32's own scale: yo[o][row][col] *= 2^-(e_row + e_col)
+    {
+        int wex[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wex[j] = p.uexp[n0 + wn0 + j * 32 + li];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int er = __builtin_amdgcn_ds_bpermute(((r & 3) + 8 * (r >> 2) + 4 * lh) * 4, h_ex);
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int o = 0; o < 4; ++o) yo[o][j][r] = ldexpf(yo[o][j][r], -(er + wex[j]));
+        }
+    }
+
+    // ---- epilogue: for each output position (a,b): transpose through LDS, then coalesced float4 rows
+    constexpr int LDC = BN + 4;
+    float* Cs = smem;  // [BM][LDC]
+    constexpr int C4_ROW = BN / 4, EROWS = THREADS / C4_ROW, E_IT = BM / EROWS;
+    const int e_row0 = tid / C4_ROW, e_c = (tid % C4_ROW) * 4;
+    const int n = n0 + e_c;
+    f32x4 bias4 = (f32x4)(0.f);
+    if (p.bias && n < p.Co) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+    f32x4 cs = (f32x4)(0.f), ds = (f32x4)(0.f);
+    const bool fused = p.mask_src || p.dot_src || p.part_cs || p.part_dot;  // workgroup-uniform
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = wm0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                Cs[row * LDC + wn0 + j * 32 + li] = yo[o][j][r];
+            }
+        __syncthreads();
+        if (n < p.Co) {
+            if (fused) wino_epilogue_rows<true, E_IT, EROWS, LDC, (E_IT < 4 ? E_IT : 4)>(p, Cs, m0, e_row0, e_c, n, o >> 1, o & 1, bias4, cs, ds);
+            else wino_epilogue_rows<false, E_IT, EROWS, LDC, (E_IT < 4 ? E_IT : 4)>(p, Cs, m0, e_row0, e_c, n, o >> 1, o & 1, bias4, cs, ds);
+        }
+    }
+    wino_write_partials<THREADS, C4_ROW, EROWS>(p, smem, tid, n, tm, cs, ds);
+}
+
+// U2 = the two f16 terms of G g G^T * 2^e_row: header [RP] exponents + [RP] flags (int32), then planes [16][2][RP][CP] (f16 bits).
+// One workgroup per output-channel row: the row maximum runs over all 16 positions and all channels (common.h "h2"); a 16-channel
+// group of one position more than 2^kH2WindowW below it sets the row's flag.
+__global__ void __launch_bounds__(256) wino_weight_transform_h2(const float* __restrict__ w, int* __restrict__ hdr, unsigned short* __restrict__ planes,
+                                                                int R, int C, int RP, int CP, long sr, long sc, long sky, long skx, int flip,
+                                                                float scale) {
+    __shared__ float red[256];
+    __shared__ int s_flag;
+    const int r = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) s_flag = 0;
+    auto transform = [&](int c, float (&v)[16]) {
+        float g[3][3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                int sy = flip ? 2 - ky : ky, sx = flip ? 2 - kx : kx;
+                g[ky][kx] = (r < R && c < C) ? scale * w[r * sr + c * sc + sy * sky + sx * skx] : 0.f;
+            }
+        float u[4][3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            u[0][j] = g[0][j];
+            u[1][j] = 0.5f * (g[0][j] + g[1][j] + g[2][j]);
+            u[2][j] = 0.5f * (g[0][j] - g[1][j] + g[2][j]);
+            u[3][j] = g[2][j];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i * 4 + 0] = u[i][0];
+            v[i * 4 + 1] = 0.5f * (u[i][0] + u[i][1] + u[i][2]);
+            v[i * 4 + 2] = 0.5f * (u[i][0] - u[i][1] + u[i][2]);
+            v[i * 4 + 3] = u[i][2];
+        }
+    };
+    float m = 0.f;
+    for (int c = tid; c < CP; c += 256) {
+        float v[16];
+        transform(c, v);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) m = fmaxf(m, fabsf(v[q]));
+    }
+    red[tid] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]);
+        __syncthreads();
+    }
+    const float rowmax = red[0];
+    const int e = gif::h2_exp_for(__float_as_uint(rowmax), gif::kH2TargetW);
+    const float sc2 = gif::h2_pow2(e);
+    const size_t plane = (size_t)RP * CP;
+    bool narrow = false;
+    for (int c = tid; c < CP; c += 256) {  // (CP is a multiple of 32: whole 16-lane groups stay together)
+        float v[16];
+        transform(c, v);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            unsigned h, l;
+            gif::split_pair_h2(v[q], 0.f, sc2, h, l);
+            unsigned short* o = planes + (size_t)q * 2 * plane + (size_t)r * CP + c;
+            o[0] = (unsigned short)(h & 0xffffu);
+            o[plane] = (unsigned short)(l & 0xffffu);
+            float gm = fabsf(v[q]);  // maximum over the 16 channels of this lane's group
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) gm = fmaxf(gm, __shfl_xor(gm, d, 16));
+            if (gm > 0.f && (int)(__float_as_uint(rowmax) >> 23) - (int)(__float_as_uint(gm) >> 23) > gif::kH2WindowW) narrow = true;
+        }
+    }
+    if (narrow) atomicOr(&s_flag, 1);
+    __syncthreads();
+    if (tid == 0) {
+        hdr[r] = e;
+        hdr[RP + r] = s_flag;
+    }
 }
 
 // U3 = the three bf16 terms of G g G^T: [16][3][RP][CP]
@@ -978,9 +1332,12 @@ int gif_winograd_weight_f32x3(const float* w, void* U3, int R, int C, int RP, in
     return gif::check_launch("winograd_weight_f32x3");
 }
 
-int gif_conv3x3_winograd_f32x3(const float* x, const void* U3, float* y, float* V, int B, int H, int W, int C, int Co,
-                               const gif_conv_epilogue* e, gif_stream_t stream) {
-    GIF_REQUIRE(x && U3 && y && V && B >= 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "winograd_x3: bad dims (H, W must be even)");
+}  // extern "C"
+
+// U2 != NULL: the f16x2 GEMM on U2 followed by its guarded bf16x3 twin on U3 (a no-op unless the gate was raised; U3 may be NULL: unguarded)
+static int conv3x3_winograd_x3_impl(const float* x, const void* U2, const void* U3, float* y, float* V, int B, int H, int W, int C, int Co,
+                                    const gif_conv_epilogue* e, gif_stream_t stream) {
+    GIF_REQUIRE(x && (U3 || U2) && y && V && B >= 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "winograd_x3: bad dims (H, W must be even)");
     GIF_REQUIRE(C > 0 && Co > 0 && C % 4 == 0 && Co % 4 == 0, "winograd_x3: channels must be multiples of 4");
     if (B == 0) return 0;
     const long ntiles = (long)B * (H / 2) * (W / 2);
@@ -1010,20 +1367,39 @@ int gif_conv3x3_winograd_f32x3(const float* x, const void* U3, float* y, float* 
     // 128 x 128 blocks (4 x 2 waves) by default; GIF_WINO_X3_TILE=256 selects 256 x 64 (8 x 1 waves: every V fragment split
     // once instead of twice) — measured equal (2.998 / 2.141 / 1.790 ms vs 2.993 / 2.133 / 1.757 ms on the three big layers)
     static const int sq = getenv("GIF_WINO_X3_TILE") ? atoi(getenv("GIF_WINO_X3_TILE")) != 256 : 1;
-    const int bm = sq ? 128 : 256, bn = sq ? 128 : 64;
+    const int bm = (sq || U2) ? 128 : 256, bn = (sq || U2) ? 128 : 64;
     p.tiles_m = (int)(ntiles_pad / bm);
     p.tiles_n = p.RP / bn;
     WinoSums sums;
     if (int rc = sums.begin(p, e, B, H, W, Co, bm, "conv3x3_winograd_f32x3")) return rc;
     const size_t lds = (size_t)WNSTAGE * ((size_t)bm * WBK * sizeof(float) + 3 * (size_t)bn * 64);
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
+    if (U2) {
+        const int* hdr = static_cast<const int*>(U2);
+        WinoParams q = p;
+        q.uexp = hdr;
+        q.U = reinterpret_cast<const float*>(static_cast<const char*>(U2) + gif::h2_header_bytes(p.RP));
+        if (U3) {
+            const gif::H2Gate gt = gif::h2_next_gate();
+            q.gate = gt.word; q.gate_gen = gt.gen;
+        }
+        const size_t lds2 = (size_t)WNSTAGE * ((size_t)128 * WBK * sizeof(float) + 2 * (size_t)128 * 64);
+        static gif::LdsAttr attr2;
+        attr2.ensure(reinterpret_cast<const void*>(wino_gemm_h2<128, 128>), lds2);
+        hipLaunchKernelGGL((wino_gemm_h2<128, 128>), grid, dim3(512), lds2, s, q);
+        if (!q.gate) {  // unguarded
+            if (int rc = sums.finish(p, B, H, W, Co, bm, s)) return rc;
+            return gif::check_launch("conv3x3_winograd_f32h2");
+        }
+        p.gate = q.gate; p.gate_gen = q.gate_gen; p.h2_stats = gif::h2_stats_words();
+    }
 #define GIF_WINO_X3_LAUNCH(D, BM_, BN_)                                                        \
     {                                                                                          \
         static gif::LdsAttr attr;                                                              \
         attr.ensure(reinterpret_cast<const void*>(wino_gemm_x3<D, BM_, BN_>), lds);            \
         hipLaunchKernelGGL((wino_gemm_x3<D, BM_, BN_>), grid, dim3(512), lds, s, p);           \
     }
-    if (!sq) GIF_WINO_X3_LAUNCH(0, 256, 64)
+    if (!sq && !U2) GIF_WINO_X3_LAUNCH(0, 256, 64)
     else if (dbg == 1) GIF_WINO_X3_LAUNCH(1, 128, 128)
     else if (dbg == 2) GIF_WINO_X3_LAUNCH(2, 128, 128)
     else if (dbg == 4) GIF_WINO_X3_LAUNCH(4, 128, 128)
@@ -1032,5 +1408,34 @@ int gif_conv3x3_winograd_f32x3(const float* x, const void* U3, float* y, float* 
 #undef GIF_WINO_X3_LAUNCH
     if (int rc = sums.finish(p, B, H, W, Co, bm, s)) return rc;
     return gif::check_launch("conv3x3_winograd_f32x3");
+}
+
+extern "C" {
+
+int gif_conv3x3_winograd_f32x3(const float* x, const void* U3, float* y, float* V, int B, int H, int W, int C, int Co,
+                               const gif_conv_epilogue* e, gif_stream_t stream) {
+    return conv3x3_winograd_x3_impl(x, nullptr, U3, y, V, B, H, W, C, Co, e, stream);
+}
+
+/* f16x2 (ABI 4): U2 from gif_winograd_weight_f32h2 (gif_winograd_weight_f32h2_bytes), U3 the bf16x3 transform of the same weights for
+ * the guarded fallback (NULL: unguarded); same pack dims as the bf16x3 GEMM */
+int64_t gif_winograd_weight_f32h2_bytes(int RP, int CP) {
+    if (RP <= 0 || CP <= 0) return 0;
+    return (int64_t)gif::h2_header_bytes(RP) + 16LL * 2 * RP * CP * 2;
+}
+
+int gif_winograd_weight_f32h2(const float* w, void* U2, int R, int C, int RP, int CP, int64_t sr, int64_t sc, int64_t sky,
+                              int64_t skx, int flip, float scale, gif_stream_t stream) {
+    GIF_REQUIRE(w && U2 && R > 0 && C > 0 && RP >= R && CP >= C && RP % 128 == 0 && CP % 32 == 0, "winograd_weight_f32h2: bad arguments");
+    int* hdr = static_cast<int*>(U2);
+    unsigned short* planes = reinterpret_cast<unsigned short*>(static_cast<char*>(U2) + gif::h2_header_bytes(RP));
+    wino_weight_transform_h2<<<RP, 256, 0, gif::as_stream(stream)>>>(w, hdr, planes, R, C, RP, CP, sr, sc, sky, skx, flip, scale);
+    return gif::check_launch("winograd_weight_f32h2");
+}
+
+int gif_conv3x3_winograd_f32h2(const float* x, const void* U2, const void* U3, float* y, float* V, int B, int H, int W, int C, int Co,
+                               const gif_conv_epilogue* e, gif_stream_t stream) {
+    GIF_REQUIRE(U2, "conv3x3_winograd_f32h2: null U2");
+    return conv3x3_winograd_x3_impl(x, U2, U3, y, V, B, H, W, C, Co, e, stream);
 }
 }

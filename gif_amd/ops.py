@@ -218,6 +218,7 @@ H2_CONV = os.environ.get("GIF_H2_CONV", "1") != "0"    # f16x2 mode: direct fwd 
 H2_WGRAD = os.environ.get("GIF_H2_WGRAD", "0") != "0"
 
 
+H2_WINO = os.environ.get("GIF_H2_WINO", "1") != "0"    # f16x2 mode: Winograd fwd / dgrad GEMM
 H2_GUARD = True  # False: f16x2 launches run without their guarded bf16x3 twin (tests only: shows what the guard protects against)
 
 
@@ -339,6 +340,20 @@ def conv3x3_winograd(x, w, rows_are_out: bool, cout_act: int, wscale=1.0, keep_v
     V = torch.empty((lib.gif_winograd_workspace_floats(B, H, W, C),), device=x.device, dtype=torch.float32)
     out = empty_nhwc(B, cout_act, H, W, x.device)
     e = _epilogue(out_bchw=(B, cout_act, H, W), **epi)
+    if x3 and H2_WINO and get_fp32_mfma_mode() == "f16x2":  # f16x2 GEMM + its guarded bf16x3 twin on U
+
+        def build2():
+            RP, CP = ctypes.c_int(), ctypes.c_int()
+            _lib.check(lib.gif_winograd_pack_dims_x3(cout_act, C, ctypes.byref(RP), ctypes.byref(CP)), "winograd_pack_dims")
+            U2 = torch.empty((lib.gif_winograd_weight_f32h2_bytes(RP.value, CP.value),), device=x.device, dtype=torch.uint8)
+            _lib.check(lib.gif_winograd_weight_f32h2(w.data_ptr(), U2.data_ptr(), R, Cc, RP.value, CP.value, sr, sc, sky, skx,
+                                                     0 if rows_are_out else 1, float(wscale), _stream()), "winograd_weight_f32h2")
+            return U2
+
+        U2 = _cached_weight_op(w, ("wino_h2", rows_are_out, cout_act, C, float(wscale)), build2)
+        _lib.check(lib.gif_conv3x3_winograd_f32h2(x.data_ptr(), U2.data_ptr(), U.data_ptr() if H2_GUARD else None, out.data_ptr(),
+                                                  V.data_ptr(), B, H, W, C, cout_act, ctypes.byref(e), _stream()), "conv3x3_winograd_f32h2")
+        return (out, V) if keep_v else out
     fn = lib.gif_conv3x3_winograd_f32x3 if x3 else lib.gif_conv3x3_winograd_f32
     _lib.check(fn(x.data_ptr(), U.data_ptr(), out.data_ptr(), V.data_ptr(), B, H, W, C, cout_act, ctypes.byref(e), _stream()),
                "conv3x3_winograd")

@@ -82,8 +82,8 @@ int gif_conv2d_pack_dims_x3(int cout, int cin, int* RP, int* CP); /* like gif_co
 int gif_pack_weight_f32x3(const float* w, void* wp3, int R, int C, int KH, int KW, int RP, int CP, int64_t sr, int64_t sc,
                           int64_t sky, int64_t skx, float scale, gif_stream_t stream);
 /* gif_conv2d_fwd_f32x3 / gif_conv2d_bwd_data_f32x3: declared next to their _f32 namesakes below */
-/* The f16x2 entry points (ABI 4).  gif_pack_weight_f32h2 writes wp2 = [RP + 32 int32: the rows' exponents, then a flag word the
- * packing sets when a 16-channel group of some row falls out of the precision window][tap][2][RP][CP] f16 (hi, lo planes of
+/* The f16x2 entry points (ABI 4).  gif_pack_weight_f32h2 writes wp2 = [RP int32: the rows' exponents][RP int32: row flags the
+ * packing sets when a 16-channel group of the row falls out of the precision window][tap][2][RP][CP] f16 (hi, lo planes of
  * scale * w * 2^e_row; RP/CP from gif_conv2d_pack_dims_x3; gif_pack_weight_f32h2_bytes of device memory).  The convolution entry
  * points take BOTH packings of the same weights: wp2 for the f16x2 kernels and wp3 (gif_pack_weight_f32x3) for the guarded
  * fallback; wp3 == NULL runs unguarded.  Eligibility as for bf16x3 (gif_conv2d_x3_eligible; no tap-dense variant). */
@@ -281,6 +281,13 @@ int gif_conv3x3_winograd_f32(const float* x, const float* U, float* y, float* V,
 int gif_winograd_pack_dims_x3(int cout, int cin, int* RP, int* CP);
 int gif_winograd_weight_f32x3(const float* w, void* U3, int R, int C, int RP, int CP, int64_t sr, int64_t sc, int64_t sky,
                               int64_t skx, int flip, float scale, gif_stream_t stream);
+/* f16x2 (ABI 4): U2 = [RP exponents][RP flags][16][2][RP][CP] f16 (gif_winograd_weight_f32h2_bytes), pack dims as for the bf16x3
+ * GEMM; gif_conv3x3_winograd_f32h2 runs the f16x2 GEMM and then its guarded bf16x3 twin on U3 (NULL: unguarded). */
+int64_t gif_winograd_weight_f32h2_bytes(int RP, int CP);
+int gif_winograd_weight_f32h2(const float* w, void* U2, int R, int C, int RP, int CP, int64_t sr, int64_t sc, int64_t sky,
+                              int64_t skx, int flip, float scale, gif_stream_t stream);
+int gif_conv3x3_winograd_f32h2(const float* x, const void* U2, const void* U3, float* y, float* V, int B, int H, int W, int C, int Co,
+                               const gif_conv_epilogue* e, gif_stream_t stream);
 int gif_conv3x3_winograd_f32x3(const float* x, const void* U3, float* y, float* V, int B, int H, int W, int C, int Co,
                                const gif_conv_epilogue* e, gif_stream_t stream);
 /* Weight gradient of the same convolution via Winograd F(3x3,2x2) (replaces autograd's wgrad of the F.conv2d calls

@@ -63,7 +63,7 @@ def test_fp32_mfma_mode_api_without_gpu():
         ops.set_fp32_mfma_mode("f16x2")
         assert ops.get_fp32_mfma_mode() == "f16x2" and lib.gif_get_fp32_mfma_mode() == 2 and ops.split_mode()
         assert lib.gif_set_fp32_mfma_mode(5) == -1 and b"unknown mode" in lib.gif_last_error()
-        assert lib.gif_pack_weight_f32h2_bytes(3, 3, 128, 128) == (128 + 32) * 4 + 9 * 2 * 128 * 128 * 2
+        assert lib.gif_pack_weight_f32h2_bytes(3, 3, 128, 128) == 2 * 128 * 4 + 9 * 2 * 128 * 128 * 2
     finally:
         lib.gif_set_fp32_mfma_mode(before)
         ops._fp32_mode_cache = None

@@ -48,7 +48,7 @@ def test_mode_api_and_default():
     ops.set_fp32_mfma_mode("bf16x3")
     assert lib.gif_get_fp32_mfma_mode() == 1 and ops.split_mode()
     assert lib.gif_set_fp32_mfma_mode(3) != 0 and b"unknown mode" in lib.gif_last_error()
-    assert lib.gif_pack_weight_f32h2_bytes(3, 3, 128, 128) == (128 + 32) * 4 + 9 * 2 * 128 * 128 * 2
+    assert lib.gif_pack_weight_f32h2_bytes(3, 3, 128, 128) == 2 * 128 * 4 + 9 * 2 * 128 * 128 * 2
 
 
 # (B, Cin, Cout, K, stride, pad, H): what each case exercises on the f16x2 side
@@ -262,3 +262,69 @@ def test_f16x2_rescale_path_unguarded_equals_guarded():
     assert ops.h2_fallback_stats() == 0 and torch.equal(y, y_u)
     ops.set_fp32_mfma_mode("native")
     assert _err(y, ref) <= 1.5 * _err(ops.conv_fwd(x, w, spec), ref) + 2e-7
+
+
+# ------------------------------------------------------------------------------------------------ Winograd GEMM (wino_gemm_h2)
+@pytest.mark.parametrize("case", [(4, 128, 128, 64), (2, 256, 512, 32), (3, 512, 256, 16), (2, 128, 128, 34), (32, 128, 128, 64), (2, 128, 192, 32)])
+def test_f16x2_winograd_fwd_dgrad_vs_fp64(case, monkeypatch):
+    """wino_gemm_h2 (V fragments split under ONE running exponent per Winograd tile over all 16 positions, pre-split U2, fused output
+    transform + epilogue on the descaled accumulators) against fp64 next to the native Winograd GEMM; 34^2: ragged tile rows;
+    192 output channels are not a multiple of the 128-wide tile and stay on the native GEMM in every mode."""
+    from gif_amd import ops
+    monkeypatch.setattr(ops, "WINOGRAD", True)
+    monkeypatch.setattr(ops, "WINOGRAD_MIN_TILES", 1)
+    B, ci, co, h = case
+    torch.manual_seed(sum(case))
+    spec = ops.ConvSpec(3, 3, 1, 1)
+    x = _cl(torch.randn(B, ci, h, h, device="cuda"))
+    w = torch.randn(co, ci, 3, 3, device="cuda") / (ci * 9) ** 0.5
+    sc, sd = torch.rand(B, ci, device="cuda") + 0.5, torch.rand(B, co, device="cuda") + 0.5
+    bias = torch.randn(co, device="cuda")
+    res = _cl(torch.randn(B, co, h, h, device="cuda"))
+    gy = _cl(torch.randn(B, co, h, h, device="cuda"))
+    z = F.conv2d(x.double() * sc.double()[:, :, None, None], w.double(), padding=1) * sd.double()[:, :, None, None]
+    ref_f = 2 ** 0.5 * F.leaky_relu(z + res.double() + bias.double()[None, :, None, None], 0.2)
+    ref_d = F.conv_transpose2d(gy.double() * sd.double()[:, :, None, None], w.double(), padding=1) * sc.double()[:, :, None, None]
+    out = {}
+    for mode in ("native", "f16x2"):
+        ops.set_fp32_mfma_mode(mode)
+        n0 = ops.prof_winograd_calls()
+        y = ops.conv_fwd(x, w, spec, in_scale=sc, out_scale=sd, bias=bias, residual=res, act=True, slope=0.2, gain=2 ** 0.5)
+        gx = ops.conv_bwd_data(gy, w, spec, (h, h), in_scale=sd, out_scale=sc)
+        assert ops.prof_winograd_calls() == n0 + 2, "both passes must have taken the Winograd path"
+        out[mode] = (_err(y, ref_f), _err(gx, ref_d))
+    assert ops.h2_fallback_stats() == 0
+    for en, ex in zip(out["native"], out["f16x2"]):
+        assert en < 1e-5 and ex <= 1.5 * en + 2e-7, (case, out)
+
+
+@pytest.mark.parametrize("kind", ["grow", "scales", "ties", "window", "1e-38", "1e30"])
+def test_f16x2_winograd_adversarial(kind, monkeypatch):
+    from gif_amd import ops
+    monkeypatch.setattr(ops, "WINOGRAD", True)
+    monkeypatch.setattr(ops, "WINOGRAD_MIN_TILES", 1)
+    B, C, H = 2, 128, 32
+    g = torch.Generator().manual_seed(len(kind) + 40)
+    w = torch.randn(C, C, 3, 3, generator=g) / 34
+    if kind in ADV:
+        x = ADV[kind](B, C, H, g)
+    elif kind == "window":
+        x = torch.randn(B, C, H, H, generator=g)
+        x[:, 32:48] *= 2.0 ** -24
+        w[:, 32:48] *= 2.0 ** 24
+    else:
+        x = torch.randn(B, C, H, H, generator=g) * float(kind)
+    x, w = _cl(x.cuda()), w.cuda()
+    spec = ops.ConvSpec(3, 3, 1, 1)
+    ref = F.conv2d(x.double(), w.double(), padding=1)
+    out = {}
+    for mode in ("native", "f16x2"):
+        ops.set_fp32_mfma_mode(mode)
+        n0 = ops.prof_winograd_calls()
+        y = ops.conv_fwd(x, w, spec)
+        assert ops.prof_winograd_calls() == n0 + 1 and torch.isfinite(y).all()
+        out[mode] = _err(y, ref)
+    fb = ops.h2_fallback_stats()
+    print(f"\n[f16x2 winograd adversarial] {kind}: {out} fallbacks {fb}")
+    assert fb == (1 if kind == "window" else fb if kind == "scales" else 0), (kind, fb)
+    assert out["f16x2"] <= 1.5 * out["native"] + 2e-7, (kind, out)
