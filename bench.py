@@ -65,7 +65,7 @@ def parse():
     ap.add_argument("--dtype", type=str, default="f32", choices=["f32", "f16"],
                     help="activation dtype: f32 = the reference's (headline); f16 = BASELINE configs[4] (f16 activations, fp32 "
                          "weights / demodulation / accumulation, loss scaling) — use with --res 1024 --batch 8")
-    ap.add_argument("--fp32-mfma", type=str, default=None, choices=["native", "bf16x3"],
+    ap.add_argument("--fp32-mfma", type=str, default=None, choices=["native", "bf16x3", "f16x2"],
                     help="fp32 contraction mode of the conv kernels (default: GIF_FP32_MFMA, else bf16x3 — fp32 tensors, every fp32 "
                          "operand split exactly into 3 bf16 terms, 6 bf16 MFMA products, fp32 accumulation)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -177,7 +177,8 @@ def cpu_baseline(res, step_idx, batch, threads, timeout_s):
 
 
 WINOGRAD_EXECUTED = 16.0 / 36.0
-BF16X3_EXECUTED = 6.0  # bf16 MFMA FLOPs the bf16x3 kernels execute per algorithmic fp32 FLOP  # MFMA FLOPs a Winograd F(2x2,3x3)/F(3x3,2x2) GEMM executes per algorithmic FLOP
+BF16X3_EXECUTED = 6.0  # bf16 MFMA FLOPs the bf16x3 kernels execute per algorithmic fp32 FLOP
+F16X2_EXECUTED = 3.0   # f16 MFMA FLOPs the f16x2 kernels execute per algorithmic fp32 FLOP (hi*hi + hi*lo + lo*hi)
 
 # family id -> (description, executed MFMA fraction of the algorithmic FLOPs, key in profiles/pmc_traffic.json)
 FAMILIES = {
@@ -203,6 +204,12 @@ FAMILIES = {
          "U, fused output transform and epilogue)", BF16X3_EXECUTED * WINOGRAD_EXECUTED, "wino_gemm_x3"),
     11: ("conv_wgrad_mfma<float, bf16x3> in planes mode (Winograd F(3x3,2x2) weight-gradient GEMMs on the bf16 matrix cores)",
          BF16X3_EXECUTED * WINOGRAD_EXECUTED, "conv_wgrad_mfma_x3"),
+    13: ("conv_gather_mfma_glds<float, f16x2> (fp32 direct fwd / dgrad / stride-2 / transposed conv on the f16 matrix cores: two f16 terms per "
+         "operand under per-row power-of-two scales — running row exponent with exact accumulator rescale, per-row weight exponents — 3 "
+         "v_mfma_f32_32x32x16_f16 products per fp32 product, fp32 accumulation; the time includes the guarded bf16x3 twin launch, a no-op "
+         "unless an operand left the precision window)", F16X2_EXECUTED, "conv_gather_mfma_glds_h2"),
+    14: ("wino_gemm_h2 (Winograd F(2x2,3x3) fwd / dgrad GEMM on the f16 matrix cores: f16x2 split of V in the kernel under one running "
+         "exponent per tile row, pre-split U, fused output transform and epilogue)", F16X2_EXECUTED * WINOGRAD_EXECUTED, "wino_gemm_h2"),
     12: ("conv_gather_mfma_glds<float, bf16x3> in the tap-dense K order (3x3 layers with 8..28 contraction channels: the 6->12->24 "
          "condition-noise convs and the 24->C layers that inject their result; same kernels as the bf16x3 direct family, so no separate "
          "PMC traffic)", BF16X3_EXECUTED, None),
@@ -210,9 +217,11 @@ FAMILIES = {
 FAMILY_KEYS = {0: "roofline_conv_direct", 1: "roofline_wgrad_direct", 2: "roofline_conv_winograd", 3: "roofline_wgrad_winograd",
                5: "roofline_conv_direct_small_cin", 6: "roofline_conv_f16", 7: "roofline_wgrad_f16",
                8: "roofline_conv_direct_bf16x3", 9: "roofline_wgrad_direct_bf16x3", 10: "roofline_conv_winograd_bf16x3",
-               11: "roofline_wgrad_winograd_bf16x3", 12: "roofline_conv_direct_bf16x3_tapdense"}
+               11: "roofline_wgrad_winograd_bf16x3", 12: "roofline_conv_direct_bf16x3_tapdense", 13: "roofline_conv_direct_f16x2",
+               14: "roofline_conv_winograd_f16x2"}
 FAMILY_PEAK = {6: PEAK_F16_MFMA_TFLOPS, 7: PEAK_F16_MFMA_TFLOPS, 8: PEAK_F16_MFMA_TFLOPS, 9: PEAK_F16_MFMA_TFLOPS,
-               10: PEAK_F16_MFMA_TFLOPS, 11: PEAK_F16_MFMA_TFLOPS, 12: PEAK_F16_MFMA_TFLOPS}
+               10: PEAK_F16_MFMA_TFLOPS, 11: PEAK_F16_MFMA_TFLOPS, 12: PEAK_F16_MFMA_TFLOPS, 13: PEAK_F16_MFMA_TFLOPS,
+               14: PEAK_F16_MFMA_TFLOPS}
 
 
 def load_pmc():
@@ -230,6 +239,10 @@ def family_ceiling(fam, exec_frac, mfma_peak):
     FLOPs it executes per algorithmic (direct-convolution, fp32) FLOP."""
     if fam in (8, 9, 12):
         return mfma_peak / exec_frac, "bf16x3 fp32-exact = 2500 / 6 (six bf16 MFMA products per fp32 product, bf16 dense peak 2500 TFLOP/s)"
+    if fam == 13:
+        return mfma_peak / exec_frac, "f16x2 = 2500 / 3 (three f16 MFMA products per fp32 product, f16 dense peak 2500 TFLOP/s)"
+    if fam == 14:
+        return mfma_peak / exec_frac, "Winograd on f16x2 = 2500 / (3 * 16/36) (F(2x2,3x3) executes 16/36 of the products, each as three f16 MFMA products)"
     if fam in (10, 11):
         return mfma_peak / exec_frac, "Winograd on bf16x3 = 2500 / (6 * 16/36) (F(2x2,3x3) executes 16/36 of the products, each as six bf16 MFMA products)"
     if fam in (2, 3):
@@ -302,7 +315,7 @@ def roofline_objects(ops, steps, wall_s):
         "mfma_kernel_ms_per_step": mfma_ms / steps,
         "frac_while_mfma_kernels_run": executed_peak_s / (mfma_ms * 1e-3) if mfma_ms else None,
         "note": "MFMA FLOPs actually executed (direct kernels: all; Winograd GEMMs: 16/36 of the algorithmic count), each priced "
-                "at the dense peak of the MFMA type it ran on (fp32 157.3 TF, f16 / bf16 2500 TF; bf16x3: 6 executed per algorithmic): time at peak / wall time of the "
+                "at the dense peak of the MFMA type it ran on (fp32 157.3 TF, f16 / bf16 2500 TF; bf16x3: 6 executed per algorithmic, f16x2: 3): time at peak / wall time of the "
                 "timed region"}
     return out
 
@@ -456,10 +469,21 @@ def main():
             cond = mesh()  # config 3: rasterised condition, inside the timed region
         return trainer.step(it, real, cond, idx)
 
-    it = 0
+    # R1 share of the timed region = steps / r1_every (review item): the trainer runs R1 when (i + 1) % r1_every == 0; start the
+    # iteration counter so that round(steps / r1_every) R1 iterations fall inside the timed steps (and none when that rounds to 0)
+    n_r1 = int(round(args.steps / args.r1_every)) if args.r1_every else 0
+    if not args.r1_every:
+        it = 0
+    elif n_r1 > 0:
+        first = args.warmup + max((args.steps - (n_r1 - 1) * args.r1_every) // 2, 0)   # index of the first timed R1 iteration
+        it = (args.r1_every - 1 - first) % args.r1_every
+    else:
+        it = (-args.warmup) % args.r1_every  # the timed steps are iterations 1 .. steps of an R1 period: no R1 iteration among them
+    it0 = it
     for _ in range(args.warmup):
         run_step(it, batch())
         it += 1
+    r1_timed = sum(1 for k in range(args.steps) if args.r1_every and (it + k + 1) % args.r1_every == 0)
 
     def sync():
         torch.cuda.synchronize()
@@ -472,8 +496,11 @@ def main():
     data = [batch() for _ in range(min(args.steps, 4))]  # synthetic batches resident in HBM before the timed region
     prof_steps = 0
     if not args.no_prof:
-        for fam in range(13):
+        for fam in range(15):
             ops.prof_read(fam)
+    h2_mode = args.dtype != "f16" and ops.get_fp32_mfma_mode() == "f16x2"
+    if h2_mode:
+        ops.h2_fallback_stats(reset=True)
     sync()
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -521,7 +548,13 @@ def main():
                     + ("f16 activations / f16 MFMA with fp32 accumulation, fp32 weights + demodulation, dynamic loss scaling "
                        "(BASELINE configs[4])" if f16 else
                        "fp32 tensors and fp32 accumulation; contractions on "
-                       + ("the bf16 matrix cores via the exact 3-way bf16 split (bf16x3: 6 products per fp32 product, error vs fp64 <= "
+                       + ("the f16 matrix cores via a two-term f16 split under per-row power-of-two scales (f16x2: 3 products per fp32 product, "
+                          "error vs fp64 <= the native fp32 MFMA path on in-window operands, guarded bf16x3 fallback otherwise) for the direct "
+                          "fwd / dgrad kernels and the Winograd GEMMs with >= 24 contraction channels; bf16x3 (6 products) for the weight "
+                          "gradients and, in a tap-dense K order, the 3x3 convs with 8..28 contraction channels; the 9-channel D input layer "
+                          "(1x1), ToRGB's data gradient and the small-channel weight gradients on native fp32 MFMA"
+                          if fp32_mode == "f16x2" else
+                          "the bf16 matrix cores via the exact 3-way bf16 split (bf16x3: 6 products per fp32 product, error vs fp64 <= "
                           "the native fp32 MFMA path) for every direct, weight-gradient and Winograd GEMM with >= 24 contraction "
                           "channels and, in a tap-dense K order, the 3x3 convs with 8..28 (the 6->12->24 condition-noise convs); the "
                           "9-channel D input layer (1x1), ToRGB's data gradient and the small-channel weight gradients on native fp32 MFMA"
@@ -540,6 +573,8 @@ def main():
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": workload, "global_batch": world * B, "resolution": args.res, "parallelism": f"dp{world}",
                        "fp32_mfma": None if f16 else fp32_mode,
+                       "f16x2_fallback_launches_timed": ops.h2_fallback_stats() if h2_mode else None,
+                       "r1_iterations_timed": r1_timed, "first_iteration_index": it0,
                        "algorithmic_tflop_per_image": fl_img / 1e12,
                        "grad_bucket_mb": {"G": trainer.g_bucket.flat.numel() * 4 / 1e6, "D": trainer.d_bucket.flat.numel() * 4 / 1e6},
                        "overlap_comm": bool(trainer.overlap_comm),
@@ -556,7 +591,7 @@ def main():
                                    "note": "whole step, ALGORITHMIC direct-convolution FLOPs (Winograd executes fewer, bf16x3 six "
                                            "times more on a 16x faster pipe: see executed_mfma_frac_wall) incl. HBM-bound kernels, "
                                            "optimiser, host; per GPU.  peak = the fp32-input MFMA peak: a reference for the fp32 "
-                                           "workload, not the ceiling of the bf16x3 kernels (2500 / 6 = 417 fp32-equivalent TFLOP/s)"},
+                                           "workload, not the ceiling of the bf16x3 / f16x2 kernels (2500 / 6 = 417, 2500 / 3 = 833 fp32-equivalent TFLOP/s)"},
         }
         if not args.no_prof:
             out.update(roofline_objects(ops, prof_steps, dt * prof_steps / args.steps))

@@ -61,6 +61,7 @@ PROTOTYPES = {
     "gif_conv2d_x3_eligible": (c_int, [c_int, c_int]),
     "gif_pack_weight_f32h2_bytes": (c_i64, [c_int, c_int, c_int, c_int]),
     "gif_pack_weight_f32h2": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_float, P]),
+    "gif_pack_weight_f32h2x3": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_float, P]),
     "gif_conv2d_fwd_f32h2": (c_int, [P, P, P, P, GP, EP, P]),
     "gif_conv2d_bwd_data_f32h2": (c_int, [P, P, P, P, GP, EP, P]),
     "gif_h2_fallback_stats": (c_int, [ctypes.POINTER(ctypes.c_uint64), c_int]),
@@ -84,7 +85,7 @@ PROTOTYPES = {
     "gif_conv3x3_winograd_f32": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, EP, P]),
     "gif_conv3x3_winograd_f32x3": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, EP, P]),
     "gif_winograd_weight_f32h2_bytes": (c_i64, [c_int, c_int]),
-    "gif_winograd_weight_f32h2": (c_int, [P, P, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_int, c_float, P]),
+    "gif_winograd_weight_f32h2": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_int, c_float, P]),
     "gif_conv3x3_winograd_f32h2": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, EP, P]),
     "gif_conv3x3_winograd_wgrad_splits": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "gif_conv3x3_winograd_wgrad_f32": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),

@@ -58,8 +58,10 @@ int fp32_mfma_mode();
 // (ALGORITHMIC direct-conv flops; the kernel executes 16/36 of them), 3 Winograd wgrad GEMM (same convention),
 // 4 Winograd transforms (HBM bytes), 5 direct conv fwd/dgrad on the register-staged kernel (Cin < 32; flops),
 // 6 / 7 f16 conv / wgrad, 8 / 9 bf16x3 conv fwd/dgrad / wgrad (algorithmic flops; the bf16 pipe executes 6x),
-// 10 / 11 bf16x3 Winograd GEMM fwd/dgrad / Winograd wgrad plane GEMMs (algorithmic flops; execute 6 * 16/36 of them)
-#define GIF_PROF_FAMILIES 13
+// 10 / 11 bf16x3 Winograd GEMM fwd/dgrad / Winograd wgrad plane GEMMs (algorithmic flops; execute 6 * 16/36 of them),
+// 12 bf16x3 direct conv in the tap-dense K order, 13 / 14 f16x2 direct conv fwd/dgrad / f16x2 Winograd GEMM (algorithmic flops; the
+// f16 pipe executes 3x / 3 * 16/36 of them; the op's time includes its guarded bf16x3 twin launch)
+#define GIF_PROF_FAMILIES 15
 struct ProfScope {
     int family;
     hipStream_t stream;

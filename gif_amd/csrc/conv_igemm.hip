@@ -1747,7 +1747,7 @@ int conv2d_fwd_impl(const void* big, const void* wp, void* small, const gif_conv
     if (x3 == 2) h2_operands(p, wp, wp_fallback);
     p.M = p.B * p.Hp * p.Wp;
     double flops = 2.0 * p.M * (double)p.Co * p.Ci * p.ntaps;
-    const int fam = sizeof(T) == 2 ? 6 : dense ? 12 : x3 ? 8 : (p.Ci >= 32 ? 0 : 5);
+    const int fam = sizeof(T) == 2 ? 6 : dense ? 12 : x3 == 2 ? 13 : x3 ? 8 : (p.Ci >= 32 ? 0 : 5);
     FusedSums sums;
     if (int rc = sums.begin(p, e, p.M, p.Co, p.B, (long)p.Hp * p.Wp, true, who)) return rc;
     gif::ProfScope prof(fam, flops, gif::as_stream(stream), p.M, p.Co, p.Ci, p.ntaps * 10 + g->stride);
@@ -1816,7 +1816,7 @@ int conv2d_bwd_data_impl(const void* small, const void* wp, void* big, const gif
     // algorithmic FLOPs of a transposed conv: every small-side pixel scatters through every tap
     double flops = 2.0 * g->B * (double)g->Hs * g->Ws * g->KH * g->KW * (double)g->Cs * g->Cb;
     {
-        const int fam = sizeof(T) == 2 ? 6 : dense ? 12 : x3 ? 8 : (base.Ci >= 32 ? 0 : 5);
+        const int fam = sizeof(T) == 2 ? 6 : dense ? 12 : x3 == 2 ? 13 : x3 ? 8 : (base.Ci >= 32 ? 0 : 5);
         gif::ProfScope prof(fam, flops, s, g->B * g->Hb * g->Wb, base.Co, base.Ci, -(g->KH * g->KW * 10 + g->stride));
         // small transposed convs: every phase alone would sit on the 64x64-tile path with a partly filled chip
         auto run_phases = [&]() -> int {

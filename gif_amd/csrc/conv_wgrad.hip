@@ -731,9 +731,10 @@ __global__ void pack_weight_x3_dense_kernel(const float* __restrict__ w, unsigne
 // scale * w * 2^e.  A 16-channel K group (the kernels' k-groups: 16 consecutive padded channels of one tap) whose maximum lies more
 // than 2^kH2WindowW below the row maximum sets the flag: its values no longer carry 22 bits, launches using the row take the bf16x3
 // fallback.
+// planes3 != NULL: the bf16x3 packing wp3[t][3][RP][CP] of the same weights (the guarded fallback's operand) in the same pass.
 __global__ void __launch_bounds__(256) pack_weight_h2_kernel(const float* __restrict__ w, int* __restrict__ hdr, unsigned short* __restrict__ planes,
-                                                             int R, int C, int KH, int KW, int RP, int CP, long sr, long sc, long sky, long skx,
-                                                             float scale) {
+                                                             unsigned short* __restrict__ planes3, int R, int C, int KH, int KW, int RP, int CP,
+                                                             long sr, long sc, long sky, long skx, float scale) {
     __shared__ float red[256];
     __shared__ int s_flag;
     const int r = blockIdx.x, tid = threadIdx.x;
@@ -772,6 +773,14 @@ __global__ void __launch_bounds__(256) pack_weight_h2_kernel(const float* __rest
             gif::split_pair_h2(v0, v1, sc2, h, l);
             *reinterpret_cast<unsigned*>(o + k) = h;
             *reinterpret_cast<unsigned*>(o + plane + k) = l;
+            if (planes3) {
+                unsigned m3;
+                gif::split_pair(v0, v1, h, m3, l);
+                unsigned short* o3 = planes3 + (size_t)t * 3 * plane + (size_t)r * CP + c0 + k;
+                *reinterpret_cast<unsigned*>(o3) = h;
+                *reinterpret_cast<unsigned*>(o3 + plane) = m3;
+                *reinterpret_cast<unsigned*>(o3 + 2 * plane) = l;
+            }
         }
         if (gm > 0.f && (int)(__float_as_uint(rowmax) >> 23) - (int)(__float_as_uint(gm) >> 23) > gif::kH2WindowW) narrow = true;
     }
@@ -1229,8 +1238,20 @@ int gif_pack_weight_f32h2(const float* w, void* wp2, int R, int C, int KH, int K
                 "pack_weight_f32h2: bad arguments");
     int* hdr = static_cast<int*>(wp2);
     unsigned short* planes = reinterpret_cast<unsigned short*>(static_cast<char*>(wp2) + gif::h2_header_bytes(RP));
-    pack_weight_h2_kernel<<<RP, 256, 0, gif::as_stream(stream)>>>(w, hdr, planes, R, C, KH, KW, RP, CP, sr, sc, sky, skx, scale);
+    pack_weight_h2_kernel<<<RP, 256, 0, gif::as_stream(stream)>>>(w, hdr, planes, nullptr, R, C, KH, KW, RP, CP, sr, sc, sky, skx, scale);
     return gif::check_launch("pack_weight_f32h2");
+}
+
+/* both packings of the same weights in ONE launch: wp2 (f16x2, as gif_pack_weight_f32h2) and wp3 (bf16x3, as gif_pack_weight_f32x3) */
+int gif_pack_weight_f32h2x3(const float* w, void* wp2, void* wp3, int R, int C, int KH, int KW, int RP, int CP, int64_t sr, int64_t sc,
+                            int64_t sky, int64_t skx, float scale, gif_stream_t stream) {
+    GIF_REQUIRE(w && wp2 && wp3 && R > 0 && C > 0 && RP >= R && CP >= C && KH > 0 && KW > 0 && RP % 32 == 0 && CP % 32 == 0,
+                "pack_weight_f32h2x3: bad arguments");
+    int* hdr = static_cast<int*>(wp2);
+    unsigned short* planes = reinterpret_cast<unsigned short*>(static_cast<char*>(wp2) + gif::h2_header_bytes(RP));
+    pack_weight_h2_kernel<<<RP, 256, 0, gif::as_stream(stream)>>>(w, hdr, planes, static_cast<unsigned short*>(wp3), R, C, KH, KW, RP, CP, sr,
+                                                                  sc, sky, skx, scale);
+    return gif::check_launch("pack_weight_f32h2x3");
 }
 
 /* K steps (32-float chunks) of the tap-dense order, or 0 if the mode does not apply: 3x3 kernels, 8 <= cin_act < 32, cin_act % 4 == 0 */

@@ -1029,9 +1029,10 @@ __global__ void __launch_bounds__(512, 1) wino_gemm_h2(const WinoParams p) {
 // U2 = the two f16 terms of G g G^T * 2^e_row: header [RP] exponents + [RP] flags (int32), then planes [16][2][RP][CP] (f16 bits).
 // One workgroup per output-channel row: the row maximum runs over all 16 positions and all channels (common.h "h2"); a 16-channel
 // group of one position more than 2^kH2WindowW below it sets the row's flag.
+// U3 != NULL: the bf16x3 transform [16][3][RP][CP] of the same weights (the guarded fallback's operand) in the same pass.
 __global__ void __launch_bounds__(256) wino_weight_transform_h2(const float* __restrict__ w, int* __restrict__ hdr, unsigned short* __restrict__ planes,
-                                                                int R, int C, int RP, int CP, long sr, long sc, long sky, long skx, int flip,
-                                                                float scale) {
+                                                                unsigned short* __restrict__ U3, int R, int C, int RP, int CP, long sr, long sc,
+                                                                long sky, long skx, int flip, float scale) {
     __shared__ float red[256];
     __shared__ int s_flag;
     const int r = blockIdx.x, tid = threadIdx.x;
@@ -1089,6 +1090,14 @@ __global__ void __launch_bounds__(256) wino_weight_transform_h2(const float* __r
             unsigned short* o = planes + (size_t)q * 2 * plane + (size_t)r * CP + c;
             o[0] = (unsigned short)(h & 0xffffu);
             o[plane] = (unsigned short)(l & 0xffffu);
+            if (U3) {
+                unsigned m3;
+                gif::split_pair(v[q], 0.f, h, m3, l);
+                unsigned short* o3 = U3 + (size_t)q * 3 * plane + (size_t)r * CP + c;
+                o3[0] = (unsigned short)(h & 0xffffu);
+                o3[plane] = (unsigned short)(m3 & 0xffffu);
+                o3[2 * plane] = (unsigned short)(l & 0xffffu);
+            }
             float gm = fabsf(v[q]);  // maximum over the 16 channels of this lane's group
 #pragma unroll
             for (int d = 1; d < 16; d <<= 1) gm = fmaxf(gm, __shfl_xor(gm, d, 16));
@@ -1353,7 +1362,7 @@ static int conv3x3_winograd_x3_impl(const float* x, const void* U2, const void* 
         gif::ProfScope prof_t(4, 4.0 * ((double)B * H * W * C + 16.0 * ntiles_pad * p.CP), s, (int)((long)B * H * W), C, 0, 1);
         if (int rc = gif::winograd_input_transform(x, e ? e->in_scale : nullptr, V, B, H, W, C, s)) return rc;
     }
-    gif::ProfScope prof(10, flops, s, (int)((long)B * H * W), Co, C, 2091);
+    gif::ProfScope prof(U2 ? 14 : 10, flops, s, (int)((long)B * H * W), Co, C, 2091);
     p.V = V; p.U = static_cast<const float*>(U3); p.y = y;
     p.out_scale = e ? e->out_scale : nullptr;
     p.bias = e ? e->bias : nullptr;
@@ -1424,12 +1433,14 @@ int64_t gif_winograd_weight_f32h2_bytes(int RP, int CP) {
     return (int64_t)gif::h2_header_bytes(RP) + 16LL * 2 * RP * CP * 2;
 }
 
-int gif_winograd_weight_f32h2(const float* w, void* U2, int R, int C, int RP, int CP, int64_t sr, int64_t sc, int64_t sky,
+/* U3 (optional): also write the bf16x3 transform of the same weights (gif_winograd_weight_f32x3's output) in the same launch */
+int gif_winograd_weight_f32h2(const float* w, void* U2, void* U3, int R, int C, int RP, int CP, int64_t sr, int64_t sc, int64_t sky,
                               int64_t skx, int flip, float scale, gif_stream_t stream) {
     GIF_REQUIRE(w && U2 && R > 0 && C > 0 && RP >= R && CP >= C && RP % 128 == 0 && CP % 32 == 0, "winograd_weight_f32h2: bad arguments");
     int* hdr = static_cast<int*>(U2);
     unsigned short* planes = reinterpret_cast<unsigned short*>(static_cast<char*>(U2) + gif::h2_header_bytes(RP));
-    wino_weight_transform_h2<<<RP, 256, 0, gif::as_stream(stream)>>>(w, hdr, planes, R, C, RP, CP, sr, sc, sky, skx, flip, scale);
+    wino_weight_transform_h2<<<RP, 256, 0, gif::as_stream(stream)>>>(w, hdr, planes, static_cast<unsigned short*>(U3), R, C, RP, CP, sr, sc,
+                                                                     sky, skx, flip, scale);
     return gif::check_launch("winograd_weight_f32h2");
 }
 

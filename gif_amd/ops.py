@@ -282,6 +282,26 @@ def pack_weight(w: torch.Tensor, rows_are_out: bool, cout_act: int, cin_act: int
     return _cached_weight_op(w, ("pack", rows_are_out, cout_act, cin_act, float(scale), dtype, bool(x3), bool(tapdense), bool(h2)), build)
 
 
+def pack_weight_h2x3(w: torch.Tensor, rows_are_out: bool, cout_act: int, cin_act: int, scale: float = 1.0):
+    """(wp2, wp3): the f16x2 packing and the bf16x3 packing (the guarded fallback's operand) of the same weight view, ONE launch."""
+    lib = _lib.load()
+    O, I, KH, KW = w.shape
+    so, si, sky, skx = w.stride()
+    R, C, sr, sc = (O, I, so, si) if rows_are_out else (I, O, si, so)
+    assert R <= cout_act and C <= cin_act, (R, cout_act, C, cin_act)
+
+    def build():
+        RP, CP = ctypes.c_int(), ctypes.c_int()
+        _lib.check(lib.gif_conv2d_pack_dims_x3(cout_act, cin_act, ctypes.byref(RP), ctypes.byref(CP)), "pack_dims")
+        wp2 = torch.empty((lib.gif_pack_weight_f32h2_bytes(KH, KW, RP.value, CP.value),), device=w.device, dtype=torch.uint8)
+        wp3 = torch.empty((KH * KW, 3, RP.value, CP.value), device=w.device, dtype=torch.bfloat16)
+        _lib.check(lib.gif_pack_weight_f32h2x3(w.data_ptr(), wp2.data_ptr(), wp3.data_ptr(), R, C, KH, KW, RP.value, CP.value, sr, sc, sky, skx,
+                                               float(scale), _stream()), "pack_weight_f32h2x3")
+        return wp2, wp3
+
+    return _cached_weight_op(w, ("pack_h2x3", rows_are_out, cout_act, cin_act, float(scale)), build)
+
+
 # Winograd F(2x2,3x3) dispatch for stride-1 / pad-1 3x3 convs (conv_winograd.hip).  GIF_WINOGRAD=0 forces the direct
 # implicit-GEMM kernels; below GIF_WINOGRAD_MIN_TILES 2x2 tiles the launch cannot fill the chip and the direct path wins.
 WINOGRAD = os.environ.get("GIF_WINOGRAD", "1") != "0"
@@ -322,10 +342,18 @@ def conv3x3_winograd(x, w, rows_are_out: bool, cout_act: int, wscale=1.0, keep_v
     # bf16x3: the GEMM's 128-wide N tile wants full tiles; other channel counts stay on the native GEMM (GIF_WINO_X3=0: A/B)
     x3 = WINOGRAD_X3 and split_mode() and cout_act % 128 == 0
 
+    h2 = x3 and H2_WINO and get_fp32_mfma_mode() == "f16x2"
+
     def build():
         RP, CP = ctypes.c_int(), ctypes.c_int()
         dims = lib.gif_winograd_pack_dims_x3 if x3 else lib.gif_winograd_pack_dims
         _lib.check(dims(cout_act, C, ctypes.byref(RP), ctypes.byref(CP)), "winograd_pack_dims")
+        if h2:  # the f16x2 transform and the bf16x3 transform (the guarded fallback's operand) in one launch
+            U2 = torch.empty((lib.gif_winograd_weight_f32h2_bytes(RP.value, CP.value),), device=x.device, dtype=torch.uint8)
+            U3 = torch.empty((16, 3, RP.value, CP.value), device=x.device, dtype=torch.bfloat16)
+            _lib.check(lib.gif_winograd_weight_f32h2(w.data_ptr(), U2.data_ptr(), U3.data_ptr(), R, Cc, RP.value, CP.value, sr, sc, sky, skx,
+                                                     0 if rows_are_out else 1, float(wscale), _stream()), "winograd_weight_f32h2")
+            return U2, U3
         if x3:
             U = torch.empty((16, 3, RP.value, CP.value), device=x.device, dtype=torch.bfloat16)
             fn = lib.gif_winograd_weight_f32x3
@@ -336,22 +364,13 @@ def conv3x3_winograd(x, w, rows_are_out: bool, cout_act: int, wscale=1.0, keep_v
                       _stream()), "winograd_weight")
         return U
 
-    U = _cached_weight_op(w, ("wino", rows_are_out, cout_act, C, float(wscale), x3), build)
+    U = _cached_weight_op(w, ("wino", rows_are_out, cout_act, C, float(wscale), x3, h2), build)
     V = torch.empty((lib.gif_winograd_workspace_floats(B, H, W, C),), device=x.device, dtype=torch.float32)
     out = empty_nhwc(B, cout_act, H, W, x.device)
     e = _epilogue(out_bchw=(B, cout_act, H, W), **epi)
-    if x3 and H2_WINO and get_fp32_mfma_mode() == "f16x2":  # f16x2 GEMM + its guarded bf16x3 twin on U
-
-        def build2():
-            RP, CP = ctypes.c_int(), ctypes.c_int()
-            _lib.check(lib.gif_winograd_pack_dims_x3(cout_act, C, ctypes.byref(RP), ctypes.byref(CP)), "winograd_pack_dims")
-            U2 = torch.empty((lib.gif_winograd_weight_f32h2_bytes(RP.value, CP.value),), device=x.device, dtype=torch.uint8)
-            _lib.check(lib.gif_winograd_weight_f32h2(w.data_ptr(), U2.data_ptr(), R, Cc, RP.value, CP.value, sr, sc, sky, skx,
-                                                     0 if rows_are_out else 1, float(wscale), _stream()), "winograd_weight_f32h2")
-            return U2
-
-        U2 = _cached_weight_op(w, ("wino_h2", rows_are_out, cout_act, C, float(wscale)), build2)
-        _lib.check(lib.gif_conv3x3_winograd_f32h2(x.data_ptr(), U2.data_ptr(), U.data_ptr() if H2_GUARD else None, out.data_ptr(),
+    if h2:  # f16x2 GEMM + its guarded bf16x3 twin
+        U2, U3 = U
+        _lib.check(lib.gif_conv3x3_winograd_f32h2(x.data_ptr(), U2.data_ptr(), U3.data_ptr() if H2_GUARD else None, out.data_ptr(),
                                                   V.data_ptr(), B, H, W, C, cout_act, ctypes.byref(e), _stream()), "conv3x3_winograd_f32h2")
         return (out, V) if keep_v else out
     fn = lib.gif_conv3x3_winograd_f32x3 if x3 else lib.gif_conv3x3_winograd_f32
@@ -386,13 +405,14 @@ def conv_fwd(big, w, spec: ConvSpec, wscale=1.0, keep_v=False, **epi):
         return conv_fwd(big, w, spec, wscale, **epi), None
     x3 = x3_conv(dt, Cb, big, spec)
     dense = x3_tapdense(dt, Cb, spec, False, epi, Cs) and big.numel() * 4 <= X3_MAX_INPUT_BYTES
-    wp = pack_weight(w, True, Cs, Cb, wscale, dt, x3=x3, tapdense=dense)
+    h2 = h2_conv(x3, dense)
+    wp = None if h2 else pack_weight(w, True, Cs, Cb, wscale, dt, x3=x3, tapdense=dense)
     # out_f32 (f16 activations only): fp32 result, e.g. the RGB image of ToRGB
     out = empty_nhwc(B, Cs, Hs, Ws, big.device, torch.float32 if epi.get("out_f32") else dt)
     g = _geom(B, Hb, Wb, Cb, Hs, Ws, Cs, spec)
     e = _epilogue(out_bchw=(B, Cs, Hs, Ws), dtype=dt, **epi)
-    if h2_conv(x3, dense):  # f16x2 kernels + the bf16x3 packing for their guarded fallback
-        wp2 = pack_weight(w, True, Cs, Cb, wscale, dt, h2=True)
+    if h2:  # f16x2 kernels + the bf16x3 packing for their guarded fallback
+        wp2, wp = pack_weight_h2x3(w, True, Cs, Cb, wscale)
         _lib.check(_lib.load().gif_conv2d_fwd_f32h2(big.data_ptr(), wp2.data_ptr(), wp.data_ptr() if H2_GUARD else None, out.data_ptr(), ctypes.byref(g),
                                                     ctypes.byref(e), _stream()), "conv2d_fwd_f32h2")
         return out
@@ -414,12 +434,13 @@ def conv_bwd_data(small, w, spec: ConvSpec, big_hw, wscale=1.0, **epi):
         return conv3x3_winograd(small, w, False, Cb, wscale, **epi)
     x3 = x3_conv(dt, Cs, small, spec)
     dense = x3_tapdense(dt, Cs, spec, True, epi, Cb) and small.numel() * 4 <= X3_MAX_INPUT_BYTES
-    wp = pack_weight(w, False, Cb, Cs, wscale, dt, x3=x3, tapdense=dense)
+    h2 = h2_conv(x3, dense)
+    wp = None if h2 else pack_weight(w, False, Cb, Cs, wscale, dt, x3=x3, tapdense=dense)
     out = empty_nhwc(B, Cb, Hb, Wb, small.device, dt)
     g = _geom(B, Hb, Wb, Cb, Hs, Ws, Cs, spec)
     e = _epilogue(out_bchw=(B, Cb, Hb, Wb), dtype=dt, **epi)
-    if h2_conv(x3, dense):
-        wp2 = pack_weight(w, False, Cb, Cs, wscale, dt, h2=True)
+    if h2:
+        wp2, wp = pack_weight_h2x3(w, False, Cb, Cs, wscale)
         _lib.check(_lib.load().gif_conv2d_bwd_data_f32h2(small.data_ptr(), wp2.data_ptr(), wp.data_ptr() if H2_GUARD else None, out.data_ptr(), ctypes.byref(g),
                                                          ctypes.byref(e), _stream()), "conv2d_bwd_data_f32h2")
         return out

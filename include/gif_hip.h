@@ -90,6 +90,9 @@ int gif_pack_weight_f32x3(const float* w, void* wp3, int R, int C, int KH, int K
 int64_t gif_pack_weight_f32h2_bytes(int KH, int KW, int RP, int CP);
 int gif_pack_weight_f32h2(const float* w, void* wp2, int R, int C, int KH, int KW, int RP, int CP, int64_t sr, int64_t sc,
                           int64_t sky, int64_t skx, float scale, gif_stream_t stream);
+/* wp2 and wp3 (= gif_pack_weight_f32x3's output) of the same weights in one launch */
+int gif_pack_weight_f32h2x3(const float* w, void* wp2, void* wp3, int R, int C, int KH, int KW, int RP, int CP, int64_t sr, int64_t sc,
+                            int64_t sky, int64_t skx, float scale, gif_stream_t stream);
 /* out2[0] = guarded launches that took the bf16x3 fallback on the current device since the last reset (synchronises the device) */
 int gif_h2_fallback_stats(uint64_t* out2, int reset);
 /* Tap-dense K order for 3x3 layers with 8 <= cin_act < 32 contraction channels (the condition-noise convs 6->12->24 and the 24->C
@@ -284,8 +287,8 @@ int gif_winograd_weight_f32x3(const float* w, void* U3, int R, int C, int RP, in
 /* f16x2 (ABI 4): U2 = [RP exponents][RP flags][16][2][RP][CP] f16 (gif_winograd_weight_f32h2_bytes), pack dims as for the bf16x3
  * GEMM; gif_conv3x3_winograd_f32h2 runs the f16x2 GEMM and then its guarded bf16x3 twin on U3 (NULL: unguarded). */
 int64_t gif_winograd_weight_f32h2_bytes(int RP, int CP);
-int gif_winograd_weight_f32h2(const float* w, void* U2, int R, int C, int RP, int CP, int64_t sr, int64_t sc, int64_t sky,
-                              int64_t skx, int flip, float scale, gif_stream_t stream);
+int gif_winograd_weight_f32h2(const float* w, void* U2, void* U3 /* optional: the bf16x3 transform too */, int R, int C, int RP, int CP,
+                              int64_t sr, int64_t sc, int64_t sky, int64_t skx, int flip, float scale, gif_stream_t stream);
 int gif_conv3x3_winograd_f32h2(const float* x, const void* U2, const void* U3, float* y, float* V, int B, int H, int W, int C, int Co,
                                const gif_conv_epilogue* e, gif_stream_t stream);
 int gif_conv3x3_winograd_f32x3(const float* x, const void* U3, float* y, float* V, int B, int H, int W, int C, int Co,
