@@ -165,9 +165,16 @@ __device__ __forceinline__ void split_pair_scalar(const float a0, const float a1
 //   weights: one exponent per packed row, chosen by the packing kernel (row maximum -> [2^14, 2^15));
 //   activations: a RUNNING exponent per row inside the kernel: a new row maximum is scaled into [2^13, 2^14) and the row's
 //   accumulators are multiplied by the (exact) power of two; later elements may grow 4x before the next rescale.
-// Guard ("window"): every 16-element K group of every operand row must lie within 2^-kH2Window of the row maximum (all-zero groups
-// excepted) — then the group's largest element carries >= 22 bits.  A launch that sees a narrower group raises its gate word and
-// is recomputed by the bf16x3 kernel (gated relaunch: the bf16x3 launch that follows returns at once unless the gate is raised).
+// Guard ("window").  An element is represented to max(2^-22 |x|, 2^-25 * 2^-e): 22 bits relative, or an absolute floor of 2^-38 of
+// its row maximum (the maximum is scaled to >= 2^13).  For a dot product over K groups of 16 elements let w_a(g) / w_b(g) be the
+// "spread" of group g in its row (log2 of row maximum / group maximum).  The floors contribute at most 2^-38 A B 2^-w_b(g) and
+// 2^-38 A B 2^-w_a(g) per group; the dot product's largest group product is A B 2^-m with m = min_g (w_a(g) + w_b(g)) — the error
+// floor is 2^(m - 38) of it, next to the native fp32 kernel's 2^-24 of the same quantity.  m <= the window of whichever operand
+// has ALL its (non-zero) groups inside it, so ONE in-window operand is enough: weights whose rows the packing did not flag (all
+// groups within 2^kH2WindowW: m <= 16, floor 2^-22) make every activation harmless — smooth activations, ReLU-sparse gradients
+// and the differencing positions of a Winograd transform produce near-zero groups all the time.  Only a launch in which a row
+// with a group beyond 2^kH2Window meets a FLAGGED weight row (weight gradient: narrow groups on both sides) raises its gate word
+// and is recomputed by the bf16x3 kernel (gated relaunch: the bf16x3 launch that follows returns at once unless the gate is raised).
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 constexpr int kH2Target = 13;        // activations: a new row maximum lands in [2^13, 2^14)
 constexpr int kH2TargetW = 14;       // weights (static): the row maximum lands in [2^14, 2^15)

@@ -973,15 +973,19 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
 #endif
         if constexpr (H2) {
             // guard: a row one of whose 16-element K groups lies more than 2^kH2Window below the row maximum (the group's values no
-            // longer carry 22 bits) raises the launch's gate: the bf16x3 launch that follows recomputes the op (common.h)
+            // longer carry 22 bits) ...
             bool wide = false;
 #pragma unroll
             for (int i = 0; i < MT; ++i)
                 wide |= (int)(__float_as_uint(h_max[i]) >> 23) - (int)((h_gmin[i] + 1u) >> 23) > gif::kH2Window;
             if (p.gate) {
+                // ... AND one of the weight rows it meets was flagged by the packing: a narrow group only costs accuracy where the OTHER
+                // operand is narrow too (common.h: the error floor is 2^(m - 38) of the dot product's largest group product, m = the
+                // smallest sum of the two operands' group spreads; one in-window operand bounds m by its window)
+                bool wflag = false;
 #pragma unroll
-                for (int j = 0; j < NT; ++j) wide |= p.wexp[p.RP + n0 + wn0 + j * 32 + li] != 0;  // rows flagged by the weight packing
-                if (__builtin_amdgcn_ballot_w64(wide) != 0 && lane == 0) atomicMax(p.gate, p.gate_gen);
+                for (int j = 0; j < NT; ++j) wflag |= p.wexp[p.RP + n0 + wn0 + j * 32 + li] != 0;
+                if (__builtin_amdgcn_ballot_w64(wide) != 0 && __builtin_amdgcn_ballot_w64(wflag) != 0 && lane == 0) atomicMax(p.gate, p.gate_gen);
             }
             // back to the operands' own scale: acc[row][col] *= 2^-(e_row + e_col)
             int wex[NT];

@@ -588,11 +588,15 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q, ((X3 == 2 && WAVES_P *
             group(1, -1);
         }
         if constexpr (H2) {
-            bool wide = false;
+            bool wide_p = false, wide_q = false;  // (a narrow group only costs accuracy where the other operand is narrow too: common.h)
 #pragma unroll
-            for (int f = 0; f < NF; ++f)
-                wide |= (int)(__float_as_uint(h_max[f]) >> 23) - (int)((h_gmin[f] + 1u) >> 23) > gif::kH2Window;
-            if (p.gate && __builtin_amdgcn_ballot_w64(wide) != 0 && lane == 0) atomicMax(p.gate, p.gate_gen);
+            for (int f = 0; f < NF; ++f) {
+                const bool wd = (int)(__float_as_uint(h_max[f]) >> 23) - (int)((h_gmin[f] + 1u) >> 23) > gif::kH2Window;
+                if (f < MT) wide_p |= wd;
+                else wide_q |= wd;
+            }
+            if (p.gate && __builtin_amdgcn_ballot_w64(wide_p) != 0 && __builtin_amdgcn_ballot_w64(wide_q) != 0 && lane == 0)
+                atomicMax(p.gate, p.gate_gen);
 #if GIF_H2_WG_DBG & 8
 #pragma unroll
             for (int z = 0; z < 16; ++z) asm volatile("s_nop 15");

@@ -972,15 +972,18 @@ __global__ void __launch_bounds__(512, 1) wino_gemm_h2(const WinoParams p) {
         }
     }
 
-    // guard (common.h): a 16-element K group more than 2^kH2Window below its row's maximum raises the launch's gate; so does a
-    // weight row the packing flagged
+    // guard (common.h): a 16-element K group more than 2^kH2Window below its row's maximum meeting a weight row the packing flagged
+    // raises the launch's gate
     {
         // (the tracking step after the last stage looked at ring data nobody uses: its statistics may only widen the window check,
         // never narrow it — a spurious fallback at worst; rows >= ntiles are padding and may hold anything: same remark)
-        bool wide = m0 + wm0 + li < p.ntiles && (int)(__float_as_uint(h_max) >> 23) - (int)((h_gmin + 1u) >> 23) > gif::kH2Window;
+        const bool wide = m0 + wm0 + li < p.ntiles && (int)(__float_as_uint(h_max) >> 23) - (int)((h_gmin + 1u) >> 23) > gif::kH2Window;
+        bool wflag = false;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) wide |= p.uexp[p.RP + n0 + wn0 + j * 32 + li] != 0;
-        if (p.gate && __builtin_amdgcn_ballot_w64(wide) != 0 && lane == 0) atomicMax(p.gate, p.gate_gen);
+        for (int j = 0; j < NT; ++j) wflag |= p.uexp[p.RP + n0 + wn0 + j * 32 + li] != 0;
+        // (both operands narrow somewhere: common.h — smooth activations give near-zero groups at the differencing positions of B^T d B
+        // all the time, which costs nothing against in-window weights)
+        if (p.gate && __builtin_amdgcn_ballot_w64(wide) != 0 && __builtin_amdgcn_ballot_w64(wflag) != 0 && lane == 0) atomicMax(p.gate, p.gate_gen);
     }
     // back to fp32's own scale: yo[o][row][col] *= 2^-(e_row + e_col)
     {

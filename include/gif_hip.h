@@ -58,12 +58,15 @@ int gif_f16_overflow_watch(int on);
  *            peak => 833 TFLOP/s of fp32-equivalent work) and the result is multiplied by 2^-(e_a + e_b).  The dropped lo*lo is
  *            <= 2^-22 |a*b|.  Weight rows get their exponent from the packing kernel; activation rows carry a RUNNING exponent
  *            inside the kernel (a new row maximum is scaled into [2^13, 2^14); when a row outgrows its exponent its fp32
- *            accumulators are multiplied by the exact power of two).  Precision contract: every 16-element K group of every
- *            operand row is represented to >= 22 bits relative to the group's own maximum, provided the group's maximum lies
- *            within 2^14 (activations) / 2^16 (weights) of the row maximum; a launch that meets a narrower (non-zero) group
- *            raises a device-side gate and the op is recomputed by the BF16X3 kernels in the same stream ("guarded fallback":
- *            the bf16x3 launch that follows every f16x2 launch returns at once unless the gate is raised; no host
- *            synchronisation; gif_h2_fallback_stats counts the fallbacks taken; GIF_H2_GUARD=0 removes the guard).
+ *            accumulators are multiplied by the exact power of two).  Precision contract: elements carry 22 bits, or an
+ *            absolute floor of 2^-38 of their row maximum; the floors cost at most 2^(m - 38) of a dot product's largest
+ *            16-element group product, m = min over the K groups of the two operands' summed spreads (log2 row maximum / group
+ *            maximum).  One operand with every non-zero group inside its window (2^14 activations / 2^16 weights) bounds m
+ *            by that window (floor <= 2^-22; native fp32 MFMA: 2^-24 of the same quantity).  A launch in which BOTH operands
+ *            have a group outside their windows raises a device-side gate and the op is recomputed by the BF16X3 kernels in
+ *            the same stream ("guarded fallback": the bf16x3 launch that follows every f16x2 launch returns at once unless the
+ *            gate is raised; no host synchronisation; gif_h2_fallback_stats counts the fallbacks taken; GIF_H2_GUARD=0 removes
+ *            the guard).  Operands are 22-bit: results that cancel to < 2^-20 of their terms show it (tests/test_gpu_f16x2.py).
  *            Measured error against an fp64 convolution: 1.0-1.3 x the native fp32 MFMA path (tests/test_gpu_f16x2.py).
  *            Layers the f16x2 kernels do not take (tap-dense thin layers, Winograd GEMMs not built for it) run BF16X3.
  *            Default: the GIF_FP32_MFMA environment variable ("native" / "bf16x3" / "f16x2"), else F16X2. */
