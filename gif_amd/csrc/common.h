@@ -195,6 +195,18 @@ __device__ __forceinline__ void split_pair_h2(const float a0, const float a1, co
     hi = __builtin_bit_cast(unsigned, h);
     lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{r0, r1}, f16x2_t));
 }
+// the same with two scalar multiplies / subtracts (no v_pk_*_f32 with a register-pair element select)
+__device__ __forceinline__ void split_pair_h2_scalar(const float a0, const float a1, const float sc, unsigned& hi, unsigned& lo) {
+    float x0 = a0 * sc;
+    asm volatile("" : "+v"(x0));
+    const float x1 = a1 * sc;
+    const f16x2_t h = __builtin_convertvector(f32x2_t{x0, x1}, f16x2_t);
+    float r0 = x0 - (float)h[0];
+    asm volatile("" : "+v"(r0));
+    const float r1 = x1 - (float)h[1];
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{r0, r1}, f16x2_t));
+}
 // header of an f16x2 weight packing: int32 exponents of the RP rows, then RP int32 row flags ("a 16-element K group of this row
 // lies outside the window": launches that use the row take the bf16x3 fallback); the f16 planes follow.
 inline size_t h2_header_bytes(int RP) { return (size_t)2 * RP * sizeof(int); }

@@ -863,7 +863,11 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
             float a0 = ra[f][e / 2][(e % 2) * 2], a1 = ra[f][e / 2][(e % 2) * 2 + 1];
             if constexpr (H2) {
                 unsigned h, l;
-                gif::split_pair_h2(a0, a1, h_sc[f], h, l);
+                // (two row tiles per lane: hipcc keeps the two scales in one register pair and selects the odd one with op_sel:[0,1] on
+                // v_pk_mul_f32 / v_pk_fma_f32 — that form returned wrong products in the weight-gradient kernel whenever two waves
+                // shared a SIMD, conv_wgrad.hip; the scalar form is two instructions longer)
+                if constexpr (MT > 1) gif::split_pair_h2_scalar(a0, a1, h_sc[f], h, l);
+                else gif::split_pair_h2(a0, a1, h_sc[f], h, l);
                 sa[slot][0][f][e] = h; sa[slot][1][f][e] = l;
             } else {
                 if (SCALE) { a0 *= rs[f][e / 2][(e % 2) * 2]; a1 *= rs[f][e / 2][(e % 2) * 2 + 1]; }

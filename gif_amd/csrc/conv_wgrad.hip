@@ -70,10 +70,7 @@ template <typename T, int BP, int BQ, int WAVES_P, int WAVES_Q, bool GLDS, int B
 // (f16x2, 4 waves: "at least 2 workgroups per CU" caps the budget at 256 registers, which makes hipcc keep the accumulators in
 // architectural VGPRs — the rare rescale path multiplies them with VALU instructions; from AGPRs that costs 64 temporaries and the
 // kernel would no longer fit two waves per SIMD)
-#ifndef GIF_H2_WG_DBG
-#define GIF_H2_WG_DBG 0
-#endif
-__global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q, ((X3 == 2 && WAVES_P * WAVES_Q == 4 && !(GIF_H2_WG_DBG & 2)) || (X3 == 1 && (GIF_H2_WG_DBG & 16) && WAVES_P * WAVES_Q == 4)) ? 2 : 1) conv_wgrad_mfma(const WgradParams p) {
+__global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q, (X3 == 2 && WAVES_P * WAVES_Q == 4) ? 2 : 1) conv_wgrad_mfma(const WgradParams p) {
     constexpr bool F16 = sizeof(T) == 2;
     if constexpr (X3 == 1) {
         if (p.gate) {  // guarded fallback of an f16x2 launch: nothing to do unless that launch raised the gate
@@ -436,9 +433,6 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q, ((X3 == 2 && WAVES_P *
         };
         // f16x2: per-sample scale, group maximum and exponent decision of fragment f of the raw group just read
         auto track = [&](int f) __attribute__((always_inline)) {
-#if GIF_H2_WG_DBG & 32
-            if (f >= 0) { h_sc[f] = 1024.f; h_ex[f] = 10; return; }  // debug: fixed scale, no tracking instructions at all
-#endif
             if constexpr (H2) {
                 float* v = f < MT ? ra[f] : rb[f - MT];
                 if (TAB) {
@@ -450,13 +444,8 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q, ((X3 == 2 && WAVES_P *
                 m = fmaxf(fmaxf(m, fabsf(v[3])), fabsf(v[4]));
                 m = fmaxf(fmaxf(m, fabsf(v[5])), fabsf(v[6]));
                 m = fmaxf(m, fabsf(v[7]));
-#if !(GIF_H2_WG_DBG & 64)
                 const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
                 m = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));  // the channel's 16 pixels of this group
-#endif
-#if GIF_H2_WG_DBG & 128
-                m = fmaxf(m, __shfl_xor(m, 32));
-#endif
                 h_max[f] = fmaxf(h_max[f], m);
                 h_gmin[f] = min(h_gmin[f], __float_as_uint(m) - 1u);
                 h_dl[f] = 0;
@@ -490,11 +479,16 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q, ((X3 == 2 && WAVES_P *
             const int f = k / 4, e = k % 4;
             if constexpr (H2) {
                 unsigned h, l;
+                // scalar multiplies / subtracts: with several scales per lane hipcc keeps them in register pairs and picks the odd element
+                // with `op_sel:[0,1]` on v_pk_mul_f32 / v_pk_fma_f32 — the kernel then dropped products in lanes 16-31 / 48-63 of the
+                // second tile of each operand whenever two of its waves shared a SIMD (correct with one workgroup per CU, and with the
+                // scale as a constant: tools/probes/h2_wgrad_debug.py); cause on the hardware side not established
+                const float scv = h_sc[f];
                 if (f < MT) {
-                    gif::split_pair_h2(ra[f][2 * e], ra[f][2 * e + 1], h_sc[f], h, l);
+                    gif::split_pair_h2_scalar(ra[f][2 * e], ra[f][2 * e + 1], scv, h, l);
                     sa[slot][0][f][e] = h; sa[slot][1][f][e] = l;
                 } else {
-                    gif::split_pair_h2(rb[f - MT][2 * e], rb[f - MT][2 * e + 1], h_sc[f], h, l);
+                    gif::split_pair_h2_scalar(rb[f - MT][2 * e], rb[f - MT][2 * e + 1], scv, h, l);
                     sb[slot][0][f - MT][e] = h; sb[slot][1][f - MT][e] = l;
                 }
             } else {
@@ -523,7 +517,7 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q, ((X3 == 2 && WAVES_P *
             }
         };
         constexpr int NPROD = H2 ? 3 : 6;
-        constexpr int LEAD = (H2 && !(GIF_H2_WG_DBG & 1)) ? 3 : 6;  // MFMAs ahead of the first piece: they cover the latency of the 32 ds_read_b32 (issued as 20 ds_read2)
+        constexpr int LEAD = H2 ? 3 : 6;  // MFMAs ahead of the first piece: they cover the latency of the 32 ds_read_b32 (issued as 20 ds_read2)
         auto group = [&](int slot, int nslot) __attribute__((always_inline)) {
             constexpr int TA6[6] = {2, 0, 1, 1, 0, 0}, TB6[6] = {0, 2, 1, 0, 1, 0};
             constexpr int TA3[3] = {1, 0, 0}, TB3[3] = {0, 1, 0};
@@ -548,7 +542,7 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q, ((X3 == 2 && WAVES_P *
                         // f16x2 has half the MFMAs to hide twice the steps under: two steps per MFMA slot
                         if (nslot >= 0 && n >= LEAD) {
 #pragma unroll
-                            for (int rep2 = 0; rep2 < ((H2 && !(GIF_H2_WG_DBG & 1)) ? 2 : 1); ++rep2)
+                            for (int rep2 = 0; rep2 < (H2 ? 2 : 1); ++rep2)
                                 if (q < NSTEP) prep(nslot, q++);
                             __builtin_amdgcn_sched_barrier(0);
                         }
@@ -557,7 +551,7 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q, ((X3 == 2 && WAVES_P *
 #pragma unroll
                 for (; q < NSTEP; ++q) prep(nslot, q);
                 if constexpr (H2) {
-                    if (h_need && !(GIF_H2_WG_DBG & 4)) rescale();
+                    if (h_need) rescale();
                 }
             }
         };
@@ -597,10 +591,6 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q, ((X3 == 2 && WAVES_P *
             }
             if (p.gate && __builtin_amdgcn_ballot_w64(wide_p) != 0 && __builtin_amdgcn_ballot_w64(wide_q) != 0 && lane == 0)
                 atomicMax(p.gate, p.gate_gen);
-#if GIF_H2_WG_DBG & 8
-#pragma unroll
-            for (int z = 0; z < 16; ++z) asm volatile("s_nop 15");
-#endif
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll

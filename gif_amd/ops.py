@@ -213,9 +213,7 @@ def split_mode() -> bool:
 
 
 H2_CONV = os.environ.get("GIF_H2_CONV", "1") != "0"    # f16x2 mode: direct fwd / dgrad kernels (A/B knobs per kernel family)
-# f16x2 weight-gradient kernels (direct and Winograd plane GEMMs): OFF — the 128 x 128 instantiation returns wrong sums when two of its
-# workgroups share a CU (correct with one; tools/probes/h2_wgrad_debug.py), cause not found yet; weight gradients stay on bf16x3
-H2_WGRAD = os.environ.get("GIF_H2_WGRAD", "0") != "0"
+H2_WGRAD = os.environ.get("GIF_H2_WGRAD", "1") != "0"  # f16x2 mode: weight-gradient kernels (direct and Winograd plane GEMMs)
 
 
 H2_WINO = os.environ.get("GIF_H2_WINO", "1") != "0"    # f16x2 mode: Winograd fwd / dgrad GEMM

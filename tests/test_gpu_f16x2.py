@@ -352,3 +352,69 @@ def test_f16x2_winograd_adversarial(kind, monkeypatch):
     print(f"\n[f16x2 winograd adversarial] {kind}: {out} fallbacks {fb}")
     assert fb == (1 if kind == "window" else 0), (kind, fb)
     assert out["f16x2"] <= 1.5 * out["native"] + 2e-7, (kind, out)
+
+
+# ------------------------------------------------------------------------------------------------ weight gradients (conv_wgrad_mfma<..., 2>)
+WGRAD_CASES = [
+    (4, 128, 128, 3, 1, 1, 64, False),    # 128x128 tiles, 9 taps, 113 splits: two workgroups per CU (the configuration that exposed the
+                                          # packed-fp32 operand-select problem, conv_wgrad.hip)
+    (4, 128, 256, 3, 2, 0, 65, False),    # stride 2
+    (4, 24, 128, 3, 1, 1, 64, False),     # thin big side: 128x32 tiles on two waves
+    (2, 256, 256, 1, 1, 0, 32, False),    # 1x1
+    (3, 160, 96, 3, 1, 1, 20, False),     # ragged channel counts, pixel count not a multiple of the stage
+    (32, 128, 128, 3, 1, 1, 32, False),   # batch 32
+    (4, 128, 128, 3, 1, 1, 64, True),     # Winograd F(3x3,2x2): the 16 plane GEMMs on the same kernel
+    (2, 256, 512, 3, 1, 1, 32, True),
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_f16x2_weight_gradient_vs_fp64(case, monkeypatch):
+    """Both operands are activations: each carries a running per-channel exponent (rows = channels, K = pixels); plain and with
+    per-sample scales on both sides (the modulated convolution's weight gradient)."""
+    from gif_amd import ops
+    B, ci, co, k, s, p, h, wino = case
+    monkeypatch.setattr(ops, "WINOGRAD", wino)
+    monkeypatch.setattr(ops, "WINOGRAD_MIN_TILES", 1)
+    monkeypatch.setattr(ops, "WINOGRAD_WGRAD_MIN_TILES", 1)
+    torch.manual_seed(sum(case[:7]))
+    spec = ops.ConvSpec(k, k, s, p)
+    x = _cl(torch.randn(B, ci, h, h, device="cuda"))
+    hs, ws_ = spec.small_hw(h, h)
+    gy = _cl(torch.randn(B, co, hs, ws_, device="cuda"))
+    sc, sd = torch.rand(B, ci, device="cuda") + 0.5, torch.rand(B, co, device="cuda") + 0.5
+    wd = torch.zeros(co, ci, k, k, device="cuda", dtype=torch.float64, requires_grad=True)
+    (ref,) = torch.autograd.grad(F.conv2d(x.double(), wd, stride=s, padding=p), wd, gy.double())
+    wd2 = torch.zeros(co, ci, k, k, device="cuda", dtype=torch.float64, requires_grad=True)
+    (ref_s,) = torch.autograd.grad(F.conv2d(x.double() * sc.double()[:, :, None, None], wd2, stride=s, padding=p), wd2,
+                                   gy.double() * sd.double()[:, :, None, None])
+    out = {}
+    for mode in ("native", "f16x2"):
+        ops.set_fp32_mfma_mode(mode)
+        n0 = ops.prof_winograd_calls()
+        out[mode] = (_err(ops.conv_wgrad(gy, x, spec, co, ci), ref), _err(ops.conv_wgrad(gy, x, spec, co, ci, small_scale=sd, big_scale=sc), ref_s))
+        assert (ops.prof_winograd_calls() > n0) == wino
+    assert ops.h2_fallback_stats() == 0
+    for en, ex in zip(out["native"], out["f16x2"]):
+        assert en < 1e-5 and ex <= 1.5 * en + 2e-7, (case, out)
+
+
+def test_f16x2_weight_gradient_growing_and_sparse_channels():
+    """Channels whose magnitude grows 2^12 over the pixel axis (rescales of rows AND columns of the accumulators), half of the pixels
+    exactly zero (ReLU-style): no fallback, fp32-grade."""
+    from gif_amd import ops
+    g = torch.Generator().manual_seed(9)
+    B, C, H = 4, 128, 64
+    ramp = torch.pow(2.0, torch.arange(H) * (12.0 / H))[None, None, :, None]
+    x = torch.randn(B, C, H, H, generator=g) * ramp
+    gy = torch.relu(torch.randn(B, C, H, H, generator=g)) * ramp.flip(2)
+    x, gy = _cl(x.cuda()), _cl(gy.cuda())
+    spec = ops.ConvSpec(3, 3, 1, 1)
+    wd = torch.zeros(C, C, 3, 3, device="cuda", dtype=torch.float64, requires_grad=True)
+    (ref,) = torch.autograd.grad(F.conv2d(x.double(), wd, padding=1), wd, gy.double())
+    out = {}
+    for mode in ("native", "f16x2"):
+        ops.set_fp32_mfma_mode(mode)
+        out[mode] = _err(ops.conv_wgrad(gy, x, spec, C, C), ref)
+    assert ops.h2_fallback_stats() == 0
+    assert out["f16x2"] <= 1.5 * out["native"] + 2e-7, out
