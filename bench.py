@@ -210,6 +210,10 @@ FAMILIES = {
          "unless an operand left the precision window)", F16X2_EXECUTED, "conv_gather_mfma_glds_h2"),
     14: ("wino_gemm_h2 (Winograd F(2x2,3x3) fwd / dgrad GEMM on the f16 matrix cores: f16x2 split of V in the kernel under one running "
          "exponent per tile row, pre-split U, fused output transform and epilogue)", F16X2_EXECUTED * WINOGRAD_EXECUTED, "wino_gemm_h2"),
+    15: ("conv_wgrad_mfma<float, f16x2> (fp32 weight gradient on the f16 matrix cores: both operands split in the kernel under running "
+         "per-channel exponents, 3 products)", F16X2_EXECUTED, "conv_wgrad_mfma_h2"),
+    16: ("conv_wgrad_mfma<float, f16x2> in planes mode (Winograd F(3x3,2x2) weight-gradient GEMMs on the f16 matrix cores)",
+         F16X2_EXECUTED * WINOGRAD_EXECUTED, "conv_wgrad_mfma_h2"),
     12: ("conv_gather_mfma_glds<float, bf16x3> in the tap-dense K order (3x3 layers with 8..28 contraction channels: the 6->12->24 "
          "condition-noise convs and the 24->C layers that inject their result; same kernels as the bf16x3 direct family, so no separate "
          "PMC traffic)", BF16X3_EXECUTED, None),
@@ -218,10 +222,10 @@ FAMILY_KEYS = {0: "roofline_conv_direct", 1: "roofline_wgrad_direct", 2: "roofli
                5: "roofline_conv_direct_small_cin", 6: "roofline_conv_f16", 7: "roofline_wgrad_f16",
                8: "roofline_conv_direct_bf16x3", 9: "roofline_wgrad_direct_bf16x3", 10: "roofline_conv_winograd_bf16x3",
                11: "roofline_wgrad_winograd_bf16x3", 12: "roofline_conv_direct_bf16x3_tapdense", 13: "roofline_conv_direct_f16x2",
-               14: "roofline_conv_winograd_f16x2"}
+               14: "roofline_conv_winograd_f16x2", 15: "roofline_wgrad_direct_f16x2", 16: "roofline_wgrad_winograd_f16x2"}
 FAMILY_PEAK = {6: PEAK_F16_MFMA_TFLOPS, 7: PEAK_F16_MFMA_TFLOPS, 8: PEAK_F16_MFMA_TFLOPS, 9: PEAK_F16_MFMA_TFLOPS,
                10: PEAK_F16_MFMA_TFLOPS, 11: PEAK_F16_MFMA_TFLOPS, 12: PEAK_F16_MFMA_TFLOPS, 13: PEAK_F16_MFMA_TFLOPS,
-               14: PEAK_F16_MFMA_TFLOPS}
+               14: PEAK_F16_MFMA_TFLOPS, 15: PEAK_F16_MFMA_TFLOPS, 16: PEAK_F16_MFMA_TFLOPS}
 
 
 def load_pmc():
@@ -239,9 +243,9 @@ def family_ceiling(fam, exec_frac, mfma_peak):
     FLOPs it executes per algorithmic (direct-convolution, fp32) FLOP."""
     if fam in (8, 9, 12):
         return mfma_peak / exec_frac, "bf16x3 fp32-exact = 2500 / 6 (six bf16 MFMA products per fp32 product, bf16 dense peak 2500 TFLOP/s)"
-    if fam == 13:
+    if fam in (13, 15):
         return mfma_peak / exec_frac, "f16x2 = 2500 / 3 (three f16 MFMA products per fp32 product, f16 dense peak 2500 TFLOP/s)"
-    if fam == 14:
+    if fam in (14, 16):
         return mfma_peak / exec_frac, "Winograd on f16x2 = 2500 / (3 * 16/36) (F(2x2,3x3) executes 16/36 of the products, each as three f16 MFMA products)"
     if fam in (10, 11):
         return mfma_peak / exec_frac, "Winograd on bf16x3 = 2500 / (6 * 16/36) (F(2x2,3x3) executes 16/36 of the products, each as six bf16 MFMA products)"
@@ -496,7 +500,7 @@ def main():
     data = [batch() for _ in range(min(args.steps, 4))]  # synthetic batches resident in HBM before the timed region
     prof_steps = 0
     if not args.no_prof:
-        for fam in range(15):
+        for fam in range(17):
             ops.prof_read(fam)
     h2_mode = args.dtype != "f16" and ops.get_fp32_mfma_mode() == "f16x2"
     if h2_mode:
@@ -550,8 +554,8 @@ def main():
                        "fp32 tensors and fp32 accumulation; contractions on "
                        + ("the f16 matrix cores via a two-term f16 split under per-row power-of-two scales (f16x2: 3 products per fp32 product, "
                           "error vs fp64 <= the native fp32 MFMA path on in-window operands, guarded bf16x3 fallback otherwise) for the direct "
-                          "fwd / dgrad kernels and the Winograd GEMMs with >= 24 contraction channels; bf16x3 (6 products) for the weight "
-                          "gradients and, in a tap-dense K order, the 3x3 convs with 8..28 contraction channels; the 9-channel D input layer "
+                          "fwd / dgrad kernels, the weight gradients and the Winograd GEMMs with >= 24 contraction channels; bf16x3 (6 products) "
+                          "in a tap-dense K order for the 3x3 convs with 8..28 contraction channels; the 9-channel D input layer "
                           "(1x1), ToRGB's data gradient and the small-channel weight gradients on native fp32 MFMA"
                           if fp32_mode == "f16x2" else
                           "the bf16 matrix cores via the exact 3-way bf16 split (bf16x3: 6 products per fp32 product, error vs fp64 <= "

@@ -60,8 +60,9 @@ int fp32_mfma_mode();
 // 6 / 7 f16 conv / wgrad, 8 / 9 bf16x3 conv fwd/dgrad / wgrad (algorithmic flops; the bf16 pipe executes 6x),
 // 10 / 11 bf16x3 Winograd GEMM fwd/dgrad / Winograd wgrad plane GEMMs (algorithmic flops; execute 6 * 16/36 of them),
 // 12 bf16x3 direct conv in the tap-dense K order, 13 / 14 f16x2 direct conv fwd/dgrad / f16x2 Winograd GEMM (algorithmic flops; the
-// f16 pipe executes 3x / 3 * 16/36 of them; the op's time includes its guarded bf16x3 twin launch)
-#define GIF_PROF_FAMILIES 15
+// f16 pipe executes 3x / 3 * 16/36 of them; the op's time includes its guarded bf16x3 twin launch), 15 / 16 f16x2 weight gradient /
+// f16x2 Winograd weight-gradient plane GEMMs (same conventions)
+#define GIF_PROF_FAMILIES 17
 struct ProfScope {
     int family;
     hipStream_t stream;

@@ -1484,7 +1484,10 @@ static int conv2d_wgrad_f32_impl(const float* small, const float* big, float* ws
         return gif::check_launch("conv2d_wgrad(small)");
     }
     {
-        gif::ProfScope prof(x3 ? 9 : 1, flops, s, (int)p.Ntot, g->Cs, g->Cb, p.T * 10 + g->stride + (small_scale || big_scale ? 100 : 0));
+        static const int x3_simple_p = getenv("GIF_X3_WGRAD_SIMPLE") ? atoi(getenv("GIF_X3_WGRAD_SIMPLE")) : 0;
+        const bool tab_p = (small_scale || big_scale) && tab_fits;
+        const bool h2_p = x3 && x3_mode == 2 && !x3_simple_p && (x3_thin || !tab_p || HWs % 32 == 0);  // (the same condition as below)
+        gif::ProfScope prof(h2_p ? 15 : x3 ? 9 : 1, flops, s, (int)p.Ntot, g->Cs, g->Cb, p.T * 10 + g->stride + (small_scale || big_scale ? 100 : 0));
         const char* env = getenv("GIF_CONV_VARIANT");
         const int variant = env ? atoi(env) : 0;
         const bool glds = !small_scale && !big_scale && variant != 1;
@@ -1602,7 +1605,9 @@ static int conv3x3_winograd_wgrad_impl(const float* x, const float* gy, float* V
         if (int rc = gif::winograd_gy_transform(gy, small_scale, Mg, B, H, W, Cs, s)) return rc;
     }
     x3 = x3 && tile_of(CsP) == 128 && tile_of(CbP) == 128;
-    gif::ProfScope prof(x3 ? 11 : 3, flops, s, (int)((long)B * H * W), Cs, Cb, 1091 + (small_scale || big_scale ? 100 : 0));
+    static const int x3_simple_p = getenv("GIF_X3_WGRAD_SIMPLE") ? atoi(getenv("GIF_X3_WGRAD_SIMPLE")) : 0;
+    gif::ProfScope prof((x3 && x3_mode == 2 && !x3_simple_p) ? 16 : x3 ? 11 : 3, flops, s, (int)((long)B * H * W), Cs, Cb,
+                        1091 + (small_scale || big_scale ? 100 : 0));
     WgradParams p{};
     p.sm = Mg; p.bg = V; p.ws = ws; p.ss = nullptr; p.bs = nullptr;
     // one "image" of 1 x ntiles pixels per plane, 1x1 taps
