@@ -116,6 +116,7 @@ PROTOTYPES = {
     "gif_conv2d_pack_dims_f16": (c_int, [c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "gif_pack_weight_f16": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_float, P]),
     "gif_conv2d_f16_halo_eligible": (c_int, [c_int] * 7),
+    "gif_conv2d_f16_halo_enable": (c_int, [c_int]),
     "gif_conv2d_fwd_f16": (c_int, [P, P, P, GP, EP, P]),
     "gif_conv2d_bwd_data_f16": (c_int, [P, P, P, GP, EP, P]),
     "gif_conv2d_wgrad_dims_f16": (c_int, [c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),

@@ -26,6 +26,7 @@
 // six v_mfma_f32_32x32x16_bf16 products per fp32 product, fp32 accumulation — the default mode, see glds_body and DESIGN.md 3a).
 #include <stdlib.h>
 
+#include <atomic>
 #include <type_traits>
 
 #include "common.h"
@@ -1446,7 +1447,11 @@ int launch_halo_impl(GatherParams& p, hipStream_t s) {
     p.tiles_n = 1;
     const size_t lds = (size_t)halo_lds_floats<BN, CP>() * sizeof(float) + (size_t)p.ntaps * BN * CP * 2;
     auto kern = conv_halo_f16<BN, CP>;
+#ifdef GIF_HALO_PROBE  // ablation bits of tools/probes (results are wrong when set): never in the production library
     p.halo_dbg = getenv("GIF_HALO_DBG") ? atoi(getenv("GIF_HALO_DBG")) : 0;
+#else
+    p.halo_dbg = 0;
+#endif
     attr.ensure(reinterpret_cast<const void*>(kern), lds);
     p.zero = gif::zero_page16();
     if (!p.zero) return -101;
@@ -1455,6 +1460,12 @@ int launch_halo_impl(GatherParams& p, hipStream_t s) {
     t_last_bm = 256;
     hipLaunchKernelGGL(kern, dim3((unsigned)p.tiles_m), dim3(256), lds, s, p);
     return 0;
+}
+
+// GIF_F16_HALO=0 / gif_conv2d_f16_halo_enable(0): the gather kernel everywhere (A/B knob; read once, tests use the setter)
+inline std::atomic<int>& halo_switch() {
+    static std::atomic<int> on{getenv("GIF_F16_HALO") ? (atoi(getenv("GIF_F16_HALO")) != 0) : 1};
+    return on;
 }
 
 // bytes of the weight slices a halo launch stages in LDS: [ntaps][BN][CP] halfs
@@ -1468,8 +1479,7 @@ inline long halo_weight_bytes(const GatherParams& p) {
 // sub-grid that fills at least one patch.  The modulation-gradient dot fusion needs whole patches (one partial row per patch,
 // Hp * Wp / 256 of them per sample).  GIF_F16_HALO=0: A/B knob (the gather kernel).
 inline bool halo_eligible(const GatherParams& p) {
-    const char* env = getenv("GIF_F16_HALO");  // read per launch: tests flip it inside one process
-    if ((env && atoi(env) == 0) || p.is != 1 || p.RP > 64 || p.CP > 64 || p.m_begin != 0) return false;
+    if (!halo_switch().load(std::memory_order_relaxed) || p.is != 1 || p.RP > 64 || p.CP > 64 || p.m_begin != 0) return false;
     if (p.nky < 1 || p.nky > 3 || p.nkx < 1 || p.nkx > 3 || (p.ddy != 1 && p.ddy != -1) || (p.ddx != 1 && p.ddx != -1)) return false;
     if (p.Hp < 16 || p.Wp < 16 || (long)p.B * gif::cdiv(p.Hp, 16) * gif::cdiv(p.Wp, 16) >= (1L << 23)) return false;
     if (p.part_dot && (p.Hp % 16 || p.Wp % 16)) return false;
@@ -1933,6 +1943,11 @@ int gif_conv2d_fwd_f32x3_tapdense(const float* big, const void* wp3, float* smal
 int gif_conv2d_bwd_data_f32x3_tapdense(const float* small, const void* wp3, float* big, const gif_conv_geom* g,
                                        const gif_conv_epilogue* e, gif_stream_t stream) {
     return conv2d_bwd_data_impl<float>(small, wp3, big, g, e, stream, "conv2d_bwd_data_f32x3_tapdense", 1, true);
+}
+
+int gif_conv2d_f16_halo_enable(int on) {
+    halo_switch().store(on ? 1 : 0, std::memory_order_relaxed);
+    return 0;
 }
 
 // would a FORWARD f16 convolution of this shape (activation channel counts, output grid Hs x Ws) run the halo kernel?

@@ -807,7 +807,8 @@ struct PackSrc {
 };
 
 template <typename T>
-__global__ void __launch_bounds__(256) pack_nhwc_kernel(PackSrc s0, PackSrc s1, T* __restrict__ dst, int H, int W, int Cp, long npix) {
+__global__ void __launch_bounds__(256) pack_nhwc_kernel(PackSrc s0, PackSrc s1, T* __restrict__ dst, int H, int W, int Cp, long npix,
+                                                        unsigned* sat_flag) {
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < npix; idx += (long)gridDim.x * blockDim.x) {
         const int x = (int)(idx % W);
         const long r = idx / W;
@@ -826,7 +827,9 @@ __global__ void __launch_bounds__(256) pack_nhwc_kernel(PackSrc s0, PackSrc s1, 
                 else if (b1 && ch >= s1.c_off && ch < s1.c_off + s1.C) t = b1[(ch - s1.c_off) * s1.sc];
                 v[k] = t;
             }
-            gif::store4(out + c, make_float4(v[0], v[1], v[2], v[3]));
+            // (PackNhwcFn is also the backward of UnpackNhwcFn: in R1's double backward this store carries f16 gradients, so a clamp or a
+            // non-finite value must reach the loss scaler like every other f16 gradient store — advisor finding, round 4)
+            gif::store4_flag(out + c, make_float4(v[0], v[1], v[2], v[3]), sat_flag);
         }
     }
 }
@@ -852,7 +855,7 @@ int pack_nhwc_impl(const float* src0, int C0, int off0, const int64_t* st0, cons
     PackSrc s0{src0, C0, off0, st0[0], st0[1], st0[2], st0[3]};
     PackSrc s1{src1, src1 ? C1 : 0, off1, src1 ? st1[0] : 0, src1 ? st1[1] : 0, src1 ? st1[2] : 0, src1 ? st1[3] : 0};
     const long npix = (long)B * H * W;
-    pack_nhwc_kernel<T><<<ew_grid(npix), 256, 0, gif::as_stream(stream)>>>(s0, s1, dst, H, W, Cp, npix);
+    pack_nhwc_kernel<T><<<ew_grid(npix), 256, 0, gif::as_stream(stream)>>>(s0, s1, dst, H, W, Cp, npix, sizeof(T) == 2 ? gif::f16_sat_flag() : nullptr);
     return gif::check_launch("pack_nhwc");
 }
 

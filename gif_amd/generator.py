@@ -95,13 +95,24 @@ class Generator(nn.Module):
             inject_index = random.sample(list(range(step)), len(style) - 1)
         crossover = 0
         rgb = None
+        convs = []
         if len(style) < 2 and mixing_range == (-1, -1):
             # one w for every layer: all modulation linears of this pass in one launch (layers.modulation_bank)
-            convs = []
             for i in range(self.start_step, min(step, len(self.progression) - 1) + 1):
                 blk = self.progression[i]
                 convs += [blk.st_cv1.conv] + ([] if blk.one_conv_block else [blk.st_cv2.conv]) + [self.to_rgb[i].conv]
             modulation_bank(convs, style[0])
+        try:
+            rgb = self._synthesise(style, out, noise, step, inject_index, crossover, rgb, mixing_range)
+        finally:
+            # the banked (style, s) pairs hold autograd-graph tensors: a forward that raises or leaves early must not keep them (and the
+            # activations behind them) alive until the next forward (advisor finding, round 4)
+            for c in convs:
+                c._banked = None
+        # internal RGB carries zero padding channels in NHWC; hand back the reference's fp32 [B,3,R,R] NCHW tensor
+        return [rgb[:, :3].float().contiguous()]
+
+    def _synthesise(self, style, out, noise, step, inject_index, crossover, rgb, mixing_range):
         for i in range(self.start_step, len(self.progression)):
             if mixing_range == (-1, -1):
                 if crossover < len(inject_index) and i > inject_index[crossover]:
@@ -115,8 +126,7 @@ class Generator(nn.Module):
             rgb = self.to_rgb[i](out, style_step, rgb)
             if i == step:
                 break
-        # internal RGB carries zero padding channels in NHWC; hand back the reference's fp32 [B,3,R,R] NCHW tensor
-        return [rgb[:, :3].float().contiguous()]
+        return rgb
 
 
 class StyledGenerator(nn.Module):

@@ -280,13 +280,13 @@ class ModulatedConv2d(nn.Module):
                                       out_hw=(2 * height + self.kernel_size - 2, 2 * width + self.kernel_size - 2),
                                       wscale=self.scale)
             return GF.blur_bias_act(out, self.blur.kernel, self.blur.pad, residual, bias, slope, gain)
-        if self.downsample or d is None:
-            return GF.bias_act(self.forward(input, style), bias, residual, slope, gain)
+        if self.downsample or d is None:  # (the scales are already computed — possibly by the modulation bank: no second launch)
+            return GF.bias_act(self.forward(input, style, scales=(s, d)), bias, residual, slope, gain)
         return GF.modulated_conv2d_act(input, w, s, d, residual, bias, self.padding, self.scale, slope, gain)
 
-    def forward(self, input, style):
+    def forward(self, input, style, scales=None):
         batch, in_act, height, width = input.shape
-        s, d = self._padded_scales(style, in_act, input.dtype)
+        s, d = self._padded_scales(style, in_act, input.dtype) if scales is None else scales
         w = self.weight.squeeze(0)  # [Cout, Cin, k, k]
         if self.upsample:
             # conv_transpose2d(x, W^T, stride 2): underlying forward conv maps Cout -> Cin, so canonical = W^T view

@@ -869,12 +869,13 @@ def linear_bank_bwd(x, weights, grads, scale, want_x, want_w, want_b, x_cols=Non
     M, K = x.shape[0], weights[0].shape[1]
     segs, keep = _bank_segs(weights)
     gws = gbs = None
+    new = torch.zeros_like if M == 0 else torch.empty_like  # (an empty batch launches nothing: the gradients are zeros, not garbage)
     if want_w:
-        gws = [torch.empty_like(w, memory_format=torch.contiguous_format) for w in weights]
+        gws = [new(w, memory_format=torch.contiguous_format) for w in weights]
     if want_b:
-        gbs = [torch.empty((w.shape[0],), device=x.device, dtype=torch.float32) for w in weights]
+        gbs = [(torch.zeros if M == 0 else torch.empty)((w.shape[0],), device=x.device, dtype=torch.float32) for w in weights]
     if want_b and not want_w:  # the column sums ride on the weight-gradient launch
-        gws = [torch.empty_like(w, memory_format=torch.contiguous_format) for w in weights]
+        gws = [new(w, memory_format=torch.contiguous_format) for w in weights]
     for i, (g, w, gs) in enumerate(zip(segs, weights, grads)):
         gs = gs.contiguous()
         assert gs.shape == (M, w.shape[0]) and gs.dtype == torch.float32, (gs.shape, gs.dtype)

@@ -342,8 +342,15 @@ class GifTrainer:
         # FLOPs, half the launches of the D step, 2 x the rows for the 4x4 .. 16x16 layers that cannot fill the chip at batch 32,
         # and every D parameter receives ONE gradient instead of two that autograd has to add.  R1 iterations keep the separate
         # calls (the penalty differentiates the real half only).  GIF_FUSE_D=0 / fuse_d_passes=False: A/B.
-        self.fuse_d_passes = (os.environ.get("GIF_FUSE_D", "1") != "0") if fuse_d_passes is None else bool(fuse_d_passes)
         self.overlap_comm = _dist_on(process_group) if overlap_comm is None else overlap_comm
+        # With more than one rank and deferred exchanges the default is the TWO-call path: the fused pass needs the generated batch
+        # first, i.e. it has to complete G's exchange + Adam + EMA before any D work starts, while the two-call path hides them under
+        # D's forward on the real images.  The fused pass is worth ~1 ms on one GPU; an exposed 125 MB all-reduce costs more.  (No
+        # multi-GPU node was available to measure it: advisor finding of round 4; `comm_exposed_ms` in the bench line reports it.)
+        fuse_default = (os.environ.get("GIF_FUSE_D", "1") != "0") and not (self.overlap_comm and _dist_on(process_group))
+        if "GIF_FUSE_D" in os.environ and os.environ["GIF_FUSE_D"] != "0":
+            fuse_default = True  # an explicit GIF_FUSE_D=1 keeps the fused pass for the A/B
+        self.fuse_d_passes = fuse_default if fuse_d_passes is None else bool(fuse_d_passes)
         self._d_update_pending = False
         self._g_update_pending = False
         self.g_running_decay = 0.5 ** (32 / (10 * 1000))

@@ -467,6 +467,8 @@ int gif_pack_weight_f16(const float* w, void* wp, int R, int C, int KH, int KW, 
  * the weight fragments in registers.  Same contracts, same epilogue.  GIF_F16_HALO=0 (read per launch) keeps the gather kernel.
  * The query answers for a FORWARD convolution with these activation channel counts on an Hs x Ws output grid. */
 int gif_conv2d_f16_halo_eligible(int cin, int cout, int KH, int KW, int stride, int Hs, int Ws);
+/* A/B switch of the f16 halo kernels (default on; the environment variable GIF_F16_HALO=0 sets the initial value, read once) */
+int gif_conv2d_f16_halo_enable(int on);
 int gif_conv2d_fwd_f16(const void* big, const void* wp, void* small, const gif_conv_geom* g, const gif_conv_epilogue* e,
                        gif_stream_t stream);
 int gif_conv2d_bwd_data_f16(const void* small, const void* wp, void* big, const gif_conv_geom* g,

@@ -35,7 +35,7 @@ def assert_close(got, ref, tol, what=""):
     assert e <= tol, f"{what}: rel err {e:.3e} > {tol:.1e} (ref max {ref.abs().max().item():.3e})"
 
 
-def assert_grads_close(got, ref, names, tight, loose=5e-2, max_outlier_frac=0.10, l2_tol=None, what="grads"):
+def assert_grads_close(got, ref, names, tight, loose=5e-2, max_outlier_frac=0.10, l2_tol=None, what="grads", max_outliers=None):
     """Whole-model gradients against the oracle's autograd.
 
     fp32 rounding leaves a handful of near-zero pre-activations on the other side of a (leaky) ReLU than in the oracle's own
@@ -47,7 +47,9 @@ def assert_grads_close(got, ref, names, tight, loose=5e-2, max_outlier_frac=0.10
     3e-4 and 7e-4 — round 3 allowed 25 % and up to `loose` = 5e-2, under which a regression from a few marginal outliers to a
     fifth of the model would have passed; that test now also passes loose=2e-3, three times its observed worst tensor); and
     the relative L2 error over all parameters together within `l2_tol` (default 10 * tight).  A wrong operand,
-    scale or missing term shows up as O(1) errors in whole groups of tensors and fails all three."""
+    scale or missing term shows up as O(1) errors in whole groups of tensors and fails all three.
+    `max_outliers` (round 5, review item 7): an ABSOLUTE cap on the tensors above `tight` instead of the fraction — the 256x256
+    test passes its observed counts + 2 (5 of 38, 8 of 223)."""
     import torch
     errs, num, den = [], 0.0, 0.0
     for k, a, b in zip(names, got, ref):
@@ -63,7 +65,7 @@ def assert_grads_close(got, ref, names, tight, loose=5e-2, max_outlier_frac=0.10
     worst = ", ".join(f"{k} {e:.2e}" for e, k in errs[:3])
     assert errs[0][0] <= loose, f"{what}: worst tensors {worst}"
     n_out = sum(1 for e, _ in errs if e > tight)
-    limit = 0 if max_outlier_frac == 0 else max(2, max_outlier_frac * len(errs))
+    limit = max_outliers if max_outliers is not None else (0 if max_outlier_frac == 0 else max(2, max_outlier_frac * len(errs)))
     assert n_out <= limit, f"{what}: {n_out} of {len(errs)} tensors above {tight:.0e}: {worst}"
     l2 = (num / max(den, 1e-300)) ** 0.5
     l2_tol = 10 * tight if l2_tol is None else l2_tol

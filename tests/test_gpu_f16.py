@@ -235,7 +235,9 @@ def test_f16_generator_and_discriminator_vs_fp32_oracle(res, step, batch):
         sgot = d(ref.cuda(), condition=cond.cuda())[0]
         e = ((sgot.cpu() - sref).abs().max() / (sref.abs().max() + 1.0)).item()
         print(f"f16 discriminator at {res}x{res}: score error {e:.3e}")
-        assert e <= 3e-2, e
+        # measured 3.6e-4 (32^2), 1.3e-4 (256^2), relative to max|score| + 1: the score is a 512 -> 1 linear map of D's last 4x4
+        # activations, whose f16 rounding (u = 4.9e-4 each, independent) averages down by the 8192-term sum; 1e-3 = ~3 x observed
+        assert e <= 1e-3, e
 
 
 def test_f16_gradients_and_training_iteration():

@@ -195,10 +195,100 @@ def test_full_backward_256_batch4_vs_oracle():
     g_named = dict(G.named_parameters())
     g_grads_d = dict(zip(g_keys, torch.autograd.grad(g_loss_d, [g_named[k] for k in g_keys], allow_unused=True)))
     # every parameter gradient of both networks; tolerance policy: gpu_util.assert_grads_close (activation sign flips)
-    for keys, got, ref, what in ((d_keys, d_grads_d, d_grads_r, "D"), (g_keys, g_grads_d, g_grads_r, "G")):
+    # (review item 7: the cap on tensors between 3e-4 and 2e-3 is the observed count + 2 — 3 of D's 38 and 6 of G's 223 — not 10 %)
+    for keys, got, ref, what, cap in ((d_keys, d_grads_d, d_grads_r, "D", 5), (g_keys, g_grads_d, g_grads_r, "G", 8)):
         worst, n_out, l2 = assert_grads_close([got[k] for k in keys], [ref[k] for k in keys], keys, tight=3e-4, loose=2e-3,
-                                              what=f"{what} parameter gradients at 256x256, batch 4")
+                                              max_outliers=cap, what=f"{what} parameter gradients at 256x256, batch 4")
         print(f"{what}: worst tensor {worst:.2e}, {n_out} of {len(keys)} tensors above 3e-4, relative L2 over all parameters {l2:.2e}")
+
+
+
+def test_f16_full_backward_256_vs_oracle():
+    """Row N1 (BASELINE configs[4]: f16 activations, fp32 demodulation) as a TRAINING configuration: the D loss, the R1 penalty and
+    the G loss at 256x256, batch 2 — every parameter gradient of both networks and the R1 penalties of the f16-activation HIP path
+    against the fp32 CPU oracle's autograd (review item 4b: the f16 gradients used to be compared with the HIP fp32 path only, at
+    32x32, with 5e-2 / 0.3 / 25 % tolerances).  The three gradient sets are checked separately because they differ in kind:
+      * G loss and plain D loss (first-order): the signal crosses ~27 + 27 f16-rounded tensors (u = 2^-11 each, forward and
+        backward) and a leaky ReLU per layer whose branch flips for ~1 pre-activation in 2000 at f16 resolution; the 4x4 .. 16x16
+        layers see few positions, so single flips move their gradients by percents;
+      * the R1 term differentiates D twice: its parameter gradients carry the rounding of the first backward's f16 activation
+        gradients through a second backward.
+    What bounds them (measured, scale-independent: 2^12, 2^18 give the same figures, i.e. no underflow): NOT the accumulation of
+    unit round-offs (sqrt(54) u = 3.6e-3) but the leaky-ReLU branch flips — a pre-activation whose f16-path value differs from the
+    fp32 one by eps (1-2.4e-3 of the activation scale: the forward analysis of tests/test_gpu_f16.py) lands on the other side of
+    zero with probability ~0.8 eps, and a flipped element's backward factor jumps between 1 and 0.2: a relative L2 perturbation of
+    0.8 sqrt(0.8 eps) = 2.3-3.5e-2 of the gradient signal crossing that layer.  Measured: D 1.8e-2, G 1.5e-2 relative L2 over all
+    parameters, R1 term 0.9e-2; worst tensors at the 4x4 .. 16x16 layers (few positions per sum): 0.14.  The bounds asserted are
+    2 x those measurements, per set: relative L2 over all parameters, the worst tensor, and the number of tensors above 0.1.
+    (R1 set: weights only — d R1 / d bias is identically zero for a piecewise-linear D, both sides return rounding noise there.)"""
+    import statistics
+    from gif_amd import losses
+    from oracle import stylegan2_ref as R
+    torch.manual_seed(0)
+    G, D = _build(256, vocab=16)
+    g_sd = R.seeded_state_dict(G.state_dict(), 51)
+    d_sd = R.seeded_state_dict(D.state_dict(), 52)
+    G.load_state_dict(g_sd, strict=True)
+    D.load_state_dict(d_sd, strict=True)
+    gen = torch.Generator().manual_seed(53)
+    B = 2
+    real = torch.rand(B, 3, 256, 256, generator=gen) * 2 - 1
+    cond = torch.rand(B, 6, 256, 256, generator=gen) * 2 - 1
+    idx = torch.randint(0, 16, (B,), generator=gen)
+    # ---- fp32 oracle
+    gl, dl = _leaves(g_sd), _leaves(d_sd)
+    real_r = real.clone().requires_grad_(True)
+    fake_r = R.generator_forward(gl, cond, 6, idx)
+    rs = R.discriminator_forward(dl, real_r, cond, 256)
+    r1_r = R.grad_penalty_loss([real_r], rs)
+    d_plain_r = F.softplus(-rs).mean() + F.softplus(R.discriminator_forward(dl, fake_r.detach(), cond, 256)).mean()
+    d_keys = [k for k, v in dl.items() if v.requires_grad]
+    ref_sets = {"D plain": dict(zip(d_keys, torch.autograd.grad(d_plain_r, [dl[k] for k in d_keys], retain_graph=True))),
+                "D R1": dict(zip(d_keys, torch.autograd.grad(r1_r.mean(), [dl[k] for k in d_keys], allow_unused=True)))}
+    g_loss_r = F.softplus(-R.discriminator_forward(dl, fake_r, cond, 256)).mean()
+    g_keys = [k for k, v in gl.items() if v.requires_grad]
+    ref_sets["G"] = dict(zip(g_keys, torch.autograd.grad(g_loss_r, [gl[k] for k in g_keys], allow_unused=True)))
+    # ---- HIP, f16 activations, static loss scale 2^12 (R1's inner gradient on scores pre-multiplied by 2^10, as the trainer does)
+    H16 = torch.float16
+    G, D = G.cuda().set_activation_dtype(H16), D.cuda().set_activation_dtype(H16)
+    condd, idxd = cond.cuda(), idx.cuda()
+    real_d = real.cuda().requires_grad_(True)
+    S = 2.0 ** int(os.environ.get("GIF_TEST_F16_LOG2_SCALE", "12"))
+    fake_d = G(condd, None, step=6, alpha=1, input_indices=idxd)
+    rs_d, _ = D([real_d], condition=condd)
+    r1_d = losses.grad_penalty_loss([real_d], rs_d, step=None, grad_scale=2.0 ** 10)
+    e_r1 = rel_err(r1_d, r1_r)
+    d_plain_d = F.softplus(-rs_d).mean() + F.softplus(D([fake_d[0].detach()], condition=condd)[0]).mean()
+    d_named, g_named = dict(D.named_parameters()), dict(G.named_parameters())
+
+    def grads(loss, named, keys, **kw):
+        return dict(zip(keys, ((None if g is None else g / S) for g in
+                               torch.autograd.grad(loss * S, [named[k] for k in keys], allow_unused=True, **kw))))
+    got_sets = {"D plain": grads(d_plain_d, d_named, d_keys, retain_graph=True), "D R1": grads(r1_d.mean(), d_named, d_keys)}
+    g_loss_d = F.softplus(-D(fake_d, condition=condd)[0]).mean()
+    got_sets["G"] = grads(g_loss_d, g_named, g_keys)
+    u = 2.0 ** -11
+    print(f"\nf16 @256: losses D {d_plain_d.item():.5f} vs {d_plain_r.item():.5f}, G {g_loss_d.item():.5f} vs {g_loss_r.item():.5f}; "
+          f"R1 penalties rel err {e_r1:.2e} ({e_r1 / u:.1f} u)")
+    assert abs(d_plain_d.item() - d_plain_r.item()) < 4 * u * max(1.0, abs(d_plain_r.item()))   # measured 0.3 u
+    assert abs(g_loss_d.item() - g_loss_r.item()) < 4 * u * max(1.0, abs(g_loss_r.item()))       # measured 0.5 u
+    assert e_r1 < 12 * u, e_r1                                                                   # measured 5.7 u
+    # (relative L2 over all parameters, worst tensor, tensors above 32 u) allowed = 2 x measured, see the printed line
+    BOUNDS = {"D plain": (3.7e-2, 0.29, 4), "D R1": (1.8e-2, 0.3, 4), "G": (3.0e-2, 0.12, 2)}
+    for what in ("D plain", "D R1", "G"):
+        ref, got = ref_sets[what], got_sets[what]
+        keys = [k for k in ref if ref[k] is not None and ref[k].abs().max().item() > 0 and not (what == "D R1" and k.endswith("bias"))]
+        errs = sorted(((rel_err(got[k], ref[k]), k) for k in keys), reverse=True)
+        num = sum((got[k].detach().float().cpu() - ref[k]).pow(2).sum().item() for k in keys)
+        den = sum(ref[k].pow(2).sum().item() for k in keys)
+        l2 = (num / den) ** 0.5
+        n32 = sum(1 for e, _ in errs if e > 0.1)
+        print(f"{what}: relative L2 over all parameters {l2:.2e} ({l2 / u:.1f} u); worst tensors "
+              + ", ".join(f"{k} {e:.2e}" for e, k in errs[:3]) + f"; median {statistics.median(e for e, _ in errs):.2e}; "
+              f"{n32} of {len(errs)} tensors above 0.1")
+        l2_b, worst_b, n_b = BOUNDS[what]
+        if not os.environ.get("GIF_TEST_F16_EXPLORE"):
+            assert l2 <= l2_b and errs[0][0] <= worst_b and n32 <= n_b, (what, l2, errs[0], n32, BOUNDS[what])
 
 
 def test_config3_at_stated_size_vs_oracle():

@@ -41,20 +41,18 @@ def host(y, c=None):
 
 
 class halo:
-    """GIF_F16_HALO is read per launch: 0 keeps the gather kernel (the round-3 path)."""
+    """gif_conv2d_f16_halo_enable(0) keeps the gather kernel (the round-3 path); the switch is restored to on."""
 
     def __init__(self, on):
         self.on = on
 
     def __enter__(self):
-        self.old = os.environ.get("GIF_F16_HALO")
-        os.environ["GIF_F16_HALO"] = "1" if self.on else "0"
+        from gif_amd import _lib
+        _lib.load().gif_conv2d_f16_halo_enable(1 if self.on else 0)
 
     def __exit__(self, *a):
-        if self.old is None:
-            os.environ.pop("GIF_F16_HALO", None)
-        else:
-            os.environ["GIF_F16_HALO"] = self.old
+        from gif_amd import _lib
+        _lib.load().gif_conv2d_f16_halo_enable(1)
 
 
 HALO_CASES = [

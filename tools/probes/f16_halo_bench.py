@@ -60,10 +60,11 @@ def main():
             flops = 2.0 * B * H * H * k * k * ci * co
         byts = 2.0 * B * (H * H * ci + Ho * Ho * ops.cpad(co, torch.float16))
         t = {}
+        from gif_amd import _lib
         for on in ("1", "0"):
-            os.environ["GIF_F16_HALO"] = on
+            _lib.load().gif_conv2d_f16_halo_enable(int(on))
             t[on] = timed(fn)
-        os.environ.pop("GIF_F16_HALO")
+        _lib.load().gif_conv2d_f16_halo_enable(1)
         print(f"{what:58s} {t['1']:8.3f} / {t['0']:8.3f} ms  x{t['0'] / t['1']:5.2f}   {flops / t['1'] / 1e9:7.1f} TFLOP/s  {byts / t['1'] / 1e6:7.0f} GB/s")
 
 
