@@ -726,23 +726,25 @@ __global__ void pack_weight_x3_dense_kernel(const float* __restrict__ w, unsigne
 // than 2^kH2WindowW below the row maximum sets the flag: its values no longer carry 22 bits, launches using the row take the bf16x3
 // fallback.
 // planes3 != NULL: the bf16x3 packing wp3[t][3][RP][CP] of the same weights (the guarded fallback's operand) in the same pass.
+// The row's T * CP values are read from HBM ONCE into LDS (the canonical tensor is walked with a stride of 9 or 9 * Cin floats:
+// the second read cost as much as the first; 28 -> 17 us per pack, 86 packs per training iteration).
 __global__ void __launch_bounds__(256) pack_weight_h2_kernel(const float* __restrict__ w, int* __restrict__ hdr, unsigned short* __restrict__ planes,
                                                              unsigned short* __restrict__ planes3, int R, int C, int KH, int KW, int RP, int CP,
                                                              long sr, long sc, long sky, long skx, float scale) {
+    extern __shared__ float row_vals[];  // [KH * KW][CP]
     __shared__ float red[256];
     __shared__ int s_flag;
     const int r = blockIdx.x, tid = threadIdx.x;
     if (tid == 0) s_flag = 0;
-    const int gpt = CP / 16, ngroups = KH * KW * gpt;  // 16-channel groups per tap / per row
-    auto value = [&](int t, int c) -> float {
-        const int ky = t / KW, kx = t - ky * KW;
-        return (r < R && c < C) ? scale * w[r * sr + c * sc + ky * sky + kx * skx] : 0.f;
-    };
+    const int T = KH * KW, n = T * CP;
     float m = 0.f;
-    for (int g = tid; g < ngroups; g += 256) {
-        const int t = g / gpt, c0 = (g - t * gpt) * 16;
-#pragma unroll 4
-        for (int k = 0; k < 16; ++k) m = fmaxf(m, fabsf(value(t, c0 + k)));
+    for (int e = tid; e < n; e += 256) {
+        // (c fastest over the threads for rows = output channels: consecutive threads walk the input channels, 9 floats apart)
+        const int t = e / CP, c = e - t * CP;
+        const int ky = t / KW, kx = t - ky * KW;
+        const float v = (r < R && c < C) ? scale * w[r * sr + c * sc + ky * sky + kx * skx] : 0.f;
+        row_vals[e] = v;
+        m = fmaxf(m, fabsf(v));
     }
     red[tid] = m;
     __syncthreads();
@@ -751,17 +753,19 @@ __global__ void __launch_bounds__(256) pack_weight_h2_kernel(const float* __rest
         __syncthreads();
     }
     const float rowmax = red[0];
-    const int e = gif::h2_exp_for(__float_as_uint(rowmax), gif::kH2TargetW);
-    const float sc2 = gif::h2_pow2(e);
+    const int e2 = gif::h2_exp_for(__float_as_uint(rowmax), gif::kH2TargetW);
+    const float sc2 = gif::h2_pow2(e2);
     const size_t plane = (size_t)RP * CP;
+    const int gpt = CP / 16, ngroups = T * gpt;  // 16-channel groups per tap / per row
     bool narrow = false;
     for (int g = tid; g < ngroups; g += 256) {
         const int t = g / gpt, c0 = (g - t * gpt) * 16;
+        const float* src = row_vals + t * CP + c0;
         unsigned short* o = planes + (size_t)t * 2 * plane + (size_t)r * CP + c0;
         float gm = 0.f;
 #pragma unroll 4
         for (int k = 0; k < 16; k += 2) {
-            const float v0 = value(t, c0 + k), v1 = value(t, c0 + k + 1);
+            const float v0 = src[k], v1 = src[k + 1];
             gm = fmaxf(gm, fmaxf(fabsf(v0), fabsf(v1)));
             unsigned h, l;
             gif::split_pair_h2(v0, v1, sc2, h, l);
@@ -781,7 +785,7 @@ __global__ void __launch_bounds__(256) pack_weight_h2_kernel(const float* __rest
     if (narrow) atomicOr(&s_flag, 1);
     __syncthreads();
     if (tid == 0) {
-        hdr[r] = e;
+        hdr[r] = e2;
         hdr[RP + r] = s_flag;
     }
 }
@@ -1232,7 +1236,9 @@ int gif_pack_weight_f32h2(const float* w, void* wp2, int R, int C, int KH, int K
                 "pack_weight_f32h2: bad arguments");
     int* hdr = static_cast<int*>(wp2);
     unsigned short* planes = reinterpret_cast<unsigned short*>(static_cast<char*>(wp2) + gif::h2_header_bytes(RP));
-    pack_weight_h2_kernel<<<RP, 256, 0, gif::as_stream(stream)>>>(w, hdr, planes, nullptr, R, C, KH, KW, RP, CP, sr, sc, sky, skx, scale);
+    const size_t lds = (size_t)KH * KW * CP * sizeof(float);
+    GIF_REQUIRE(lds <= 64 * 1024, "pack_weight_f32h2: a row of %d x %d values does not fit the staging LDS", KH * KW, CP);
+    pack_weight_h2_kernel<<<RP, 256, lds, gif::as_stream(stream)>>>(w, hdr, planes, nullptr, R, C, KH, KW, RP, CP, sr, sc, sky, skx, scale);
     return gif::check_launch("pack_weight_f32h2");
 }
 
@@ -1243,8 +1249,10 @@ int gif_pack_weight_f32h2x3(const float* w, void* wp2, void* wp3, int R, int C, 
                 "pack_weight_f32h2x3: bad arguments");
     int* hdr = static_cast<int*>(wp2);
     unsigned short* planes = reinterpret_cast<unsigned short*>(static_cast<char*>(wp2) + gif::h2_header_bytes(RP));
-    pack_weight_h2_kernel<<<RP, 256, 0, gif::as_stream(stream)>>>(w, hdr, planes, static_cast<unsigned short*>(wp3), R, C, KH, KW, RP, CP, sr,
-                                                                  sc, sky, skx, scale);
+    const size_t lds = (size_t)KH * KW * CP * sizeof(float);
+    GIF_REQUIRE(lds <= 64 * 1024, "pack_weight_f32h2x3: a row of %d x %d values does not fit the staging LDS", KH * KW, CP);
+    pack_weight_h2_kernel<<<RP, 256, lds, gif::as_stream(stream)>>>(w, hdr, planes, static_cast<unsigned short*>(wp3), R, C, KH, KW, RP, CP, sr,
+                                                                    sc, sky, skx, scale);
     return gif::check_launch("pack_weight_f32h2x3");
 }
 
