@@ -351,6 +351,10 @@ class GifTrainer:
         if "GIF_FUSE_D" in os.environ and os.environ["GIF_FUSE_D"] != "0":
             fuse_default = True  # an explicit GIF_FUSE_D=1 keeps the fused pass for the A/B
         self.fuse_d_passes = fuse_default if fuse_d_passes is None else bool(fuse_d_passes)
+        # Experiment (review item 2 of round 4, profiles/r5_two_streams.txt): in the two-call D step the no-grad generator forward that
+        # produces the fake batch is independent of D's forward on the real images; GIF_TWO_STREAMS=1 runs it on a second HIP stream.
+        self.two_streams = os.environ.get("GIF_TWO_STREAMS", "0") == "1"
+        self._side = None
         self._d_update_pending = False
         self._g_update_pending = False
         self.g_running_decay = 0.5 ** (32 / (10 * 1000))
@@ -437,6 +441,16 @@ class GifTrainer:
                 D.stddev_chunks = 1
             d_loss = F.softplus(-scores[:nb]).mean() + F.softplus(scores[nb:]).mean()
             return self._d_backward_and_update(d_loss, sc, watch)
+        side_fake = False
+        if fake is None and self.two_streams:
+            self._finish_g_update()
+            main = torch.cuda.current_stream()
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            self._side.wait_stream(main)  # the inputs and G's parameters are final on the main stream
+            with torch.cuda.stream(self._side), torch.no_grad():
+                fake = G(cond, None, step=self.res_step, alpha=self.alpha, input_indices=input_indices)[0]
+            side_fake = True
         real_scores, _ = D([real_image], condition=cond, step=self.res_step, alpha=self.alpha)
         real_loss = F.softplus(-real_scores).mean()
         if r1_step:
@@ -449,6 +463,9 @@ class GifTrainer:
             self._finish_g_update()  # G's exchange of the previous iteration ran under the D forward above
             with torch.no_grad():  # the reference detaches the fake image right after the forward (train.py:160)
                 fake = G(cond, None, step=self.res_step, alpha=self.alpha, input_indices=input_indices)[0]
+        if side_fake:
+            torch.cuda.current_stream().wait_stream(self._side)
+            fake.record_stream(torch.cuda.current_stream())
         fake_scores, _ = D([fake.detach()], condition=cond, step=self.res_step, alpha=self.alpha)
         fake_loss = F.softplus(fake_scores).mean()
         d_loss = real_loss + fake_loss
