@@ -214,6 +214,7 @@ FAMILIES = {
          "per-channel exponents, 3 products)", F16X2_EXECUTED, "conv_wgrad_mfma_h2"),
     16: ("conv_wgrad_mfma<float, f16x2> in planes mode (Winograd F(3x3,2x2) weight-gradient GEMMs on the f16 matrix cores)",
          F16X2_EXECUTED * WINOGRAD_EXECUTED, "conv_wgrad_mfma_h2"),
+    17: ("conv_gather_mfma_glds<float, f16x2> in the tap-dense K order (3x3 layers with 8..28 contraction channels)", F16X2_EXECUTED, None),
     12: ("conv_gather_mfma_glds<float, bf16x3> in the tap-dense K order (3x3 layers with 8..28 contraction channels: the 6->12->24 "
          "condition-noise convs and the 24->C layers that inject their result; same kernels as the bf16x3 direct family, so no separate "
          "PMC traffic)", BF16X3_EXECUTED, None),
@@ -222,10 +223,12 @@ FAMILY_KEYS = {0: "roofline_conv_direct", 1: "roofline_wgrad_direct", 2: "roofli
                5: "roofline_conv_direct_small_cin", 6: "roofline_conv_f16", 7: "roofline_wgrad_f16",
                8: "roofline_conv_direct_bf16x3", 9: "roofline_wgrad_direct_bf16x3", 10: "roofline_conv_winograd_bf16x3",
                11: "roofline_wgrad_winograd_bf16x3", 12: "roofline_conv_direct_bf16x3_tapdense", 13: "roofline_conv_direct_f16x2",
-               14: "roofline_conv_winograd_f16x2", 15: "roofline_wgrad_direct_f16x2", 16: "roofline_wgrad_winograd_f16x2"}
+               14: "roofline_conv_winograd_f16x2", 15: "roofline_wgrad_direct_f16x2", 16: "roofline_wgrad_winograd_f16x2",
+               17: "roofline_conv_direct_f16x2_tapdense"}
 FAMILY_PEAK = {6: PEAK_F16_MFMA_TFLOPS, 7: PEAK_F16_MFMA_TFLOPS, 8: PEAK_F16_MFMA_TFLOPS, 9: PEAK_F16_MFMA_TFLOPS,
                10: PEAK_F16_MFMA_TFLOPS, 11: PEAK_F16_MFMA_TFLOPS, 12: PEAK_F16_MFMA_TFLOPS, 13: PEAK_F16_MFMA_TFLOPS,
-               14: PEAK_F16_MFMA_TFLOPS, 15: PEAK_F16_MFMA_TFLOPS, 16: PEAK_F16_MFMA_TFLOPS}
+               14: PEAK_F16_MFMA_TFLOPS, 15: PEAK_F16_MFMA_TFLOPS, 16: PEAK_F16_MFMA_TFLOPS,
+               17: PEAK_F16_MFMA_TFLOPS}
 
 
 def load_pmc():
@@ -243,7 +246,7 @@ def family_ceiling(fam, exec_frac, mfma_peak):
     FLOPs it executes per algorithmic (direct-convolution, fp32) FLOP."""
     if fam in (8, 9, 12):
         return mfma_peak / exec_frac, "bf16x3 fp32-exact = 2500 / 6 (six bf16 MFMA products per fp32 product, bf16 dense peak 2500 TFLOP/s)"
-    if fam in (13, 15):
+    if fam in (13, 15, 17):
         return mfma_peak / exec_frac, "f16x2 = 2500 / 3 (three f16 MFMA products per fp32 product, f16 dense peak 2500 TFLOP/s)"
     if fam in (14, 16):
         return mfma_peak / exec_frac, "Winograd on f16x2 = 2500 / (3 * 16/36) (F(2x2,3x3) executes 16/36 of the products, each as three f16 MFMA products)"
@@ -500,7 +503,7 @@ def main():
     data = [batch() for _ in range(min(args.steps, 4))]  # synthetic batches resident in HBM before the timed region
     prof_steps = 0
     if not args.no_prof:
-        for fam in range(17):
+        for fam in range(18):
             ops.prof_read(fam)
     h2_mode = args.dtype != "f16" and ops.get_fp32_mfma_mode() == "f16x2"
     if h2_mode:

@@ -62,6 +62,10 @@ PROTOTYPES = {
     "gif_pack_weight_f32h2_bytes": (c_i64, [c_int, c_int, c_int, c_int]),
     "gif_pack_weight_f32h2": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_float, P]),
     "gif_pack_weight_f32h2x3": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_float, P]),
+    "gif_pack_weight_f32h2_tapdense_bytes": (c_i64, [c_int, c_int, c_int, c_int]),
+    "gif_pack_weight_f32h2x3_tapdense": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_i64, c_float, P]),
+    "gif_conv2d_fwd_f32h2_tapdense": (c_int, [P, P, P, P, GP, EP, P]),
+    "gif_conv2d_bwd_data_f32h2_tapdense": (c_int, [P, P, P, P, GP, EP, P]),
     "gif_conv2d_fwd_f32h2": (c_int, [P, P, P, P, GP, EP, P]),
     "gif_conv2d_bwd_data_f32h2": (c_int, [P, P, P, P, GP, EP, P]),
     "gif_h2_fallback_stats": (c_int, [ctypes.POINTER(ctypes.c_uint64), c_int]),

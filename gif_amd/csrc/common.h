@@ -61,8 +61,8 @@ int fp32_mfma_mode();
 // 10 / 11 bf16x3 Winograd GEMM fwd/dgrad / Winograd wgrad plane GEMMs (algorithmic flops; execute 6 * 16/36 of them),
 // 12 bf16x3 direct conv in the tap-dense K order, 13 / 14 f16x2 direct conv fwd/dgrad / f16x2 Winograd GEMM (algorithmic flops; the
 // f16 pipe executes 3x / 3 * 16/36 of them; the op's time includes its guarded bf16x3 twin launch), 15 / 16 f16x2 weight gradient /
-// f16x2 Winograd weight-gradient plane GEMMs (same conventions)
-#define GIF_PROF_FAMILIES 17
+// f16x2 Winograd weight-gradient plane GEMMs (same conventions), 17 f16x2 direct conv in the tap-dense K order
+#define GIF_PROF_FAMILIES 18
 struct ProfScope {
     int family;
     hipStream_t stream;

@@ -539,7 +539,7 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
     // (Ci = 8) zero padding.  Instead K runs densely over (tap, channel): 16-byte chunk q = 8 * step + lane chunk belongs to tap
     // q / (Ci/4), channels 4 * (q % (Ci/4)).. — each DMA lane fetches its own tap's pixel; the weights are packed in the same order
     // (gif_pack_weight_f32x3_tapdense).  9 taps of 24 channels = 7 steps instead of 9, of 12 channels = 4, of 8 channels = 3.
-    const int dense_cpt = X3 == 1 ? p.dense : 0;
+    const int dense_cpt = X3 ? p.dense : 0;
     const int src_c4 = dense_cpt ? 0 : (pair ? (lchunk & (CH / 2 - 1)) : lchunk) * EPC;
     const bool b_lane_ok = (BN % RPP == 0) || t_row < BN;
 
@@ -658,9 +658,9 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
     };
     int ld_step = 0;
     auto issue_dense = [&](int buf) __attribute__((always_inline)) {
-        if constexpr (X3 == 1) {
+        if constexpr (X3 != 0) {
             const int q = ld_step * CH + lchunk;
-            const int t = (q * ((65536 + dense_cpt - 1) / dense_cpt)) >> 16;  // q / cpt (exact for q < 128)
+            const int t = (q * ((65536 + dense_cpt - 1) / (dense_cpt > 0 ? dense_cpt : 1))) >> 16;  // q / cpt (exact for q < 128)
             const int ch = (q - t * dense_cpt) * EPC;
             const int ta = (t * 11) >> 5, tb = t - 3 * ta;  // 3x3 tap grid: t / 3, t % 3 (t < 12)
             const int dy = p.dy0 + ta * p.ddy, dx = p.dx0 + tb * p.ddx;
@@ -685,7 +685,7 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
         if constexpr (F16 && !X3) {
             if (pair) { issue_pair(buf); return; }
         }
-        if constexpr (X3 == 1) {
+        if constexpr (X3 != 0) {
             if (dense_cpt) { issue_dense(buf); return; }
         }
         const int dy = p.dy0 + ld_a * p.ddy, dx = p.dx0 + ld_b * p.ddx;
@@ -1765,7 +1765,7 @@ int conv2d_fwd_impl(const void* big, const void* wp, void* small, const gif_conv
     if (x3 == 2) h2_operands(p, wp, wp_fallback);
     p.M = p.B * p.Hp * p.Wp;
     double flops = 2.0 * p.M * (double)p.Co * p.Ci * p.ntaps;
-    const int fam = sizeof(T) == 2 ? 6 : dense ? 12 : x3 == 2 ? 13 : x3 ? 8 : (p.Ci >= 32 ? 0 : 5);
+    const int fam = sizeof(T) == 2 ? 6 : dense ? (x3 == 2 ? 17 : 12) : x3 == 2 ? 13 : x3 ? 8 : (p.Ci >= 32 ? 0 : 5);
     FusedSums sums;
     if (int rc = sums.begin(p, e, p.M, p.Co, p.B, (long)p.Hp * p.Wp, true, who)) return rc;
     gif::ProfScope prof(fam, flops, gif::as_stream(stream), p.M, p.Co, p.Ci, p.ntaps * 10 + g->stride);
@@ -1834,7 +1834,7 @@ int conv2d_bwd_data_impl(const void* small, const void* wp, void* big, const gif
     // algorithmic FLOPs of a transposed conv: every small-side pixel scatters through every tap
     double flops = 2.0 * g->B * (double)g->Hs * g->Ws * g->KH * g->KW * (double)g->Cs * g->Cb;
     {
-        const int fam = sizeof(T) == 2 ? 6 : dense ? 12 : x3 == 2 ? 13 : x3 ? 8 : (base.Ci >= 32 ? 0 : 5);
+        const int fam = sizeof(T) == 2 ? 6 : dense ? (x3 == 2 ? 17 : 12) : x3 == 2 ? 13 : x3 ? 8 : (base.Ci >= 32 ? 0 : 5);
         gif::ProfScope prof(fam, flops, s, g->B * g->Hb * g->Wb, base.Co, base.Ci, -(g->KH * g->KW * 10 + g->stride));
         // small transposed convs: every phase alone would sit on the 64x64-tile path with a partly filled chip
         auto run_phases = [&]() -> int {
@@ -1933,6 +1933,17 @@ int gif_conv2d_fwd_f32h2(const float* big, const void* wp2, const void* wp3, flo
 int gif_conv2d_bwd_data_f32h2(const float* small, const void* wp2, const void* wp3, float* big, const gif_conv_geom* g,
                               const gif_conv_epilogue* e, gif_stream_t stream) {
     return conv2d_bwd_data_impl<float>(small, wp2, big, g, e, stream, "conv2d_bwd_data_f32h2", 2, false, wp3);
+}
+
+/* tap-dense K order on the f16x2 kernels (packings from gif_pack_weight_f32h2x3_tapdense; wp3 == NULL: unguarded) */
+int gif_conv2d_fwd_f32h2_tapdense(const float* big, const void* wp2, const void* wp3, float* small, const gif_conv_geom* g,
+                                  const gif_conv_epilogue* e, gif_stream_t stream) {
+    return conv2d_fwd_impl<float>(big, wp2, small, g, e, stream, "conv2d_fwd_f32h2_tapdense", 2, true, wp3);
+}
+
+int gif_conv2d_bwd_data_f32h2_tapdense(const float* small, const void* wp2, const void* wp3, float* big, const gif_conv_geom* g,
+                                       const gif_conv_epilogue* e, gif_stream_t stream) {
+    return conv2d_bwd_data_impl<float>(small, wp2, big, g, e, stream, "conv2d_bwd_data_f32h2_tapdense", 2, true, wp3);
 }
 
 int gif_conv2d_fwd_f32x3_tapdense(const float* big, const void* wp3, float* small, const gif_conv_geom* g,

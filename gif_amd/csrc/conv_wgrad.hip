@@ -727,22 +727,31 @@ __global__ void pack_weight_x3_dense_kernel(const float* __restrict__ w, unsigne
 // fallback.
 // planes3 != NULL: the bf16x3 packing wp3[t][3][RP][CP] of the same weights (the guarded fallback's operand) in the same pass.
 // The row's T * CP values are read from HBM ONCE into LDS (the canonical tensor is walked with a stride of 9 or 9 * Cin floats:
-// the second read cost as much as the first; 28 -> 17 us per pack, 86 packs per training iteration).
+// the second read cost as much as the first; 28.6 -> 15.5 us per pack, 86 packs per training iteration: profiles/r5_kernel_stats.md).
 __global__ void __launch_bounds__(256) pack_weight_h2_kernel(const float* __restrict__ w, int* __restrict__ hdr, unsigned short* __restrict__ planes,
                                                              unsigned short* __restrict__ planes3, int R, int C, int KH, int KW, int RP, int CP,
-                                                             long sr, long sc, long sky, long skx, float scale) {
+                                                             long sr, long sc, long sky, long skx, float scale, int dense_cpt, int dense_steps) {
+    // dense_cpt > 0: the tap-dense K order of a 3x3 kernel (gif_pack_weight_f32x3_tapdense): "taps" = dense_steps K steps of CP = 32
+    // floats, float k of step st = float k % 4 of 16-byte chunk q = 8 st + k / 4 = tap q / cpt, channel 4 (q % cpt) + k % 4
     extern __shared__ float row_vals[];  // [KH * KW][CP]
     __shared__ float red[256];
     __shared__ int s_flag;
     const int r = blockIdx.x, tid = threadIdx.x;
     if (tid == 0) s_flag = 0;
-    const int T = KH * KW, n = T * CP;
+    const int T = dense_cpt ? dense_steps : KH * KW, n = T * CP;
     float m = 0.f;
     for (int e = tid; e < n; e += 256) {
         // (c fastest over the threads for rows = output channels: consecutive threads walk the input channels, 9 floats apart)
-        const int t = e / CP, c = e - t * CP;
+        int t = e / CP, c = e - t * CP;
+        bool ok = r < R;
+        if (dense_cpt) {
+            const int q = t * 8 + c / 4;
+            t = q / dense_cpt;
+            c = (q - t * dense_cpt) * 4 + c % 4;
+            ok = ok && t < 9;
+        }
         const int ky = t / KW, kx = t - ky * KW;
-        const float v = (r < R && c < C) ? scale * w[r * sr + c * sc + ky * sky + kx * skx] : 0.f;
+        const float v = (ok && c < C) ? scale * w[r * sr + c * sc + ky * sky + kx * skx] : 0.f;
         row_vals[e] = v;
         m = fmaxf(m, fabsf(v));
     }
@@ -1238,7 +1247,7 @@ int gif_pack_weight_f32h2(const float* w, void* wp2, int R, int C, int KH, int K
     unsigned short* planes = reinterpret_cast<unsigned short*>(static_cast<char*>(wp2) + gif::h2_header_bytes(RP));
     const size_t lds = (size_t)KH * KW * CP * sizeof(float);
     GIF_REQUIRE(lds <= 64 * 1024, "pack_weight_f32h2: a row of %d x %d values does not fit the staging LDS", KH * KW, CP);
-    pack_weight_h2_kernel<<<RP, 256, lds, gif::as_stream(stream)>>>(w, hdr, planes, nullptr, R, C, KH, KW, RP, CP, sr, sc, sky, skx, scale);
+    pack_weight_h2_kernel<<<RP, 256, lds, gif::as_stream(stream)>>>(w, hdr, planes, nullptr, R, C, KH, KW, RP, CP, sr, sc, sky, skx, scale, 0, 0);
     return gif::check_launch("pack_weight_f32h2");
 }
 
@@ -1252,8 +1261,29 @@ int gif_pack_weight_f32h2x3(const float* w, void* wp2, void* wp3, int R, int C, 
     const size_t lds = (size_t)KH * KW * CP * sizeof(float);
     GIF_REQUIRE(lds <= 64 * 1024, "pack_weight_f32h2x3: a row of %d x %d values does not fit the staging LDS", KH * KW, CP);
     pack_weight_h2_kernel<<<RP, 256, lds, gif::as_stream(stream)>>>(w, hdr, planes, static_cast<unsigned short*>(wp3), R, C, KH, KW, RP, CP, sr,
-                                                                    sc, sky, skx, scale);
+                                                                    sc, sky, skx, scale, 0, 0);
     return gif::check_launch("pack_weight_f32h2x3");
+}
+
+/* tap-dense K order (gif_conv2d_x3_tapdense_steps): wp2 = [2 RP int32 header][steps][2][RP][32] f16, wp3 = [steps][3][RP][32] bf16 (as
+ * gif_pack_weight_f32x3_tapdense writes it), one launch */
+int64_t gif_pack_weight_f32h2_tapdense_bytes(int cin_act, int KH, int KW, int RP) {
+    const int steps = gif_conv2d_x3_tapdense_steps(cin_act, KH, KW);
+    if (steps <= 0 || RP <= 0) return 0;
+    return (int64_t)gif::h2_header_bytes(RP) + (int64_t)steps * 2 * RP * 32 * 2;
+}
+
+int gif_pack_weight_f32h2x3_tapdense(const float* w, void* wp2, void* wp3, int R, int C, int cin_act, int KH, int KW, int RP, int64_t sr,
+                                     int64_t sc, int64_t sky, int64_t skx, float scale, gif_stream_t stream) {
+    const int steps = gif_conv2d_x3_tapdense_steps(cin_act, KH, KW);
+    GIF_REQUIRE(w && wp2 && wp3 && R > 0 && C > 0 && RP >= R && RP % 32 == 0 && cin_act >= C && steps > 0,
+                "pack_weight_f32h2x3_tapdense: bad arguments");
+    int* hdr = static_cast<int*>(wp2);
+    unsigned short* planes = reinterpret_cast<unsigned short*>(static_cast<char*>(wp2) + gif::h2_header_bytes(RP));
+    const size_t lds = (size_t)steps * 32 * sizeof(float);
+    pack_weight_h2_kernel<<<RP, 256, lds, gif::as_stream(stream)>>>(w, hdr, planes, static_cast<unsigned short*>(wp3), R, C, KH, KW, RP, 32, sr,
+                                                                    sc, sky, skx, scale, cin_act / 4, steps);
+    return gif::check_launch("pack_weight_f32h2x3_tapdense");
 }
 
 /* K steps (32-float chunks) of the tap-dense order, or 0 if the mode does not apply: 3x3 kernels, 8 <= cin_act < 32, cin_act % 4 == 0 */

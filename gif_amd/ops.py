@@ -220,9 +220,15 @@ H2_WINO = os.environ.get("GIF_H2_WINO", "1") != "0"    # f16x2 mode: Winograd fw
 H2_GUARD = True  # False: f16x2 launches run without their guarded bf16x3 twin (tests only: shows what the guard protects against)
 
 
+# f16x2 mode: the tap-dense launches (3x3 layers with 8..28 contraction channels) stay on the bf16x3 tap-dense kernel by default — the f16x2 form
+# (gif_conv2d_*_f32h2_tapdense, tests/test_gpu_f16x2.py) measured SLOWER in the step: 200.0 vs 198.5 ms in one call (24 -> 128 at 256^2: 7.9 vs
+# 6.7 ms per step; these launches are bound by their per-lane tap gathers, not by the matrix pipe, and the row tracking adds VALU work)
+H2_DENSE = os.environ.get("GIF_H2_DENSE", "0") != "0"
+
+
 def h2_conv(x3: bool, dense: bool) -> bool:
     """This bf16x3-eligible direct launch runs the f16x2 kernels (three f16 products under per-row scales, guarded bf16x3 fallback)."""
-    return bool(x3) and not dense and H2_CONV and get_fp32_mfma_mode() == "f16x2"
+    return (bool(x3) or bool(dense)) and (H2_DENSE or not dense) and H2_CONV and get_fp32_mfma_mode() == "f16x2"
 
 
 def x3_tapdense(dtype, cin_act: int, spec, transposed: bool, epi, cout_act: int = 64) -> bool:
@@ -280,7 +286,7 @@ def pack_weight(w: torch.Tensor, rows_are_out: bool, cout_act: int, cin_act: int
     return _cached_weight_op(w, ("pack", rows_are_out, cout_act, cin_act, float(scale), dtype, bool(x3), bool(tapdense), bool(h2)), build)
 
 
-def pack_weight_h2x3(w: torch.Tensor, rows_are_out: bool, cout_act: int, cin_act: int, scale: float = 1.0):
+def pack_weight_h2x3(w: torch.Tensor, rows_are_out: bool, cout_act: int, cin_act: int, scale: float = 1.0, tapdense=False):
     """(wp2, wp3): the f16x2 packing and the bf16x3 packing (the guarded fallback's operand) of the same weight view, ONE launch."""
     lib = _lib.load()
     O, I, KH, KW = w.shape
@@ -291,13 +297,20 @@ def pack_weight_h2x3(w: torch.Tensor, rows_are_out: bool, cout_act: int, cin_act
     def build():
         RP, CP = ctypes.c_int(), ctypes.c_int()
         _lib.check(lib.gif_conv2d_pack_dims_x3(cout_act, cin_act, ctypes.byref(RP), ctypes.byref(CP)), "pack_dims")
+        if tapdense:
+            steps = lib.gif_conv2d_x3_tapdense_steps(cin_act, KH, KW)
+            wp2 = torch.empty((lib.gif_pack_weight_f32h2_tapdense_bytes(cin_act, KH, KW, RP.value),), device=w.device, dtype=torch.uint8)
+            wp3 = torch.empty((steps, 3, RP.value, 32), device=w.device, dtype=torch.bfloat16)
+            _lib.check(lib.gif_pack_weight_f32h2x3_tapdense(w.data_ptr(), wp2.data_ptr(), wp3.data_ptr(), R, C, cin_act, KH, KW, RP.value, sr, sc,
+                                                            sky, skx, float(scale), _stream()), "pack_weight_f32h2x3_tapdense")
+            return wp2, wp3
         wp2 = torch.empty((lib.gif_pack_weight_f32h2_bytes(KH, KW, RP.value, CP.value),), device=w.device, dtype=torch.uint8)
         wp3 = torch.empty((KH * KW, 3, RP.value, CP.value), device=w.device, dtype=torch.bfloat16)
         _lib.check(lib.gif_pack_weight_f32h2x3(w.data_ptr(), wp2.data_ptr(), wp3.data_ptr(), R, C, KH, KW, RP.value, CP.value, sr, sc, sky, skx,
                                                float(scale), _stream()), "pack_weight_f32h2x3")
         return wp2, wp3
 
-    return _cached_weight_op(w, ("pack_h2x3", rows_are_out, cout_act, cin_act, float(scale)), build)
+    return _cached_weight_op(w, ("pack_h2x3", rows_are_out, cout_act, cin_act, float(scale), bool(tapdense)), build)
 
 
 # Winograd F(2x2,3x3) dispatch for stride-1 / pad-1 3x3 convs (conv_winograd.hip).  GIF_WINOGRAD=0 forces the direct
@@ -410,8 +423,8 @@ def conv_fwd(big, w, spec: ConvSpec, wscale=1.0, keep_v=False, **epi):
     g = _geom(B, Hb, Wb, Cb, Hs, Ws, Cs, spec)
     e = _epilogue(out_bchw=(B, Cs, Hs, Ws), dtype=dt, **epi)
     if h2:  # f16x2 kernels + the bf16x3 packing for their guarded fallback
-        wp2, wp = pack_weight_h2x3(w, True, Cs, Cb, wscale)
-        _lib.check(_lib.load().gif_conv2d_fwd_f32h2(big.data_ptr(), wp2.data_ptr(), wp.data_ptr() if H2_GUARD else None, out.data_ptr(), ctypes.byref(g),
+        wp2, wp = pack_weight_h2x3(w, True, Cs, Cb, wscale, tapdense=dense)
+        _lib.check((_lib.load().gif_conv2d_fwd_f32h2_tapdense if dense else _lib.load().gif_conv2d_fwd_f32h2)(big.data_ptr(), wp2.data_ptr(), wp.data_ptr() if H2_GUARD else None, out.data_ptr(), ctypes.byref(g),
                                                     ctypes.byref(e), _stream()), "conv2d_fwd_f32h2")
         return out
     fn = _lib.load().gif_conv2d_fwd_f32x3_tapdense if dense else _lib.load().gif_conv2d_fwd_f32x3 if x3 else _fn("conv2d_fwd", dt)
@@ -438,8 +451,8 @@ def conv_bwd_data(small, w, spec: ConvSpec, big_hw, wscale=1.0, **epi):
     g = _geom(B, Hb, Wb, Cb, Hs, Ws, Cs, spec)
     e = _epilogue(out_bchw=(B, Cb, Hb, Wb), dtype=dt, **epi)
     if h2:
-        wp2, wp = pack_weight_h2x3(w, False, Cb, Cs, wscale)
-        _lib.check(_lib.load().gif_conv2d_bwd_data_f32h2(small.data_ptr(), wp2.data_ptr(), wp.data_ptr() if H2_GUARD else None, out.data_ptr(), ctypes.byref(g),
+        wp2, wp = pack_weight_h2x3(w, False, Cb, Cs, wscale, tapdense=dense)
+        _lib.check((_lib.load().gif_conv2d_bwd_data_f32h2_tapdense if dense else _lib.load().gif_conv2d_bwd_data_f32h2)(small.data_ptr(), wp2.data_ptr(), wp.data_ptr() if H2_GUARD else None, out.data_ptr(), ctypes.byref(g),
                                                          ctypes.byref(e), _stream()), "conv2d_bwd_data_f32h2")
         return out
     fn = (_lib.load().gif_conv2d_bwd_data_f32x3_tapdense if dense else _lib.load().gif_conv2d_bwd_data_f32x3 if x3

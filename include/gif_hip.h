@@ -96,6 +96,10 @@ int gif_pack_weight_f32h2(const float* w, void* wp2, int R, int C, int KH, int K
 /* wp2 and wp3 (= gif_pack_weight_f32x3's output) of the same weights in one launch */
 int gif_pack_weight_f32h2x3(const float* w, void* wp2, void* wp3, int R, int C, int KH, int KW, int RP, int CP, int64_t sr, int64_t sc,
                             int64_t sky, int64_t skx, float scale, gif_stream_t stream);
+/* the tap-dense K order (below) for the f16x2 kernels: both packings in one launch */
+int64_t gif_pack_weight_f32h2_tapdense_bytes(int cin_act, int KH, int KW, int RP);
+int gif_pack_weight_f32h2x3_tapdense(const float* w, void* wp2, void* wp3, int R, int C, int cin_act, int KH, int KW, int RP, int64_t sr,
+                                     int64_t sc, int64_t sky, int64_t skx, float scale, gif_stream_t stream);
 /* out2[0] = guarded launches that took the bf16x3 fallback on the current device since the last reset (synchronises the device) */
 int gif_h2_fallback_stats(uint64_t* out2, int reset);
 /* Tap-dense K order for 3x3 layers with 8 <= cin_act < 32 contraction channels (the condition-noise convs 6->12->24 and the 24->C
@@ -241,6 +245,10 @@ int gif_conv2d_fwd_f32h2(const float* big, const void* wp2, const void* wp3, flo
                          const gif_conv_epilogue* e, gif_stream_t stream);
 int gif_conv2d_bwd_data_f32h2(const float* small, const void* wp2, const void* wp3, float* big, const gif_conv_geom* g,
                               const gif_conv_epilogue* e, gif_stream_t stream);
+int gif_conv2d_fwd_f32h2_tapdense(const float* big, const void* wp2, const void* wp3, float* small, const gif_conv_geom* g,
+                                  const gif_conv_epilogue* e, gif_stream_t stream);
+int gif_conv2d_bwd_data_f32h2_tapdense(const float* small, const void* wp2, const void* wp3, float* big, const gif_conv_geom* g,
+                                       const gif_conv_epilogue* e, gif_stream_t stream);
 int gif_conv2d_fwd_f32x3_tapdense(const float* big, const void* wp3, float* small, const gif_conv_geom* g,
                                   const gif_conv_epilogue* e, gif_stream_t stream);
 int gif_conv2d_bwd_data_f32x3_tapdense(const float* small, const void* wp3, float* big, const gif_conv_geom* g,

@@ -418,3 +418,44 @@ def test_f16x2_weight_gradient_growing_and_sparse_channels():
         out[mode] = _err(ops.conv_wgrad(gy, x, spec, C, C), ref)
     assert ops.h2_fallback_stats() == 0
     assert out["f16x2"] <= 1.5 * out["native"] + 2e-7, out
+
+
+# ------------------------------------------------------------------------------------------------ tap-dense K order on the f16x2 kernels
+@pytest.mark.parametrize("case", [(4, 24, 128, 1, 96), (4, 12, 24, 1, 64), (3, 24, 256, 1, 40), (2, 28, 64, 1, 24), (4, 24, 64, 2, 33)])
+def test_f16x2_tapdense_forward_and_data_gradient_vs_fp64(case, monkeypatch):
+    """3x3 layers with 8..28 contraction channels (the condition-noise convs and the 24 -> C layers): K runs densely over (tap, channel),
+    a 16-element K group may straddle two taps; forward with the fused epilogue and the stride-1 data gradient."""
+    from gif_amd import ops
+    B, ci, co, st, h = case
+    torch.manual_seed(sum(case))
+    pad = 1 if st == 1 else 0
+    spec = ops.ConvSpec(3, 3, st, pad)
+    # force the mode for every case (the dispatch keeps some thin launches on their old kernels: measured, ops.x3_tapdense)
+    monkeypatch.setattr(ops, "x3_tapdense", lambda dt, cin, sp, tr, epi, cout=64: (
+        ops.X3_TAPDENSE and 8 <= cin < 32 and not (tr and sp.stride != 1) and epi.get("in_scale") is None and ops.split_mode()))
+    x = _cl(torch.randn(B, ci, h, h, device="cuda"))
+    w = torch.randn(co, ci, 3, 3, device="cuda") / (ci * 9) ** 0.5
+    bias = torch.randn(ops.pad4(co), device="cuda")
+    hs = spec.small_hw(h, h)[0]
+    res = _cl(torch.randn(B, ops.pad4(co), hs, hs, device="cuda"))
+    ref = F.conv2d(x.double(), w.double(), stride=st, padding=pad)
+    ref_e = 2 ** 0.5 * F.leaky_relu(ref + res[:, :co].double() + bias[:co].double()[None, :, None, None], 0.2)
+    gy = _cl(torch.randn(B, ci, hs, hs, device="cuda"))
+    w2 = torch.randn(ci, co, 3, 3, device="cuda") / (ci * 9) ** 0.5
+    op = h - ((hs - 1) * st + 3 - 2 * pad)
+    ref_d = F.conv_transpose2d(gy.double(), w2.double(), stride=st, padding=pad, output_padding=op)
+    e = {}
+    for mode in ("native", "f16x2"):
+        ops.set_fp32_mfma_mode(mode)
+        e[mode] = (_err(ops.conv_fwd(x, w, spec)[:, :co], ref),
+                   _err(ops.conv_fwd(x, w, spec, bias=bias, residual=res, act=True)[:, :co], ref_e),
+                   _err(ops.conv_bwd_data(gy, w2, spec, (h, h))[:, :co], ref_d))
+    assert ops.h2_fallback_stats() == 0
+    for en, ex in zip(e["native"], e["f16x2"]):
+        assert en < 1e-5 and ex <= 1.5 * en + 2e-7, (case, e)
+    # the same launch in bf16x3 mode (its tap-dense kernel): same result at fp32 accuracy, padding channels zero
+    ops.set_fp32_mfma_mode("f16x2")
+    y2 = ops.conv_fwd(x, w, spec)
+    ops.set_fp32_mfma_mode("bf16x3")
+    y3 = ops.conv_fwd(x, w, spec)
+    assert _err(y2, y3.double()) < 5e-6 and (y2[:, co:] == 0).all()
