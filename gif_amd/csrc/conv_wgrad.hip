@@ -631,6 +631,244 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q, (X3 == 2 && WAVES_P * 
         }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// f16x2 weight gradient, cooperative pre-split through LDS ("v2", round 5).  In conv_wgrad_mfma<..., 2> every wave gathers its operand
+// fragments with eight ds_read_b32 each and splits them itself: every element is read and split by TWO waves (2 x 2 wave layout) and the
+// loop is VALU-bound (136 VALU per 12 MFMAs).  Here a stage (32 pixels x 128 + 128 channels of fp32, landed by LDS-DMA as before) is
+// converted ONCE: thread c of the 256 owns channel c (0..127: small side, 128..255: big side), reads its 32 pixels (conflict free:
+// consecutive threads = consecutive channels), keeps the channel's running exponent PRIVATELY (no lane exchange), splits them into
+// the two f16 terms and writes them as two 64-byte rows [channel][32 pixels] — the layout of the pre-split weights of the direct
+// kernel (16-byte chunks XOR-swizzled with (row >> 2) & 3): an MFMA operand (8 consecutive pixels of one channel) is then ONE
+// ds_read_b128 per term.  Per thread and stage: ~120 VALU + 24 LDS operations for the conversion, 16 ds_read_b128 + 24 MFMAs for the
+// products (before: 272 VALU, 64 ds_read_b32).  Exponent changes travel through a small LDS array: the converting thread stores its
+// channel's change, raises the stage's flag, and the MFMA waves multiply their accumulators (rows and columns) before the stage's
+// products.  LDS: raw fp32 stage 32 KB (single buffer: the next stage's DMA is issued once the conversion has read it) + operand
+// planes 32 KB => two workgroups per CU, whose phases interleave.  128 x 128 tiles, 4 waves as 2 x 2.
+template <bool TAB>
+__global__ void __launch_bounds__(256, 2) conv_wgrad_h2v2(const WgradParams p) {
+    constexpr int BP = 128, BQ = 128, BKP = 32, THREADS = 256, MT = 2, NT = 2, P_ROWS = 8, Q_ROWS = 8, P_IT = 4, Q_IT = 4;
+    extern __shared__ __attribute__((aligned(16))) float wg_smem[];
+    float (*Ps)[BP] = reinterpret_cast<float (*)[BP]>(wg_smem);                         // [32][128] fp32
+    float (*Qs)[BQ] = reinterpret_cast<float (*)[BQ]>(wg_smem + BKP * BP);              // [32][128] fp32
+    unsigned short* Op = reinterpret_cast<unsigned short*>(wg_smem + BKP * (BP + BQ));  // [2 terms][256 channels][32 pixels] f16
+    int* dexp = reinterpret_cast<int*>(Op + 2 * 256 * 32);                              // [256] exponent change of the stage
+    int* fexp = dexp + 256;                                                             // [256] final exponents
+    int* flags = fexp + 256;                                                            // [0], [1]: a channel changed (stage parity); [2], [3]: narrow group on the P / Q side
+    float* Stab = reinterpret_cast<float*>(flags + 8);                                  // TAB: [stab_nb][256]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wp0 = (wave >> 1) * 64, wq0 = (wave & 1) * 64;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = lid % p.tiles_pq;
+    const int t = (lid / p.tiles_pq) % p.T;
+    const int split = lid / (p.tiles_pq * p.T);
+    const int tq = tile % p.tiles_q, tp = tile / p.tiles_q;
+    const int r0 = tp * BP, c0 = tq * BQ;
+    const bool planes = p.sm_plane != 0;
+    const int ky = planes ? 0 : t / p.KW, kx = planes ? 0 : t - ky * p.KW;
+    const float* const smb = static_cast<const float*>(p.sm) + (size_t)t * p.sm_plane;
+    const float* const bgb = static_cast<const float*>(p.bg) + (size_t)t * p.bg_plane;
+    const float* const pzero = static_cast<const float*>(p.zero);
+    const int n_begin = (int)((long)split * p.chunk);
+    int n_end = n_begin + (int)p.chunk;
+    if (n_end > (int)p.Ntot) n_end = (int)p.Ntot;
+    const unsigned HWs = (unsigned)(p.Hs * p.Ws);
+
+    const int p_row = tid / (BP / 4), p_ch = r0 + (tid % (BP / 4)) * 4;
+    const int q_row = tid / (BQ / 4), q_ch = c0 + (tid % (BQ / 4)) * 4;
+    const bool p_ch_ok = p_ch < p.Cs, q_ch_ok = q_ch < p.Cb;
+    int tab_row = 0, tab_rem = 0;
+    if (tid < 8) flags[tid] = 0;
+    if (TAB) {
+        const int b_first = n_begin / (int)HWs;
+        for (int e = tid; e < p.stab_nb * (BP + BQ); e += THREADS) {
+            int bl = e / (BP + BQ), c = e - bl * (BP + BQ);
+            int b = b_first + bl;
+            float v = 0.f;
+            if (b < p.B) {
+                if (c < BP) v = (r0 + c < p.Cs) ? (p.ss ? p.ss[(size_t)b * p.Cs + r0 + c] : 1.f) : 0.f;
+                else v = (c0 + c - BP < p.Cb) ? (p.bs ? p.bs[(size_t)b * p.Cb + c0 + c - BP] : 1.f) : 0.f;
+            }
+            Stab[e] = v;
+        }
+        tab_rem = n_begin - b_first * (int)HWs;
+    }
+    int p_n[P_IT], q_n[Q_IT], q_b[Q_IT], q_oy[Q_IT], q_ox[Q_IT];
+#pragma unroll
+    for (int it = 0; it < P_IT; ++it) p_n[it] = n_begin + p_row + it * P_ROWS;
+#pragma unroll
+    for (int it = 0; it < Q_IT; ++it) {
+        int n = n_begin + q_row + it * Q_ROWS;
+        q_n[it] = n;
+        unsigned b = (unsigned)n / HWs;
+        unsigned r = (unsigned)n - b * HWs;
+        unsigned oy = r / (unsigned)p.Ws;
+        q_b[it] = (int)b; q_oy[it] = (int)oy; q_ox[it] = (int)(r - oy * (unsigned)p.Ws);
+    }
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto load_global = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < P_IT; ++it) {
+            const bool ok = p_ch_ok && p_n[it] < n_end;
+            const float* g = ok ? smb + (p_n[it] * p.Cs + p_ch) : pzero;
+            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(&Ps[it * P_ROWS][0] + wave_u * 256), 16, 0, 0);
+            p_n[it] += BKP;
+        }
+#pragma unroll
+        for (int it = 0; it < Q_IT; ++it) {
+            const int iy = q_oy[it] * p.stride + ky - p.pad, ix = q_ox[it] * p.stride + kx - p.pad;
+            const bool ok = q_ch_ok && q_n[it] < n_end && (unsigned)iy < (unsigned)p.Hb && (unsigned)ix < (unsigned)p.Wb;
+            const float* g = ok ? bgb + (((q_b[it] * p.Hb + iy) * p.Wb + ix) * p.Cb + q_ch) : pzero;
+            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(&Qs[it * Q_ROWS][0] + wave_u * 256), 16, 0, 0);
+            q_n[it] += BKP;
+            q_ox[it] += BKP;
+            if (p.Ws >= BKP) {  // uniform: at most one row wrap per stage
+                const bool wx = q_ox[it] >= p.Ws;
+                q_ox[it] -= wx ? p.Ws : 0;
+                q_oy[it] += wx ? 1 : 0;
+                const bool wy = q_oy[it] >= p.Hs;
+                q_oy[it] -= wy ? p.Hs : 0;
+                q_b[it] += wy ? 1 : 0;
+            } else {
+                while (q_ox[it] >= p.Ws) { q_ox[it] -= p.Ws; ++q_oy[it]; }
+                while (q_oy[it] >= p.Hs) { q_oy[it] -= p.Hs; ++q_b[it]; }
+            }
+        }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- this thread's channel (conversion role): running exponent and the guard's statistics, all private
+    const float* const rawcol = tid < 128 ? &Ps[0][tid] : &Qs[0][tid - 128];
+    unsigned short* const oprow = Op + tid * 32;
+    const int wsw = (tid >> 2) & 3;
+    int h_ex = 126;
+    float h_sc = gif::h2_pow2(126), h_lim = gif::kH2Limit * gif::h2_pow2(-126), h_max = 0.f;
+    unsigned h_gmin = 0xFFFFFFFFu;
+    auto convert = [&](int par) __attribute__((always_inline)) {
+        float v[32];
+#pragma unroll
+        for (int e = 0; e < 32; ++e) v[e] = rawcol[e * 128];
+        if (TAB) {
+            const float sv = Stab[tab_row * (BP + BQ) + tid];
+#pragma unroll
+            for (int e = 0; e < 32; ++e) v[e] *= sv;
+            tab_rem += BKP;
+            if (tab_rem >= (int)HWs) { tab_rem -= (int)HWs; ++tab_row; }
+        }
+        float m0 = 0.f, m1 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { m0 = fmaxf(m0, fabsf(v[e])); m1 = fmaxf(m1, fabsf(v[16 + e])); }
+        const float m = fmaxf(m0, m1);
+        h_max = fmaxf(h_max, m);
+        h_gmin = min(h_gmin, min(__float_as_uint(m0) - 1u, __float_as_uint(m1) - 1u));
+        int d = 0;
+        if (m > h_lim) {  // this channel outgrew its exponent (private state: plain divergence; rare after the first stages)
+            const int ne = gif::h2_exp_for(__float_as_uint(m), gif::kH2Target);
+            d = ne - h_ex;
+            h_ex = ne;
+            h_sc = gif::h2_pow2(ne);
+            h_lim = ldexpf(gif::kH2Limit, -ne);
+            atomicOr(&flags[par], 1);
+        }
+        dexp[tid] = d;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {  // 8 pixels = one 16-byte chunk of each term
+            gif::u32x4_t hi4, lo4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                unsigned h, l;
+                gif::split_pair_h2(v[8 * j + 2 * k], v[8 * j + 2 * k + 1], h_sc, h, l);
+                hi4[k] = h; lo4[k] = l;
+            }
+            const int phys = (j ^ wsw) << 3;
+            *reinterpret_cast<gif::u32x4_t*>(oprow + phys) = hi4;
+            *reinterpret_cast<gif::u32x4_t*>(oprow + 256 * 32 + phys) = lo4;
+        }
+    };
+    // ---- product role
+    const int rsw = (li >> 2) & 3;  // (row >> 2) & 3 of every operand row this lane reads (tile bases are multiples of 32)
+    auto products = [&](int par) __attribute__((always_inline)) {
+        if (flags[par] != 0) {  // workgroup-uniform: some channel of this stage changed its exponent: acc *= 2^(row change + column change)
+            int dc[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) dc[j] = dexp[128 + wq0 + j * 32 + li];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dr = dexp[wp0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j][r] = ldexpf(acc[i][j][r], dr + dc[j]);
+                }
+        }
+        if (tid == 0) flags[par ^ 1] = 0;  // the next stage's conversions raise it again (they start behind the next barrier)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            gif::u32x4_t sa[2][MT], sb[2][NT];
+            const int ch = ((2 * g + lh) ^ rsw) << 3;
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) sa[tt][i] = *reinterpret_cast<const gif::u32x4_t*>(Op + (tt * 256 + wp0 + i * 32 + li) * 32 + ch);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) sb[tt][j] = *reinterpret_cast<const gif::u32x4_t*>(Op + (tt * 256 + 128 + wq0 + j * 32 + li) * 32 + ch);
+            }
+            constexpr int TA3[3] = {1, 0, 0}, TB3[3] = {0, 1, 0};  // lo*hi, hi*lo, hi*hi
+#pragma unroll
+            for (int t3 = 0; t3 < 3; ++t3)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gif::f16x8_t, sa[TA3[t3]][i]),
+                                                                           __builtin_bit_cast(gif::f16x8_t, sb[TB3[t3]][j]), acc[i][j], 0, 0, 0);
+        }
+    };
+
+    if (n_begin < n_end) {
+        load_global();
+        int par = 0;
+        for (int n0 = n_begin; n0 < n_end; n0 += BKP) {
+            __syncthreads();  // the stage's fp32 tiles have landed (vmcnt(0) of every wave); the previous stage's operand reads are done
+            convert(par);
+            __syncthreads();  // operand planes complete; the raw buffer is free again
+            if (n0 + BKP < n_end) load_global();
+            __builtin_amdgcn_sched_barrier(0);
+            products(par);
+            par ^= 1;
+        }
+    }
+    // final exponents and the guard (a narrow group only costs accuracy where the other side is narrow too: common.h)
+    __syncthreads();
+    fexp[tid] = h_ex;
+    if ((int)(__float_as_uint(h_max) >> 23) - (int)((h_gmin + 1u) >> 23) > gif::kH2Window) atomicOr(&flags[tid < 128 ? 2 : 3], 1);
+    __syncthreads();
+    if (tid == 0 && p.gate && flags[2] != 0 && flags[3] != 0) atomicMax(p.gate, p.gate_gen);
+    int ec[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) ec[j] = fexp[128 + wq0 + j * 32 + li];
+    float* out = p.ws + ((size_t)split * p.T + t) * p.RP * p.CP;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rl = wp0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int er = fexp[rl];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) out[(size_t)(r0 + rl) * p.CP + c0 + wq0 + j * 32 + li] = ldexpf(acc[i][j][r], -(er + ec[j]));
+        }
+}
+
 template <typename T, int BP, int BQ, int WP_, int WQ_, bool GLDS, int BKP, bool TAB = false, int X3 = 0>
 void wgrad_launch(dim3 grid, int threads, hipStream_t s, const WgradParams& p) {
     static gif::LdsAttr attr;
@@ -639,6 +877,23 @@ void wgrad_launch(dim3 grid, int threads, hipStream_t s, const WgradParams& p) {
     auto kern = conv_wgrad_mfma<T, BP, BQ, WP_, WQ_, GLDS, BKP, TAB, X3>;
     attr.ensure(reinterpret_cast<const void*>(kern), lds);
     hipLaunchKernelGGL(kern, grid, dim3(threads), lds, s, p);
+}
+
+// GIF_H2_WGRAD_V2=0: the per-wave-split f16x2 kernel (conv_wgrad_mfma<..., 2>) instead of the cooperative pre-split one (A/B)
+inline bool h2v2_on() {
+    static const int on = getenv("GIF_H2_WGRAD_V2") ? atoi(getenv("GIF_H2_WGRAD_V2")) != 0 : 1;
+    return on != 0;
+}
+inline void wgrad_launch_v2(bool tab, dim3 grid, hipStream_t s, const WgradParams& p) {
+    static gif::LdsAttr attr[2];
+    const size_t lds = (size_t)32 * 256 * 4 + (size_t)2 * 256 * 32 * 2 + (size_t)(512 + 8) * 4 + (size_t)(tab ? p.stab_nb * 256 : 0) * sizeof(float);
+    if (tab) {
+        attr[1].ensure(reinterpret_cast<const void*>(conv_wgrad_h2v2<true>), lds);
+        hipLaunchKernelGGL(conv_wgrad_h2v2<true>, grid, dim3(256), lds, s, p);
+    } else {
+        attr[0].ensure(reinterpret_cast<const void*>(conv_wgrad_h2v2<false>), lds);
+        hipLaunchKernelGGL(conv_wgrad_h2v2<false>, grid, dim3(256), lds, s, p);
+    }
 }
 
 // wgrad tiles follow the SAME row/col padding as the forward packing (gif_conv2d_pack_dims(Cs, Cb)):
@@ -1540,6 +1795,7 @@ static int conv2d_wgrad_f32_impl(const float* small, const float* big, float* ws
             const gif::H2Gate gt = gif::h2_next_gate();
             p.gate = gt.word; p.gate_gen = gt.gen; p.h2_stats = gif::h2_stats_words();
             if (x3_thin) wgrad_launch<float, 128, 32, 2, 1, true, 32, false, 2>(grid, 128, s, p);
+            else if (h2v2_on()) wgrad_launch_v2(tab, grid, s, p);
             else if (tab) wgrad_launch<float, 128, 128, 2, 2, true, 32, true, 2>(grid, 256, s, p);
             else wgrad_launch<float, 128, 128, 2, 2, true, 32, false, 2>(grid, 256, s, p);
         }
@@ -1670,7 +1926,8 @@ static int conv3x3_winograd_wgrad_impl(const float* x, const float* gy, float* V
     if (h2) {
         const gif::H2Gate gt = gif::h2_next_gate();
         p.gate = gt.word; p.gate_gen = gt.gen; p.h2_stats = gif::h2_stats_words();
-        wgrad_launch<float, 128, 128, 2, 2, true, 32, false, 2>(grid, 256, s, p);
+        if (h2v2_on()) wgrad_launch_v2(false, grid, s, p);
+        else wgrad_launch<float, 128, 128, 2, 2, true, 32, false, 2>(grid, 256, s, p);
     }
     if (h2 && !p.gate) {}
     else if (x3 && !x3_simple) wgrad_launch<float, 128, 128, 2, 2, true, 32, false, 1>(grid, 256, s, p);
