@@ -768,7 +768,7 @@ __global__ void __launch_bounds__(512, 1) wino_gemm_x3(const WinoParams p) {
 // accumulator AND the four output accumulators of that row are multiplied by the exact power of two (160 registers, rare).
 // U2 = gif_winograd_weight_f32h2: [16][2][RP][CP] f16 planes of G g G^T * 2^e_row, one exponent per output channel over all positions.
 // Block 128 x 128, 8 waves as 4 (M) x 2 (N), wave tile 32 tiles x 64 couts, 3-stage ring: 48 KB of fp32 V + 48 KB of f16 planes.
-template <int BM = 128, int BN = 128>
+template <int BM = 128, int BN = 128, int NST = 3>
 __global__ void __launch_bounds__(512, 1) wino_gemm_h2(const WinoParams p) {
     constexpr int THREADS = 512, PROWS = THREADS / 8;
     constexpr int LD = WBK, CH = WBK / 4, RB = 64 / WBK, RPW = 64 / CH;
@@ -778,8 +778,8 @@ __global__ void __launch_bounds__(512, 1) wino_gemm_h2(const WinoParams p) {
     constexpr int B2_BLK = 2 * BN / 16;     // 16 one-KiB blocks (16 rows x 64 B) per stage
     constexpr int B2_IT = B2_BLK / 8;       // 2 per wave
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                                                                    // [NSTAGE][BM][LD] fp32
-    unsigned short* B2 = reinterpret_cast<unsigned short*>(smem + WNSTAGE * BM * LD);   // [NSTAGE][2][BN][32] f16
+    float* As = smem;                                                                    // [NST][BM][LD] fp32
+    unsigned short* B2 = reinterpret_cast<unsigned short*>(smem + NST * BM * LD);       // [NST][2][BN][32] f16
     const unsigned short* const U2 = reinterpret_cast<const unsigned short*>(p.U);
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -942,10 +942,15 @@ __global__ void __launch_bounds__(512, 1) wino_gemm_h2(const WinoParams p) {
         for (int j = 0; j < NT; ++j) acc[j] = (f32x16)(0.f);
     };
 
-    // DMA instructions per stage and wave: 2 (V) + 2 (planes): the newest stage stays in flight
-    auto wait_newest_in_flight = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); };
-    issue(0);
-    issue(1);  // nsteps >= 16
+    // DMA instructions per stage and wave: 2 (V) + 2 (planes); NST - 2 stages stay in flight across the barrier (ring of NST stages)
+    auto wait_newest_in_flight = [&]() __attribute__((always_inline)) {
+        if (NST == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (NST == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    };
+    static_assert(NST >= 3 && NST <= 5, "ring depth");
+#pragma unroll
+    for (int st = 0; st < NST - 1; ++st) issue(st);  // nsteps >= 16
     wait_newest_in_flight();
     __builtin_amdgcn_s_barrier();
     read_a(0, 0);
@@ -957,13 +962,14 @@ __global__ void __launch_bounds__(512, 1) wino_gemm_h2(const WinoParams p) {
 
     int cur = 0, kc_in_pos = 0, pos = 0;
     for (int step = 0; step < nsteps; ++step) {
-        if (step + 2 < nsteps) issue(cur >= 1 ? cur - 1 : 2);  // (cur + 2) % 3: last read before the previous stage's barrier
+        if (step + NST - 1 < nsteps) issue(cur >= 1 ? cur - 1 : NST - 1);  // (cur + NST - 1) % NST: last read before the previous stage's barrier
         __builtin_amdgcn_sched_barrier(0);
         group(0, cur, 1);
-        if (step + 2 < nsteps) wait_newest_in_flight();
+        // stage step + 1 must have landed before its operands are read (this stage's are all in registers by now)
+        if (step + NST - 1 < nsteps) wait_newest_in_flight();
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        cur = cur == 2 ? 0 : cur + 1;
+        cur = cur == NST - 1 ? 0 : cur + 1;
         group(1, cur, 0);  // (after the last stage this prepares operands nobody uses: the reads stay inside the ring)
         if (++kc_in_pos == kchunks) {
             fold(pos);
@@ -1395,10 +1401,21 @@ static int conv3x3_winograd_x3_impl(const float* x, const void* U2, const void* 
             const gif::H2Gate gt = gif::h2_next_gate();
             q.gate = gt.word; q.gate_gen = gt.gen;
         }
-        const size_t lds2 = (size_t)WNSTAGE * ((size_t)128 * WBK * sizeof(float) + 2 * (size_t)128 * 64);
-        static gif::LdsAttr attr2;
-        attr2.ensure(reinterpret_cast<const void*>(wino_gemm_h2<128, 128>), lds2);
-        hipLaunchKernelGGL((wino_gemm_h2<128, 128>), grid, dim3(512), lds2, s, q);
+        // ring depth 3 / 4 / 5 (96 / 128 / 160 KB): measured equal — 2.648 / 2.638 / 2.686 ms on 128 -> 128 at 256^2, batch 32: the GEMM does
+        // not wait for its DMA; GIF_WINO_H2_STAGES keeps the A/B
+        static const int nst = getenv("GIF_WINO_H2_STAGES") ? atoi(getenv("GIF_WINO_H2_STAGES")) : 3;
+        const size_t lds2 = (size_t)(nst == 3 ? 3 : nst == 5 ? 5 : 4) * ((size_t)128 * WBK * sizeof(float) + 2 * (size_t)128 * 64);
+        static gif::LdsAttr attr2[3];
+        if (nst == 3) {
+            attr2[0].ensure(reinterpret_cast<const void*>(wino_gemm_h2<128, 128, 3>), lds2);
+            hipLaunchKernelGGL((wino_gemm_h2<128, 128, 3>), grid, dim3(512), lds2, s, q);
+        } else if (nst == 5) {
+            attr2[2].ensure(reinterpret_cast<const void*>(wino_gemm_h2<128, 128, 5>), lds2);
+            hipLaunchKernelGGL((wino_gemm_h2<128, 128, 5>), grid, dim3(512), lds2, s, q);
+        } else {
+            attr2[1].ensure(reinterpret_cast<const void*>(wino_gemm_h2<128, 128, 4>), lds2);
+            hipLaunchKernelGGL((wino_gemm_h2<128, 128, 4>), grid, dim3(512), lds2, s, q);
+        }
         if (!q.gate) {  // unguarded
             if (int rc = sums.finish(p, B, H, W, Co, bm, s)) return rc;
             return gif::check_launch("conv3x3_winograd_f32h2");

@@ -12,11 +12,12 @@ from gif_amd import _lib, ops  # noqa: E402
 lib = _lib.load()
 read = lib.gif_debug_x3_probe_read
 read.restype, read.argtypes = ctypes.c_int, [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
-ops.set_fp32_mfma_mode("bf16x3")
+MODE = os.environ.get("GIF_PROBE_MODE", "bf16x3")
+ops.set_fp32_mfma_mode(MODE)
 ops.WINOGRAD = False
 B = 32
 out = (ctypes.c_ulonglong * 4)()
-print("bf16x3 direct kernel, per wave and K loop: share of the loop's cycles spent waiting for the wave's own DMA (s_waitcnt vmcnt(0)) and at the barrier")
+print(MODE + " direct kernel, per wave and K loop: share of the loop's cycles spent waiting for the wave's own DMA (s_waitcnt vmcnt(0)) and at the barrier")
 for name, cin, cout, H, k, stride in (("128->128 3x3 @256", 128, 128, 256, 3, 1), ("256->256 3x3 @128", 256, 256, 128, 3, 1),
                                       ("512->512 3x3 @64", 512, 512, 64, 3, 1), ("512->512 3x3 @16", 512, 512, 16, 3, 1),
                                       ("128->256 3x3 s2 @256", 128, 256, 257, 3, 2), ("256->128 1x1 @256", 256, 128, 256, 1, 1)):
