@@ -934,7 +934,11 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
         const long long probe_t0 = clock64();
 #endif
         for (int step = 0; step + 1 < nsteps; ++step) {
+#ifdef GIF_NO_DMA_PROBE  // timing probe (tools/probes/no_dma_probe.sh): the K loop without its LDS-DMA issue — results are WRONG
+            if (step < 1) issue(cur ^ 1);
+#else
             issue(cur ^ 1);
+#endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int g = 0; g + 1 < KG; ++g) {
