@@ -40,6 +40,8 @@ struct WgradParams {
     unsigned* gate;
     unsigned gate_gen;
     unsigned* h2_stats;
+    // conv_wgrad_h2v2<.., TAPS>: the 128 tile columns hold `tpt` taps x Cb channels (thin big side), `tgroups` column tiles cover the T taps
+    int tpt, tgroups;
 };
 
 // XCD-aware, bijective block remap: XCD k (= blockIdx % 8 by dispatch order) gets a contiguous range of logical ids.
@@ -644,7 +646,10 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q, (X3 == 2 && WAVES_P * 
 // channel's change, raises the stage's flag, and the MFMA waves multiply their accumulators (rows and columns) before the stage's
 // products.  LDS: raw fp32 stage 32 KB (single buffer: the next stage's DMA is issued once the conversion has read it) + operand
 // planes 32 KB => two workgroups per CU, whose phases interleave.  128 x 128 tiles, 4 waves as 2 x 2.
-template <bool TAB>
+// TAPS (round 5, thin big side: the 24-channel condition-noise maps): a 128 x 32 tile per tap stages 16 KB of gy for every 4 KB of x and
+// sits on the LDS-DMA fill rate (13 FLOP per staged byte: 80 TFLOP/s measured).  Here the 128 tile columns are `tpt` TAPS x Cb channels
+// (5 x 24): gy is staged once per 5 taps, every column's thread gathers x at ITS tap's shift; 9 taps = 2 column tiles.
+template <bool TAB, bool TAPS = false>
 __global__ void __launch_bounds__(256, 2) conv_wgrad_h2v2(const WgradParams p) {
     constexpr int BP = 128, BQ = 128, BKP = 32, THREADS = 256, MT = 2, NT = 2, P_ROWS = 8, Q_ROWS = 8, P_IT = 4, Q_IT = 4;
     extern __shared__ __attribute__((aligned(16))) float wg_smem[];
@@ -661,14 +666,18 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_h2v2(const WgradParams p) {
     const int wp0 = (wave >> 1) * 64, wq0 = (wave & 1) * 64;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int tile = lid % p.tiles_pq;
-    const int t = (lid / p.tiles_pq) % p.T;
-    const int split = lid / (p.tiles_pq * p.T);
+    const int TG = TAPS ? p.tgroups : p.T;
+    const int t = (lid / p.tiles_pq) % TG;  // TAPS: the tap GROUP
+    const int split = lid / (p.tiles_pq * TG);
     const int tq = tile % p.tiles_q, tp = tile / p.tiles_q;
-    const int r0 = tp * BP, c0 = tq * BQ;
-    const bool planes = p.sm_plane != 0;
-    const int ky = planes ? 0 : t / p.KW, kx = planes ? 0 : t - ky * p.KW;
-    const float* const smb = static_cast<const float*>(p.sm) + (size_t)t * p.sm_plane;
-    const float* const bgb = static_cast<const float*>(p.bg) + (size_t)t * p.bg_plane;
+    const int r0 = tp * BP, c0 = TAPS ? 0 : tq * BQ;
+    const bool planes = !TAPS && p.sm_plane != 0;
+    // TAPS: this thread's four staged columns belong to tap t * tpt + q_tl (lanes past the last tap stage zeros)
+    const int q_tl = TAPS ? ((tid % (BQ / 4)) * 4) / p.Cb : 0;
+    const int q_tap = TAPS ? t * p.tpt + q_tl : t;
+    const int ky = planes ? 0 : q_tap / p.KW, kx = planes ? 0 : q_tap - ky * p.KW;
+    const float* const smb = static_cast<const float*>(p.sm) + (TAPS ? 0 : (size_t)t * p.sm_plane);
+    const float* const bgb = static_cast<const float*>(p.bg) + (TAPS ? 0 : (size_t)t * p.bg_plane);
     const float* const pzero = static_cast<const float*>(p.zero);
     const int n_begin = (int)((long)split * p.chunk);
     int n_end = n_begin + (int)p.chunk;
@@ -676,8 +685,8 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_h2v2(const WgradParams p) {
     const unsigned HWs = (unsigned)(p.Hs * p.Ws);
 
     const int p_row = tid / (BP / 4), p_ch = r0 + (tid % (BP / 4)) * 4;
-    const int q_row = tid / (BQ / 4), q_ch = c0 + (tid % (BQ / 4)) * 4;
-    const bool p_ch_ok = p_ch < p.Cs, q_ch_ok = q_ch < p.Cb;
+    const int q_row = tid / (BQ / 4), q_ch = TAPS ? (tid % (BQ / 4)) * 4 - q_tl * p.Cb : c0 + (tid % (BQ / 4)) * 4;
+    const bool p_ch_ok = p_ch < p.Cs, q_ch_ok = TAPS ? (q_tl < p.tpt && q_tap < p.T) : q_ch < p.Cb;
     int tab_row = 0, tab_rem = 0;
     if (tid < 8) flags[tid] = 0;
     if (TAB) {
@@ -857,7 +866,18 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_h2v2(const WgradParams p) {
     int ec[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) ec[j] = fexp[128 + wq0 + j * 32 + li];
-    float* out = p.ws + ((size_t)split * p.T + t) * p.RP * p.CP;
+    float* out = p.ws + ((size_t)split * p.T + (TAPS ? 0 : t)) * p.RP * p.CP;
+    long ocol[NT];  // column offset inside the split's [T][RP][CP] block (TAPS: the column's own tap plane), < 0: padding column
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int c = wq0 + j * 32 + li;
+        if (TAPS) {
+            const int tl = c / p.Cb, tap = t * p.tpt + tl;
+            ocol[j] = (tl < p.tpt && tap < p.T) ? (long)tap * p.RP * p.CP + (c - tl * p.Cb) : -1;
+        } else {
+            ocol[j] = c0 + c;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -865,7 +885,8 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_h2v2(const WgradParams p) {
             const int rl = wp0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             const int er = fexp[rl];
 #pragma unroll
-            for (int j = 0; j < NT; ++j) out[(size_t)(r0 + rl) * p.CP + c0 + wq0 + j * 32 + li] = ldexpf(acc[i][j][r], -(er + ec[j]));
+            for (int j = 0; j < NT; ++j)
+                if (!TAPS || ocol[j] >= 0) out[(size_t)(r0 + rl) * p.CP + ocol[j]] = ldexpf(acc[i][j][r], -(er + ec[j]));
         }
 }
 
@@ -884,10 +905,25 @@ inline bool h2v2_on() {
     static const int on = getenv("GIF_H2_WGRAD_V2") ? atoi(getenv("GIF_H2_WGRAD_V2")) != 0 : 1;
     return on != 0;
 }
-inline void wgrad_launch_v2(bool tab, dim3 grid, hipStream_t s, const WgradParams& p) {
-    static gif::LdsAttr attr[2];
+// GIF_H2_WGRAD_TAPS=0: the thin-big-side layers on the 128 x 32 per-tap tiles (A/B)
+inline bool thin_taps_on() {
+    static const int on = getenv("GIF_H2_WGRAD_TAPS") ? atoi(getenv("GIF_H2_WGRAD_TAPS")) != 0 : 1;
+    return on != 0;
+}
+// taps per 128-column tile and the number of column tiles for a thin big side of Cb (<= 32) channels
+inline void thin_tap_tiles(int Cb, int T, int* tpt, int* tgroups) {
+    int n = 128 / Cb;
+    if (n > T) n = T;
+    *tpt = n;
+    *tgroups = (T + n - 1) / n;
+}
+inline void wgrad_launch_v2(bool tab, dim3 grid, hipStream_t s, const WgradParams& p, bool taps = false) {
+    static gif::LdsAttr attr[3];
     const size_t lds = (size_t)32 * 256 * 4 + (size_t)2 * 256 * 32 * 2 + (size_t)(512 + 8) * 4 + (size_t)(tab ? p.stab_nb * 256 : 0) * sizeof(float);
-    if (tab) {
+    if (taps) {
+        attr[2].ensure(reinterpret_cast<const void*>(conv_wgrad_h2v2<false, true>), lds);
+        hipLaunchKernelGGL((conv_wgrad_h2v2<false, true>), grid, dim3(256), lds, s, p);
+    } else if (tab) {
         attr[1].ensure(reinterpret_cast<const void*>(conv_wgrad_h2v2<true>), lds);
         hipLaunchKernelGGL(conv_wgrad_h2v2<true>, grid, dim3(256), lds, s, p);
     } else {
@@ -1711,6 +1747,13 @@ int gif_conv2d_wgrad_splits(const gif_conv_geom* g) {
     // (scaled launches of the same geometry use 128-row tiles: they simply get half the splits they could use)
     long Ntot = (long)g->B * g->Hs * g->Ws;
     long tiles = (long)(RP / tile_rows(g->Cs, g->Cb, false, Ntot)) * (CP / tile_of(g->Cb)) * g->KH * g->KW;
+    if (tile_of(g->Cs) == 128 && tile_of(g->Cb) == 32 && g->KH * g->KW > 1 && thin_taps_on()) {
+        // thin big side: the f16x2 kernel puts several taps into one column tile (fewer, larger workgroups per split); the count is
+        // only a count — the other kernels take the same one
+        int tpt, tg;
+        thin_tap_tiles(g->Cb, g->KH * g->KW, &tpt, &tg);
+        tiles = (long)(RP / 128) * tg;
+    }
     // 2 workgroups fit per CU (64 KB LDS each) => 512 concurrent slots on 256 CUs: fill k full rounds of 512
     // and never spill a few blocks into an extra, almost empty round (floor, not ceil)
     long want = tiles >= 1024 ? 1 : 1024 / tiles;
@@ -1794,7 +1837,12 @@ static int conv2d_wgrad_f32_impl(const float* small, const float* big, float* ws
         if (h2) {
             const gif::H2Gate gt = gif::h2_next_gate();
             p.gate = gt.word; p.gate_gen = gt.gen; p.h2_stats = gif::h2_stats_words();
-            if (x3_thin) wgrad_launch<float, 128, 32, 2, 1, true, 32, false, 2>(grid, 128, s, p);
+            if (x3_thin && thin_taps_on() && p.T > 1 && h2v2_on()) {
+                // several taps per 128-column tile (conv_wgrad_h2v2<false, true>); the guarded twin below keeps its per-tap grid
+                WgradParams q = p;
+                thin_tap_tiles(g->Cb, p.T, &q.tpt, &q.tgroups);
+                wgrad_launch_v2(false, dim3((unsigned)(p.tiles_pq * q.tgroups * nsplit)), s, q, true);
+            } else if (x3_thin) wgrad_launch<float, 128, 32, 2, 1, true, 32, false, 2>(grid, 128, s, p);
             else if (h2v2_on()) wgrad_launch_v2(tab, grid, s, p);
             else if (tab) wgrad_launch<float, 128, 128, 2, 2, true, 32, true, 2>(grid, 256, s, p);
             else wgrad_launch<float, 128, 128, 2, 2, true, 32, false, 2>(grid, 256, s, p);

@@ -359,7 +359,11 @@ WGRAD_CASES = [
     (4, 128, 128, 3, 1, 1, 64, False),    # 128x128 tiles, 9 taps, 113 splits: two workgroups per CU (the configuration that exposed the
                                           # packed-fp32 operand-select problem, conv_wgrad.hip)
     (4, 128, 256, 3, 2, 0, 65, False),    # stride 2
-    (4, 24, 128, 3, 1, 1, 64, False),     # thin big side: 128x32 tiles on two waves
+    (4, 24, 128, 3, 1, 1, 64, False),     # thin big side: 5 taps x 24 channels per 128-column tile (conv_wgrad_h2v2<.., TAPS>), 2 tiles
+    (2, 24, 256, 3, 1, 1, 33, False),     # ... two row tiles, pixel count not a multiple of the stage
+    (2, 28, 128, 3, 1, 1, 20, False),     # ... 4 taps x 28 channels, three column tiles (4 + 4 + 1 taps)
+    (2, 32, 160, 3, 1, 1, 16, False),     # ... 4 x 32: no padding columns inside the tile; ragged rows
+    (2, 20, 128, 3, 2, 0, 33, False),     # ... 6 x 20, stride 2
     (2, 256, 256, 1, 1, 0, 32, False),    # 1x1
     (3, 160, 96, 3, 1, 1, 20, False),     # ragged channel counts, pixel count not a multiple of the stage
     (32, 128, 128, 3, 1, 1, 32, False),   # batch 32
@@ -418,6 +422,29 @@ def test_f16x2_weight_gradient_growing_and_sparse_channels():
         out[mode] = _err(ops.conv_wgrad(gy, x, spec, C, C), ref)
     assert ops.h2_fallback_stats() == 0
     assert out["f16x2"] <= 1.5 * out["native"] + 2e-7, out
+
+
+def test_f16x2_thin_weight_gradient_guard_falls_back_per_tap():
+    """The multi-tap tile's guarded twin is the per-tap bf16x3 kernel on its own grid, same workspace: 16 input channels and the
+    gradient on half of every image row 2^-24 .. 2^24 apart make both sides wide -> the fallback runs and the result stays fp32-grade."""
+    from gif_amd import ops
+    g = torch.Generator().manual_seed(21)
+    B, ci, co, H = 2, 24, 128, 32
+    x = torch.randn(B, ci, H, H, generator=g)
+    gy = torch.randn(B, co, H, H, generator=g)
+    x[:, :, :, :16] *= 2.0 ** -24   # whole 16-pixel K groups of the centre-column taps
+    gy[:, :, :, :16] *= 2.0 ** 24
+    x, gy = _cl(x.cuda()), _cl(gy.cuda())
+    spec = ops.ConvSpec(3, 3, 1, 1)
+    wd = torch.zeros(co, ci, 3, 3, device="cuda", dtype=torch.float64, requires_grad=True)
+    (ref,) = torch.autograd.grad(F.conv2d(x.double(), wd, padding=1), wd, gy.double())
+    ops.set_fp32_mfma_mode("native")
+    en = _err(ops.conv_wgrad(gy, x, spec, co, ci), ref)
+    ops.set_fp32_mfma_mode("f16x2")
+    ops.h2_fallback_stats(reset=True)
+    ex = _err(ops.conv_wgrad(gy, x, spec, co, ci), ref)
+    assert ops.h2_fallback_stats(reset=True) == 1
+    assert ex <= 1.5 * en + 2e-7, (en, ex)
 
 
 # ------------------------------------------------------------------------------------------------ tap-dense K order on the f16x2 kernels
