@@ -893,8 +893,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_h2v2(const WgradParams p) {
 template <typename T, int BP, int BQ, int WP_, int WQ_, bool GLDS, int BKP, bool TAB = false, int X3 = 0>
 void wgrad_launch(dim3 grid, int threads, hipStream_t s, const WgradParams& p) {
     static gif::LdsAttr attr;
-    static const size_t lds_pad = getenv("GIF_WG_LDS_PAD") ? (size_t)atoi(getenv("GIF_WG_LDS_PAD")) : 0;  // debug: forces one workgroup per CU
-    const size_t lds = (size_t)2 * BKP * (BP + BQ) * sizeof(T) + (size_t)(TAB ? p.stab_nb * (BP + BQ) : 0) * sizeof(float) + lds_pad;
+    const size_t lds = (size_t)2 * BKP * (BP + BQ) * sizeof(T) + (size_t)(TAB ? p.stab_nb * (BP + BQ) : 0) * sizeof(float);
     auto kern = conv_wgrad_mfma<T, BP, BQ, WP_, WQ_, GLDS, BKP, TAB, X3>;
     attr.ensure(reinterpret_cast<const void*>(kern), lds);
     hipLaunchKernelGGL(kern, grid, dim3(threads), lds, s, p);
