@@ -1565,7 +1565,11 @@ int launch(GatherParams& p, hipStream_t s) {
             // workgroup per CU (112 KB + table), still two waves per SIMD, a quarter less operand traffic per MFMA.
             static const int big_off = getenv("GIF_X3_BIG") ? atoi(getenv("GIF_X3_BIG")) == 0 : 0;
             const long tn = p.RP / 128, tiles256 = (long)gif::cdiv(p.M, 256) * tn;
-            if (p.x3 && !big_off && tiles256 >= 512) {
+            // tap-dense layers (K = 9 taps x 8..28 channels: 3..7 stages): one 8-wave workgroup per CU spends most of a tile in its
+            // prologue and epilogue with nothing else resident; two 4-wave workgroups per CU on 128x128 tiles: 24 -> 256 at 128^2 129 ->
+            // 133 TFLOP/s, 24 -> 512 at 64^2 130 -> 134, the family in the step 8.57 -> 8.19 ms (GIF_DENSE_TILE=256: A/B)
+            static const int dense128 = getenv("GIF_DENSE_TILE") ? atoi(getenv("GIF_DENSE_TILE")) != 256 : 1;
+            if (p.x3 && !big_off && tiles256 >= 512 && !(p.dense && dense128)) {
                 const long slots = 256, full = tiles256 / slots, rem = tiles256 % slots;
                 if (!p.no_split && rem > 0 && rem * 2 <= slots && slots % tn == 0) {  // nearly empty last round: remainder rows on 64x64 tiles
                     const int M = p.M;
