@@ -640,7 +640,7 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q, (X3 == 2 && WAVES_P * 
 // converted ONCE: thread c of the 256 owns channel c (0..127: small side, 128..255: big side), reads its 32 pixels (conflict free:
 // consecutive threads = consecutive channels), keeps the channel's running exponent PRIVATELY (no lane exchange), splits them into
 // the two f16 terms and writes them as two 64-byte rows [channel][32 pixels] — the layout of the pre-split weights of the direct
-// kernel (16-byte chunks XOR-swizzled with (row >> 2) & 3): an MFMA operand (8 consecutive pixels of one channel) is then ONE
+// kernel (16-byte chunks XOR-swizzled, here with the f(row) below): an MFMA operand (8 consecutive pixels of one channel) is then ONE
 // ds_read_b128 per term.  Per thread and stage: ~120 VALU + 24 LDS operations for the conversion, 16 ds_read_b128 + 24 MFMAs for the
 // products (before: 272 VALU, 64 ds_read_b32).  Exponent changes travel through a small LDS array: the converting thread stores its
 // channel's change, raises the stage's flag, and the MFMA waves multiply their accumulators (rows and columns) before the stage's
@@ -759,7 +759,11 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_h2v2(const WgradParams p) {
     // ---- this thread's channel (conversion role): running exponent and the guard's statistics, all private
     const float* const rawcol = tid < 128 ? &Ps[0][tid] : &Qs[0][tid - 128];
     unsigned short* const oprow = Op + tid * 32;
-    const int wsw = (tid >> 2) & 3;
+    // 16-byte chunk swizzle of the operand planes: f(row) = bit 2 | (bit 1 ^ bit 3) << 1 of the row index.  ds_write_b128 is serviced in groups
+    // of 8 CONTIGUOUS lanes on 32 banks (two 64-byte rows per bank window), ds_read_b128 in the four non-contiguous 16-lane groups of the
+    // microarchitecture guide's LDS table on 64 banks; this f puts both on distinct 16-byte slots (the direct kernel's (row >> 2) & 3 is
+    // conflict free for the reads only: the conversion's stores ran 2-way, 109 M conflict cycles per launch in the round's PMC pass)
+    const int wsw = ((tid >> 2) & 1) | ((((tid >> 1) ^ (tid >> 3)) & 1) << 1);
     int h_ex = 126;
     float h_sc = gif::h2_pow2(126), h_lim = gif::kH2Limit * gif::h2_pow2(-126), h_max = 0.f;
     unsigned h_gmin = 0xFFFFFFFFu;
@@ -805,7 +809,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_h2v2(const WgradParams p) {
         }
     };
     // ---- product role
-    const int rsw = (li >> 2) & 3;  // (row >> 2) & 3 of every operand row this lane reads (tile bases are multiples of 32)
+    const int rsw = ((li >> 2) & 1) | ((((li >> 1) ^ (li >> 3)) & 1) << 1);  // f(row) of every operand row this lane reads (tile bases are multiples of 32)
     auto products = [&](int par) __attribute__((always_inline)) {
         if (flags[par] != 0) {  // workgroup-uniform: some channel of this stage changed its exponent: acc *= 2^(row change + column change)
             int dc[NT];
