@@ -476,9 +476,14 @@ __device__ __forceinline__ buf_rsrc_t make_buf_rsrc(const void*) { return {}; }
 __device__ __forceinline__ void buf_load_lds16(buf_rsrc_t, __attribute__((address_space(3))) void*, unsigned, int) {}
 #endif
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool SCALE, int BK, int X3 = 0>
+// NST: stages of the LDS operand ring.  2 everywhere except the 8-wave f16x2 kernel (one workgroup per CU: 3 x 48 KB fit), whose stage
+// is half as long as the bf16x3 one it replaced: with two stages the DMA of stage s + 1 is issued when stage s starts and a first-touch
+// (HBM) row is not there a stage later (x3_sync_probe, f16x2: 3-15 % of the K loop waiting for the wave's own DMA on 3x3 layers, 38 %
+// on 1x1); with three it has two stages to land.
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool SCALE, int BK, int X3 = 0, int NST = 2>
 __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, const int nwg) {
     constexpr bool F16 = sizeof(T) == 2;
+    static_assert(NST == 2 || (NST == 3 && X3 == 2), "three-stage ring: f16x2 schedule only");
     static_assert(!X3 || !F16, "the split path is an fp32 mode");
     constexpr int EPC = 16 / sizeof(T);  // elements per 16-byte chunk
     constexpr int LD = BK;             // unpadded LDS row (elements)
@@ -509,9 +514,9 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
         }
     }
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    T* As = reinterpret_cast<T*>(smem);  // [2][BM][LD]
-    T* Bs = As + 2 * BM * LD;            // [2][BN][LD]
-    unsigned short* const B3 = reinterpret_cast<unsigned short*>(Bs);  // X3: [2][NPL][BN][32] bf16 / f16
+    T* As = reinterpret_cast<T*>(smem);  // [NST][BM][LD]
+    T* Bs = As + NST * BM * LD;          // [NST][BN][LD]
+    unsigned short* const B3 = reinterpret_cast<unsigned short*>(Bs);  // X3: [NST][NPL][BN][32] bf16 / f16
     const T* const px = static_cast<const T*>(p.x);
     const T* const pw = static_cast<const T*>(p.wp);
     const T* const pzero = static_cast<const T*>(p.zero);
@@ -588,7 +593,7 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
     // samples this tile touches are parked in an LDS table and multiplied into the A fragments after the operand read
     // ("weight modulation" applied on the activation side; algebraically identical).  Filled BEFORE the first DMA so no
     // ordinary global load is outstanding while DMAs are in flight (hipcc would drain them with vmcnt(0)).
-    T* Stab = X3 ? reinterpret_cast<T*>(B3 + 2 * NPL * BN * 32) : As + 2 * (BM + BN) * LD;  // [stab_nb][stab_stride], row tails zeroed
+    T* Stab = X3 ? reinterpret_cast<T*>(B3 + NST * NPL * BN * 32) : As + 2 * (BM + BN) * LD;  // [stab_nb][stab_stride], row tails zeroed
     int s_row[MT];
     if (SCALE) {
         const int b_first = m0 / HWp;
@@ -656,10 +661,12 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
         for (int k = 0; k < 2; ++k)
             if (++ld_b == p.nkx) { ld_b = 0; ++ld_a; }
     };
-    int ld_step = 0;
+    // (the dense order counts its K steps in ld_a, which the tap-grid order does not need there: with a counter of its own hipcc merged
+    // "++ld_step" and "++ld_a" into ONE store through a selected address, which kept both on the stack — a scratch load + s_waitcnt
+    // vmcnt(0) per stage and, the DMA's SGPR offsets no longer provably uniform, a waterfall loop around every buffer_load … lds)
     auto issue_dense = [&](int buf) __attribute__((always_inline)) {
         if constexpr (X3 != 0) {
-            const int q = ld_step * CH + lchunk;
+            const int q = ld_a * CH + lchunk;
             const int t = (q * ((65536 + dense_cpt - 1) / (dense_cpt > 0 ? dense_cpt : 1))) >> 16;  // q / cpt (exact for q < 128)
             const int ch = (q - t * dense_cpt) * EPC;
             const int ta = (t * 11) >> 5, tb = t - 3 * ta;  // 3x3 tap grid: t / 3, t % 3 (t < 12)
@@ -671,14 +678,14 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
                 const unsigned voff = (a_voff[it] + tap_bytes) | (__builtin_amdgcn_ubfe(a_mask[it], (unsigned)t, 1u) - 1u);
                 buf_load_lds16(rs_a, (lptr_t)(Ad + it * RPP * LD), voff, 0);
             }
-            const int so_b = ld_step * NPL * p.RP * p.CP * 2;
+            const int so_b = ld_a * NPL * p.RP * p.CP * 2;
 #pragma unroll
             for (int it = 0; it < B3_IT; ++it) {
                 const int blk = wave + it * NWAVES;  // wave-uniform
                 if (B3_BLK % NWAVES == 0 || blk < B3_BLK)
                     buf_load_lds16(rs_b, (lptr_t)(B3 + (buf * B3_BLK + blk) * 512), (unsigned)(b3_off[it] * 2), so_b);
             }
-            ++ld_step;
+            ++ld_a;
         }
     };
     auto issue = [&](int buf) __attribute__((always_inline)) {
@@ -923,7 +930,16 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
             }
         };
         static_assert(KG == 2, "bf16x3 / f16x2: 32 floats per K chunk");
+        // DMA instructions per stage and wave (NST == 3: the newest stage stays in flight across the mid-stage sync)
+        constexpr int DMA_PER_STAGE = A_IT + B3_IT;
+        static_assert(NST == 2 || B3_BLK % NWAVES == 0, "three-stage ring: every wave issues the same number of pieces");
         issue(0);
+        if constexpr (NST == 3) {
+            if (nsteps > 1) {
+                issue(1);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_STAGE) : "memory");
+            }
+        }
         __syncthreads();
         read_raw(0, 0, 0, 0);
         track();  // (f16x2: first exponents; the accumulators are still zero)
@@ -937,7 +953,12 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
 #ifdef GIF_NO_DMA_PROBE  // timing probe (tools/probes/no_dma_probe.sh): the K loop without its LDS-DMA issue — results are WRONG
             if (step < 1) issue(cur ^ 1);
 #else
-            issue(cur ^ 1);
+            if constexpr (NST == 3) {
+                // stage step + 2 into the buffer of stage step - 1 (its last operand read preceded the previous mid-stage barrier)
+                if (step + 2 < nsteps) issue(cur == 0 ? 2 : cur - 1);
+            } else {
+                issue(cur ^ 1);
+            }
 #endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -956,10 +977,18 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
                 probe_sync += clock64() - tb;
             }
 #else
-            __syncthreads();
+            if constexpr (NST == 3) {
+                // stage step + 1 has landed (this wave's pieces; behind the barrier everybody's), stage step + 2 may stay in flight
+                if (step + 2 < nsteps) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(DMA_PER_STAGE) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            } else {
+                __syncthreads();
+            }
 #endif
             cmp_kc = next_kc(cmp_kc);
-            cur ^= 1;
+            if constexpr (NST == 3) cur = cur == 2 ? 0 : cur + 1;
+            else cur ^= 1;
             read_raw(cur, 0, cmp_kc, 0);
             __builtin_amdgcn_sched_barrier(0);
             group((KG - 1) & 1, 0);
@@ -1083,11 +1112,11 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
     conv_epilogue<BM, BN, 32, MT, NT, T, THREADS>(p, acc, smem, m0, n0, wm0, wn0, tid, li, lh, HWp);
 }
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool SCALE, int BK, int X3 = 0>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool SCALE, int BK, int X3 = 0, int NST = 2>
 // (f16x2 on 4 waves: min. 2 workgroups per CU = a 256-register budget, so that the accumulators stay in architectural VGPRs for
 // the VALU rescale path — see conv_wgrad.hip)
 __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, (X3 == 2 && WAVES_M * WAVES_N == 4) ? 2 : 1) conv_gather_mfma_glds(const GatherParams p) {
-    glds_body<T, BM, BN, WAVES_M, WAVES_N, SCALE, BK, X3>(p, (int)blockIdx.x, (int)gridDim.x);
+    glds_body<T, BM, BN, WAVES_M, WAVES_N, SCALE, BK, X3, NST>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Up to 4 independent problems (the output-parity phases of a small transposed convolution) in ONE launch: each phase
@@ -1098,13 +1127,13 @@ struct MultiParams {
     int nph;
 };
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool SCALE, int BK, int X3 = 0>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool SCALE, int BK, int X3 = 0, int NST = 2>
 __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, (X3 == 2 && WAVES_M * WAVES_N == 4) ? 2 : 1) conv_gather_mfma_glds_multi(const MultiParams mp) {
     const int b = (int)blockIdx.x;
     int k = 0;
     while (k + 1 < mp.nph && b >= mp.wg_end[k]) ++k;  // wave-uniform
     const int begin = k ? mp.wg_end[k - 1] : 0;
-    glds_body<T, BM, BN, WAVES_M, WAVES_N, SCALE, BK, X3>(mp.ph[k], b - begin, mp.wg_end[k] - begin);
+    glds_body<T, BM, BN, WAVES_M, WAVES_N, SCALE, BK, X3, NST>(mp.ph[k], b - begin, mp.wg_end[k] - begin);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1334,21 +1363,27 @@ inline size_t scale_table(GatherParams& p) {
 }
 
 // LDS bytes of the double-buffered operand tiles: 128-byte rows; X3: the weight tile is three 64-byte-row bf16 tiles
-template <int BM, int BN, int X3>
-constexpr size_t stage_bytes() { return X3 ? (size_t)2 * BM * 128 + (size_t)2 * (X3 == 2 ? 2 : 3) * BN * 64 : (size_t)2 * (BM + BN) * 128; }
+template <int BM, int BN, int X3, int NST = 2>
+constexpr size_t stage_bytes() { return X3 ? (size_t)NST * BM * 128 + (size_t)NST * (X3 == 2 ? 2 : 3) * BN * 64 : (size_t)2 * (BM + BN) * 128; }
 
-template <typename T, int BM, int BN, int WMv, int WNv, bool SCALE, int X3 = 0>
+// GIF_H2_RING=2: two-stage operand ring in the 8-wave f16x2 kernels too (A/B)
+inline bool h2_ring3() {
+    static const int on = getenv("GIF_H2_RING") ? atoi(getenv("GIF_H2_RING")) != 2 : 1;
+    return on != 0;
+}
+
+template <typename T, int BM, int BN, int WMv, int WNv, bool SCALE, int X3 = 0, int NST = 2>
 int launch_glds_impl(GatherParams& p, hipStream_t s) {
     constexpr int BK = 128 / sizeof(T);  // 128-byte LDS rows
     static gif::LdsAttr attr;
     p.tiles_m = gif::cdiv(p.M - p.m_begin, BM);
     p.tiles_n = p.RP / BN;
-    size_t lds = stage_bytes<BM, BN, X3>();
+    size_t lds = stage_bytes<BM, BN, X3, NST>();
     p.stab_nb = 0;
     p.stab_stride = 0;
     if (SCALE) lds += scale_table<T, BM>(p);
     if (lds > 160 * 1024) return -100;  // fp32 caller falls back to the register-staged kernel
-    auto kern = conv_gather_mfma_glds<T, BM, BN, WMv, WNv, SCALE, BK, X3>;
+    auto kern = conv_gather_mfma_glds<T, BM, BN, WMv, WNv, SCALE, BK, X3, NST>;
     attr.ensure(reinterpret_cast<const void*>(kern), lds);
     // passed as a kernel argument: a GOT load inside the K loop costs a scalar memory round trip + s_waitcnt per stage
     p.zero = gif::zero_page16();
@@ -1362,7 +1397,7 @@ int launch_glds_impl(GatherParams& p, hipStream_t s) {
 
 // all phases in one launch (64x64 tiles for the low-resolution layers, 256x128 / 8 waves for the big bf16x3 ones: one grid
 // instead of up to eight launches with a partly filled last round each); returns -100 if the configuration does not fit
-template <typename T, bool SCALE, int X3 = 0, int BM = 64, int BN = 64, int WMv = 2, int WNv = 2>
+template <typename T, bool SCALE, int X3 = 0, int BM = 64, int BN = 64, int WMv = 2, int WNv = 2, int NST = 2>
 int launch_glds_multi(GatherParams* ph, int nph, hipStream_t s) {
     constexpr int BK = 128 / sizeof(T);
     static gif::LdsAttr attr;
@@ -1375,7 +1410,7 @@ int launch_glds_multi(GatherParams* ph, int nph, hipStream_t s) {
         GatherParams& p = ph[i];
         p.tiles_m = gif::cdiv(p.M - p.m_begin, BM);
         p.tiles_n = p.RP / BN;
-        size_t lds = stage_bytes<BM, BN, X3>();
+        size_t lds = stage_bytes<BM, BN, X3, NST>();
         p.stab_nb = 0;
         p.stab_stride = 0;
         if (SCALE) lds += scale_table<T, BM>(p);
@@ -1391,7 +1426,7 @@ int launch_glds_multi(GatherParams* ph, int nph, hipStream_t s) {
     if (lds_max > 160 * 1024) return -100;
     t_part_rows += rows;
     t_last_bm = BM;
-    auto kern = conv_gather_mfma_glds_multi<T, BM, BN, WMv, WNv, SCALE, BK, X3>;
+    auto kern = conv_gather_mfma_glds_multi<T, BM, BN, WMv, WNv, SCALE, BK, X3, NST>;
     attr.ensure(reinterpret_cast<const void*>(kern), lds_max);
     hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(64 * WMv * WNv), lds_max, s, mp);
     return 0;
@@ -1401,6 +1436,13 @@ template <typename T, int BM, int BN, int WMv, int WNv>
 int launch_glds(GatherParams& p, hipStream_t s) {
     if constexpr (sizeof(T) == 4) {
         if constexpr (WNv == 1 || (BM == 64 && BN == 64)) {  // the wave layouts the f16x2 kernels are built for
+            if constexpr (WMv * WNv == 8) {
+                if (p.x3 == 2 && h2_ring3()) {
+                    const int rc = p.in_scale ? launch_glds_impl<T, BM, BN, WMv, WNv, true, 2, 3>(p, s)
+                                              : launch_glds_impl<T, BM, BN, WMv, WNv, false, 2, 3>(p, s);
+                    if (rc != -100) return rc;  // (-100: the scale table did not fit beside three stages)
+                }
+            }
             if (p.x3 == 2)
                 return p.in_scale ? launch_glds_impl<T, BM, BN, WMv, WNv, true, 2>(p, s)
                                   : launch_glds_impl<T, BM, BN, WMv, WNv, false, 2>(p, s);
@@ -1866,8 +1908,10 @@ int conv2d_bwd_data_impl(const void* small, const void* wp, void* big, const gif
                                   (long)ph[i].B * ph[i].Hi * ph[i].Wi * ph[i].Ci < (1L << 31) &&
                                   (long)ph[i].B * ph[i].Ho * ph[i].Wo * ph[i].Co < (1L << 31);
                     if (big_all)
-                        merged = (ph[0].x3 == 2 ? (base.in_scale ? launch_glds_multi<T, true, 2, 256, 128, 8, 1>(ph, nph, s)
-                                                                 : launch_glds_multi<T, false, 2, 256, 128, 8, 1>(ph, nph, s))
+                        merged = (ph[0].x3 == 2 ? (h2_ring3() ? (base.in_scale ? launch_glds_multi<T, true, 2, 256, 128, 8, 1, 3>(ph, nph, s)
+                                                                               : launch_glds_multi<T, false, 2, 256, 128, 8, 1, 3>(ph, nph, s))
+                                                              : (base.in_scale ? launch_glds_multi<T, true, 2, 256, 128, 8, 1>(ph, nph, s)
+                                                                               : launch_glds_multi<T, false, 2, 256, 128, 8, 1>(ph, nph, s)))
                                                 : (base.in_scale ? launch_glds_multi<T, true, 1, 256, 128, 8, 1>(ph, nph, s)
                                                                  : launch_glds_multi<T, false, 1, 256, 128, 8, 1>(ph, nph, s))) == 0;
                 }
