@@ -38,11 +38,12 @@ def kernel_source_digest():
 FAMILY_OF = [  # (regex on the kernel name, family key used by bench.py); first match wins
     (r"conv_gather_mfma_glds(_multi)?<_Float16", "conv_gather_mfma_glds_f16"),
     (r"conv_wgrad_mfma<_Float16", "conv_wgrad_mfma_f16"),
-    (r"conv_gather_mfma_glds(_multi)?<float,.*, 2>$", "conv_gather_mfma_glds_h2"),  # last template argument X3: 2 = f16x2, 1 = bf16x3
+    # conv_gather_mfma_glds<T, BM, BN, WM, WN, SCALE, BK, X3, NST>: X3 (2 = f16x2, 1 = bf16x3) is the second-to-last argument, NST the last
+    (r"conv_gather_mfma_glds(_multi)?<float,.*, 2, [23]>$", "conv_gather_mfma_glds_h2"),
     (r"conv_wgrad_mfma<float,.*, 2>$|conv_wgrad_h2v2<", "conv_wgrad_mfma_h2"),  # v2 = the cooperative pre-split form (default)
     (r"wino_gemm_h2", "wino_gemm_h2"),
     # (in f16x2 mode the bf16x3 families also contain the guarded twin launches that return at once: their per-launch average is low)
-    (r"conv_gather_mfma_glds(_multi)?<float,.*, (1|true)>$", "conv_gather_mfma_glds_x3"),
+    (r"conv_gather_mfma_glds(_multi)?<float,.*, 1, 2>$", "conv_gather_mfma_glds_x3"),
     (r"conv_wgrad_mfma<float,.*, (1|true)>$", "conv_wgrad_mfma_x3"),
     (r"wino_gemm_x3", "wino_gemm_x3"),
     (r"conv_gather_mfma_glds", "conv_gather_mfma_glds"),

@@ -11,7 +11,7 @@ for f in raster_bench.txt raster_bench.json f16x2_hw_probe.txt h2_probe.txt h2_w
 v=$(python -c "import json;d=json.load(open('$O/stats_bench.json'));print(f\"{d['value']:.1f} images/s, {d['ms_per_step']:.1f} ms/step\")")
 { echo "# rocprofv3 --kernel-trace --stats, round 5 (commit $C, f16x2 default): python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-prof"; echo
   echo "7 training iterations (5 timed + 2 warm-up) at 256x256, batch 32, fp32 tensors; summarised from the rocpd database by tools/rocpd_stats.py."
-  echo "Kernels whose last template argument is 2 are the f16x2 instantiations; the same names with 1 are bf16x3 — in this mode mostly the guarded twin launches"
+  echo "conv_gather_mfma_glds<.., X3, NST>: X3 = 2 are the f16x2 instantiations (NST = stages of the operand ring), X3 = 1 bf16x3; conv_wgrad_mfma<.., X3>; the bf16x3 ones are in this mode mostly the guarded twin launches"
   echo "(min ~4 us: they return at once) plus the tap-dense thin layers.  bench line of the profiled run: $v (profiler attached)"; echo; cat $O/kernel_stats.md; } > profiles/${R}_kernel_stats.md
 s=$(python -c "import json;print(round(json.load(open('$O/bench_shapes.json'))['value'],1))")
 { echo "# Per-launch-shape timings of the profiled MFMA kernel families inside the bench region (round 5, commit $C, f16x2 default)"; echo
