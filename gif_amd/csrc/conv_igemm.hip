@@ -970,9 +970,15 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
 #ifdef GIF_X3_TIMING_PROBE
             {   // time parked at the mid-stage sync, split into the wave's own DMA wait and the barrier
                 const long long ta = clock64();
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (NST == 3 && step + 2 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_STAGE) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 const long long tb = clock64();
-                __syncthreads();
+                if constexpr (NST == 3) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                } else {
+                    __syncthreads();
+                }
                 probe_wait += tb - ta;
                 probe_sync += clock64() - tb;
             }
