@@ -483,6 +483,13 @@ def main():
         it = 0
     elif n_r1 > 0:
         first = args.warmup + max((args.steps - (n_r1 - 1) * args.r1_every) // 2, 0)   # index of the first timed R1 iteration
+        # A warm-up has to run every path the timed region runs: where the iteration count allows it, place the R1 iterations so that
+        # the LAST warm-up step is one too (the first R1 iteration of a process allocates the double-backward buffers and loads the
+        # kernels only R1 uses: 25-105 ms once, depending on the box — it used to land inside the timed region)
+        cand = args.warmup - 1 + args.r1_every
+        last = args.warmup + args.steps - 1
+        if args.warmup >= 1 and cand <= last and (last - cand) // args.r1_every + 1 == n_r1:
+            first = cand
         it = (args.r1_every - 1 - first) % args.r1_every
     else:
         it = (-args.warmup) % args.r1_every  # the timed steps are iterations 1 .. steps of an R1 period: no R1 iteration among them
@@ -491,6 +498,7 @@ def main():
         run_step(it, batch())
         it += 1
     r1_timed = sum(1 for k in range(args.steps) if args.r1_every and (it + k + 1) % args.r1_every == 0)
+    r1_warm = sum(1 for k in range(args.warmup) if args.r1_every and (it0 + k + 1) % args.r1_every == 0)
 
     def sync():
         torch.cuda.synchronize()
@@ -581,7 +589,7 @@ def main():
             "config": {"workload": workload, "global_batch": world * B, "resolution": args.res, "parallelism": f"dp{world}",
                        "fp32_mfma": None if f16 else fp32_mode,
                        "f16x2_fallback_launches_timed": ops.h2_fallback_stats() if h2_mode else None,
-                       "r1_iterations_timed": r1_timed, "first_iteration_index": it0,
+                       "r1_iterations_timed": r1_timed, "r1_iterations_warmup": r1_warm, "first_iteration_index": it0,
                        "algorithmic_tflop_per_image": fl_img / 1e12,
                        "grad_bucket_mb": {"G": trainer.g_bucket.flat.numel() * 4 / 1e6, "D": trainer.d_bucket.flat.numel() * 4 / 1e6},
                        "overlap_comm": bool(trainer.overlap_comm),
