@@ -66,8 +66,9 @@ def parse():
                     help="activation dtype: f32 = the reference's (headline); f16 = BASELINE configs[4] (f16 activations, fp32 "
                          "weights / demodulation / accumulation, loss scaling) — use with --res 1024 --batch 8")
     ap.add_argument("--fp32-mfma", type=str, default=None, choices=["native", "bf16x3", "f16x2"],
-                    help="fp32 contraction mode of the conv kernels (default: GIF_FP32_MFMA, else bf16x3 — fp32 tensors, every fp32 "
-                         "operand split exactly into 3 bf16 terms, 6 bf16 MFMA products, fp32 accumulation)")
+                    help="fp32 contraction mode of the conv kernels (default: GIF_FP32_MFMA, else f16x2 — fp32 tensors, every fp32 operand "
+                         "split into two f16 terms under per-row power-of-two scales, 3 f16 MFMA products, fp32 accumulation, "
+                         "guarded bf16x3 fallback; bf16x3: 3 bf16 terms, 6 products; native: v_mfma_f32_32x32x2_f32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4, help="CPU baseline batch (BASELINE.md §3: 4; 32 does not fit)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = calibrate: fastest of {all host cores, 64, 32, 16}")
