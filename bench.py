@@ -36,6 +36,25 @@ PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s is what a flo
 PMC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # written by tools/pmc_to_json.py from rocprofv3 --pmc passes
 
 
+def r1_start_iteration(steps, warmup, r1_every):
+    """Iteration index of the FIRST warm-up step.  The trainer runs R1 when (i + 1) % r1_every == 0; the counter starts so that
+    round(steps / r1_every) R1 iterations fall inside the timed steps (none when that rounds to 0), and — where the iteration count
+    allows it — so that the LAST warm-up step is an R1 iteration too: a warm-up has to run every path the timed region runs (the first R1
+    iteration of a process allocates the double-backward buffers and loads the kernels only R1 uses: 25-105 ms once, depending on the
+    box; it used to land inside the timed region)."""
+    if not r1_every:
+        return 0
+    n_r1 = int(round(steps / r1_every))
+    if n_r1 > 0:
+        first = warmup + max((steps - (n_r1 - 1) * r1_every) // 2, 0)  # index of the first timed R1 iteration
+        cand = warmup - 1 + r1_every
+        last = warmup + steps - 1
+        if warmup >= 1 and cand <= last and (last - cand) // r1_every + 1 == n_r1:
+            first = cand
+        return (r1_every - 1 - first) % r1_every
+    return (-warmup) % r1_every  # the timed steps are iterations 1 .. steps of an R1 period: no R1 iteration among them
+
+
 def kernel_source_digest():
     """sha1 over the kernel sources (gif_amd/csrc/*.hip, *.h, include/*.h): what profiles/pmc_traffic.json was measured on vs what
     this run executes (the GPU box has no .git, so a commit hash cannot be compared there)."""
@@ -477,23 +496,8 @@ def main():
             cond = mesh()  # config 3: rasterised condition, inside the timed region
         return trainer.step(it, real, cond, idx)
 
-    # R1 share of the timed region = steps / r1_every (review item): the trainer runs R1 when (i + 1) % r1_every == 0; start the
-    # iteration counter so that round(steps / r1_every) R1 iterations fall inside the timed steps (and none when that rounds to 0)
-    n_r1 = int(round(args.steps / args.r1_every)) if args.r1_every else 0
-    if not args.r1_every:
-        it = 0
-    elif n_r1 > 0:
-        first = args.warmup + max((args.steps - (n_r1 - 1) * args.r1_every) // 2, 0)   # index of the first timed R1 iteration
-        # A warm-up has to run every path the timed region runs: where the iteration count allows it, place the R1 iterations so that
-        # the LAST warm-up step is one too (the first R1 iteration of a process allocates the double-backward buffers and loads the
-        # kernels only R1 uses: 25-105 ms once, depending on the box — it used to land inside the timed region)
-        cand = args.warmup - 1 + args.r1_every
-        last = args.warmup + args.steps - 1
-        if args.warmup >= 1 and cand <= last and (last - cand) // args.r1_every + 1 == n_r1:
-            first = cand
-        it = (args.r1_every - 1 - first) % args.r1_every
-    else:
-        it = (-args.warmup) % args.r1_every  # the timed steps are iterations 1 .. steps of an R1 period: no R1 iteration among them
+    # R1 share of the timed region = steps / r1_every (review item): r1_start_iteration
+    it = r1_start_iteration(args.steps, args.warmup, args.r1_every)
     it0 = it
     for _ in range(args.warmup):
         run_step(it, batch())
