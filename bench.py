@@ -81,6 +81,10 @@ def parse():
     ap.add_argument("--render-cond", action="store_true",
                     help="config 3: rasterise the 6-channel condition from a posed mesh inside the timed region")
     ap.add_argument("--gen-reg", type=str, default="None", help="None | PATH_LEN_REG | DIRECT_GRAD_REG (train.py:203-215)")
+    ap.add_argument("--texture-interp", action="store_true",
+                    help="run 29 (configurations.py:217): add the texture-space interpolation loss to every generator step "
+                         "(train.py:222-238) on synthetic FLAME labels — a synthetic blend-shape mesh stands in for the FLAME layer, "
+                         "a synthetic UV chart for the licensed texture space; NOT part of the headline line")
     ap.add_argument("--dtype", type=str, default="f32", choices=["f32", "f16"],
                     help="activation dtype: f32 = the reference's (headline); f16 = BASELINE configs[4] (f16 activations, fp32 "
                          "weights / demodulation / accumulation, loss scaling) — use with --res 1024 --batch 8")
@@ -103,6 +107,10 @@ def parse():
                          "bit-identical losses and parameters, tests/test_gpu_models.py).  The line says so and counts one forward less.")
     ap.add_argument("--no-overlap-comm", action="store_true", help="complete each gradient exchange + optimiser step in place "
                     "(default with > 1 rank: deferred to where the network is next used)")
+    ap.add_argument("--two-call-d", action="store_true",
+                    help="D step as two discriminator calls (train.py:142, :169) instead of one pass over [real; fake]: with > 1 rank it "
+                         "hides G's gradient exchange under D's forward on the real images (A/B for the multi-GPU run; default: fused at "
+                         "every rank count, so that N = 1 and N > 1 issue the same launches)")
     ap.add_argument("--check-replicas", action="store_true",
                     help="after the run: sha1 of every rank's G / D / G_ema parameters -> `param_digest`, `replicas_identical`")
     return ap.parse_args()
@@ -403,6 +411,26 @@ class MeshConditions:
         return self.render.render_condition(v_ndc, self.f, self.tex, self.res, self.res)
 
 
+def texture_interp_loss(batch, res, dev):
+    """--texture-interp: losses.InterpolatedTextureLoss with its FLAME-dependent parts injected: the condition
+    of the interpolated FLAME batch is RENDERED inside the timed region (vertex normals + two rasteriser passes), the generator runs
+    on batch - 1 images of one fixed identity, their textures are lifted into the 256x256 UV space and batch - 1 random pairs are
+    compared (loss_functions/losses.py:162-243)."""
+    import numpy as np
+    from gif_amd import data, losses, render
+    from gif_amd.texture_space import FlameTextureSpace
+    m = np.load(os.path.join(ROOT, "tests", "golden", "body_mesh.npz"))
+    flame = data.SyntheticFlame(m["vertices"], dev, seed=5)
+    faces = torch.from_numpy(m["faces"]).to(dev)
+    v = torch.from_numpy(m["vertices"]).to(dev)
+    vtx_tex = (v - v.amin(dim=0, keepdim=True)) / (v.amax(dim=0, keepdim=True) - v.amin(dim=0, keepdim=True))
+    tex_dec = FlameTextureSpace(data.synthetic_texture_data(m["faces"], fill=0.6, seed=6), None, flame=flame, faces=faces).to(dev)
+    ys, xs = np.meshgrid(np.linspace(-1, 1, 256), np.linspace(-1, 1, 256), indexing="ij")
+    face_mask = torch.from_numpy((((xs / 0.8) ** 2 + (ys / 0.9) ** 2) <= 1).astype(np.float32))[None, None].to(dev)
+    return losses.InterpolatedTextureLoss(batch, face_mask, flm_tex_dec=tex_dec,
+                                          render_condition=render.FlameConditionRenderer(flame, faces, vtx_tex, res, res))
+
+
 def free_port():
     import socket
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
@@ -477,24 +505,35 @@ def main():
         D = Discriminator(size=args.res, num_color_chnls=9, channel_multiplier=2)
     G_ema.load_state_dict(G.state_dict())
     G, G_ema, D = G.to(dev), G_ema.to(dev), D.to(dev)
+    tex_loss = texture_interp_loss(args.batch, args.res, dev) if args.texture_interp else None
     trainer = GifTrainer(G, D, G_ema, step=res_step, alpha=1.0, r1_every=args.r1_every, gen_reg_type=args.gen_reg,
+                         texture_loss=tex_loss, max_ids=args.vocab,
                          act_dtype=torch.float16 if args.dtype == "f16" else None,
                          overlap_comm=False if args.no_overlap_comm else None,
-                         reuse_generator_forward=args.reuse_generator_forward)
+                         reuse_generator_forward=args.reuse_generator_forward,
+                         fuse_d_passes=False if args.two_call_d else None)
 
     from gif_amd.data import SyntheticBatches
     B = args.batch
     batches = SyntheticBatches(B, args.res, args.vocab, dev, seed=1234, rank=rank)  # every rank draws its own data
     mesh = MeshConditions(B, args.res, dev, seed=99 + rank) if args.render_cond else None
 
+    flame_gen = torch.Generator(device=dev).manual_seed(4321 + rank)
+
     def batch():
-        return next(batches)
+        b = next(batches)
+        if tex_loss is not None:  # FLAME labels of the batch (dataset_loaders.py: flm_lbls), synthetic
+            from gif_amd.data import synthetic_flame_labels
+            lbl = synthetic_flame_labels(B, dev, flame_gen)
+            lbl[:, 157:159] = 0.0  # (the camera offset of the labels is made for a head mesh; the stand-in template is centred)
+            b = b + (lbl,)
+        return b
 
     def run_step(it, b):
-        real, cond, idx = b
+        real, cond, idx = b[:3]
         if mesh is not None:
             cond = mesh()  # config 3: rasterised condition, inside the timed region
-        return trainer.step(it, real, cond, idx)
+        return trainer.step(it, real, cond, idx, flame_batch=b[3] if len(b) > 3 else None)
 
     # R1 share of the timed region = steps / r1_every (review item): r1_start_iteration
     it = r1_start_iteration(args.steps, args.warmup, args.r1_every)
@@ -559,11 +598,13 @@ def main():
     if rank == 0:
         imgs = world * B * args.steps
         value = imgs / dt
-        fl_img = flops_per_image(args.res, args.r1_every, generator_forwards=1 if args.reuse_generator_forward else 2)
+        fl_img = flops_per_image(args.res, args.r1_every, generator_forwards=1 if args.reuse_generator_forward else 2,
+                                 extra_generator_fwd_bwd=(B - 1) / B if args.texture_interp else 0.0)
         step_tflops = value * fl_img / 1e12 / world
         f16 = args.dtype == "f16"
         fp32_mode = ops.get_fp32_mfma_mode()
-        peak = PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS
+        # peak of the MFMA type the contractions are actually fed to: the f16 / bf16 pipe unless --fp32-mfma native
+        peak = PEAK_F32_MFMA_TFLOPS if (not f16 and fp32_mode == "native") else PEAK_F16_MFMA_TFLOPS
         workload = (f"GIF run-29 G+D training iteration, {args.res}x{args.res}, batch {B}/GPU, R1 every {args.r1_every}th step, "
                     + ("f16 activations / f16 MFMA with fp32 accumulation, fp32 weights + demodulation, dynamic loss scaling "
                        "(BASELINE configs[4])" if f16 else
@@ -586,6 +627,9 @@ def main():
             workload += "; condition rasterised from a posed mesh inside the timed region (configs[2])"
         if args.gen_reg.upper() != "NONE":
             workload += f"; generator regulariser {args.gen_reg.upper()}"
+        if args.texture_interp:
+            workload += (f"; texture-space interpolation loss on every generator step (train.py:222-238: {B - 1} extra generator images "
+                         "from a condition rendered in the timed region, UV texture lifting, pairwise loss; synthetic FLAME stand-in)")
         out = {
             "metric": f"G+D train-step images/sec at {args.res}x{args.res}, batch {B}/GPU",
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -593,6 +637,7 @@ def main():
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": workload, "global_batch": world * B, "resolution": args.res, "parallelism": f"dp{world}",
                        "fp32_mfma": None if f16 else fp32_mode,
+                       "non_default_env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("GIF_")},
                        "f16x2_fallback_launches_timed": ops.h2_fallback_stats() if h2_mode else None,
                        "r1_iterations_timed": r1_timed, "r1_iterations_warmup": r1_warm, "first_iteration_index": it0,
                        "algorithmic_tflop_per_image": fl_img / 1e12,
@@ -608,10 +653,12 @@ def main():
                           "single process: no gradient exchange"),
             "step_mfma_roofline": {"achieved": step_tflops, "peak": peak, "unit": "TFLOP/s",
                                    "frac": step_tflops / peak,
-                                   "note": "whole step, ALGORITHMIC direct-convolution FLOPs (Winograd executes fewer, bf16x3 six "
-                                           "times more on a 16x faster pipe: see executed_mfma_frac_wall) incl. HBM-bound kernels, "
-                                           "optimiser, host; per GPU.  peak = the fp32-input MFMA peak: a reference for the fp32 "
-                                           "workload, not the ceiling of the bf16x3 / f16x2 kernels (2500 / 6 = 417, 2500 / 3 = 833 fp32-equivalent TFLOP/s)"},
+                                   "frac_of_fp32_input_mfma_peak": step_tflops / PEAK_F32_MFMA_TFLOPS,
+                                   "note": "whole step, ALGORITHMIC direct-convolution FLOPs (Winograd executes fewer, f16x2 three / bf16x3 six "
+                                           "times more: see executed_mfma_frac_wall) incl. HBM-bound kernels, optimiser, host; per GPU.  "
+                                           "peak = the dense peak of the MFMA type the contractions are fed to (f16 / bf16: 2500; --fp32-mfma "
+                                           "native: 157.3).  frac_of_fp32_input_mfma_peak is context only (the fp32-input pipe is 16x slower "
+                                           "and is not what these kernels run on; it can exceed 1)"},
         }
         if not args.no_prof:
             out.update(roofline_objects(ops, prof_steps, dt * prof_steps / args.steps))

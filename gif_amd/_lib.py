@@ -10,6 +10,17 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgif_hip.so")
 
 c_int, c_i64, c_float, c_void_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+
+
+def knob(name, default):
+    """Value of an A/B / ablation / probe environment knob.  Such GIF_* variables (they select measured-slower, diagnostic or
+    deliberately wrong paths) are honoured ONLY in a process that opted in with GIF_EXPERIMENTAL=1, so that a stray variable in a
+    production environment changes neither dispatch nor numerics; otherwise the default is returned (csrc/common.h gif::knob is
+    the same gate for the knobs the library reads).  NOT gated: GIF_FP32_MFMA (the documented contraction-mode switch),
+    GIF_PROF_DUMP (profiling output), GIF_FORCE_DIST (test hook: collective code paths in a one-rank group; changes no arithmetic)."""
+    if os.environ.get("GIF_EXPERIMENTAL", "0") in ("", "0"):
+        return default
+    return os.environ.get(name, default)
 P = c_void_p  # every device pointer travels as an integer address
 
 

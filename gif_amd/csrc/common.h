@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "gif_hip.h"
 
@@ -34,6 +35,15 @@ inline int check_launch(const char* what) {
     } while (0)
 
 inline hipStream_t as_stream(gif_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// A/B, ablation and probe knobs (GIF_* environment variables that select a measured-slower, diagnostic or deliberately wrong
+// path) are honoured ONLY in a process that opted in with GIF_EXPERIMENTAL=1: a stray variable in a production environment
+// can change neither dispatch nor numerics.  NOT gated (documented interface): GIF_FP32_MFMA (contraction mode, gif_hip.h),
+// GIF_PROF_DUMP (profiling output).  The Python side mirrors this in gif_amd._lib.knob.
+inline const char* knob(const char* name) {
+    static const bool on = [] { const char* e = ::getenv("GIF_EXPERIMENTAL"); return e && atoi(e) != 0; }();
+    return on ? ::getenv(name) : nullptr;
+}
 
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
@@ -211,13 +221,21 @@ __device__ __forceinline__ void split_pair_h2_scalar(const float a0, const float
 // header of an f16x2 weight packing: int32 exponents of the RP rows, then RP int32 row flags ("a 16-element K group of this row
 // lies outside the window": launches that use the row take the bf16x3 fallback); the f16 planes follow.
 inline size_t h2_header_bytes(int RP) { return (size_t)2 * RP * sizeof(int); }
-// gate words of the guarded launches (runtime.hip): a ring of device words and a generation counter — a kernel raises a gate with
-// atomicMax(gate, gen), the fallback launch runs iff *gate == gen; a word is reused 65536 launches later under a larger gen.
+// gate words of the guarded launches (runtime.hip).  Eager launches: a ring of device words and a generation counter — the f16x2
+// kernel raises its gate with atomicMax(gate, gen), the fallback launch runs iff *gate >= gen; a word is reused 65536 guarded launches
+// later under a larger gen, and generations only grow, so nothing is ever reset and streams do not matter.  (">=", round 6: should a
+// LATER user of the word — 65536 guarded launches on, possible only across streams — have raised it first, the earlier launch's twin
+// runs as well: a spurious bf16x3 recomputation, never a silently skipped one.)  Launches recorded by a stream CAPTURE (hipGraph)
+// cannot bake a generation into their arguments — every replay would see the value of the first — so they get a word of their own from
+// a separate pool (never shared with eager launches), generation 1 and a memset node in front of the f16x2 kernel that clears the word
+// on every replay.  The pool holds kH2CaptureGates words per device for the life of the process (a graph's words cannot be reclaimed:
+// the library does not see graph destruction); when it is exhausted the launch fails with GIF_ENOSUP instead of running unguarded.
 struct H2Gate {
     unsigned* word;
     unsigned gen;
+    int err;  // != 0: no gate could be provided (set_error has the reason); the caller returns it
 };
-H2Gate h2_next_gate();        // {NULL, 0} when the guard is switched off (GIF_H2_GUARD=0)
-unsigned* h2_stats_words();   // [0] fallback launches taken, [1] guarded launches flagged by the weight packing
+H2Gate h2_next_gate(hipStream_t s);  // {NULL, 0, 0} when the guard is switched off (GIF_H2_GUARD=0 under GIF_EXPERIMENTAL=1)
+unsigned* h2_stats_words();   // [0] guarded ops that took the fallback (one count per op), [1..3] unused
 
 }  // namespace gif

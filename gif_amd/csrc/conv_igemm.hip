@@ -509,8 +509,8 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
     if constexpr (X3 == 1) {
         // guarded fallback of an f16x2 launch (common.h): nothing to do unless that launch (or the weight packing) raised the gate
         if (p.gate) {
-            if (*p.gate != p.gate_gen) return;
-            if (bid == 0 && threadIdx.x == 0 && p.h2_stats) atomicAdd(p.h2_stats, 1u);
+            if (*p.gate < p.gate_gen) return;
+            if (bid == 0 && threadIdx.x == 0 && p.h2_stats && p.m_begin == 0) atomicAdd(p.h2_stats, 1u);  // (not the remainder launch)
         }
     }
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1374,7 +1374,7 @@ constexpr size_t stage_bytes() { return X3 ? (size_t)NST * BM * 128 + (size_t)NS
 
 // GIF_H2_RING=2: two-stage operand ring in the 8-wave f16x2 kernels too (A/B)
 inline bool h2_ring3() {
-    static const int on = getenv("GIF_H2_RING") ? atoi(getenv("GIF_H2_RING")) != 2 : 1;
+    static const int on = gif::knob("GIF_H2_RING") ? atoi(gif::knob("GIF_H2_RING")) != 2 : 1;
     return on != 0;
 }
 
@@ -1466,7 +1466,7 @@ int launch_glds(GatherParams& p, hipStream_t s) {
 // (the 4 x 2 layout splits two; GIF_X3_WAVES=42 selects it for A/B)
 template <typename T>
 int launch_big_x3(GatherParams& p, hipStream_t s) {
-    static const int layout = getenv("GIF_X3_WAVES") ? atoi(getenv("GIF_X3_WAVES")) : 81;
+    static const int layout = gif::knob("GIF_X3_WAVES") ? atoi(gif::knob("GIF_X3_WAVES")) : 81;
     return (layout == 42 && p.x3 == 1) ? launch_glds<T, 256, 128, 4, 2>(p, s) : launch_glds<T, 256, 128, 8, 1>(p, s);
 }
 
@@ -1474,7 +1474,7 @@ int launch_big_x3(GatherParams& p, hipStream_t s) {
 template <typename T>
 int launch_128(GatherParams& p, hipStream_t s) {
     if constexpr (sizeof(T) == 4) {
-        static const int layout = getenv("GIF_X3_WAVES") ? atoi(getenv("GIF_X3_WAVES")) : 81;
+        static const int layout = gif::knob("GIF_X3_WAVES") ? atoi(gif::knob("GIF_X3_WAVES")) : 81;
         if (p.x3 == 2 || (p.x3 && layout != 42)) return launch_glds<T, 128, 128, 4, 1>(p, s);
     }
     return launch_glds<T, 128, 128, 2, 2>(p, s);
@@ -1500,7 +1500,7 @@ int launch_halo_impl(GatherParams& p, hipStream_t s) {
     const size_t lds = (size_t)halo_lds_floats<BN, CP>() * sizeof(float) + (size_t)p.ntaps * BN * CP * 2;
     auto kern = conv_halo_f16<BN, CP>;
 #ifdef GIF_HALO_PROBE  // ablation bits of tools/probes (results are wrong when set): never in the production library
-    p.halo_dbg = getenv("GIF_HALO_DBG") ? atoi(getenv("GIF_HALO_DBG")) : 0;
+    p.halo_dbg = gif::knob("GIF_HALO_DBG") ? atoi(gif::knob("GIF_HALO_DBG")) : 0;
 #else
     p.halo_dbg = 0;
 #endif
@@ -1516,7 +1516,7 @@ int launch_halo_impl(GatherParams& p, hipStream_t s) {
 
 // GIF_F16_HALO=0 / gif_conv2d_f16_halo_enable(0): the gather kernel everywhere (A/B knob; read once, tests use the setter)
 inline std::atomic<int>& halo_switch() {
-    static std::atomic<int> on{getenv("GIF_F16_HALO") ? (atoi(getenv("GIF_F16_HALO")) != 0) : 1};
+    static std::atomic<int> on{gif::knob("GIF_F16_HALO") ? (atoi(gif::knob("GIF_F16_HALO")) != 0) : 1};
     return on;
 }
 
@@ -1548,7 +1548,7 @@ int launch_halo(GatherParams& p, hipStream_t s) {
 int conv_variant() {
     static int v = -1;
     if (v < 0) {
-        const char* e = getenv("GIF_CONV_VARIANT");
+        const char* e = gif::knob("GIF_CONV_VARIANT");
         v = e ? atoi(e) : 0;
     }
     return v;
@@ -1589,7 +1589,7 @@ int launch(GatherParams& p, hipStream_t s) {
         // >= 256 output channels and enough rows run 256x256 tiles on 8 waves (2 x 4, wave tile 128x64: one piece per four
         // MFMAs, 0.75 instead of 1 operand read per MFMA; 128 KB of LDS, one workgroup per CU): 512->512 at 64^2 780 -> 886
         // TFLOP/s, 256->256 at 128^2 710 -> 752.  GIF_F16_TILE256=0: A/B knob.
-        static const int t256_off = getenv("GIF_F16_TILE256") ? atoi(getenv("GIF_F16_TILE256")) == 0 : 0;
+        static const int t256_off = gif::knob("GIF_F16_TILE256") ? atoi(gif::knob("GIF_F16_TILE256")) == 0 : 0;
         if (!t256_off && c.BN == 128 && p.RP % 256 == 0 && (long)gif::cdiv(p.M, 256) * (p.RP / 256) >= 512 &&
             launch_glds<T, 256, 256, 2, 4>(p, s) == 0)
             return 0;
@@ -1611,12 +1611,12 @@ int launch(GatherParams& p, hipStream_t s) {
             // bf16x3: the pre-split weight tile (48 KB) + the fp32 activation tile (32 KB) fill half a CU's LDS exactly, and a
             // modulated conv's scale table no longer fits beside them.  Big layers run 256x128 tiles on 8 waves instead: one
             // workgroup per CU (112 KB + table), still two waves per SIMD, a quarter less operand traffic per MFMA.
-            static const int big_off = getenv("GIF_X3_BIG") ? atoi(getenv("GIF_X3_BIG")) == 0 : 0;
+            static const int big_off = gif::knob("GIF_X3_BIG") ? atoi(gif::knob("GIF_X3_BIG")) == 0 : 0;
             const long tn = p.RP / 128, tiles256 = (long)gif::cdiv(p.M, 256) * tn;
             // tap-dense layers (K = 9 taps x 8..28 channels: 3..7 stages): one 8-wave workgroup per CU spends most of a tile in its
             // prologue and epilogue with nothing else resident; two 4-wave workgroups per CU on 128x128 tiles: 24 -> 256 at 128^2 129 ->
             // 133 TFLOP/s, 24 -> 512 at 64^2 130 -> 134, the family in the step 8.57 -> 8.19 ms (GIF_DENSE_TILE=256: A/B)
-            static const int dense128 = getenv("GIF_DENSE_TILE") ? atoi(getenv("GIF_DENSE_TILE")) != 256 : 1;
+            static const int dense128 = gif::knob("GIF_DENSE_TILE") ? atoi(gif::knob("GIF_DENSE_TILE")) != 256 : 1;
             if (p.x3 && !big_off && tiles256 >= 512 && !(p.dense && dense128)) {
                 const long slots = 256, full = tiles256 / slots, rem = tiles256 % slots;
                 if (!p.no_split && rem > 0 && rem * 2 <= slots && slots % tn == 0) {  // nearly empty last round: remainder rows on 64x64 tiles
@@ -1726,6 +1726,8 @@ struct FusedSums {
     float* tmp = nullptr;
     long cap = 0;  // partial rows available per buffer
 
+    bool active() const { return colsum || dot; }
+
     int begin(GatherParams& p, const gif_conv_epilogue* e, long out_rows, int Co, int B, long hw, bool single_phase, const char* who) {
         t_part_rows = 0;
         if (!e || (!e->colsum && !e->dot)) return 0;
@@ -1771,15 +1773,17 @@ void pack_dims(int cout, int cin, int* RP, int* CP, bool x3 = false) {
 }
 
 // f16x2 launches: the packing is [header: RP row exponents + flag][planes]; the launch gets a fresh gate word (common.h)
-inline void h2_operands(GatherParams& p, const void* wp2, const void* wp_fallback) {
+inline int h2_operands(GatherParams& p, const void* wp2, const void* wp_fallback, hipStream_t s) {
     p.wexp = static_cast<const int*>(wp2);
     p.wp = static_cast<const char*>(wp2) + gif::h2_header_bytes(p.RP);
     p.gate = nullptr; p.gate_gen = 0; p.h2_stats = nullptr;
     if (wp_fallback) {
-        const gif::H2Gate gt = gif::h2_next_gate();
+        const gif::H2Gate gt = gif::h2_next_gate(s);
+        if (gt.err) return gt.err;
         p.gate = gt.word; p.gate_gen = gt.gen;
         p.h2_stats = gif::h2_stats_words();
     }
+    return 0;
 }
 // the same parameters for the guarded bf16x3 launch
 inline void h2_to_fallback(GatherParams& p, const void* wp3) {
@@ -1818,7 +1822,8 @@ int conv2d_fwd_impl(const void* big, const void* wp, void* small, const gif_conv
         if (int rc = check_tapdense(g, e, g->Cb, false, who)) return rc;
         p.dense = g->Cb / 4;
     }
-    if (x3 == 2) h2_operands(p, wp, wp_fallback);
+    if (x3 == 2)
+        if (int rc = h2_operands(p, wp, wp_fallback, gif::as_stream(stream))) return rc;
     p.M = p.B * p.Hp * p.Wp;
     double flops = 2.0 * p.M * (double)p.Co * p.Ci * p.ntaps;
     const int fam = sizeof(T) == 2 ? 6 : dense ? (x3 == 2 ? 17 : 12) : x3 == 2 ? 13 : x3 ? 8 : (p.Ci >= 32 ? 0 : 5);
@@ -1827,9 +1832,17 @@ int conv2d_fwd_impl(const void* big, const void* wp, void* small, const gif_conv
     gif::ProfScope prof(fam, flops, gif::as_stream(stream), p.M, p.Co, p.Ci, p.ntaps * 10 + g->stride);
     if (int rc = launch<T>(p, gif::as_stream(stream))) return rc;
     if (x3 == 2 && p.gate && wp_fallback) {  // guarded fallback: the same op on the bf16x3 kernels, a no-op unless the gate was raised
+        // FusedSums::finish reduces the per-tile partials through (t_part_rows, t_last_bm): normally those rows were written by the
+        // f16x2 launch, so the twin must cut the op into the SAME tiles (advisor, round 5: nothing else enforces it)
+        const int rows2 = t_part_rows, bm2 = t_last_bm;
         h2_to_fallback(p, wp_fallback);
         t_part_rows = 0;
         if (int rc = launch<T>(p, gif::as_stream(stream))) return rc;
+        if (sums.active() && (t_part_rows != rows2 || t_last_bm != bm2)) {
+            gif::set_error("%s: the guarded bf16x3 twin tiles the op differently from the f16x2 launch (%d x %d vs %d x %d rows): fused "
+                           "column sums would mix partials", who, t_part_rows, t_last_bm, rows2, bm2);
+            return GIF_ENOSUP;
+        }
     }
     if (int rc = sums.finish(p.Co, p.B, (long)p.Hp * p.Wp, gif::as_stream(stream), who)) return rc;
     return gif::check_launch(who);
@@ -1851,7 +1864,8 @@ int conv2d_bwd_data_impl(const void* small, const void* wp, void* big, const gif
     base.Ho = g->Hb; base.Wo = g->Wb; base.Co = g->Cb;
     pack_dims<T>(base.Co, base.Ci, &base.RP, &base.CP, x3 != 0);
     base.pair = (sizeof(T) == 2 && base.CP == 32) ? 1 : 0;
-    if (x3 == 2) h2_operands(base, wp, wp_fallback);
+    if (x3 == 2)
+        if (int rc = h2_operands(base, wp, wp_fallback, s)) return rc;
     if (dense) {
         if (int rc = check_tapdense(g, e, g->Cs, true, who)) return rc;
         base.dense = g->Cs / 4;
@@ -1907,7 +1921,7 @@ int conv2d_bwd_data_impl(const void* small, const void* wp, void* big, const gif
                     merged = launch_multi<T>(ph, nph, base.in_scale != nullptr, s) == 0;
                 if constexpr (sizeof(T) == 4) {
                     // big bf16x3 / f16x2 transposed convs: every phase would run 256x128 tiles on its own (bulk + remainder launch each)
-                    static const int big_multi_off = getenv("GIF_X3_MULTI_BIG") ? atoi(getenv("GIF_X3_MULTI_BIG")) == 0 : 0;
+                    static const int big_multi_off = gif::knob("GIF_X3_MULTI_BIG") ? atoi(gif::knob("GIF_X3_MULTI_BIG")) == 0 : 0;
                     bool big_all = x3 && !small_all && !big_multi_off && c.BN == 128;
                     for (int i = 0; i < nph && big_all; ++i)
                         big_all = (long)gif::cdiv(ph[i].M, 256) * (ph[i].RP / 128) >= 512 &&
@@ -1929,9 +1943,18 @@ int conv2d_bwd_data_impl(const void* small, const void* wp, void* big, const gif
         };
         if (int rc = run_phases()) return rc;
         if (x3 == 2 && base.gate && wp_fallback) {  // guarded fallback on the bf16x3 kernels (a no-op unless the gate was raised)
-            for (int i = 0; i < nph; ++i) h2_to_fallback(ph[i], wp_fallback);
+            const int rows2 = t_part_rows, bm2 = t_last_bm;
+            for (int i = 0; i < nph; ++i) {
+                h2_to_fallback(ph[i], wp_fallback);
+                if (i) ph[i].h2_stats = nullptr;  // gif_h2_fallback_stats counts OPS: only the first phase's twin reports
+            }
             t_part_rows = 0;
             if (int rc = run_phases()) return rc;
+            if (sums.active() && (t_part_rows != rows2 || t_last_bm != bm2)) {  // (see conv2d_fwd_impl)
+                gif::set_error("%s: the guarded bf16x3 twin tiles the op differently from the f16x2 launch (%d x %d vs %d x %d rows)", who,
+                               t_part_rows, t_last_bm, rows2, bm2);
+                return GIF_ENOSUP;
+            }
         }
         if (int rc = sums.finish(base.Co, g->B, (long)g->Hb * g->Wb, s, who)) return rc;
     }

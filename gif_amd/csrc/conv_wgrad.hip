@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q, (X3 == 2 && WAVES_P * 
     constexpr bool F16 = sizeof(T) == 2;
     if constexpr (X3 == 1) {
         if (p.gate) {  // guarded fallback of an f16x2 launch: nothing to do unless that launch raised the gate
-            if (*p.gate != p.gate_gen) return;
+            if (*p.gate < p.gate_gen) return;
             if (blockIdx.x == 0 && threadIdx.x == 0 && p.h2_stats) atomicAdd(p.h2_stats, 1u);
         }
     }
@@ -905,12 +905,12 @@ void wgrad_launch(dim3 grid, int threads, hipStream_t s, const WgradParams& p) {
 
 // GIF_H2_WGRAD_V2=0: the per-wave-split f16x2 kernel (conv_wgrad_mfma<..., 2>) instead of the cooperative pre-split one (A/B)
 inline bool h2v2_on() {
-    static const int on = getenv("GIF_H2_WGRAD_V2") ? atoi(getenv("GIF_H2_WGRAD_V2")) != 0 : 1;
+    static const int on = gif::knob("GIF_H2_WGRAD_V2") ? atoi(gif::knob("GIF_H2_WGRAD_V2")) != 0 : 1;
     return on != 0;
 }
 // GIF_H2_WGRAD_TAPS=0: the thin-big-side layers on the 128 x 32 per-tap tiles (A/B)
 inline bool thin_taps_on() {
-    static const int on = getenv("GIF_H2_WGRAD_TAPS") ? atoi(getenv("GIF_H2_WGRAD_TAPS")) != 0 : 1;
+    static const int on = gif::knob("GIF_H2_WGRAD_TAPS") ? atoi(gif::knob("GIF_H2_WGRAD_TAPS")) != 0 : 1;
     return on != 0;
 }
 // taps per 128-column tile and the number of column tiles for a thin big side of Cb (<= 32) channels
@@ -945,7 +945,7 @@ inline int tile_of(int c) { return c <= 32 ? 32 : 128; }
 inline bool wgrad_big_tile(int Cs, int Cb, bool scaled, long Ntot) {
     static int off = -1;
     if (off < 0) {
-        const char* e = getenv("GIF_WGRAD_BIG");
+        const char* e = gif::knob("GIF_WGRAD_BIG");
         off = (e && atoi(e) == 0) ? 1 : 0;
     }
     // (below ~16K reduction rows the halved workgroup count costs more than the operand reuse gains: measured)
@@ -1237,7 +1237,7 @@ __global__ void __launch_bounds__(1024) conv_wgrad_small_mfma(const SmallWgradPa
 inline bool small_wgrad_ok(const gif_conv_geom* g, bool scaled) {
     static int off = -1;
     if (off < 0) {
-        const char* e = getenv("GIF_SMALL_WGRAD");
+        const char* e = gif::knob("GIF_SMALL_WGRAD");
         off = (e && atoi(e) == 0) ? 1 : 0;
     }
     return !off && !scaled && g->KH == 3 && g->KW == 3 && g->stride == 1 && g->pad == 1 && g->Hs == g->Hb && g->Ws == g->Wb &&
@@ -1444,7 +1444,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_halo_f16(const HaloWgradPar
 
 // GIF_F16_HALO_WGRAD=0: A/B knob (the per-tap kernel).  Workgroups (= splits): two per CU, never more than patches.
 inline bool halo_wgrad_ok(const gif_conv_geom* g) {
-    static const int off = getenv("GIF_F16_HALO_WGRAD") ? atoi(getenv("GIF_F16_HALO_WGRAD")) == 0 : 0;
+    static const int off = gif::knob("GIF_F16_HALO_WGRAD") ? atoi(gif::knob("GIF_F16_HALO_WGRAD")) == 0 : 0;
     return !off && g->stride == 1 && g->Cs <= 32 && g->Cb <= 32 && g->KH <= 3 && g->KW <= 3 && g->Hs == g->Hb && g->Ws == g->Wb &&
            g->KH == 2 * g->pad + 1 && g->KW == 2 * g->pad + 1 && g->Hs >= 16 && g->Ws >= 16 &&
            (long)g->B * gif::cdiv(g->Hs, 16) * gif::cdiv(g->Ws, 16) >= 512;
@@ -1618,7 +1618,7 @@ static inline int wgrad_tile_f16(int Cs, int Cb) {
 // 256 x 256 tiles on 8 waves (wave tile 128 x 64) for the f16 weight gradients with multiples of 256 channels on both sides: half
 // the LDS-DMA pieces and 6 instead of 8 operand gathers per MFMA (the 128 x 128 loop is bound by both: DESIGN 3b).  GIF_F16_WGRAD256=0: A/B.
 static inline bool wgrad_tile256_f16(const gif_conv_geom* g, bool scaled) {
-    static const int off = getenv("GIF_F16_WGRAD256") ? atoi(getenv("GIF_F16_WGRAD256")) == 0 : 0;
+    static const int off = gif::knob("GIF_F16_WGRAD256") ? atoi(gif::knob("GIF_F16_WGRAD256")) == 0 : 0;
     (void)scaled;  // modulated launches too (the per-sample scale table of a 32-pixel stage is 2 KB per sample)
     return !off && g->Cs % 256 == 0 && g->Cb % 256 == 0 && (long)g->B * g->Hs * g->Ws >= 16384 && ((long)g->Hs * g->Ws) % 32 == 0;
 }
@@ -1679,7 +1679,7 @@ int gif_conv2d_wgrad_f16(const void* small, const void* big, float* ws, const fl
                             p.T * 10 + g->stride + (small_scale || big_scale ? 100 : 0));
         const size_t lds = (size_t)2 * kHwBufHalfs * sizeof(gif::f16);
         static gif::LdsAttr attr;
-        static const int tr_off = getenv("GIF_F16_HALO_WGRAD_TR") ? atoi(getenv("GIF_F16_HALO_WGRAD_TR")) == 0 : 0;  // A/B knob
+        static const int tr_off = gif::knob("GIF_F16_HALO_WGRAD_TR") ? atoi(gif::knob("GIF_F16_HALO_WGRAD_TR")) == 0 : 0;  // A/B knob
         if (tr_off) {
             attr.ensure(reinterpret_cast<const void*>(conv_wgrad_halo_f16<false>), lds);
             hipLaunchKernelGGL(conv_wgrad_halo_f16<false>, dim3((unsigned)nsplit), dim3(256), lds, hs, q);
@@ -1750,9 +1750,12 @@ int gif_conv2d_wgrad_splits(const gif_conv_geom* g) {
     // (scaled launches of the same geometry use 128-row tiles: they simply get half the splits they could use)
     long Ntot = (long)g->B * g->Hs * g->Ws;
     long tiles = (long)(RP / tile_rows(g->Cs, g->Cb, false, Ntot)) * (CP / tile_of(g->Cb)) * g->KH * g->KW;
-    if (tile_of(g->Cs) == 128 && tile_of(g->Cb) == 32 && g->KH * g->KW > 1 && thin_taps_on()) {
-        // thin big side: the f16x2 kernel puts several taps into one column tile (fewer, larger workgroups per split); the count is
-        // only a count — the other kernels take the same one
+    if (tile_of(g->Cs) == 128 && tile_of(g->Cb) == 32 && g->KH * g->KW > 1 && thin_taps_on() && h2v2_on() &&
+        gif::fp32_mfma_mode() == GIF_FP32_MFMA_F16X2) {
+        // thin big side: the f16x2 kernel (conv_wgrad_h2v2<false, true>, the only one that groups taps — the condition mirrors the
+        // `h2 && x3_thin && thin_taps_on() && h2v2_on()` of conv2d_wgrad_f32_impl under the process's contraction mode) puts several taps
+        // into one column tile: fewer, larger workgroups per split.  The native / bf16x3 kernels run one workgroup per tap and keep
+        // their own count (advisor, round 5: they got ~4.5 x the splits, i.e. workspace and unpack traffic, for nothing)
         int tpt, tg;
         thin_tap_tiles(g->Cb, g->KH * g->KW, &tpt, &tg);
         tiles = (long)(RP / 128) * tg;
@@ -1797,10 +1800,10 @@ static int conv2d_wgrad_f32_impl(const float* small, const float* big, float* ws
     if (p.stab_nb > g->B) p.stab_nb = g->B;
     const bool tab_fits = HWs % 16 == 0 && (size_t)p.stab_nb * 256 * sizeof(float) <= 64 * 1024;
     // bf16x3 tiles: 128x128, and 128x32 for the un-modulated layers with a thin big side (the 24-channel condition-noise maps)
-    static const int x3_thin_off = getenv("GIF_X3_WGRAD_THIN") ? atoi(getenv("GIF_X3_WGRAD_THIN")) == 0 : 0;
+    static const int x3_thin_off = gif::knob("GIF_X3_WGRAD_THIN") ? atoi(gif::knob("GIF_X3_WGRAD_THIN")) == 0 : 0;
     const bool x3_thin = x3 && !x3_thin_off && tile_of(g->Cs) == 128 && tile_of(g->Cb) == 32 && !small_scale && !big_scale;
     x3 = x3 && tile_of(g->Cs) == 128 && (tile_of(g->Cb) == 128 || x3_thin) && (!(small_scale || big_scale) || tab_fits);
-    const bool big_tile = !x3 && wgrad_big_tile(g->Cs, g->Cb, small_scale || big_scale, p.Ntot) && !getenv("GIF_CONV_VARIANT");
+    const bool big_tile = !x3 && wgrad_big_tile(g->Cs, g->Cb, small_scale || big_scale, p.Ntot) && !gif::knob("GIF_CONV_VARIANT");
     p.tiles_q = p.CP / bq;
     p.tiles_pq = (p.RP / (big_tile ? 256 : bp)) * p.tiles_q;
     dim3 grid((unsigned)(p.tiles_pq * p.T * nsplit));
@@ -1823,22 +1826,23 @@ static int conv2d_wgrad_f32_impl(const float* small, const float* big, float* ws
         return gif::check_launch("conv2d_wgrad(small)");
     }
     {
-        static const int x3_simple_p = getenv("GIF_X3_WGRAD_SIMPLE") ? atoi(getenv("GIF_X3_WGRAD_SIMPLE")) : 0;
+        static const int x3_simple_p = gif::knob("GIF_X3_WGRAD_SIMPLE") ? atoi(gif::knob("GIF_X3_WGRAD_SIMPLE")) : 0;
         const bool tab_p = (small_scale || big_scale) && tab_fits;
         const bool h2_p = x3 && x3_mode == 2 && !x3_simple_p && (x3_thin || !tab_p || HWs % 32 == 0);  // (the same condition as below)
         gif::ProfScope prof(h2_p ? 15 : x3 ? 9 : 1, flops, s, (int)p.Ntot, g->Cs, g->Cb, p.T * 10 + g->stride + (small_scale || big_scale ? 100 : 0));
-        const char* env = getenv("GIF_CONV_VARIANT");
+        const char* env = gif::knob("GIF_CONV_VARIANT");
         const int variant = env ? atoi(env) : 0;
         const bool glds = !small_scale && !big_scale && variant != 1;
 #define GIF_WGRAD_LAUNCH(BP_, BQ_, WP_, WQ_, TH_)                                                                  \
     if (glds) wgrad_launch<float, BP_, BQ_, WP_, WQ_, true, 32>(grid, TH_, s, p);                                        \
     else wgrad_launch<float, BP_, BQ_, WP_, WQ_, false, 32>(grid, TH_, s, p)
         const bool tab = (small_scale || big_scale) && (variant != 1 || x3) && tab_fits;
-        static const int x3_simple = getenv("GIF_X3_WGRAD_SIMPLE") ? atoi(getenv("GIF_X3_WGRAD_SIMPLE")) : 0;  // A/B: 16-pixel stages, no pipeline
+        static const int x3_simple = gif::knob("GIF_X3_WGRAD_SIMPLE") ? atoi(gif::knob("GIF_X3_WGRAD_SIMPLE")) : 0;  // A/B: 16-pixel stages, no pipeline
         // f16x2: the software-pipelined 32-pixel-stage instantiations; the launch is followed by its guarded bf16x3 twin
         const bool h2 = x3 && x3_mode == 2 && !x3_simple && (x3_thin || !tab || HWs % 32 == 0);
         if (h2) {
-            const gif::H2Gate gt = gif::h2_next_gate();
+            const gif::H2Gate gt = gif::h2_next_gate(s);
+            if (gt.err) return gt.err;
             p.gate = gt.word; p.gate_gen = gt.gen; p.h2_stats = gif::h2_stats_words();
             if (x3_thin && thin_taps_on() && p.T > 1 && h2v2_on()) {
                 // several taps per 128-column tile (conv_wgrad_h2v2<false, true>); the guarded twin below keeps its per-tap grid
@@ -1855,7 +1859,7 @@ static int conv2d_wgrad_f32_impl(const float* small, const float* big, float* ws
         } else if (x3_thin) {
             // two waves of 64x32: 3 fragment splits per 12 MFMAs (four waves of 32x32: 2 per 6 — GIF_X3_WGRAD_THIN=4 for the A/B:
             // 128x24 at 256^2 76 -> 80 TFLOP/s, 256x24 at 128^2 70 -> 78, 512x24 at 64^2 80 -> 82)
-            static const int thin4 = getenv("GIF_X3_WGRAD_THIN") ? atoi(getenv("GIF_X3_WGRAD_THIN")) == 4 : 0;
+            static const int thin4 = gif::knob("GIF_X3_WGRAD_THIN") ? atoi(gif::knob("GIF_X3_WGRAD_THIN")) == 4 : 0;
             if (thin4) wgrad_launch<float, 128, 32, 4, 1, true, 32, false, 1>(grid, 256, s, p);
             else wgrad_launch<float, 128, 32, 2, 1, true, 32, false, 1>(grid, 128, s, p);
         } else if (x3 && tab && HWs % 32 == 0 && !x3_simple) {
@@ -1950,7 +1954,7 @@ static int conv3x3_winograd_wgrad_impl(const float* x, const float* gy, float* V
         if (int rc = gif::winograd_gy_transform(gy, small_scale, Mg, B, H, W, Cs, s)) return rc;
     }
     x3 = x3 && tile_of(CsP) == 128 && tile_of(CbP) == 128;
-    static const int x3_simple_p = getenv("GIF_X3_WGRAD_SIMPLE") ? atoi(getenv("GIF_X3_WGRAD_SIMPLE")) : 0;
+    static const int x3_simple_p = gif::knob("GIF_X3_WGRAD_SIMPLE") ? atoi(gif::knob("GIF_X3_WGRAD_SIMPLE")) : 0;
     gif::ProfScope prof((x3 && x3_mode == 2 && !x3_simple_p) ? 16 : x3 ? 11 : 3, flops, s, (int)((long)B * H * W), Cs, Cb,
                         1091 + (small_scale || big_scale ? 100 : 0));
     WgradParams p{};
@@ -1972,10 +1976,11 @@ static int conv3x3_winograd_wgrad_impl(const float* x, const float* gy, float* V
     dim3 grid((unsigned)(p.tiles_pq * p.T * nsplit));
     p.zero = gif::zero_page16();
     GIF_REQUIRE(p.zero, "winograd_wgrad: zero page lookup failed");
-    static const int x3_simple = getenv("GIF_X3_WGRAD_SIMPLE") ? atoi(getenv("GIF_X3_WGRAD_SIMPLE")) : 0;
+    static const int x3_simple = gif::knob("GIF_X3_WGRAD_SIMPLE") ? atoi(gif::knob("GIF_X3_WGRAD_SIMPLE")) : 0;
     const bool h2 = x3 && x3_mode == 2 && !x3_simple;
     if (h2) {
-        const gif::H2Gate gt = gif::h2_next_gate();
+        const gif::H2Gate gt = gif::h2_next_gate(s);
+        if (gt.err) return gt.err;
         p.gate = gt.word; p.gate_gen = gt.gen; p.h2_stats = gif::h2_stats_words();
         if (h2v2_on()) wgrad_launch_v2(false, grid, s, p);
         else wgrad_launch<float, 128, 128, 2, 2, true, 32, false, 2>(grid, 256, s, p);

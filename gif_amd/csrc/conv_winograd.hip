@@ -551,7 +551,7 @@ __global__ void __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) wino_gemm_mfma(cons
 template <int DBG = 0, int BM = 256, int BN = 64>
 __global__ void __launch_bounds__(512, 1) wino_gemm_x3(const WinoParams p) {
     if (p.gate) {  // guarded fallback of an f16x2 launch: nothing to do unless that launch raised the gate
-        if (*p.gate != p.gate_gen) return;
+        if (*p.gate < p.gate_gen) return;
         if (blockIdx.x == 0 && threadIdx.x == 0 && p.h2_stats) atomicAdd(p.h2_stats, 1u);
     }
     constexpr int THREADS = 512, PROWS = THREADS / 8;
@@ -1183,7 +1183,7 @@ int winograd_input_transform(const float* x, const float* scale, float* V, int B
     // of the transform family 1.10x -> 1.065x the algorithmic count); GIF_WINO_XFORM=tile selects the one-patch-per-lane kernel,
     // rows4 / rows16 the other depths (A/B).
     static const int rows = [] {
-        const char* e = getenv("GIF_WINO_XFORM");
+        const char* e = gif::knob("GIF_WINO_XFORM");
         if (!e) return 8;
         return !strncmp(e, "rows", 4) ? atoi(e + 4) : 0;
     }();
@@ -1313,7 +1313,7 @@ int gif_conv3x3_winograd_f32(const float* x, const float* U, float* y, float* V,
     // 128-wide N tile (8 waves) whenever the output channels fill it; GIF_WINO_WN=2 / 4 forces a variant (benchmarking)
     static int force_wn = -1;
     if (force_wn < 0) {
-        const char* env = getenv("GIF_WINO_WN");
+        const char* env = gif::knob("GIF_WINO_WN");
         force_wn = env ? atoi(env) : 0;
     }
     // measured: +1-2 % on the >= 32^2 layers, slower when the launch has fewer than ~512 workgroups of 512 threads
@@ -1381,10 +1381,10 @@ static int conv3x3_winograd_x3_impl(const float* x, const void* U2, const void* 
     p.gain = e ? e->gain : 1.f;
     p.B = B; p.H = H; p.W = W; p.Co = Co;
     p.ntiles = (int)ntiles; p.ntiles_pad = (int)ntiles_pad; p.TH = H / 2; p.TW = W / 2;
-    static const int dbg = getenv("GIF_WINO_DBG") ? atoi(getenv("GIF_WINO_DBG")) : 0;
+    static const int dbg = gif::knob("GIF_WINO_DBG") ? atoi(gif::knob("GIF_WINO_DBG")) : 0;
     // 128 x 128 blocks (4 x 2 waves) by default; GIF_WINO_X3_TILE=256 selects 256 x 64 (8 x 1 waves: every V fragment split
     // once instead of twice) — measured equal (2.998 / 2.141 / 1.790 ms vs 2.993 / 2.133 / 1.757 ms on the three big layers)
-    static const int sq = getenv("GIF_WINO_X3_TILE") ? atoi(getenv("GIF_WINO_X3_TILE")) != 256 : 1;
+    static const int sq = gif::knob("GIF_WINO_X3_TILE") ? atoi(gif::knob("GIF_WINO_X3_TILE")) != 256 : 1;
     const int bm = (sq || U2) ? 128 : 256, bn = (sq || U2) ? 128 : 64;
     p.tiles_m = (int)(ntiles_pad / bm);
     p.tiles_n = p.RP / bn;
@@ -1398,12 +1398,13 @@ static int conv3x3_winograd_x3_impl(const float* x, const void* U2, const void* 
         q.uexp = hdr;
         q.U = reinterpret_cast<const float*>(static_cast<const char*>(U2) + gif::h2_header_bytes(p.RP));
         if (U3) {
-            const gif::H2Gate gt = gif::h2_next_gate();
+            const gif::H2Gate gt = gif::h2_next_gate(s);
+            if (gt.err) return gt.err;
             q.gate = gt.word; q.gate_gen = gt.gen;
         }
         // ring depth 3 / 4 / 5 (96 / 128 / 160 KB): measured equal — 2.648 / 2.638 / 2.686 ms on 128 -> 128 at 256^2, batch 32: the GEMM does
         // not wait for its DMA; GIF_WINO_H2_STAGES keeps the A/B
-        static const int nst = getenv("GIF_WINO_H2_STAGES") ? atoi(getenv("GIF_WINO_H2_STAGES")) : 3;
+        static const int nst = gif::knob("GIF_WINO_H2_STAGES") ? atoi(gif::knob("GIF_WINO_H2_STAGES")) : 3;
         const size_t lds2 = (size_t)(nst == 3 ? 3 : nst == 5 ? 5 : 4) * ((size_t)128 * WBK * sizeof(float) + 2 * (size_t)128 * 64);
         static gif::LdsAttr attr2[3];
         if (nst == 3) {

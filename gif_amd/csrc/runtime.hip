@@ -18,7 +18,9 @@ __device__ unsigned g_f16_sat_flag;
 
 // f16x2 guard (common.h): gate words of the guarded launches and the fallback statistics
 constexpr unsigned kH2GateRing = 65536;
+constexpr unsigned kH2CaptureGates = 65536;
 __device__ unsigned g_h2_gates[kH2GateRing];
+__device__ unsigned g_h2_capture_gates[kH2CaptureGates];
 __device__ unsigned g_h2_stats[4];
 
 __global__ void f16_flag_or_into(const unsigned* flag, float* found_inf) {
@@ -80,17 +82,42 @@ unsigned* h2_stats_words() {
     return h2_symbol(HIP_SYMBOL(g_h2_stats), cache);
 }
 
-H2Gate h2_next_gate() {
+H2Gate h2_next_gate(hipStream_t s) {
     static unsigned* cache[kMaxDevices] = {};
+    static unsigned* ccache[kMaxDevices] = {};
     static std::atomic<unsigned long long> next[kMaxDevices];
-    static const bool off = getenv("GIF_H2_GUARD") && atoi(getenv("GIF_H2_GUARD")) == 0;
-    if (off) return {nullptr, 0};
+    static std::atomic<unsigned long long> cnext[kMaxDevices];
+    static const bool off = gif::knob("GIF_H2_GUARD") && atoi(gif::knob("GIF_H2_GUARD")) == 0;
+    if (off) return {nullptr, 0, 0};
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess) {
+        (void)hipGetLastError();
+        cs = hipStreamCaptureStatusNone;
+    }
+    if (cs != hipStreamCaptureStatusNone) {
+        // recorded launch: a private word, cleared by a memset node on every replay, generation 1 (common.h)
+        unsigned* pool = h2_symbol(HIP_SYMBOL(g_h2_capture_gates), ccache);
+        const unsigned long long n = cnext[current_device()].fetch_add(1, std::memory_order_relaxed);
+        if (!pool || n >= kH2CaptureGates) {
+            set_error("f16x2 guard: the %u gate words for stream-captured launches are used up (each captured guarded launch keeps one "
+                      "for the life of the process); re-use the captured graphs or run eagerly", kH2CaptureGates);
+            return {nullptr, 0, GIF_ENOSUP};
+        }
+        if (hipMemsetAsync(pool + n, 0, sizeof(unsigned), s) != hipSuccess) {
+            set_error("f16x2 guard: hipMemsetAsync of a captured gate word failed");
+            return {nullptr, 0, GIF_ENOSUP};
+        }
+        return {pool + n, 1u, 0};
+    }
     unsigned* ring = h2_symbol(HIP_SYMBOL(g_h2_gates), cache);
-    if (!ring) return {nullptr, 0};
+    if (!ring) {
+        set_error("f16x2 guard: gate ring lookup failed");
+        return {nullptr, 0, GIF_ENOSUP};
+    }
     const unsigned long long n = next[current_device()].fetch_add(1, std::memory_order_relaxed);
     // the words start at zero, generations at 1; a word's generation only grows (atomicMax), so a stale raise of an earlier
-    // launch on the same word never equals a later launch's generation
-    return {ring + (n % kH2GateRing), (unsigned)(n / kH2GateRing) + 1u};
+    // launch on the same word never reaches a later launch's generation
+    return {ring + (n % kH2GateRing), (unsigned)(n / kH2GateRing) + 1u, 0};
 }
 
 void LdsAttr::ensure(const void* kernel, size_t bytes) {
@@ -208,8 +235,8 @@ int gif_set_fp32_mfma_mode(int mode) {
 
 int gif_get_fp32_mfma_mode(void) { return gif::fp32_mfma_mode(); }
 
-/* f16x2 guard statistics of the current device since the last reset: out[0] = guarded launches that took the bf16x3 fallback.
- * Synchronises the device. */
+/* f16x2 guard statistics of the current device since the last reset: out[0] = guarded ops that took the bf16x3 fallback (the first
+ * twin launch of an op counts: phases and remainder launches do not), out[1] = 0.  Synchronises the device. */
 int gif_h2_fallback_stats(uint64_t* out2, int reset) {
     unsigned* st = gif::h2_stats_words();
     GIF_REQUIRE(st && out2, "h2_fallback_stats: null pointer");
@@ -219,7 +246,7 @@ int gif_h2_fallback_stats(uint64_t* out2, int reset) {
     if (e == hipSuccess && reset) e = hipMemset(st, 0, sizeof(h));
     if (e != hipSuccess) { gif::set_error("h2_fallback_stats: %s", hipGetErrorString(e)); return (int)e; }
     out2[0] = h[0];
-    out2[1] = h[1];
+    out2[1] = 0;
     return 0;
 }
 

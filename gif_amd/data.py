@@ -9,6 +9,7 @@ Here batches are produced and resized on the GPU so that a multi-GPU run is neve
 The LMDB wire format itself ('{res}-{idx:05d}' keys, prepare_lmdb/create_deca_rendered_lmdb.py:78-93) is out of scope:
 lmdb is not installed and no dataset is available.
 """
+import numpy as np
 import torch
 from torch.autograd import Function
 
@@ -71,3 +72,69 @@ class SyntheticBatches:
         cond = torch.rand(self.B, 6, self.R, self.R, device=self.device, generator=self.gen) * 2 - 1
         idx = torch.randint(0, self.vocab, (self.B,), device=self.device, generator=self.gen)
         return real, cond, idx
+
+
+def _rodrigues(r):
+    """Axis-angle [B,3] -> rotation matrices [B,3,3]."""
+    theta = r.norm(dim=1, keepdim=True).clamp_min(1e-8)
+    k = r / theta
+    K = torch.zeros(r.shape[0], 3, 3, device=r.device, dtype=r.dtype)
+    K[:, 0, 1], K[:, 0, 2], K[:, 1, 0] = -k[:, 2], k[:, 1], k[:, 2]
+    K[:, 1, 2], K[:, 2, 0], K[:, 2, 1] = -k[:, 0], -k[:, 1], k[:, 0]
+    s, c = torch.sin(theta)[:, :, None], torch.cos(theta)[:, :, None]
+    return torch.eye(3, device=r.device, dtype=r.dtype)[None] + s * K + (1 - c) * torch.bmm(K, K)
+
+
+class SyntheticFlame:
+    """Stand-in for the FLAME layer of the absent `photometric_optimization` submodule (licensed assets), with the
+    call signature FlameTextureSpace.forward uses (model/stg2_generator.py:362-364): (shape_params [B,100], expression_params
+    [B,50], pose_params [B,6]) -> (vertices [B,V,3], None, None).  A linear blend-shape model over a template mesh (smooth,
+    low-frequency displacement fields) followed by the global rotation pose_params[:, :3] (axis-angle): the same tensor shapes
+    and the same amount of arithmetic as FLAME's shape / expression blend and root rotation — what a synthetic-data run of the
+    texture-interpolation loss needs, NOT a face model."""
+
+    def __init__(self, template, device, n_shape=100, n_exp=50, seed=0, amplitude=2e-3):
+        g = torch.Generator().manual_seed(seed)
+        t = torch.as_tensor(np.asarray(template), dtype=torch.float32)
+        V = t.shape[0]
+
+        def basis(n):
+            freq = torch.randn(n, 3, generator=g) * 3.0
+            phase = torch.rand(n, 1, generator=g) * 6.2831853
+            direction = torch.nn.functional.normalize(torch.randn(n, 1, 3, generator=g), dim=2)
+            field = torch.sin(freq @ t.t() + phase)[:, :, None] * direction  # [n,V,3]
+            return (amplitude * field).reshape(n, V * 3)
+
+        self.template = t.reshape(1, V * 3).to(device)
+        self.shape_basis, self.exp_basis = basis(n_shape).to(device), basis(n_exp).to(device)
+
+    def __call__(self, shape_params, expression_params, pose_params):
+        B = shape_params.shape[0]
+        v = (self.template + shape_params @ self.shape_basis + expression_params @ self.exp_basis).view(B, -1, 3)
+        return torch.bmm(v, _rodrigues(pose_params[:, :3]).transpose(1, 2)), None, None
+
+
+def synthetic_texture_data(faces, T=256, fill=0.6, seed=0):
+    """Stand-in for cnst.flame_texture_space_dat_file (licensed): the dict FlameTextureSpace.__init__ reads
+    (stg2_generator.py:348-353).  A centred disc of `fill` of the TxT texture is valid; texels are assigned to the faces in
+    raster order (neighbouring texels share a face or sit on neighbouring ones, like a real UV chart) with random
+    barycentric coordinates."""
+    rng = np.random.RandomState(seed)
+    faces = np.asarray(faces)
+    ys, xs = np.meshgrid(np.arange(T), np.arange(T), indexing="ij")
+    r2 = (xs - T / 2 + 0.5) ** 2 + (ys - T / 2 + 0.5) ** 2
+    valid = np.flatnonzero((r2 <= fill * T * T / np.pi).reshape(-1))
+    fidx = (np.arange(len(valid)) * (len(faces) / max(len(valid), 1))).astype(np.int64)
+    return {"x_coords": xs.reshape(-1), "y_coords": ys.reshape(-1), "valid_pixel_ids": valid,
+            "valid_pixel_3d_faces": faces[fidx], "valid_pixel_b_coords": rng.dirichlet([1, 1, 1], len(valid)).astype(np.float32)}
+
+
+def synthetic_flame_labels(batch_size, device, generator=None, n_labels=159):
+    """FLAME labels `flm_lbls` [B,159] in the layout of constants.INDICES (shape 0:100, expression 100:150, pose 150:156,
+    camera 156:159) with magnitudes of fitted FFHQ parameters: unit-normal shape / expression codes, small rotations, an
+    orthographic camera that keeps the template inside the image."""
+    lbl = torch.randn(batch_size, n_labels, device=device, generator=generator)
+    lbl[:, 150:156] *= 0.15
+    lbl[:, 156] = 0.95 + 0.05 * lbl[:, 156].clamp(-1, 1)
+    lbl[:, 157:159] = 0.02 * lbl[:, 157:159].clamp(-2, 2) + torch.tensor([0.0, 0.35], device=device)
+    return lbl

@@ -14,11 +14,12 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
+from . import _lib
 from . import functional as GF
 from .ops import cpad, pad4
 
 
-_SKINNY_MAX_ROWS = int(os.environ.get("GIF_SKINNY_MAX_ROWS", "512"))  # above: the implicit-GEMM conv kernels take over
+_SKINNY_MAX_ROWS = int(_lib.knob("GIF_SKINNY_MAX_ROWS", "512"))  # above: the implicit-GEMM conv kernels take over
 
 
 def _pad_vec(v, n):
@@ -301,7 +302,7 @@ class ModulatedConv2d(nn.Module):
         return out
 
 
-_STYLE_BANK = os.environ.get("GIF_STYLE_BANK", "1") != "0"
+_STYLE_BANK = _lib.knob("GIF_STYLE_BANK", "1") != "0"
 
 
 def modulation_bank(convs, style):

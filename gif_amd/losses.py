@@ -100,6 +100,16 @@ class PathLengthRegularizor:
 # --------------------------------------------------------------------------------------------------------
 # texture-interpolation loss (loss_functions/losses.py:127-243) — the FLAME-free core
 # --------------------------------------------------------------------------------------------------------
+def interpolate_flame_labels(flm_lbls, t=None):
+    """train.py:224-227: neighbouring samples' FLAME parameters (shape / expression / pose / camera: the first 159 labels) are
+    blended with ONE random weight t ~ U(0,1) for the whole batch (np.random.uniform, like the reference; pass t to replay a
+    draw); light and texture codes (labels 159..) stay those of the first sample of each pair.  [B,L] -> [B-1,L]."""
+    if t is None:
+        t = np.random.uniform(0, 1)
+    a = flm_lbls[:-1, :159] + t * (flm_lbls[1:, :159] - flm_lbls[:-1, :159])
+    return torch.cat((a, flm_lbls[:-1, 159:]), dim=-1)
+
+
 class _TexPairLossFn(Function):
     """mean(sigmoid(((a - b) * ma * mb)^2) * f): one fused HIP reduction + one pointwise backward (once differentiable)."""
 

@@ -107,7 +107,7 @@ def _geom(B, Hb, Wb, Cb, Hs, Ws, Cs, spec: ConvSpec):
 
 
 # Gradient-producer fusions (gif_conv_epilogue ABI 2).  GIF_FUSE_GRAD=0 keeps every backward on the stand-alone passes (A/B).
-FUSE_GRAD = os.environ.get("GIF_FUSE_GRAD", "1") != "0"
+FUSE_GRAD = _lib.knob("GIF_FUSE_GRAD", "1") != "0"
 
 
 class GradFuse:
@@ -163,7 +163,7 @@ def _epilogue(in_scale=None, out_scale=None, bias=None, residual=None, act=False
 # gradient), so the results are kept until the parameter changes.  An entry is keyed on the identity of the BASE tensor (a
 # weak reference proves it is still the same object), its data pointer and in-place version counter (optimisers, copy_,
 # load_state_dict and FlatAdam all bump it) and the view geometry — never on an address alone.
-WEIGHT_CACHE = os.environ.get("GIF_WEIGHT_CACHE", "1") != "0"
+WEIGHT_CACHE = _lib.knob("GIF_WEIGHT_CACHE", "1") != "0"
 _weight_cache = {}
 _WEIGHT_CACHE_MAX = 512
 
@@ -192,8 +192,8 @@ def _cached_weight_op(w, tag, build):
     return out
 
 
-X3_TAPDENSE = os.environ.get("GIF_X3_TAPDENSE", "1") != "0"  # tap-dense K order for 3x3 layers with 8..28 contraction channels (A/B)
-X3_MIN_CIN = int(os.environ.get("GIF_X3_MIN_CIN", "24"))  # gif_conv2d_x3_eligible: >= 24 (one zero-padded 32-float K chunk)
+X3_TAPDENSE = _lib.knob("GIF_X3_TAPDENSE", "1") != "0"  # tap-dense K order for 3x3 layers with 8..28 contraction channels (A/B)
+X3_MIN_CIN = int(_lib.knob("GIF_X3_MIN_CIN", "24"))  # gif_conv2d_x3_eligible: >= 24 (one zero-padded 32-float K chunk)
 
 
 X3_MAX_INPUT_BYTES = (1 << 32) - (1 << 26)  # the bf16x3 / f16 kernels address their input through 32-bit buffer offsets (conv_igemm.hip)
@@ -212,18 +212,18 @@ def split_mode() -> bool:
     return get_fp32_mfma_mode() in ("bf16x3", "f16x2")
 
 
-H2_CONV = os.environ.get("GIF_H2_CONV", "1") != "0"    # f16x2 mode: direct fwd / dgrad kernels (A/B knobs per kernel family)
-H2_WGRAD = os.environ.get("GIF_H2_WGRAD", "1") != "0"  # f16x2 mode: weight-gradient kernels (direct and Winograd plane GEMMs)
+H2_CONV = _lib.knob("GIF_H2_CONV", "1") != "0"    # f16x2 mode: direct fwd / dgrad kernels (A/B knobs per kernel family)
+H2_WGRAD = _lib.knob("GIF_H2_WGRAD", "1") != "0"  # f16x2 mode: weight-gradient kernels (direct and Winograd plane GEMMs)
 
 
-H2_WINO = os.environ.get("GIF_H2_WINO", "1") != "0"    # f16x2 mode: Winograd fwd / dgrad GEMM
+H2_WINO = _lib.knob("GIF_H2_WINO", "1") != "0"    # f16x2 mode: Winograd fwd / dgrad GEMM
 H2_GUARD = True  # False: f16x2 launches run without their guarded bf16x3 twin (tests only: shows what the guard protects against)
 
 
 # f16x2 mode: the tap-dense launches (3x3 layers with 8..28 contraction channels) stay on the bf16x3 tap-dense kernel by default — the f16x2 form
 # (gif_conv2d_*_f32h2_tapdense, tests/test_gpu_f16x2.py) measured SLOWER in the step: 200.0 vs 198.5 ms in one call (24 -> 128 at 256^2: 7.9 vs
 # 6.7 ms per step; these launches are bound by their per-lane tap gathers, not by the matrix pipe, and the row tracking adds VALU work)
-H2_DENSE = os.environ.get("GIF_H2_DENSE", "0") != "0"
+H2_DENSE = _lib.knob("GIF_H2_DENSE", "0") != "0"
 
 
 def h2_conv(x3: bool, dense: bool) -> bool:
@@ -315,11 +315,16 @@ def pack_weight_h2x3(w: torch.Tensor, rows_are_out: bool, cout_act: int, cin_act
 
 # Winograd F(2x2,3x3) dispatch for stride-1 / pad-1 3x3 convs (conv_winograd.hip).  GIF_WINOGRAD=0 forces the direct
 # implicit-GEMM kernels; below GIF_WINOGRAD_MIN_TILES 2x2 tiles the launch cannot fill the chip and the direct path wins.
-WINOGRAD = os.environ.get("GIF_WINOGRAD", "1") != "0"
-WINOGRAD_MIN_TILES = int(os.environ.get("GIF_WINOGRAD_MIN_TILES", "8192"))
-WINOGRAD_WGRAD = os.environ.get("GIF_WINOGRAD_WGRAD", "1") != "0"
-WINOGRAD_X3 = os.environ.get("GIF_WINO_X3", "1") != "0"  # bf16x3 mode: Winograd fwd/dgrad GEMMs on the bf16x3 kernel too
-WINOGRAD_WGRAD_MIN_TILES = int(os.environ.get("GIF_WINOGRAD_WGRAD_MIN_TILES", "2048"))  # split-K fills the chip earlier
+WINOGRAD = _lib.knob("GIF_WINOGRAD", "1") != "0"
+WINOGRAD_MIN_TILES = int(_lib.knob("GIF_WINOGRAD_MIN_TILES", "8192"))
+WINOGRAD_WGRAD = _lib.knob("GIF_WINOGRAD_WGRAD", "1") != "0"
+WINOGRAD_X3 = _lib.knob("GIF_WINO_X3", "1") != "0"  # bf16x3 mode: Winograd fwd/dgrad GEMMs on the bf16x3 kernel too
+WINOGRAD_WGRAD_MIN_TILES = int(_lib.knob("GIF_WINOGRAD_WGRAD_MIN_TILES", "2048"))  # split-K fills the chip earlier
+# Per-channel-count rule (round 6, profiles/r6_dispatch_ab.md): the smaller of the two channel counts must reach these for the
+# Winograd route — forward / data gradient and weight gradient separately (the weight gradient re-uses the forward's V when both
+# take the route, otherwise it runs its own input transform).
+WINOGRAD_MIN_C = int(_lib.knob("GIF_WINOGRAD_MIN_C", "0"))
+WINOGRAD_WGRAD_MIN_C = int(_lib.knob("GIF_WINOGRAD_WGRAD_MIN_C", "0"))
 _winograd_calls = 0
 
 
@@ -328,11 +333,12 @@ def prof_winograd_calls():
     return _winograd_calls
 
 
-def winograd_eligible(spec: ConvSpec, B, H, W, cin_act, cout_act=64, min_tiles=None, dtype=torch.float32):
+def winograd_eligible(spec: ConvSpec, B, H, W, cin_act, cout_act=64, min_tiles=None, dtype=torch.float32, min_c=None):
     # cout < 48 wastes over a quarter of the GEMM's 64-wide N tile; the direct 256x32 kernel is faster there (measured)
     min_tiles = WINOGRAD_MIN_TILES if min_tiles is None else min_tiles
+    min_c = WINOGRAD_MIN_C if min_c is None else min_c
     return (WINOGRAD and dtype == torch.float32 and tuple(spec) == (3, 3, 1, 1) and H % 2 == 0 and W % 2 == 0 and cin_act >= 32 and cout_act >= 48
-            and B * (H // 2) * (W // 2) >= min_tiles)
+            and min(cin_act, cout_act) >= min_c and B * (H // 2) * (W // 2) >= min_tiles)
 
 
 def conv3x3_winograd(x, w, rows_are_out: bool, cout_act: int, wscale=1.0, keep_v=False, **epi):
@@ -509,7 +515,8 @@ def conv_wgrad(small, big, spec: ConvSpec, O, I, wscale=1.0, small_scale=None, b
     _, Cb, Hb, Wb = big.shape
     assert O <= Cs and I <= Cb
     if (WINOGRAD_WGRAD and (Hb, Wb) == (Hs, Ws) and Cs >= 64 and Cb >= 64
-            and winograd_eligible(spec, B, Hs, Ws, Cb, Cs, min(WINOGRAD_MIN_TILES, WINOGRAD_WGRAD_MIN_TILES), dtype=dt)):
+            and winograd_eligible(spec, B, Hs, Ws, Cb, Cs, min(WINOGRAD_MIN_TILES, WINOGRAD_WGRAD_MIN_TILES), dtype=dt,
+                                  min_c=WINOGRAD_WGRAD_MIN_C)):
         return conv3x3_winograd_wgrad(small, big, O, I, wscale, small_scale, big_scale, big_v)
     g = _geom(B, Hb, Wb, Cb, Hs, Ws, Cs, spec)
     RP, CP = ctypes.c_int(), ctypes.c_int()

@@ -98,3 +98,27 @@ def render_condition(vertices_ndc, faces, vertex_texture, h=256, w=256):
     normal_img = quantize_8bit(normal_img) * 2 - 1
     tex_img = quantize_8bit(tex_img) * 2 - 1
     return torch.cat((tex_img, normal_img), dim=1)
+
+
+class FlameConditionRenderer:
+    """callable flame_batch [N, >=159] -> (rend_flm, norma_map_img), both [N,3,h,w] in [-1,1]: the role
+    OverLayViz.get_rendered_mesh + the [-1,1] scaling play in InterpolatedTextureLoss.get_image_and_textures
+    (loss_functions/losses.py:184-215).  `flame` is the FLAME layer (absent submodule: injected; gif_amd.data.SyntheticFlame for
+    synthetic runs), `vertex_texture` [V,3] in [0,1] replaces the SH-lit albedo render (out of scope)."""
+
+    def __init__(self, flame, faces, vertex_texture, h=256, w=256):
+        self.flame, self.faces, self.vertex_texture, self.h, self.w = flame, faces, vertex_texture, h, w
+
+    def vertices(self, flame_batch):
+        """(FLAME vertices, vertices in NDC with the y flip of stg2_generator.py:368, camera)."""
+        shape, exp = flame_batch[:, 0:100], flame_batch[:, 100:150]
+        pose, cam = flame_batch[:, 150:156], flame_batch[:, 156:159]
+        verts, _, _ = self.flame(shape_params=shape, expression_params=exp, pose_params=pose)
+        trans = batch_orth_proj(verts, cam)
+        return verts, torch.cat([trans[:, :, :1], -trans[:, :, 1:]], 2), cam
+
+    def __call__(self, flame_batch):
+        _, v_ndc, _ = self.vertices(flame_batch)
+        tex = self.vertex_texture[None].expand(v_ndc.shape[0], -1, -1)
+        cond = render_condition(v_ndc, self.faces, tex, self.h, self.w)
+        return cond[:, :3], cond[:, 3:]

@@ -17,6 +17,7 @@ import torch
 import torch.distributed as dist
 import torch.nn.functional as F
 
+from . import _lib
 from . import losses
 from .optim import FlatAdam
 
@@ -296,7 +297,8 @@ class GifTrainer:
     def __init__(self, generator, discriminator, g_running, step=6, alpha=1.0, r1_every=16, gen_reg_type='None',
                  embedding_reg_weight=0.0, lr=0.002, fused_adam=None, process_group=None,
                  reuse_generator_forward=False, overlap_comm=None, sync_initial_state=True, act_dtype=None,
-                 loss_scale=2.0 ** 12, fuse_d_passes=None):
+                 loss_scale=2.0 ** 12, fuse_d_passes=None, texture_loss=None, adaptive_interp_loss=False, max_ids=None,
+                 flame_un_normalizer=None):
         self.G, self.D, self.G_ema = generator, discriminator, g_running
         # act_dtype=torch.float16: BASELINE config 5 — f16 activations in G and D (fp32 master weights, demodulation,
         # accumulation, optimiser), dynamic loss scaling on the device.  None keeps whatever the modules are set to.
@@ -331,6 +333,15 @@ class GifTrainer:
             dev = next(generator.parameters()).device
             self.g_scaler, self.d_scaler = DeviceLossScaler(dev, loss_scale), DeviceLossScaler(dev, loss_scale)
         self.pl_reg = losses.PathLengthRegularizor() if self.gen_reg_type == 'PATH_LEN_REG' else None
+        # Texture-space interpolation loss of run 29 (train.py:222-238, configurations.py:217): texture_loss is a
+        # losses.InterpolatedTextureLoss whose FLAME-dependent parts (texture decoder, condition renderer) were injected;
+        # g_step(flame_batch=) applies it on every generator step, like `args.apply_texture_space_interpolation_loss`.
+        # adaptive_interp_loss: train.py:233-234; max_ids: args.embedding_vocab_size (default: the generator's code book size);
+        # flame_un_normalizer: dataset.un_normalize_flame (train.py:228), identity when None.
+        self.texture_loss = texture_loss
+        self.adaptive_interp_loss = bool(adaptive_interp_loss)
+        self.max_ids = max_ids if max_ids is not None else getattr(generator, "embedding_vocab_size", 1)
+        self.flame_un_normalizer = flame_un_normalizer
         # Optional (off by default, NOT used by bench.py): the reference runs the generator twice per iteration on
         # identical inputs and identical weights (train.py:157 and :197 — G only changes at :243).  With this flag the
         # forward is executed once with autograd enabled; the D step consumes fake.detach(), the G step back-propagates
@@ -343,17 +354,20 @@ class GifTrainer:
         # and every D parameter receives ONE gradient instead of two that autograd has to add.  R1 iterations keep the separate
         # calls (the penalty differentiates the real half only).  GIF_FUSE_D=0 / fuse_d_passes=False: A/B.
         self.overlap_comm = _dist_on(process_group) if overlap_comm is None else overlap_comm
-        # With more than one rank and deferred exchanges the default is the TWO-call path: the fused pass needs the generated batch
-        # first, i.e. it has to complete G's exchange + Adam + EMA before any D work starts, while the two-call path hides them under
-        # D's forward on the real images.  The fused pass is worth ~1 ms on one GPU; an exposed 125 MB all-reduce costs more.  (No
-        # multi-GPU node was available to measure it: advisor finding of round 4; `comm_exposed_ms` in the bench line reports it.)
-        fuse_default = (os.environ.get("GIF_FUSE_D", "1") != "0") and not (self.overlap_comm and _dist_on(process_group))
-        if "GIF_FUSE_D" in os.environ and os.environ["GIF_FUSE_D"] != "0":
-            fuse_default = True  # an explicit GIF_FUSE_D=1 keeps the fused pass for the A/B
+        # The fused pass is the default at EVERY rank count (round 6): a multi-GPU run then issues exactly the launch sequence every
+        # single-GPU number was taken on, and `comm_exposed_ms` is the only difference between N = 1 and N > 1.  Its price with deferred
+        # exchanges: the fused pass needs the generated batch first, so G's exchange + Adam + EMA complete before any D work starts
+        # and G's all-reduce (125 MB) is exposed — predicted 0.7-1.5 ms per step on 8 GPUs — where the two-call path would
+        # hide it under D's forward on the real images at ~1 ms of extra launches.  fuse_d_passes=False (bench.py --two-call-d) keeps
+        # the two-call schedule for the A/B on hardware; GIF_FUSE_D=0 does the same under GIF_EXPERIMENTAL=1.
+        fuse_default = _lib.knob("GIF_FUSE_D", "1") != "0"
         self.fuse_d_passes = fuse_default if fuse_d_passes is None else bool(fuse_d_passes)
         # Experiment (review item 2 of round 4, profiles/r5_two_streams.txt): in the two-call D step the no-grad generator forward that
-        # produces the fake batch is independent of D's forward on the real images; GIF_TWO_STREAMS=1 runs it on a second HIP stream.
-        self.two_streams = os.environ.get("GIF_TWO_STREAMS", "0") == "1"
+        # produces the fake batch is independent of D's forward on the real images; GIF_TWO_STREAMS=1 (+ GIF_EXPERIMENTAL=1) runs it on
+        # a second HIP stream.  Packed-weight cache entries built on the side stream would later be consumed (and freed) on the main
+        # stream — a cross-stream use-after-free hazard in the caching allocator (advisor, round 5) — so the cache is switched off
+        # for the side-stream forward (it re-packs its weights; `fake`, the only tensor that leaves the block, gets record_stream).
+        self.two_streams = _lib.knob("GIF_TWO_STREAMS", "0") == "1"
         self._side = None
         self._d_update_pending = False
         self._g_update_pending = False
@@ -448,8 +462,13 @@ class GifTrainer:
             if self._side is None:
                 self._side = torch.cuda.Stream()
             self._side.wait_stream(main)  # the inputs and G's parameters are final on the main stream
-            with torch.cuda.stream(self._side), torch.no_grad():
-                fake = G(cond, None, step=self.res_step, alpha=self.alpha, input_indices=input_indices)[0]
+            from . import ops
+            cache_was, ops.WEIGHT_CACHE = ops.WEIGHT_CACHE, False  # nothing allocated on the side stream may outlive the block
+            try:
+                with torch.cuda.stream(self._side), torch.no_grad():
+                    fake = G(cond, None, step=self.res_step, alpha=self.alpha, input_indices=input_indices)[0]
+            finally:
+                ops.WEIGHT_CACHE = cache_was
             side_fake = True
         real_scores, _ = D([real_image], condition=cond, step=self.res_step, alpha=self.alpha)
         real_loss = F.softplus(-real_scores).mean()
@@ -484,8 +503,9 @@ class GifTrainer:
             self._d_optim_step()
         return d_loss.detach()
 
-    def g_step(self, cond, input_indices, fake=None):
-        """train.py:189-252"""
+    def g_step(self, cond, input_indices, fake=None, flame_batch=None):
+        """train.py:189-252.  flame_batch: the FLAME labels `flm_lbls` [B, >=159] of the batch — with a texture_loss installed the
+        texture-space interpolation loss (train.py:222-238) is added on them."""
         G, D = self.G, self.D
         self._finish_g_update()
         requires_grad(G, True)
@@ -516,6 +536,16 @@ class GifTrainer:
                 loss = loss + 1e-8 * 8 * losses.grad_penalty_loss([cond], torch.pow(fake[-1], 2), step=None).mean()
         if self.embedding_reg_weight:
             loss = loss + self.embedding_reg_weight * losses.l2_reg(G.z_to_w)
+        if self.texture_loss is not None and flame_batch is not None:
+            # train.py:222-238: the texture must stay the same when the face moves with different FLAME parameters
+            flm_intrp_batch = losses.interpolate_flame_labels(flame_batch)
+            if self.flame_un_normalizer is not None:
+                flm_intrp_batch = self.flame_un_normalizer(flm_intrp_batch)
+            interp_loss = self.texture_loss.tex_sp_intrp_loss(flm_intrp_batch, G, step=self.res_step, alpha=self.alpha,
+                                                              max_ids=self.max_ids)
+            if self.adaptive_interp_loss:
+                interp_loss = interp_loss * (0.25 * loss.detach() / interp_loss.detach())
+            loss = loss + interp_loss
         with watch():
             (loss if sc is None else loss * sc.scale).backward()
         if sc is not None:
@@ -524,16 +554,16 @@ class GifTrainer:
         requires_grad(G, False)
         return loss.detach()
 
-    def step(self, i, real_image, cond, input_indices):
+    def step(self, i, real_image, cond, input_indices, flame_batch=None):
         if self.reuse_generator_forward:
             self._finish_g_update()
             requires_grad(self.G, True)
             fake = self.G(cond, None, step=self.res_step, alpha=self.alpha, input_indices=input_indices)
             d_loss = self.d_step(i, real_image, cond, input_indices, fake=fake[0])
-            g_loss = self.g_step(cond, input_indices, fake=fake)
+            g_loss = self.g_step(cond, input_indices, fake=fake, flame_batch=flame_batch)
             return d_loss, g_loss
         d_loss = self.d_step(i, real_image, cond, input_indices)
-        g_loss = self.g_step(cond, input_indices)
+        g_loss = self.g_step(cond, input_indices, flame_batch=flame_batch)
         return d_loss, g_loss
 
 
@@ -541,12 +571,14 @@ class GifTrainer:
 F_G_256, F_D_256 = 52.33e9, 46.58e9
 
 
-def flops_per_image(res=256, r1_every=16, generator_forwards=2):
-    """generator_forwards: 2 = the reference's iteration (train.py:155, :195); 1 = GifTrainer(reuse_generator_forward=True)"""
+def flops_per_image(res=256, r1_every=16, generator_forwards=2, extra_generator_fwd_bwd=0.0):
+    """generator_forwards: 2 = the reference's iteration (train.py:155, :195); 1 = GifTrainer(reuse_generator_forward=True);
+    extra_generator_fwd_bwd: additional generator forward + backward passes per image of the batch (the texture-interpolation loss
+    runs one on batch - 1 images: (B - 1) / B)."""
     table = {64: (17.34e9, 16.46e9), 128: (33.76e9, 31.51e9), 256: (F_G_256, F_D_256), 512: (75.82e9, 61.69e9),
              1024: (111.71e9, 76.87e9)}
     fg, fd = table[res]
-    fl = 2 * ((2 + generator_forwards) * fg + 8 * fd)
+    fl = 2 * ((2 + generator_forwards + 3 * extra_generator_fwd_bwd) * fg + 8 * fd)
     if r1_every:
         fl += 2 * 3 * fd / r1_every
     return fl

@@ -65,9 +65,17 @@ int gif_f16_overflow_watch(int on);
  *            by that window (floor <= 2^-22; native fp32 MFMA: 2^-24 of the same quantity).  A launch in which BOTH operands
  *            have a group outside their windows raises a device-side gate and the op is recomputed by the BF16X3 kernels in
  *            the same stream ("guarded fallback": the bf16x3 launch that follows every f16x2 launch returns at once unless the
- *            gate is raised; no host synchronisation; gif_h2_fallback_stats counts the fallbacks taken; GIF_H2_GUARD=0 removes
- *            the guard).  Operands are 22-bit: results that cancel to < 2^-20 of their terms show it (tests/test_gpu_f16x2.py).
- *            Measured error against an fp64 convolution: 1.0-1.3 x the native fp32 MFMA path (tests/test_gpu_f16x2.py).
+ *            gate is raised; no host synchronisation; gif_h2_fallback_stats counts the OPS that fell back — a transposed
+ *            convolution's phases and a bulk + remainder launch pair count once).  Eager launches take their gate from a ring
+ *            of 65536 words under a growing generation: nothing is reset, any number of streams.  Launches recorded by a
+ *            stream capture (hipGraph) get a private word that a memset node clears on every replay — safe to replay, but
+ *            each captured guarded launch keeps one of 65536 words per device for the life of the process (GIF_ENOSUP when
+ *            they are used up: re-use graphs instead of re-capturing them).  Operands are 22-bit: results that cancel to
+ *            < 2^-20 of their terms show it (2.1-2.5 x the native kernel's error there).  An Inf operand element comes out
+ *            as NaN (the low term of an infinite high term is Inf - Inf), where NATIVE / BF16X3 propagate the Inf.
+ *            Measured error against an fp64 convolution (tests/test_gpu_f16x2.py): 0.6-0.8 x the native fp32 MFMA path on
+ *            normal data (16 exact products are summed before the accumulator rounds), held to <= 1.5 x on every adversarial
+ *            operand set but exact cancellation (bound 4).
  *            Layers the f16x2 kernels do not take (tap-dense thin layers, Winograd GEMMs not built for it) run BF16X3.
  *            Default: the GIF_FP32_MFMA environment variable ("native" / "bf16x3" / "f16x2"), else F16X2. */
 #define GIF_FP32_MFMA_NATIVE 0
@@ -100,7 +108,8 @@ int gif_pack_weight_f32h2x3(const float* w, void* wp2, void* wp3, int R, int C, 
 int64_t gif_pack_weight_f32h2_tapdense_bytes(int cin_act, int KH, int KW, int RP);
 int gif_pack_weight_f32h2x3_tapdense(const float* w, void* wp2, void* wp3, int R, int C, int cin_act, int KH, int KW, int RP, int64_t sr,
                                      int64_t sc, int64_t sky, int64_t skx, float scale, gif_stream_t stream);
-/* out2[0] = guarded launches that took the bf16x3 fallback on the current device since the last reset (synchronises the device) */
+/* out2[0] = guarded OPS that took the bf16x3 fallback on the current device since the last reset, out2[1] = 0 (reserved);
+ * synchronises the device */
 int gif_h2_fallback_stats(uint64_t* out2, int reset);
 /* Tap-dense K order for 3x3 layers with 8 <= cin_act < 32 contraction channels (the condition-noise convs 6->12->24 and the 24->C
  * layers that inject their result, stylegan2_common_layers.py:217-246): K runs over (tap, channel) without padding every tap to a

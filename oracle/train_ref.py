@@ -23,7 +23,18 @@ class RefTrainer:
         self.g_opt = torch.optim.Adam(self.g_params, lr=lr * gr, betas=(0.0, 0.99 ** gr))
         self.d_opt = torch.optim.Adam(self.d_params, lr=lr * dr, betas=(0.0, 0.99 ** dr))
 
-    def step(self, i, real, cond, idx):
+    def texture_interp_loss(self, tex):
+        """train.py:222-238 + loss_functions/losses.py:162-243 on pre-rendered inputs.  tex: dict with
+          gen_in [N,6,R,R] (rendered condition of the interpolated FLAME batch), identities [N] int64 (the one fixed identity),
+          verts / normals [N,V,3] and cam [N,3] (FlameTextureSpace.forward's mesh, stg2_generator.py:355-376), texture_data (the
+          dict of :348-353), face_mask [1,1,h,w], pairs [P,2] (the np.random.choice draw of :166-167)."""
+        from . import texture_loss_ref as TL
+        from . import texture_ref as TR
+        img = R.generator_forward(self.g, tex["gen_in"], self.res_step, tex["identities"])
+        textures, masks = TR.compute_texture_map(tex["texture_data"], img, tex["verts"], tex["normals"], tex["cam"])
+        return TL.texture_pairs_loss(tex["face_mask"], textures, masks, tex["pairs"])
+
+    def step(self, i, real, cond, idx, tex=None, adaptive_interp_loss=False):
         # ---- D step, train.py:82-178
         self.d_opt.zero_grad(set_to_none=True)
         real = real.detach().requires_grad_(True)
@@ -43,6 +54,11 @@ class RefTrainer:
             p.requires_grad_(False)
         fake = R.generator_forward(self.g, cond, self.res_step, idx)
         g_loss = F.softplus(-R.discriminator_forward(self.d, fake, cond, self.size)).mean()
+        if tex is not None:
+            interp_loss = self.texture_interp_loss(tex)
+            if adaptive_interp_loss:  # train.py:236-237
+                interp_loss = interp_loss * (0.25 * g_loss.detach() / interp_loss.detach())
+            g_loss = g_loss + interp_loss
         g_loss.backward()
         for p in self.d_params:
             p.requires_grad_(True)

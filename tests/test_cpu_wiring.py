@@ -432,3 +432,33 @@ def test_modulation_bank_is_one_call_and_equals_the_per_layer_linears(cpu, monke
     if noise is not None:
         g.generator(styles, None, noise, step=2, alpha=1)
         assert calls == []
+
+
+def test_interpolate_flame_labels_and_synthetic_flame_fixtures():
+    """Host logic of the texture-interpolation hook (train.py:224-227): neighbouring labels blended with one weight, light /
+    texture codes of the first sample kept; the synthetic FLAME stand-in and texture-space fixture have the reference's shapes."""
+    import numpy as np
+    from gif_amd import data, losses
+    lbl = torch.arange(4 * 236, dtype=torch.float32).view(4, 236)
+    out = losses.interpolate_flame_labels(lbl, t=0.25)
+    assert out.shape == (3, 236)
+    assert torch.allclose(out[:, :159], lbl[:-1, :159] + 0.25 * (lbl[1:, :159] - lbl[:-1, :159]))
+    assert torch.equal(out[:, 159:], lbl[:-1, 159:])
+    np.random.seed(3)
+    t = np.random.uniform(0, 1)
+    np.random.seed(3)
+    assert torch.allclose(losses.interpolate_flame_labels(lbl), losses.interpolate_flame_labels(lbl, t))
+    tmpl = np.random.RandomState(0).randn(50, 3).astype(np.float32)
+    flame = data.SyntheticFlame(tmpl, "cpu", seed=1)
+    lab = data.synthetic_flame_labels(3, "cpu", torch.Generator().manual_seed(2))
+    v, a, b = flame(shape_params=lab[:, :100], expression_params=lab[:, 100:150], pose_params=lab[:, 150:156])
+    assert v.shape == (3, 50, 3) and a is None and b is None
+    v0, _, _ = flame(torch.zeros(1, 100), torch.zeros(1, 50), torch.zeros(1, 6))
+    assert torch.allclose(v0[0], torch.from_numpy(tmpl), atol=1e-6)  # zero parameters = the template
+    R = data._rodrigues(torch.tensor([[0.0, 0.0, np.pi / 2]]))
+    assert torch.allclose(R[0] @ torch.tensor([1.0, 0.0, 0.0]), torch.tensor([0.0, 1.0, 0.0]), atol=1e-6)
+    faces = np.random.RandomState(1).randint(0, 50, (80, 3))
+    td = data.synthetic_texture_data(faces, T=64, fill=0.5)
+    n = len(td["valid_pixel_ids"])
+    assert td["valid_pixel_3d_faces"].shape == (n, 3) and td["valid_pixel_b_coords"].shape == (n, 3)
+    assert abs(n / 64 ** 2 - 0.5) < 0.05 and np.allclose(td["valid_pixel_b_coords"].sum(1), 1, atol=1e-5)

@@ -328,14 +328,14 @@ def test_model_gradients_fused_equal_standalone(res, step, f16, monkeypatch):
 
 
 # ------------------------------------------------------------------------------------------------ RCCL with more than one rank
-def _run_bench(nproc, extra, port):
+def _run_bench(nproc, extra, port, steps=3, r1_every=2, env_extra=None):
     import json
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(env_extra or {}))
     # the driver's command form: no launcher around it, bench.py spawns its own ranks (bench.self_launch); `port` is unused
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(nproc), "--steps", "3", "--warmup", "1", "--res", "64",
-           "--batch", "8", "--vocab", "64", "--r1-every", "2", "--no-cpu-baseline", "--no-prof", "--check-replicas"] + extra
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(nproc), "--steps", str(steps), "--warmup", "1", "--res", "64",
+           "--batch", "8", "--vocab", "64", "--r1-every", str(r1_every), "--no-cpu-baseline", "--no-prof", "--check-replicas"] + extra
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
@@ -343,17 +343,45 @@ def _run_bench(nproc, extra, port):
     return json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
 
 
+def _check_comm_fields(line, ranks):
+    import math
+    assert line["n_gpus"] == ranks and line["replicas"]["ranks"] == ranks and line["replicas"]["backend"] == "nccl"
+    assert line["replicas"]["replicas_identical"]
+    assert "comm_exposed_ms" in line and math.isfinite(line["comm_exposed_ms"]) and line["comm_exposed_ms"] >= 0.0
+    assert math.isfinite(line["value"]) and line["value"] > 0
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs of one node (RCCL over xGMI); the round's boxes have one")
 def test_bench_two_ranks_on_rccl_replicas_identical_and_overlap_equals_in_place():
-    """`python bench.py --gpus 2` (self-launching two ranks on RCCL): the replicas stay bit-identical, RCCL reports two ranks, and
-    the deferred (overlapped) exchange + optimiser schedule gives exactly the weights of the in-place schedule."""
-    a = _run_bench(2, [], 29631)
-    assert a["n_gpus"] == 2 and a["replicas"]["ranks"] == 2 and a["replicas"]["backend"] == "nccl"
-    assert a["replicas"]["replicas_identical"]
-    assert a["config"]["overlap_comm"] is True and a["comm_exposed_ms"] >= 0.0
-    b = _run_bench(2, ["--no-overlap-comm"], 29633)
-    assert b["config"]["overlap_comm"] is False and b["replicas"]["replicas_identical"]
-    assert a["replicas"]["param_digest"] == b["replicas"]["param_digest"], "overlapped and in-place schedules must give identical weights"
+    """`python bench.py --gpus 2` (self-launching two ranks on RCCL), 17 timed steps at R1 every 16th (one R1 iteration inside), for
+    BOTH D-step schedules (fused default, --two-call-d): the replicas stay bit-identical, RCCL reports two ranks, `comm_exposed_ms`
+    is present and finite, and the deferred (overlapped) exchange + optimiser schedule gives exactly the weights of the in-place
+    schedule."""
+    for extra in ([], ["--two-call-d"]):
+        a = _run_bench(2, extra, 29631, steps=17, r1_every=16)
+        _check_comm_fields(a, 2)
+        assert a["config"]["overlap_comm"] is True and a["config"]["r1_iterations_timed"] == 1
+        assert ("two calls" in a["config"]["d_step_discriminator_passes"]) == bool(extra)
+        b = _run_bench(2, extra + ["--no-overlap-comm"], 29633, steps=17, r1_every=16)
+        _check_comm_fields(b, 2)
+        assert b["config"]["overlap_comm"] is False
+        assert a["replicas"]["param_digest"] == b["replicas"]["param_digest"], "overlapped and in-place schedules must give identical weights"
+
+
+def test_bench_forced_collectives_take_the_single_gpu_launch_sequence():
+    """SCALE's N = 1 line must equal BENCH: a run with the collective code paths forced on (GIF_FORCE_DIST=1, one rank — what an
+    N > 1 rank executes apart from the size of the group) takes the SAME D-step path as the plain single-process run (the fused pass
+    over [real; fake]) and ends with bit-identical weights; --two-call-d is reported as such.  17 steps, one R1 iteration inside."""
+    plain = _run_bench(1, [], 0, steps=17, r1_every=16)
+    forced = _run_bench(1, [], 0, steps=17, r1_every=16, env_extra={"GIF_FORCE_DIST": "1"})
+    assert plain["config"]["d_step_discriminator_passes"] == forced["config"]["d_step_discriminator_passes"]
+    assert "one pass" in forced["config"]["d_step_discriminator_passes"]
+    _check_comm_fields(forced, 1)
+    assert forced["config"]["overlap_comm"] is True and plain["config"]["overlap_comm"] is False
+    assert forced["replicas"]["param_digest"] == plain["replicas"]["param_digest"], "deferred exchanges must not change the weights"
+    two = _run_bench(1, ["--two-call-d"], 0, steps=17, r1_every=16, env_extra={"GIF_FORCE_DIST": "1"})
+    _check_comm_fields(two, 1)
+    assert "two calls" in two["config"]["d_step_discriminator_passes"]
 
 
 def test_bench_single_rank_collective_code_path_and_line_contract():
