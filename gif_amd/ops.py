@@ -322,9 +322,12 @@ WINOGRAD_X3 = _lib.knob("GIF_WINO_X3", "1") != "0"  # bf16x3 mode: Winograd fwd/
 WINOGRAD_WGRAD_MIN_TILES = int(_lib.knob("GIF_WINOGRAD_WGRAD_MIN_TILES", "2048"))  # split-K fills the chip earlier
 # Per-channel-count rule (round 6, profiles/r6_dispatch_ab.md): the smaller of the two channel counts must reach these for the
 # Winograd route — forward / data gradient and weight gradient separately (the weight gradient re-uses the forward's V when both
-# take the route, otherwise it runs its own input transform).
-WINOGRAD_MIN_C = int(_lib.knob("GIF_WINOGRAD_MIN_C", "0"))
-WINOGRAD_WGRAD_MIN_C = int(_lib.knob("GIF_WINOGRAD_WGRAD_MIN_C", "0"))
+# take the route, otherwise it runs its own input transform).  Under f16x2 the direct kernels beat the Winograd route on the
+# 128-channel layers (one A/B call, alternating arms, ms per step: 184.8 / 184.4 with 0 / 0; 187.0 / 186.0 with 256 / 0; 186.4 / 185.4
+# with 0 / 256; 182.5 / 182.8 with 256 / 256; 188.3 with 512 / 512; 204.3 without Winograd) — the two halves only pay together: a
+# direct forward leaves the weight gradient without a V to re-use.
+WINOGRAD_MIN_C = int(_lib.knob("GIF_WINOGRAD_MIN_C", "256"))
+WINOGRAD_WGRAD_MIN_C = int(_lib.knob("GIF_WINOGRAD_WGRAD_MIN_C", "256"))
 _winograd_calls = 0
 
 

@@ -159,9 +159,11 @@ def test_bf16x3_tapdense_forward_and_data_gradient_vs_fp64(case, monkeypatch):
         assert err(fuse.colsum[:co], want.sum(dim=(0, 2, 3))) < 2e-5
 
 
-def test_bf16x3_winograd_plane_gemms_vs_fp64():
+def test_bf16x3_winograd_plane_gemms_vs_fp64(monkeypatch):
     """The 16 plane GEMMs of the Winograd weight gradient run on the same bf16x3 kernel (planes mode)."""
     from gif_amd import ops
+    monkeypatch.setattr(ops, "WINOGRAD_MIN_C", 0)  # (default dispatch: Winograd from 256 channels)
+    monkeypatch.setattr(ops, "WINOGRAD_WGRAD_MIN_C", 0)
     torch.manual_seed(5)
     B, C, H = 4, 128, 64
     x = torch.randn(B, C, H, H, device="cuda").contiguous(memory_format=torch.channels_last)
@@ -205,6 +207,8 @@ def test_bf16x3_winograd_fwd_dgrad_vs_fp64(case, monkeypatch):
     GEMM; 192 output channels are not a multiple of the 128-wide tile and must fall back to the native GEMM in both modes."""
     from gif_amd import ops
     monkeypatch.setattr(ops, "WINOGRAD_MIN_TILES", 1)
+    monkeypatch.setattr(ops, "WINOGRAD_MIN_C", 0)
+    monkeypatch.setattr(ops, "WINOGRAD_WGRAD_MIN_C", 0)
     B, ci, co, h = case
     torch.manual_seed(sum(case))
     spec = ops.ConvSpec(3, 3, 1, 1)
@@ -289,6 +293,8 @@ def test_bf16x3_adversarial_operands_vs_fp64(kind, cfg, monkeypatch):
     B, ci, co, h, wino = cfg
     monkeypatch.setattr(ops, "WINOGRAD", wino)
     monkeypatch.setattr(ops, "WINOGRAD_MIN_TILES", 1)
+    monkeypatch.setattr(ops, "WINOGRAD_MIN_C", 0)
+    monkeypatch.setattr(ops, "WINOGRAD_WGRAD_MIN_C", 0)
     g = torch.Generator().manual_seed(len(kind) * 1000 + h)
     spec = ops.ConvSpec(3, 3, 1, 1)
     x = ADV[kind](B, ci, h, g).cuda().contiguous(memory_format=torch.channels_last)

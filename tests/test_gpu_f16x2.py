@@ -252,6 +252,8 @@ def test_f16x2_one_sided_narrow_groups_need_no_fallback(wino, monkeypatch):
     from gif_amd import ops
     monkeypatch.setattr(ops, "WINOGRAD", wino)
     monkeypatch.setattr(ops, "WINOGRAD_MIN_TILES", 1)
+    monkeypatch.setattr(ops, "WINOGRAD_MIN_C", 0)
+    monkeypatch.setattr(ops, "WINOGRAD_WGRAD_MIN_C", 0)
     B, C, H = 2, 128, 32
     g = torch.Generator().manual_seed(13)
     x = torch.randn(B, C, H, H, generator=g)
@@ -297,6 +299,8 @@ def test_f16x2_winograd_fwd_dgrad_vs_fp64(case, monkeypatch):
     from gif_amd import ops
     monkeypatch.setattr(ops, "WINOGRAD", True)
     monkeypatch.setattr(ops, "WINOGRAD_MIN_TILES", 1)
+    monkeypatch.setattr(ops, "WINOGRAD_MIN_C", 0)
+    monkeypatch.setattr(ops, "WINOGRAD_WGRAD_MIN_C", 0)
     B, ci, co, h = case
     torch.manual_seed(sum(case))
     spec = ops.ConvSpec(3, 3, 1, 1)
@@ -327,6 +331,8 @@ def test_f16x2_winograd_adversarial(kind, monkeypatch):
     from gif_amd import ops
     monkeypatch.setattr(ops, "WINOGRAD", True)
     monkeypatch.setattr(ops, "WINOGRAD_MIN_TILES", 1)
+    monkeypatch.setattr(ops, "WINOGRAD_MIN_C", 0)
+    monkeypatch.setattr(ops, "WINOGRAD_WGRAD_MIN_C", 0)
     B, C, H = 2, 128, 32
     g = torch.Generator().manual_seed(len(kind) + 40)
     w = torch.randn(C, C, 3, 3, generator=g) / 34
@@ -380,6 +386,8 @@ def test_f16x2_weight_gradient_vs_fp64(case, monkeypatch):
     B, ci, co, k, s, p, h, wino = case
     monkeypatch.setattr(ops, "WINOGRAD", wino)
     monkeypatch.setattr(ops, "WINOGRAD_MIN_TILES", 1)
+    monkeypatch.setattr(ops, "WINOGRAD_MIN_C", 0)
+    monkeypatch.setattr(ops, "WINOGRAD_WGRAD_MIN_C", 0)
     monkeypatch.setattr(ops, "WINOGRAD_WGRAD_MIN_TILES", 1)
     torch.manual_seed(sum(case[:7]))
     spec = ops.ConvSpec(k, k, s, p)

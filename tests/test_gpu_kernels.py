@@ -252,6 +252,8 @@ def test_winograd_scales_and_epilogue(monkeypatch):
     assert_close(host(got), ref, 3e-5, "winograd fused epilogue")
     # dispatch: conv_fwd / conv_bwd_data route eligible shapes to Winograd once the tile threshold allows it
     monkeypatch.setattr(ops, "WINOGRAD_MIN_TILES", 0)
+    monkeypatch.setattr(ops, "WINOGRAD_MIN_C", 0)
+    monkeypatch.setattr(ops, "WINOGRAD_WGRAD_MIN_C", 0)
     assert ops.winograd_eligible(ops.ConvSpec(3, 3, 1, 1), B, H, H, Ci)
     assert not ops.winograd_eligible(ops.ConvSpec(3, 3, 2, 0), B, H, H, Ci)
     assert not ops.winograd_eligible(ops.ConvSpec(3, 3, 1, 1), B, 7, 7, Ci)

@@ -289,6 +289,8 @@ def test_goldens_with_every_eligible_layer_on_winograd(monkeypatch):
     relative L2 bound plus a cap on the number of outliers instead of an L_inf bound."""
     from gif_amd import losses, ops
     monkeypatch.setattr(ops, "WINOGRAD_MIN_TILES", 0)
+    monkeypatch.setattr(ops, "WINOGRAD_MIN_C", 0)
+    monkeypatch.setattr(ops, "WINOGRAD_WGRAD_MIN_C", 0)
     before = ops.prof_winograd_calls()
     test_generator_golden_forward_backward()
     test_generator_config1_golden()

@@ -143,6 +143,8 @@ def test_grad_fuse_conv_epilogues(case, monkeypatch):
     from gif_amd import ops
     B, Cs, Cb, K, st, pad, Hb, op, wino, mode = case
     monkeypatch.setattr(ops, "WINOGRAD", wino)
+    monkeypatch.setattr(ops, "WINOGRAD_MIN_C", 0)  # (the cases pin the route themselves; default dispatch: Winograd from 256 channels)
+    monkeypatch.setattr(ops, "WINOGRAD_WGRAD_MIN_C", 0)
     prev = ops.get_fp32_mfma_mode()
     ops.set_fp32_mfma_mode(mode)
     try:
