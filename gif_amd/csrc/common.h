@@ -47,6 +47,25 @@ inline const char* knob(const char* name) {
 
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// ---- buffer-addressed LDS-DMA (device pass only; the host pass sees empty stand-ins).  A raw buffer descriptor (stride 0) over
+// `bytes` of memory: `buffer_load_dwordx4 v_off, s[rsrc], s_off offen lds` moves 16 bytes per lane straight into LDS (lane-linear
+// destination behind the M0 base) and writes ZEROS for a lane whose byte offset (VGPR + SGPR part) is outside [0, bytes) — probed in
+// tools/probes/buffer_lds_oob_probe.hip (round 4) — so padding and tails cost one select instead of bounds checks, a 64-bit address
+// and a zero-page select per piece.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t buf_rsrc_t;
+__device__ __forceinline__ buf_rsrc_t make_buf_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ void buf_load_lds16(buf_rsrc_t r, __attribute__((address_space(3))) void* lds, unsigned voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds, 16, (int)voff, soff, 0, 0);
+}
+#else
+struct buf_rsrc_t {};
+__device__ __forceinline__ buf_rsrc_t make_buf_rsrc(const void*, unsigned) { return {}; }
+__device__ __forceinline__ void buf_load_lds16(buf_rsrc_t, __attribute__((address_space(3))) void*, unsigned, int) {}
+#endif
+
 // ---- per-device launch state (runtime.hip).  The library may be driven for several devices of one process (tensors on
 // cuda:1, DataParallel-style hosts) and from several threads (forward thread + autograd thread): nothing device-specific is
 // cached in a plain static.

@@ -649,7 +649,14 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q, (X3 == 2 && WAVES_P * 
 // TAPS (round 5, thin big side: the 24-channel condition-noise maps): a 128 x 32 tile per tap stages 16 KB of gy for every 4 KB of x and
 // sits on the LDS-DMA fill rate (13 FLOP per staged byte: 80 TFLOP/s measured).  Here the 128 tile columns are `tpt` TAPS x Cb channels
 // (5 x 24): gy is staged once per 5 taps, every column's thread gathers x at ITS tap's shift; 9 taps = 2 column tiles.
-template <bool TAB, bool TAPS = false>
+// BUF (round 6): the stage's LDS-DMA pieces go through buffer descriptors.  The small side's per-lane byte offset is loop invariant (the
+// stage travels in the instruction's SGPR offset; rows behind the split's end lie outside the descriptor and land as zeros): no VALU at
+// all per piece.  The big side keeps (ox, oy) per piece for the padding test and a running 32-bit byte offset that advances by constants
+// (+32 pixels; + a constant at a row wrap; + another at a sample wrap): ~19 VALU per piece where the 64-bit form spent ~50 — three
+// multiplies, three bounds checks, a zero-page select and the (ox, oy, b) wrap with both of its code paths; the ISA of round 5 showed
+// ~400 instructions per stage and wave for the addressing next to ~180 for the conversion and 24 MFMAs.  Needs both operands within
+// 2 GiB (checked on the host: larger launches keep the 64-bit form, BUF = false).
+template <bool TAB, bool TAPS = false, bool BUF = false>
 __global__ void __launch_bounds__(256, 2) conv_wgrad_h2v2(const WgradParams p) {
     constexpr int BP = 128, BQ = 128, BKP = 32, THREADS = 256, MT = 2, NT = 2, P_ROWS = 8, Q_ROWS = 8, P_IT = 4, Q_IT = 4;
     extern __shared__ __attribute__((aligned(16))) float wg_smem[];
@@ -704,8 +711,12 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_h2v2(const WgradParams p) {
         tab_rem = n_begin - b_first * (int)HWs;
     }
     int p_n[P_IT], q_n[Q_IT], q_b[Q_IT], q_oy[Q_IT], q_ox[Q_IT];
+    unsigned p_vo[P_IT], q_bo[Q_IT];  // BUF: byte offsets (small side: loop invariant; big side: running)
 #pragma unroll
-    for (int it = 0; it < P_IT; ++it) p_n[it] = n_begin + p_row + it * P_ROWS;
+    for (int it = 0; it < P_IT; ++it) {
+        p_n[it] = n_begin + p_row + it * P_ROWS;
+        p_vo[it] = p_ch_ok ? (unsigned)(p_n[it] * p.Cs + p_ch) * 4u : 0xFFFFFFFFu;
+    }
 #pragma unroll
     for (int it = 0; it < Q_IT; ++it) {
         int n = n_begin + q_row + it * Q_ROWS;
@@ -714,11 +725,50 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_h2v2(const WgradParams p) {
         unsigned r = (unsigned)n - b * HWs;
         unsigned oy = r / (unsigned)p.Ws;
         q_b[it] = (int)b; q_oy[it] = (int)oy; q_ox[it] = (int)(r - oy * (unsigned)p.Ws);
+        q_bo[it] = (unsigned)((((int)b * p.Hb + q_oy[it] * p.stride + ky - p.pad) * p.Wb + q_ox[it] * p.stride + kx - p.pad) * p.Cb + q_ch) * 4u;
     }
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // BUF: descriptors and the constants of the running offsets (all wave-uniform).  Small side: rows >= n_end are outside; big side: the
+    // whole tensor (a stage only reaches past n_end in the LAST split, where those rows belong to sample B: outside) — planes mode: the
+    // plane up to n_end (its padding rows are uninitialised memory)
+    const gif::buf_rsrc_t rs_p = gif::make_buf_rsrc(smb, (unsigned)n_end * (unsigned)p.Cs * 4u);
+    const gif::buf_rsrc_t rs_q = gif::make_buf_rsrc(bgb, planes ? (unsigned)n_end * (unsigned)p.Cb * 4u
+                                                                  : (unsigned)p.B * (unsigned)p.Hb * (unsigned)p.Wb * (unsigned)p.Cb * 4u);
+    const unsigned q_step = (unsigned)(BKP * p.stride * p.Cb) * 4u;
+    const unsigned q_drow = (unsigned)((p.Wb - p.Ws) * p.stride * p.Cb) * 4u;           // on top of the linear advance, mod 2^32
+    const unsigned q_dsmp = (unsigned)((p.Hb - p.Hs * p.stride) * p.Wb * p.Cb) * 4u;
+    const int q_cy = ky - p.pad, q_cx = kx - p.pad;
+    int p_soff = 0;
     auto load_global = [&]() __attribute__((always_inline)) {
+        if constexpr (BUF) {
+#pragma unroll
+            for (int it = 0; it < P_IT; ++it)
+                gif::buf_load_lds16(rs_p, (lptr_t)(&Ps[it * P_ROWS][0] + wave_u * 256), p_vo[it], p_soff);
+            p_soff += BKP * p.Cs * 4;
+#pragma unroll
+            for (int it = 0; it < Q_IT; ++it) {
+                const int iy = q_oy[it] * p.stride + q_cy, ix = q_ox[it] * p.stride + q_cx;
+                const bool ok = q_ch_ok && (unsigned)iy < (unsigned)p.Hb && (unsigned)ix < (unsigned)p.Wb;
+                gif::buf_load_lds16(rs_q, (lptr_t)(&Qs[it * Q_ROWS][0] + wave_u * 256), ok ? q_bo[it] : 0xFFFFFFFFu, 0);
+                q_bo[it] += q_step;
+                q_ox[it] += BKP;
+                if (p.Ws >= BKP) {  // uniform: at most one row wrap per stage
+                    const bool wx = q_ox[it] >= p.Ws;
+                    q_ox[it] -= wx ? p.Ws : 0;
+                    q_oy[it] += wx ? 1 : 0;
+                    q_bo[it] += wx ? q_drow : 0u;
+                    const bool wy = q_oy[it] >= p.Hs;
+                    q_oy[it] -= wy ? p.Hs : 0;
+                    q_bo[it] += wy ? q_dsmp : 0u;
+                } else {
+                    while (q_ox[it] >= p.Ws) { q_ox[it] -= p.Ws; ++q_oy[it]; q_bo[it] += q_drow; }
+                    while (q_oy[it] >= p.Hs) { q_oy[it] -= p.Hs; q_bo[it] += q_dsmp; }
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < P_IT; ++it) {
             const bool ok = p_ch_ok && p_n[it] < n_end;
@@ -920,19 +970,28 @@ inline void thin_tap_tiles(int Cb, int T, int* tpt, int* tgroups) {
     *tpt = n;
     *tgroups = (T + n - 1) / n;
 }
-inline void wgrad_launch_v2(bool tab, dim3 grid, hipStream_t s, const WgradParams& p, bool taps = false) {
-    static gif::LdsAttr attr[3];
-    const size_t lds = (size_t)32 * 256 * 4 + (size_t)2 * 256 * 32 * 2 + (size_t)(512 + 8) * 4 + (size_t)(tab ? p.stab_nb * 256 : 0) * sizeof(float);
-    if (taps) {
-        attr[2].ensure(reinterpret_cast<const void*>(conv_wgrad_h2v2<false, true>), lds);
-        hipLaunchKernelGGL((conv_wgrad_h2v2<false, true>), grid, dim3(256), lds, s, p);
-    } else if (tab) {
-        attr[1].ensure(reinterpret_cast<const void*>(conv_wgrad_h2v2<true>), lds);
-        hipLaunchKernelGGL(conv_wgrad_h2v2<true>, grid, dim3(256), lds, s, p);
+// buffer-addressed DMA of conv_wgrad_h2v2: both operands (per plane in planes mode) within 2 GiB; GIF_H2_WGRAD_BUF=0: the 64-bit form (A/B)
+inline bool h2v2_buf_ok(const WgradParams& p) {
+    static const int off = gif::knob("GIF_H2_WGRAD_BUF") ? atoi(gif::knob("GIF_H2_WGRAD_BUF")) == 0 : 0;
+    const long lim = 1L << 31;
+    return !off && (long)p.B * p.Hs * p.Ws * p.Cs * 4 <= lim && (long)p.B * p.Hb * p.Wb * p.Cb * 4 <= lim;
+}
+template <bool TAB, bool TAPS>
+inline void wgrad_launch_v2_t(dim3 grid, size_t lds, hipStream_t s, const WgradParams& p) {
+    static gif::LdsAttr attr[2];
+    if (h2v2_buf_ok(p)) {
+        attr[1].ensure(reinterpret_cast<const void*>(conv_wgrad_h2v2<TAB, TAPS, true>), lds);
+        hipLaunchKernelGGL((conv_wgrad_h2v2<TAB, TAPS, true>), grid, dim3(256), lds, s, p);
     } else {
-        attr[0].ensure(reinterpret_cast<const void*>(conv_wgrad_h2v2<false>), lds);
-        hipLaunchKernelGGL(conv_wgrad_h2v2<false>, grid, dim3(256), lds, s, p);
+        attr[0].ensure(reinterpret_cast<const void*>(conv_wgrad_h2v2<TAB, TAPS, false>), lds);
+        hipLaunchKernelGGL((conv_wgrad_h2v2<TAB, TAPS, false>), grid, dim3(256), lds, s, p);
     }
+}
+inline void wgrad_launch_v2(bool tab, dim3 grid, hipStream_t s, const WgradParams& p, bool taps = false) {
+    const size_t lds = (size_t)32 * 256 * 4 + (size_t)2 * 256 * 32 * 2 + (size_t)(512 + 8) * 4 + (size_t)(tab ? p.stab_nb * 256 : 0) * sizeof(float);
+    if (taps) wgrad_launch_v2_t<false, true>(grid, lds, s, p);
+    else if (tab) wgrad_launch_v2_t<true, false>(grid, lds, s, p);
+    else wgrad_launch_v2_t<false, false>(grid, lds, s, p);
 }
 
 // wgrad tiles follow the SAME row/col padding as the forward packing (gif_conv2d_pack_dims(Cs, Cb)):
