@@ -244,6 +244,44 @@ def test_f16x2_guard_sends_out_of_window_operands_to_bf16x3(side):
 
 
 
+def test_f16x2_guard_survives_graph_capture_and_replay():
+    """A guarded launch recorded by a stream capture gets a private gate word that a memset node clears on every replay (round 6,
+    advisor finding: a generation baked into the recorded kernel arguments would make every replay after the first raise run the
+    twin, and disable the guard once eager launches pass the word).  One captured forward conv replayed on in-window data, on
+    out-of-window data (the twin must run and repair the result), on in-window data again (the twin must NOT run) and on
+    out-of-window data again; eager guarded launches in between keep working."""
+    from gif_amd import ops
+    x_bad, w = _window_case("activation")
+    x_ok = _cl(torch.randn_like(x_bad))
+    spec = ops.ConvSpec(3, 3, 1, 1)
+    ref_ok = F.conv2d(x_ok.double(), w.double(), padding=1)
+    ref_bad = F.conv2d(x_bad.double(), w.double(), padding=1)
+    ops.set_fp32_mfma_mode("native")
+    e_native_ok, e_native_bad = _err(ops.conv_fwd(x_ok, w, spec), ref_ok), _err(ops.conv_fwd(x_bad, w, spec), ref_bad)
+    ops.set_fp32_mfma_mode("f16x2")
+    static_x = x_ok.clone(memory_format=torch.preserve_format)
+    ops.conv_fwd(static_x, w, spec)  # eager warm-up: packs the weights (cached), loads the kernels
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        y = ops.conv_fwd(static_x, w, spec)
+    torch.cuda.synchronize()
+    n0 = ops.h2_fallback_stats()
+    expect = n0
+    for k, (xin, ref, e_native) in enumerate([(x_ok, ref_ok, e_native_ok), (x_bad, ref_bad, e_native_bad), (x_ok, ref_ok, e_native_ok),
+                                             (x_bad, ref_bad, e_native_bad), (x_bad, ref_bad, e_native_bad), (x_ok, ref_ok, e_native_ok)]):
+        static_x.copy_(xin)
+        graph.replay()
+        torch.cuda.synchronize()
+        expect += 1 if xin is x_bad else 0
+        assert ops.h2_fallback_stats() == expect, (k, ops.h2_fallback_stats(), expect)
+        assert _err(y, ref) <= 1.5 * e_native + 2e-7, (k, _err(y, ref), e_native)
+        # an eager guarded launch between replays: own gate from the ring, unaffected by (and not affecting) the captured word
+        e = _err(ops.conv_fwd(x_bad, w, spec), ref_bad)
+        expect += 1
+        assert ops.h2_fallback_stats() == expect and e <= 1.5 * e_native_bad + 2e-7, (k, e)
+
+
 @pytest.mark.parametrize("wino", [False, True])
 def test_f16x2_one_sided_narrow_groups_need_no_fallback(wino, monkeypatch):
     """Only ONE operand has groups outside its window (16 activation channels at 2^-24 of the others, ordinary weights): the error
