@@ -1218,6 +1218,228 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, (X3 == 2 && WAVES_M * 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// f16x2 "row" kernel for stride-1 3x3 layers with <= 32 output channels (round 6: the C -> 24 data gradients of the condition-noise convs,
+// stylegan2_common_layers.py:405-414 backwards).  On a 256 x 32 tile the gather kernel stages 32 KB of activations per tap and K chunk for
+// 0.5 MFLOP — 14.5 FLOP per staged byte, 82-85 TFLOP/s: it sits on its LDS-DMA (profiles/r6_kxshare_probe.txt: -33 % with a third of the
+// activation pieces).  Here the M tile is 256 consecutive output pixels = whole image rows (or a 256-pixel piece of one): for one kernel
+// ROW dy and one 32-channel K chunk the input pixels of those rows PLUS one halo pixel on either side are staged ONCE ([288][32] fp32 by
+// LDS-DMA, same unpadded 128-byte rows and (row >> 1) & 7 chunk swizzle as glds_body: out-of-image pixels are out-of-range buffer offsets
+// = zeros), and the three dx taps are three operand reads of the same buffer shifted by one row each — any 32 consecutive rows stay
+// conflict free under that swizzle (16 lanes of a ds_read_b128 group = 16 distinct row indices mod 16).  A stage therefore carries 36 MFMAs
+// per wave (3 taps x 2 k-groups x 2 row tiles x 3 products) behind ONE barrier where the gather kernel has 12.  The weights of a stage (3
+// taps x 32 rows x 32 k, two f16 planes: 12 KB shared by all tiles) do not go through LDS at all: every lane keeps its operand fragments
+// in registers, loaded one stage ahead straight from L2.  4 waves x (64 pixels x 32 channels), two workgroups per CU (2 x 72 KB of LDS).
+// Running row exponents, accumulator rescale, guard and epilogue are glds_body's (the guarded twin is the gather kernel in bf16x3 on the
+// same 256-row tiles, so fused column sums / dot products land in the same partial rows).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kRowsThinA = 288;  // staged rows per stage: 256 + 2 halo pixels per image row of the tile (<= 8 rows), in whole 32-row passes
+
+__global__ void __launch_bounds__(256, 2) conv3x3_rows_thin_h2(const GatherParams p) {
+    constexpr int BM = 256, BN = 32, LD = 32, THREADS = 256, MT = 2, NT = 1, AROWS = kRowsThinA, A_IT = AROWS / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const As = smem;  // [2][AROWS][LD]
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const float* const px = static_cast<const float*>(p.x);
+    const unsigned short* const pw = static_cast<const unsigned short*>(p.wp);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm0 = wave * 64;
+    const int tile = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int m0 = tile * BM;
+    const int HWp = p.Hp * p.Wp;
+    // the tile's image rows: `segw` output pixels each, staged as `seg` buffer rows (one halo pixel on either side)
+    const int segw = p.Wp >= BM ? BM : p.Wp, seg = segw + 2, nseg = BM / segw;
+
+    // ---- activation DMA: buffer row r = tid / 8 + 32 * it holds input pixel (b, oy + dy, ox0 + j - 1) of its segment, logical 16-byte chunk
+    // (tid % 8) ^ f(r); the byte offset for dy = 0 is loop invariant, dy and the K chunk travel in the SGPR offset (base moved one image
+    // row up so that it stays >= 0), one validity bit per dy
+    unsigned a_voff[A_IT], a_mask[A_IT];
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+        const int r = (tid >> 3) + 32 * it;
+        const int sg = r / seg, j = r - sg * seg;
+        const int ms = m0 + sg * segw;
+        const bool in_tile = sg < nseg && ms < p.M;
+        const int mm = in_tile ? ms : 0;
+        const int b = mm / HWp, rr = mm - b * HWp;
+        const int oy = rr / p.Wp, ox0 = rr - oy * p.Wp;
+        const int ix = ox0 + j - 1;
+        const bool okx = in_tile && (unsigned)ix < (unsigned)p.Wi;
+        const int c4 = ((tid & 7) ^ ((r >> 1) & 7)) * 4;
+        a_voff[it] = (unsigned)(((b * p.Hi + oy) * p.Wi + ix) * p.Ci + c4) * 4u;
+        unsigned mk = 0;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) mk |= ((okx && (unsigned)(oy + d - 1) < (unsigned)p.Hi) ? 1u : 0u) << d;
+        a_mask[it] = mk | ((c4 < p.Ci) ? 0u : 0x80000000u);  // bit 31: this lane's channels are padding in the FIRST chunk already
+        (void)j;
+    }
+    const buf_rsrc_t rs_a = make_buf_rsrc(px - (size_t)p.Wi * p.Ci);
+    const int c4_lane = ((tid & 7)) * 4;  // (only its range matters below: the logical chunk is a permutation of 0..7 per row)
+    (void)c4_lane;
+
+    const int kch = p.CP / 32, nst = 3 * kch;
+    auto issue_a = [&](int buf, int st) __attribute__((always_inline)) {
+        const int ta = st / kch, kc = (st - ta * kch) * 32;
+        const int dy = p.dy0 + ta * p.ddy;  // -1, 0, 1 in the launch's order
+        const int so = ((dy + 1) * p.Wi * p.Ci + kc) * 4;
+        float* Ad = As + buf * AROWS * LD + wave * 8 * LD;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int r = (tid >> 3) + 32 * it;
+            const int c4 = ((tid & 7) ^ ((r >> 1) & 7)) * 4;
+            const unsigned bad = (__builtin_amdgcn_ubfe(a_mask[it], (unsigned)(dy + 1), 1u) - 1u) | ((kc + c4 < p.Ci) ? 0u : 0xFFFFFFFFu);
+            buf_load_lds16(rs_a, (lptr_t)(Ad + it * 32 * LD), a_voff[it] | bad, so);
+        }
+    };
+    // ---- weights: fragments of (tap column tb, k-group q, term t) of the stage, straight from the f16x2 packing [tap][2][RP][CP]
+    gif::u32x4_t sb[2][3][2][2];
+    auto issue_b = [&](auto set_tag, int st) __attribute__((always_inline)) {
+        constexpr int set = decltype(set_tag)::value;
+        const int ta = st / kch, kc = (st - ta * kch) * 32;
+#pragma unroll
+        for (int tb = 0; tb < 3; ++tb) {
+            const int widx = (p.ky0 + ta * p.kstep) * p.KW + p.kx0 + tb * p.kstep;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    sb[set][tb][q][t] = *reinterpret_cast<const gif::u32x4_t*>(pw + ((size_t)(widx * 2 + t) * p.RP + li) * p.CP + kc + q * 16 + lh * 8);
+        }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+    // running row exponents (glds_body, f16x2): lanes li and li + 32 feed the same row and agree
+    int h_ex[MT], h_dl[MT];
+    float h_sc[MT], h_lim[MT], h_max[MT];
+    unsigned h_gmin[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        h_ex[i] = 126; h_dl[i] = 0;
+        h_sc[i] = gif::h2_pow2(126); h_lim[i] = gif::kH2Limit * gif::h2_pow2(-126);
+        h_max[i] = 0.f; h_gmin[i] = 0xFFFFFFFFu;
+    }
+    // buffer row of this lane's output pixel in row tile i, before the tap shift: pixel index in the tile + 2 halo rows per image row passed
+    int a_row[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) a_row[i] = wm0 + i * 32 + li + 2 * ((wm0 + i * 32) / segw);
+
+    auto compute = [&](int buf, auto set_tag) __attribute__((always_inline)) {
+        constexpr int set = decltype(set_tag)::value;
+        const float* Ab = As + buf * AROWS * LD;
+#pragma unroll
+        for (int tb = 0; tb < 3; ++tb) {
+            const int shift = p.dx0 + tb * p.ddx + 1;  // 0, 1, 2 in the launch's order (wave-uniform)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                f32x4 ra[MT][2];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int brow = a_row[i] + shift;
+                    const int f = (brow >> 1) & 7;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) ra[i][u] = *reinterpret_cast<const f32x4*>(Ab + brow * LD + (((q * 4 + lh * 2 + u) ^ f) << 2));
+                }
+                gif::u32x4_t sa[2][MT];
+                bool need = false;
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    float m = fmaxf(fmaxf(fabsf(ra[i][0][0]), fabsf(ra[i][0][1])), fabsf(ra[i][0][2]));
+                    m = fmaxf(fmaxf(m, fabsf(ra[i][0][3])), fabsf(ra[i][1][0]));
+                    m = fmaxf(fmaxf(m, fabsf(ra[i][1][1])), fabsf(ra[i][1][2]));
+                    m = fmaxf(m, fabsf(ra[i][1][3]));
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+                    m = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+                    h_max[i] = fmaxf(h_max[i], m);
+                    h_gmin[i] = min(h_gmin[i], __float_as_uint(m) - 1u);
+                    h_dl[i] = 0;
+                    if (__builtin_amdgcn_ballot_w64(m > h_lim[i]) != 0) {  // wave-uniform, rare after a row's first groups
+                        const int ne = m > h_lim[i] ? gif::h2_exp_for(__float_as_uint(m), gif::kH2Target) : h_ex[i];
+                        h_dl[i] = ne - h_ex[i];
+                        h_ex[i] = ne;
+                        h_sc[i] = gif::h2_pow2(ne);
+                        h_lim[i] = ldexpf(gif::kH2Limit, -ne);
+                        need = true;
+                    }
+                }
+                if (need) {  // rows whose exponent changed: acc *= 2^(e' - e), exact (every earlier product has been accumulated)
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int d = __builtin_amdgcn_ds_bpermute(((r & 3) + 8 * (r >> 2) + 4 * lh) * 4, h_dl[i]);
+                            acc[i][0][r] = ldexpf(acc[i][0][r], d);
+                        }
+                }
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        unsigned h, l;
+                        gif::split_pair_h2_scalar(ra[i][e / 2][(e % 2) * 2], ra[i][e / 2][(e % 2) * 2 + 1], h_sc[i], h, l);
+                        sa[0][i][e] = h; sa[1][i][e] = l;
+                    }
+                constexpr int TA3[3] = {1, 0, 0}, TB3[3] = {0, 1, 0};  // lo*hi, hi*lo, hi*hi
+#pragma unroll
+                for (int t3 = 0; t3 < 3; ++t3)
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+                        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gif::f16x8_t, sa[TA3[t3]][i]),
+                                                                           __builtin_bit_cast(gif::f16x8_t, sb[set][tb][q][TB3[t3]]), acc[i][0], 0, 0, 0);
+            }
+        }
+    };
+
+    issue_a(0, 0);
+    issue_b(std::integral_constant<int, 0>{}, 0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) as an instruction the compiler's own wait insertion sees (it tracks the weight loads)
+    __syncthreads();
+    for (int st = 0; st < nst; st += 2) {
+        if (st + 1 < nst) {
+            issue_a(1, st + 1);
+            issue_b(std::integral_constant<int, 1>{}, st + 1);
+        }
+        compute(0, std::integral_constant<int, 0>{});
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) as an instruction the compiler's own wait insertion sees (it tracks the weight loads)
+        __syncthreads();
+        if (st + 1 < nst) {
+            if (st + 2 < nst) {
+                issue_a(0, st + 2);
+                issue_b(std::integral_constant<int, 0>{}, st + 2);
+            }
+            compute(1, std::integral_constant<int, 1>{});
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) as an instruction the compiler's own wait insertion sees (it tracks the weight loads)
+            __syncthreads();
+        }
+    }
+
+    // guard (common.h): a narrow K group in one of this wave's rows meeting a flagged weight row raises the launch's gate
+    {
+        bool wide = false;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) wide |= (int)(__float_as_uint(h_max[i]) >> 23) - (int)((h_gmin[i] + 1u) >> 23) > gif::kH2Window;
+        if (p.gate) {
+            const bool wflag = p.wexp[p.RP + li] != 0;
+            if (__builtin_amdgcn_ballot_w64(wide) != 0 && __builtin_amdgcn_ballot_w64(wflag) != 0 && lane == 0) atomicMax(p.gate, p.gate_gen);
+        }
+        const int wex = p.wexp[li];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int er = __builtin_amdgcn_ds_bpermute(((r & 3) + 8 * (r >> 2) + 4 * lh) * 4, h_ex[i]);
+                acc[i][0][r] = ldexpf(acc[i][0][r], -(er + wex));
+            }
+    }
+    conv_epilogue<BM, BN, LD, MT, NT, float, THREADS, false, 2 * AROWS * LD>(p, acc, smem, m0, 0, wm0, 0, tid, li, lh, HWp);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // f16 "halo" kernel for the thin high-resolution layers (<= 64 contraction channels, <= 64 output channels: the 512^2 / 1024^2
 // blocks of BASELINE configs[4], stg2_generator.py:159-209 at step = 7, 8; the condition-noise convs and ToRGB at every size).
 // The gather kernel above fetches every input pixel once PER TAP through the vector-memory path (9 x 64 B per output pixel at
@@ -1513,6 +1735,33 @@ int launch_glds_multi(GatherParams* ph, int nph, hipStream_t s) {
     return 0;
 }
 
+// conv3x3_rows_thin_h2: eligibility and launch (f16x2 launches of stride-1 3x3 layers with <= 32 output channels whose 256-row tiles are
+// whole image rows or 256-pixel pieces of one; GIF_H2_ROWS_THIN=0: the gather kernel, A/B)
+inline bool rows_thin_ok(const GatherParams& p) {
+    static const int off = gif::knob("GIF_H2_ROWS_THIN") ? atoi(gif::knob("GIF_H2_ROWS_THIN")) == 0 : 0;
+    const bool unit = (p.ddy == 1 || p.ddy == -1) && (p.ddx == 1 || p.ddx == -1) && p.dy0 + p.ddy == 0 && p.dx0 + p.ddx == 0;
+    return !off && p.x3 == 2 && !p.dense && !p.in_scale && p.nky == 3 && p.nkx == 3 && unit && p.is == 1 && p.os == 1 && p.ooy == 0 &&
+           p.oox == 0 && p.RP == 32 && p.CP % 32 == 0 && p.m_begin == 0 && p.M % 256 == 0 && p.Hp == p.Hi && p.Wp == p.Wi &&
+           p.Ho == p.Hp && p.Wo == p.Wp && (p.Wp % 256 == 0 || (p.Wp >= 32 && 256 % p.Wp == 0)) &&
+           ((long)p.B * p.Hi * p.Wi + p.Wi) * p.Ci * 4 < (1L << 32);
+}
+inline int launch_rows_thin(GatherParams& p, hipStream_t s) {
+    static gif::LdsAttr attr;
+    const size_t lds = (size_t)2 * kRowsThinA * 32 * sizeof(float);
+    p.tiles_m = p.M / 256;
+    p.tiles_n = 1;
+    p.stab_nb = 0;
+    p.stab_stride = 0;
+    attr.ensure(reinterpret_cast<const void*>(conv3x3_rows_thin_h2), lds);
+    p.zero = gif::zero_page16();
+    if (!p.zero) return -101;
+    p.part_row0 = t_part_rows;
+    t_part_rows += p.tiles_m;
+    t_last_bm = 256;
+    hipLaunchKernelGGL(conv3x3_rows_thin_h2, dim3((unsigned)p.tiles_m), dim3(256), lds, s, p);
+    return 0;
+}
+
 template <typename T, int BM, int BN, int WMv, int WNv>
 int launch_glds(GatherParams& p, hipStream_t s) {
     if constexpr (sizeof(T) == 4) {
@@ -1738,6 +1987,9 @@ int launch(GatherParams& p, hipStream_t s) {
             if (only_glds) return fail_f16(rc);
         }
         if constexpr (!F16) return launch_simple<128, 128, 32, 2, 2>(p, s);
+    }
+    if constexpr (!F16) {
+        if (rows_thin_ok(p)) return launch_rows_thin(p, s);  // f16x2, stride-1 3x3, <= 32 output channels: rows + halo staged once per kernel row
     }
     if (only_glds) return fail_f16(launch_glds<T, 256, 32, 4, 1>(p, s));
     if constexpr (!F16) {

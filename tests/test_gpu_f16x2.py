@@ -493,6 +493,82 @@ def test_f16x2_thin_weight_gradient_guard_falls_back_per_tap():
     assert ex <= 1.5 * en + 2e-7, (en, ex)
 
 
+# ------------------------------------------------------------------------------------------------ thin-output row kernel (round 6)
+ROWS_THIN_CASES = [  # B, C (contraction), n_out, H = W, op
+    (2, 128, 24, 256, "dgrad"),   # one image row per tile
+    (4, 256, 24, 128, "dgrad"),   # two image rows per tile: halo rows inside the staged buffer
+    (4, 512, 24, 64, "dgrad"),    # four
+    (8, 512, 24, 32, "dgrad"),    # eight rows per tile, sample boundaries inside a tile's neighbourhood
+    (1, 64, 32, 512, "dgrad"),    # a tile is a 256-pixel piece of a row; 32 outputs: no padding columns
+    (2, 128, 24, 256, "fwd"),     # forward conv with <= 32 output channels takes the same kernel
+    (4, 96, 16, 64, "fwd"),       # ragged contraction channels (3 K chunks), 16 outputs
+]
+
+
+@pytest.mark.parametrize("case", ROWS_THIN_CASES)
+def test_f16x2_rows_thin_kernel_vs_fp64(case):
+    """conv3x3_rows_thin_h2 (stride-1 3x3, <= 32 output channels, tiles = whole image rows staged ONCE per kernel row with a halo
+    pixel on either side, dx taps as shifted LDS reads, weights in registers): plain, and as a gradient producer with the
+    leaky-ReLU mask + column sums fused (the C -> 24 data gradients of the step run like that); zero padding at all four image
+    borders is exercised by every case (out-of-range buffer offsets)."""
+    from gif_amd import ops
+    B, C, n, H, op = case
+    torch.manual_seed(C + n + H)
+    spec = ops.ConvSpec(3, 3, 1, 1)
+    if op == "dgrad":  # data gradient of conv(n -> C): contraction over the C-channel gradient
+        w = torch.randn(C, n, 3, 3, device="cuda") / (n * 9) ** 0.5
+        src = _cl(torch.randn(B, C, H, H, device="cuda"))
+        ref = F.conv_transpose2d(src.double(), w.double(), padding=1)
+        run = lambda **epi: ops.conv_bwd_data(src, w, spec, (H, H), **epi)  # noqa: E731
+    else:
+        w = torch.randn(n, C, 3, 3, device="cuda") / (C * 9) ** 0.5
+        src = _cl(torch.randn(B, C, H, H, device="cuda"))
+        ref = F.conv2d(src.double(), w.double(), padding=1)
+        run = lambda **epi: ops.conv_fwd(src, w, spec, **epi)  # noqa: E731
+    out = {}
+    for mode in ("native", "f16x2"):
+        ops.set_fp32_mfma_mode(mode)
+        out[mode] = _err(run()[:, :n], ref)
+    assert ops.h2_fallback_stats() == 0
+    assert out["native"] < 1e-5 and out["f16x2"] <= 1.5 * out["native"] + 2e-7, (case, out)
+    # gradient-producer epilogue: mask of the activation the gradient flows into + bias-gradient column sums, bias, residual
+    npad = ops.pad4(n)
+    xact = _cl(torch.randn(B, npad, H, H, device="cuda"))
+    res = _cl(torch.randn(B, npad, H, H, device="cuda"))
+    fuse = ops.GradFuse(mask_src=xact, mask_slope=0.2, mask_gain=2 ** 0.5, want_colsum=True)
+    y = run(residual=res, fuse=fuse)
+    want = (ref + res[:, :n].double()) * torch.where(xact[:, :n] > 0, 1.0, 0.2).double() * 2 ** 0.5
+    assert _err(y[:, :n], want) <= 1.5 * out["native"] + 1e-6, (case, _err(y[:, :n], want))
+    assert _err(fuse.colsum[:n], want.sum(dim=(0, 2, 3))) < 2e-5, case
+
+
+def test_f16x2_rows_thin_kernel_guard_falls_back_to_the_gather_kernel():
+    """The row kernel's guarded twin is the bf16x3 gather kernel on the same 256-row tiles: 16 contraction channels at 2^-24 of the
+    others against weights at 2^24 on them (both operands out of their windows) -> the op falls back once, result fp32-grade, fused
+    column sums consistent with the stored output."""
+    from gif_amd import ops
+    g = torch.Generator().manual_seed(31)
+    B, C, n, H = 2, 128, 24, 64
+    gy = torch.randn(B, C, H, H, generator=g)
+    w = torch.randn(C, n, 3, 3, generator=g) / 15
+    gy[:, 32:48] *= 2.0 ** -24
+    w[32:48] *= 2.0 ** 24
+    gy, w = _cl(gy.cuda()), w.cuda()
+    spec = ops.ConvSpec(3, 3, 1, 1)
+    ref = F.conv_transpose2d(gy.double(), w.double(), padding=1)
+    ops.set_fp32_mfma_mode("native")
+    e_native = _err(ops.conv_bwd_data(gy, w, spec, (H, H))[:, :n], ref)
+    ops.set_fp32_mfma_mode("f16x2")
+    n0 = ops.h2_fallback_stats()
+    xact = _cl(torch.randn(B, ops.pad4(n), H, H, device="cuda"))
+    fuse = ops.GradFuse(mask_src=xact, mask_slope=0.2, mask_gain=1.0, want_colsum=True)
+    y = ops.conv_bwd_data(gy, w, spec, (H, H), fuse=fuse)
+    assert ops.h2_fallback_stats() == n0 + 1, "the launch must have taken its bf16x3 fallback"
+    want = ref * torch.where(xact[:, :n] > 0, 1.0, 0.2).double()
+    assert _err(y[:, :n], want) <= 1.5 * e_native + 2e-7, (_err(y[:, :n], want), e_native)
+    assert _err(fuse.colsum[:n], y[:, :n].double().sum(dim=(0, 2, 3))) < 1e-5
+
+
 # ------------------------------------------------------------------------------------------------ tap-dense K order on the f16x2 kernels
 @pytest.mark.parametrize("case", [(4, 24, 128, 1, 96), (4, 12, 24, 1, 64), (3, 24, 256, 1, 40), (2, 28, 64, 1, 24), (4, 24, 64, 2, 33)])
 def test_f16x2_tapdense_forward_and_data_gradient_vs_fp64(case, monkeypatch):
