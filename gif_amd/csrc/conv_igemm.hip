@@ -767,7 +767,7 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
     int sp_buf = 0, sp_so_a = 0, sp_so_b = 0;
     unsigned sp_t = 0, sp_chor = 0;
     bool sp_on = false;  // wave-uniform: this step has a stage to fetch
-    auto sp_begin = [&](int buf) __attribute__((always_inline)) {
+    [[maybe_unused]] auto sp_begin = [&](int buf) __attribute__((always_inline)) {
         const int dy = p.dy0 + ld_a * p.ddy, dx = p.dx0 + ld_b * p.ddx;
         const int widx = (p.ky0 + ld_a * p.kstep) * p.KW + p.kx0 + ld_b * p.kstep;
         sp_buf = buf;
@@ -781,7 +781,7 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
             if (++ld_b == p.nkx) { ld_b = 0; ++ld_a; }
         }
     };
-    auto sp_piece = [&](int k) __attribute__((always_inline)) {
+    [[maybe_unused]] auto sp_piece = [&](int k) __attribute__((always_inline)) {
         if constexpr (X3 != 0) {
             if (k < A_IT) {
                 T* Ad = As + sp_buf * BM * LD + wave * RPW * LD;
@@ -933,13 +933,13 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
         constexpr int NPROD_ = NPROD;
         constexpr int LEAD = H2 ? 4 : 6;  // MFMAs ahead of the first piece: they cover the LDS latency of the raw reads
         constexpr int SP_N = A_IT + B3_IT;                     // DMA pieces per stage and wave
-        constexpr int SP_EVERY = (NPROD_ * MT * NT) / SP_N > 0 ? (NPROD_ * MT * NT) / SP_N : 1;  // one piece every SP_EVERY MFMAs
+        [[maybe_unused]] constexpr int SP_EVERY = (NPROD_ * MT * NT) / SP_N > 0 ? (NPROD_ * MT * NT) / SP_N : 1;  // one piece every SP_EVERY MFMAs
         auto group = [&](int slot, int nslot, auto dma_tag) __attribute__((always_inline)) {
-            constexpr bool dma = decltype(dma_tag)::value;
+            [[maybe_unused]] constexpr bool dma = decltype(dma_tag)::value;
             constexpr int TA6[6] = {2, 0, 1, 1, 0, 0}, TB6[6] = {0, 2, 1, 0, 1, 0};
             constexpr int TA3[3] = {1, 0, 0}, TB3[3] = {0, 1, 0};
             int n = 0, piece = H2 ? -1 : 0;  // piece -1: the tracking step of f16x2
-            int spk = 0;
+            [[maybe_unused]] int spk = 0;
 #pragma unroll
             for (int t = (H2 ? 0 : GIF_X3_FIRST_TERM); t < NPROD; ++t)
 #pragma unroll
@@ -1272,12 +1272,9 @@ __global__ void __launch_bounds__(256, 2) conv3x3_rows_thin_h2(const GatherParam
         unsigned mk = 0;
 #pragma unroll
         for (int d = 0; d < 3; ++d) mk |= ((okx && (unsigned)(oy + d - 1) < (unsigned)p.Hi) ? 1u : 0u) << d;
-        a_mask[it] = mk | ((c4 < p.Ci) ? 0u : 0x80000000u);  // bit 31: this lane's channels are padding in the FIRST chunk already
-        (void)j;
+        a_mask[it] = mk;
     }
     const buf_rsrc_t rs_a = make_buf_rsrc(px - (size_t)p.Wi * p.Ci);
-    const int c4_lane = ((tid & 7)) * 4;  // (only its range matters below: the logical chunk is a permutation of 0..7 per row)
-    (void)c4_lane;
 
     const int kch = p.CP / 32, nst = 3 * kch;
     auto issue_a = [&](int buf, int st) __attribute__((always_inline)) {
