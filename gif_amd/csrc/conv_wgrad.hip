@@ -655,7 +655,7 @@ __global__ void __launch_bounds__(64 * WAVES_P * WAVES_Q, (X3 == 2 && WAVES_P * 
 // (+32 pixels; + a constant at a row wrap; + another at a sample wrap): ~19 VALU per piece where the 64-bit form spent ~50 — three
 // multiplies, three bounds checks, a zero-page select and the (ox, oy, b) wrap with both of its code paths; the ISA of round 5 showed
 // ~400 instructions per stage and wave for the addressing next to ~180 for the conversion and 24 MFMAs.  Needs both operands within
-// 2 GiB (checked on the host: larger launches keep the 64-bit form, BUF = false).
+// 3.5 GiB (checked on the host: larger launches keep the 64-bit form, BUF = false).
 template <bool TAB, bool TAPS = false, bool BUF = false>
 __global__ void __launch_bounds__(256, 2) conv_wgrad_h2v2(const WgradParams p) {
     constexpr int BP = 128, BQ = 128, BKP = 32, THREADS = 256, MT = 2, NT = 2, P_ROWS = 8, Q_ROWS = 8, P_IT = 4, Q_IT = 4;
@@ -970,10 +970,12 @@ inline void thin_tap_tiles(int Cb, int T, int* tpt, int* tgroups) {
     *tpt = n;
     *tgroups = (T + n - 1) / n;
 }
-// buffer-addressed DMA of conv_wgrad_h2v2: both operands (per plane in planes mode) within 2 GiB; GIF_H2_WGRAD_BUF=0: the 64-bit form (A/B)
+// buffer-addressed DMA of conv_wgrad_h2v2: both operands (per plane in planes mode) within 3.5 GiB; GIF_H2_WGRAD_BUF=0: the 64-bit form (A/B)
 inline bool h2v2_buf_ok(const WgradParams& p) {
     static const int off = gif::knob("GIF_H2_WGRAD_BUF") ? atoi(gif::knob("GIF_H2_WGRAD_BUF")) == 0 : 0;
-    const long lim = 1L << 31;
+    // byte offsets are unsigned 32-bit; rows a stage reaches past the end of a tensor (the last split's tail, < 32 pixels) must stay out of
+    // range without wrapping: 512 MiB of headroom below 4 GiB (the 64-sample discriminator pass on the blurred 257^2 map is 2.16 GB)
+    const long lim = (1L << 32) - (1L << 29);
     return !off && (long)p.B * p.Hs * p.Ws * p.Cs * 4 <= lim && (long)p.B * p.Hb * p.Wb * p.Cb * 4 <= lim;
 }
 template <bool TAB, bool TAPS>

@@ -449,6 +449,28 @@ def test_f16x2_weight_gradient_vs_fp64(case, monkeypatch):
         assert en < 1e-5 and ex <= 1.5 * en + 2e-7, (case, out)
 
 
+def test_f16x2_weight_gradient_operand_above_2_gib():
+    """The buffer-addressed DMA of conv_wgrad_h2v2 takes operands up to 3.5 GiB (32-bit byte offsets): the discriminator's 64-sample
+    pass on the blurred 257^2 map (128 channels: 2.16 GB) is the headline step's largest.  f16x2 against the native fp32 MFMA kernel
+    (64-bit addresses, checked against fp64 on the small cases above) on exactly that operand; the sample at the far end of the tensor
+    carries a marker so that a wrapped offset could not go unnoticed."""
+    from gif_amd import ops
+    torch.manual_seed(3)
+    B, ci, co, H = 64, 128, 32, 257
+    spec = ops.ConvSpec(3, 3, 2, 0)
+    x = _cl(torch.randn(B, ci, H, H, device="cuda"))
+    hs = spec.small_hw(H, H)[0]
+    gy = _cl(torch.randn(B, co, hs, hs, device="cuda"))
+    x[-1] *= 4.0
+    assert x.numel() * 4 > 2 ** 31
+    ops.set_fp32_mfma_mode("native")
+    ref = ops.conv_wgrad(gy, x, spec, co, ci).double()
+    ops.set_fp32_mfma_mode("f16x2")
+    got = ops.conv_wgrad(gy, x, spec, co, ci)
+    assert ops.h2_fallback_stats() == 0
+    assert _err(got, ref) < 2e-5, _err(got, ref)
+
+
 def test_f16x2_weight_gradient_growing_and_sparse_channels():
     """Channels whose magnitude grows 2^12 over the pixel axis (rescales of rows AND columns of the accumulators), half of the pixels
     exactly zero (ReLU-style): no fallback, fp32-grade."""
