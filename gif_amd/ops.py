@@ -326,8 +326,23 @@ WINOGRAD_WGRAD_MIN_TILES = int(_lib.knob("GIF_WINOGRAD_WGRAD_MIN_TILES", "2048")
 # 128-channel layers (one A/B call, alternating arms, ms per step: 184.8 / 184.4 with 0 / 0; 187.0 / 186.0 with 256 / 0; 186.4 / 185.4
 # with 0 / 256; 182.5 / 182.8 with 256 / 256; 188.3 with 512 / 512; 204.3 without Winograd) — the two halves only pay together: a
 # direct forward leaves the weight gradient without a V to re-use.
-WINOGRAD_MIN_C = int(_lib.knob("GIF_WINOGRAD_MIN_C", "256"))
-WINOGRAD_WGRAD_MIN_C = int(_lib.knob("GIF_WINOGRAD_WGRAD_MIN_C", "256"))
+# (The rule belongs to the f16x2 mode: with six bf16 products or the fp32-input MFMA per product the direct kernels are 1.4-2.3 x slower than
+# the Winograd route at 128 channels as well — those modes keep 0 / 0.  None = by mode; an int (tests, GIF_WINOGRAD_MIN_C /
+# GIF_WINOGRAD_WGRAD_MIN_C under GIF_EXPERIMENTAL=1) overrides.)
+_k = _lib.knob("GIF_WINOGRAD_MIN_C", "")
+WINOGRAD_MIN_C = int(_k) if _k != "" else None
+_k = _lib.knob("GIF_WINOGRAD_WGRAD_MIN_C", "")
+WINOGRAD_WGRAD_MIN_C = int(_k) if _k != "" else None
+del _k
+WINOGRAD_MIN_C_F16X2 = 256
+
+
+def _winograd_min_c(override):
+    if override is not None:
+        return override
+    return WINOGRAD_MIN_C_F16X2 if get_fp32_mfma_mode() == "f16x2" else 0
+
+
 _winograd_calls = 0
 
 
@@ -339,7 +354,7 @@ def prof_winograd_calls():
 def winograd_eligible(spec: ConvSpec, B, H, W, cin_act, cout_act=64, min_tiles=None, dtype=torch.float32, min_c=None):
     # cout < 48 wastes over a quarter of the GEMM's 64-wide N tile; the direct 256x32 kernel is faster there (measured)
     min_tiles = WINOGRAD_MIN_TILES if min_tiles is None else min_tiles
-    min_c = WINOGRAD_MIN_C if min_c is None else min_c
+    min_c = _winograd_min_c(WINOGRAD_MIN_C) if min_c is None else min_c
     return (WINOGRAD and dtype == torch.float32 and tuple(spec) == (3, 3, 1, 1) and H % 2 == 0 and W % 2 == 0 and cin_act >= 32 and cout_act >= 48
             and min(cin_act, cout_act) >= min_c and B * (H // 2) * (W // 2) >= min_tiles)
 
@@ -519,7 +534,7 @@ def conv_wgrad(small, big, spec: ConvSpec, O, I, wscale=1.0, small_scale=None, b
     assert O <= Cs and I <= Cb
     if (WINOGRAD_WGRAD and (Hb, Wb) == (Hs, Ws) and Cs >= 64 and Cb >= 64
             and winograd_eligible(spec, B, Hs, Ws, Cb, Cs, min(WINOGRAD_MIN_TILES, WINOGRAD_WGRAD_MIN_TILES), dtype=dt,
-                                  min_c=WINOGRAD_WGRAD_MIN_C)):
+                                  min_c=_winograd_min_c(WINOGRAD_WGRAD_MIN_C))):
         return conv3x3_winograd_wgrad(small, big, O, I, wscale, small_scale, big_scale, big_v)
     g = _geom(B, Hb, Wb, Cb, Hs, Ws, Cs, spec)
     RP, CP = ctypes.c_int(), ctypes.c_int()
