@@ -11,6 +11,7 @@ from gif_amd import ops  # noqa: E402
 
 B = int(os.environ.get("PROBE_BATCH", "32"))
 ops.set_fp32_mfma_mode(os.environ.get("GIF_PROBE_MODE", "bf16x3"))
+ops.WINOGRAD_MIN_C = ops.WINOGRAD_WGRAD_MIN_C = 0  # (round 6: the probe pins the route per launch itself)
 spec = ops.ConvSpec(3, 3, 1, 1)
 for C, H in ((128, 256), (512, 64)):
     x = torch.randn(B, C, H, H, device="cuda").contiguous(memory_format=torch.channels_last)
