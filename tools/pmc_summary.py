@@ -19,7 +19,7 @@ def main(root):
             for row in csv.DictReader(fh):
                 agg[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
     for kern, ctrs in sorted(agg.items()):
-        if not any(s in kern for s in ("conv_", "blur", "bias_act", "upfirdn", "wino_")):
+        if not any(s in kern for s in ("conv_", "conv3x3", "blur", "bias_act", "upfirdn", "wino_")):
             continue
         print(f"## {kern}")
         for c, vals in sorted(ctrs.items()):
