@@ -9,6 +9,8 @@ import torch.nn.functional as F
 sys.path.insert(0, ".")
 from gif_amd import ops  # noqa: E402
 
+ops.WINOGRAD_MIN_C = ops.WINOGRAD_WGRAD_MIN_C = 0  # (round 6: Winograd from 256 channels in f16x2 mode by default; this tool pins the route itself)
+
 CASES = [
     (4, 128, 128, 3, 1, 1, 192),
     (4, 128, 256, 3, 2, 0, 257),

@@ -7,6 +7,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from gif_amd import ops  # noqa: E402
+
+ops.WINOGRAD_MIN_C = ops.WINOGRAD_WGRAD_MIN_C = 0  # (round 6: Winograd from 256 channels in f16x2 mode by default; this tool pins the route itself)
 from tools.kernel_bench import timeit  # noqa: E402
 
 ops.set_fp32_mfma_mode("bf16x3")
