@@ -807,7 +807,13 @@ __global__ void __launch_bounds__(512, 1) wino_gemm_h2(const WinoParams p) {
         b2_off[it] = (unsigned)((size_t)term * planeU + (size_t)(n0 + r) * p.CP + (((lane & 3) ^ ((lane >> 4) & 3)) << 3));
     }
     const int kchunks = p.CP / WBK;
+#ifdef GIF_WINO_F4_PROBE  // timing probe (tools/probes/wino_f4_probe.py; results are meaningless): the GEMM of an UNFUSED F(4x4,3x3) — 36
+    // position GEMMs over a quarter of the rows, every position's accumulator stored as its own M plane (through p.residual) instead of
+    // being folded into 2x2 outputs; no output transform, no epilogue
+    const int nsteps = 36 * kchunks;
+#else
     const int nsteps = 16 * kchunks;
+#endif
     const float* vptr = p.V;
     const unsigned short* uptr = U2;
     int ld_kc = 0;
@@ -972,11 +978,30 @@ __global__ void __launch_bounds__(512, 1) wino_gemm_h2(const WinoParams p) {
         cur = cur == NST - 1 ? 0 : cur + 1;
         group(1, cur, 0);  // (after the last stage this prepares operands nobody uses: the reads stay inside the ring)
         if (++kc_in_pos == kchunks) {
+#ifdef GIF_WINO_F4_PROBE
+            {
+                float* Mp = const_cast<float*>(p.residual) + (size_t)pos * p.ntiles_pad * p.RP;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const int er = __builtin_amdgcn_ds_bpermute(((r & 3) + 8 * (r >> 2) + 4 * lh) * 4, h_ex);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        Mp[(size_t)row * p.RP + n0 + wn0 + j * 32 + li] = ldexpf(acc[j][r], -er);
+                        acc[j][r] = 0.f;
+                    }
+                }
+            }
+#else
             fold(pos);
+#endif
             kc_in_pos = 0;
             ++pos;
         }
     }
+#ifdef GIF_WINO_F4_PROBE
+    return;
+#endif
 
     // guard (common.h): a 16-element K group more than 2^kH2Window below its row's maximum meeting a weight row the packing flagged
     // raises the launch's gate
