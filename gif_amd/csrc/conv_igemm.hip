@@ -673,6 +673,9 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
             const int dy = p.dy0 + ta * p.ddy, dx = p.dx0 + tb * p.ddx;
             const unsigned tap_bytes = (unsigned)((dy * p.Wi + dx) * p.Ci + ch - min_off) * 4u;  // this LANE's tap (garbage past the last tap: masked)
             T* Ad = As + buf * BM * LD + wave * RPW * LD;
+#ifdef GIF_KXSHARE_PROBE  // (timing probe, results wrong: activation pieces on every third K step only)
+            if (ld_a % 3 == 0)
+#endif
 #pragma unroll
             for (int it = 0; it < A_IT; ++it) {
                 const unsigned voff = (a_voff[it] + tap_bytes) | (__builtin_amdgcn_ubfe(a_mask[it], (unsigned)t, 1u) - 1u);

@@ -8,7 +8,7 @@ from gif_amd import ops  # noqa: E402
 
 ops.set_fp32_mfma_mode("f16x2")
 ops.WINOGRAD = False
-SHAPES = [(32, 128, 128, 256, "fwd"), (32, 128, 128, 256, "fwd mod"), (32, 128, 128, 256, "dgrad"), (64, 128, 128, 256, "fwd"),
+SHAPES = [(32, 24, 128, 256, "fwd"), (32, 24, 256, 128, "fwd"), (32, 24, 512, 64, "fwd"), (32, 128, 128, 256, "fwd"), (32, 128, 128, 256, "fwd mod"), (32, 128, 128, 256, "dgrad"), (64, 128, 128, 256, "fwd"),
           (32, 24, 128, 256, "dgrad"), (32, 24, 256, 128, "dgrad"), (32, 24, 512, 64, "dgrad"), (32, 256, 256, 128, "fwd"), (32, 512, 512, 16, "fwd")]
 spec = ops.ConvSpec(3, 3, 1, 1)
 for B, ci, co, h, what in SHAPES:
