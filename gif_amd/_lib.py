@@ -6,6 +6,11 @@ Build it with `python -c "import __graft_entry__ as g; g.build()"` or `make -C g
 import ctypes
 import os
 
+# torch FIRST: it ships its own libamdhip64 and must be the copy the process binds — when this library (linked against the ROCm
+# install's runtime) is loaded before torch, the process ends up with two HIP runtimes and every launch from here fails with "no
+# ROCm-capable device is detected" (found in round 6: __graft_entry__.build() followed by smoke() in ONE process)
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgif_hip.so")
 
