@@ -113,3 +113,15 @@ def test_state_dict_keys_match_reference_template():
         assert torch.equal(g.state_dict()[k], v), k
     for k, v in gold["d_kernels"].items():
         assert torch.equal(d.state_dict()[k], v), k
+
+
+def test_lib_module_loads_torch_before_the_hip_library():
+    """gif_amd._lib must import torch BEFORE dlopen-ing libgif_hip.so: torch ships its own libamdhip64, and a process that binds the
+    ROCm install's copy first (library loaded before torch) ends up with two HIP runtimes — every launch then fails with "no
+    ROCm-capable device is detected" (round 6: build() + smoke() in one process).  Checked in a fresh interpreter."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import sys; sys.path.insert(0, %r); from gif_amd import _lib; assert 'torch' in sys.modules; _lib.load(); print('ok')" % root
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
