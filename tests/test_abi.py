@@ -125,3 +125,36 @@ def test_lib_module_loads_torch_before_the_hip_library():
     code = "import sys; sys.path.insert(0, %r); from gif_amd import _lib; assert 'torch' in sys.modules; _lib.load(); print('ok')" % root
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+
+
+def test_experimental_gate_over_ab_knobs(monkeypatch):
+    """A/B / ablation knobs are honoured only together with GIF_EXPERIMENTAL=1 (round 6): gif_amd._lib.knob returns the default
+    otherwise; the documented switches (GIF_FP32_MFMA) are not routed through it."""
+    from gif_amd import _lib
+    monkeypatch.setenv("GIF_WINOGRAD", "0")
+    monkeypatch.delenv("GIF_EXPERIMENTAL", raising=False)
+    assert _lib.knob("GIF_WINOGRAD", "1") == "1"
+    monkeypatch.setenv("GIF_EXPERIMENTAL", "0")
+    assert _lib.knob("GIF_WINOGRAD", "1") == "1"
+    monkeypatch.setenv("GIF_EXPERIMENTAL", "1")
+    assert _lib.knob("GIF_WINOGRAD", "1") == "0"
+    assert _lib.knob("GIF_NOT_SET_ANYWHERE", "7") == "7"
+
+
+def test_winograd_channel_rule_follows_the_contraction_mode():
+    """Round 6 dispatch: in the f16x2 mode the Winograd route starts at 256 channels on the thinner side (forward / data gradient and
+    weight gradient alike); bf16x3 and native keep the tile-count rule alone; an explicit override wins."""
+    from gif_amd import ops
+    spec = ops.ConvSpec(3, 3, 1, 1)
+    before = ops.get_fp32_mfma_mode()
+    try:
+        ops.set_fp32_mfma_mode("f16x2")
+        assert not ops.winograd_eligible(spec, 32, 256, 256, 128, 128)
+        assert ops.winograd_eligible(spec, 32, 128, 128, 256, 256)
+        assert not ops.winograd_eligible(spec, 32, 128, 128, 256, 128)  # the thinner side counts
+        assert ops.winograd_eligible(spec, 32, 256, 256, 128, 128, min_c=0)
+        for mode in ("bf16x3", "native"):
+            ops.set_fp32_mfma_mode(mode)
+            assert ops.winograd_eligible(spec, 32, 256, 256, 128, 128)
+    finally:
+        ops.set_fp32_mfma_mode(before)
