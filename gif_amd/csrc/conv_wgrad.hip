@@ -905,6 +905,9 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_h2v2(const WgradParams p) {
             __syncthreads();  // the stage's fp32 tiles have landed (vmcnt(0) of every wave); the previous stage's operand reads are done
             convert(par);
             __syncthreads();  // operand planes complete; the raw buffer is free again
+#ifdef GIF_WGRAD_NO_DMA_PROBE  // timing probe (results wrong): the K loop on stale raw data — what the per-stage DMA issue + landing costs
+            if (n0 == n_begin)
+#endif
             if (n0 + BKP < n_end) load_global();
             __builtin_amdgcn_sched_barrier(0);
             products(par);
