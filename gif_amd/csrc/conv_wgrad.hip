@@ -17,6 +17,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int BKP_MAX = 32;  // host-side rounding unit of the pixel chunks (any BKP below divides it)
 
 struct WgradParams {
@@ -973,6 +974,328 @@ inline void thin_tap_tiles(int Cb, int T, int* tpt, int* tgroups) {
     *tpt = n;
     *tgroups = (T + n - 1) / n;
 }
+// ------------------------------------------------------------------------------------------------------------------
+// f16x2 weight gradient, third form (round 6): NO raw LDS stage.  profiles/r6_wgrad_nodma_probe.txt: 28-30 % of conv_wgrad_h2v2's time
+// is its per-stage LDS-DMA — the raw fp32 stage is single-buffered (LDS budget of two workgroups per CU), so the DMA of stage s + 1 can
+// only be issued once the conversion has read stage s and has to land before the next conversion starts.  Here the converting threads
+// fetch their operands straight into REGISTERS with buffer_load_dwordx4, a whole stage ahead (8 loads = 32 VGPRs per thread and stage,
+// double buffered): thread (cg = tid / 4, po = tid % 4) owns the 4 channels 4 cg .. 4 cg + 3 of the stage (waves 0-1: small side, waves
+// 2-3: big side — roles are wave-uniform) and the 8 pixels 8 po .. 8 po + 7.  The four threads of a quad hold the 32 pixels of the same
+// channels: they agree on the group maxima with two quad-permute DPP steps (16-pixel K group maxima for the guard, the 32-pixel maximum
+// for the running exponent) and keep identical private copies of the channel state.  8 pixels of one channel = one 16-byte chunk of
+// each f16 term: the operand planes [term][channel][32 pixels] and their swizzle are v2's (its product phase is reused unchanged), as are
+// the exponent-change protocol through dexp / flags, the final descale, the guard and the partial-sum workspace.  LDS: 32 KB of planes
+// per workgroup.  Addresses: buffer descriptors as in v2 — small side: loop-invariant byte offsets + SGPR stage offset; big side: (ox,
+// oy) and a running offset of the thread's FIRST pixel per stage, the other 7 derived with at most one row wrap (host: Ws >= 32).
+// Not for the grouped-tap thin layers (conv_wgrad_h2v2<false, true>) and operands beyond 3.5 GiB: those keep v2.
+// ------------------------------------------------------------------------------------------------------------------
+// The prefetch loads are inline assembly with hand-placed s_waitcnt: as ordinary loads hipcc either sank them next to their use or drained the
+// younger stage with a vmcnt(0) ahead of every conversion (its wait insertion merges the two loop halves conservatively) — the prefetch was gone.
+// Descriptor words by hand (raw buffer, stride 0): {base lo, base hi, bytes, 0x00020000}.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4 rsrc_words(const void* base, unsigned bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+    return i32x4{(int)(unsigned)a, (int)(unsigned)(a >> 32), (int)bytes, 0x00020000};
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void asm_buf_load_x4(f32x4& dst, const i32x4 rsrc, unsigned voff, int soff) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+// wait until at most N vector-memory operations are in flight.  NOT with the fragments as "+v" operands (first version): hipcc then copied
+// them into fresh operand registers AHEAD of the wait on one path — a read of registers whose loads had not landed (wrong results whenever
+// two workgroups shared a CU).  A scheduling barrier keeps every later instruction behind the statement instead (checked in the ISA).
+template <int N>
+__device__ __forceinline__ void asm_wait_vm(f32x4 (&)[8]) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+#else
+__device__ __forceinline__ void asm_buf_load_x4(f32x4&, const i32x4, unsigned, int) {}
+template <int N>
+__device__ __forceinline__ void asm_wait_vm(f32x4 (&)[8]) {}
+#endif
+
+template <bool TAB>
+__global__ void __launch_bounds__(256, 2) conv_wgrad_h2v3(const WgradParams p) {
+    constexpr int BP = 128, BQ = 128, BKP = 32, MT = 2, NT = 2;
+    extern __shared__ __attribute__((aligned(16))) float wg_smem[];
+    unsigned short* Op = reinterpret_cast<unsigned short*>(wg_smem);  // [2 terms][256 channels][32 pixels] f16
+    int* dexp = reinterpret_cast<int*>(Op + 2 * 256 * 32);            // [256] exponent change of the stage
+    int* fexp = dexp + 256;                                           // [256] final exponents
+    int* flags = fexp + 256;                                          // [0], [1]: a channel changed (stage parity); [2], [3]: narrow group on the P / Q side
+    float* Stab = reinterpret_cast<float*>(flags + 8);                // TAB: [stab_nb][256]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wp0 = (wave >> 1) * 64, wq0 = (wave & 1) * 64;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = lid % p.tiles_pq;
+    const int t = (lid / p.tiles_pq) % p.T;
+    const int split = lid / (p.tiles_pq * p.T);
+    const int tq = tile % p.tiles_q, tp = tile / p.tiles_q;
+    const int r0 = tp * BP, c0 = tq * BQ;
+    const bool planes = p.sm_plane != 0;
+    const int ky = planes ? 0 : t / p.KW, kx = planes ? 0 : t - ky * p.KW;
+    const float* const smb = static_cast<const float*>(p.sm) + (size_t)t * p.sm_plane;
+    const float* const bgb = static_cast<const float*>(p.bg) + (size_t)t * p.bg_plane;
+    const int n_begin = (int)((long)split * p.chunk);
+    int n_end = n_begin + (int)p.chunk;
+    if (n_end > (int)p.Ntot) n_end = (int)p.Ntot;
+    const unsigned HWs = (unsigned)(p.Hs * p.Ws);
+
+    // ---- conversion role: 4 channels x 8 pixels per thread and stage
+    const int cg = tid >> 2, po = tid & 3;
+    const bool is_q = __builtin_amdgcn_readfirstlane(wave) >= 2;  // waves 2, 3 convert the big side
+    const int ch4 = (is_q ? cg - 32 : cg) * 4;                    // first of the 4 channels inside the side's 128-wide tile
+    const int gch = (is_q ? c0 : r0) + ch4;
+    const bool ch_ok = gch < (is_q ? p.Cb : p.Cs);                // channel counts are multiples of 4: all four or none
+    const int row0 = (is_q ? 128 : 0) + ch4;                      // plane row of channel 0 of this thread
+    int tab_row = 0, tab_rem = 0;
+    if (tid < 8) flags[tid] = 0;
+    if (TAB) {
+        const int b_first = n_begin / (int)HWs;
+        for (int e = tid; e < p.stab_nb * (BP + BQ); e += 256) {
+            int bl = e / (BP + BQ), c = e - bl * (BP + BQ);
+            int b = b_first + bl;
+            float v = 0.f;
+            if (b < p.B) {
+                if (c < BP) v = (r0 + c < p.Cs) ? (p.ss ? p.ss[(size_t)b * p.Cs + r0 + c] : 1.f) : 0.f;
+                else v = (c0 + c - BP < p.Cb) ? (p.bs ? p.bs[(size_t)b * p.Cb + c0 + c - BP] : 1.f) : 0.f;
+            }
+            Stab[e] = v;
+        }
+        tab_rem = n_begin - b_first * (int)HWs;
+    }
+    const i32x4 rs_p = rsrc_words(smb, (unsigned)n_end * (unsigned)p.Cs * 4u);
+    const i32x4 rs_q = rsrc_words(bgb, planes ? (unsigned)n_end * (unsigned)p.Cb * 4u
+                                                 : (unsigned)p.B * (unsigned)p.Hb * (unsigned)p.Wb * (unsigned)p.Cb * 4u);
+    // small side: byte offset of the thread's first pixel (loop invariant; pixel i adds i rows, the stage travels in the SGPR offset)
+    const unsigned p_v0 = ch_ok ? (unsigned)((n_begin + 8 * po) * p.Cs + gch) * 4u : 0xFFFFFFFFu;
+    const unsigned p_row = (unsigned)p.Cs * 4u;
+    int p_soff = 0;
+    // big side: (oy, ox) and running byte offset of the thread's first pixel of the stage
+    int q_oy, q_ox;
+    unsigned q_bo;
+    {
+        const unsigned n = (unsigned)(n_begin + 8 * po);
+        const unsigned b = n / HWs, r = n - b * HWs;
+        const unsigned oy = r / (unsigned)p.Ws;
+        q_oy = (int)oy; q_ox = (int)(r - oy * (unsigned)p.Ws);
+        q_bo = (unsigned)((((int)b * p.Hb + q_oy * p.stride + ky - p.pad) * p.Wb + q_ox * p.stride + kx - p.pad) * p.Cb + gch) * 4u;
+    }
+    const unsigned q_px = (unsigned)(p.stride * p.Cb) * 4u;                                 // one pixel along the row
+    const unsigned q_drow = (unsigned)((p.Wb - p.Ws) * p.stride * p.Cb) * 4u;               // extra at a row wrap (mod 2^32)
+    const unsigned q_dsmp = (unsigned)((p.Hb - p.Hs * p.stride) * p.Wb * p.Cb) * 4u;        // extra at a sample wrap
+    const int q_cy = ky - p.pad, q_cx = kx - p.pad;
+
+    f32x4 raw[2][8];
+    auto load_stage = [&](auto buf_tag) __attribute__((always_inline)) {
+        constexpr int bf = decltype(buf_tag)::value;
+        if (!is_q) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm_buf_load_x4(raw[bf][i], rs_p, p_v0 == 0xFFFFFFFFu ? p_v0 : p_v0 + (unsigned)i * p_row, p_soff);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                int ox = q_ox + i, oy = q_oy;
+                unsigned off = q_bo + (unsigned)i * q_px;
+                const bool wx = ox >= p.Ws;           // Ws >= 32: at most one row wrap inside the 8 pixels
+                ox -= wx ? p.Ws : 0;
+                oy += wx ? 1 : 0;
+                off += wx ? q_drow : 0u;
+                const bool wy = oy >= p.Hs;
+                oy -= wy ? p.Hs : 0;
+                off += wy ? q_dsmp : 0u;
+                const int iy = oy * p.stride + q_cy, ix = ox * p.stride + q_cx;
+                const bool ok = ch_ok && (unsigned)iy < (unsigned)p.Hb && (unsigned)ix < (unsigned)p.Wb;
+                asm_buf_load_x4(raw[bf][i], rs_q, ok ? off : 0xFFFFFFFFu, 0);
+            }
+        }
+        // advance to the next stage — in BOTH roles, unconditionally: updates of captured variables inside the role branch made hipcc
+        // route them through a selected stack address (a scratch load + s_waitcnt vmcnt(0) per stage: the prefetch was drained)
+        p_soff += BKP * p.Cs * 4;
+        q_bo += (unsigned)BKP * q_px;
+        q_ox += BKP;
+        const bool wx = q_ox >= p.Ws;  // (32 pixels: at most one row wrap)
+        q_ox -= wx ? p.Ws : 0;
+        q_oy += wx ? 1 : 0;
+        q_bo += wx ? q_drow : 0u;
+        const bool wy = q_oy >= p.Hs;
+        q_oy -= wy ? p.Hs : 0;
+        q_bo += wy ? q_dsmp : 0u;
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // private channel state (identical in the four threads of a quad)
+    int h_ex[4];
+    float h_sc[4], h_lim[4], h_max[4];
+    unsigned h_gmin[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        h_ex[k] = 126; h_sc[k] = gif::h2_pow2(126); h_lim[k] = gif::kH2Limit * gif::h2_pow2(-126); h_max[k] = 0.f; h_gmin[k] = 0xFFFFFFFFu;
+    }
+    auto quad_x1 = [](float v) __attribute__((always_inline)) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true)); };
+    auto quad_x2 = [](float v) __attribute__((always_inline)) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true)); };
+    auto convert = [&](auto buf_tag, int par) __attribute__((always_inline)) {
+        constexpr int bf = decltype(buf_tag)::value;
+        float sv[4] = {1.f, 1.f, 1.f, 1.f};
+        if (TAB) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sv[k] = Stab[tab_row * (BP + BQ) + row0 + k];
+            tab_rem += BKP;
+            if (tab_rem >= (int)HWs) { tab_rem -= (int)HWs; ++tab_row; }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = TAB ? raw[bf][i][k] * sv[k] : raw[bf][i][k];
+            float m8 = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fabsf(v[2]));
+            m8 = fmaxf(fmaxf(m8, fabsf(v[3])), fabsf(v[4]));
+            m8 = fmaxf(fmaxf(m8, fabsf(v[5])), fabsf(v[6]));
+            m8 = fmaxf(m8, fabsf(v[7]));
+            const float m16 = fmaxf(m8, quad_x1(m8));   // this thread's 16-pixel K group (pixel octets 2 (po / 2), + 1)
+            const float mo16 = quad_x2(m16);            // the stage's other K group
+            const float m = fmaxf(m16, mo16);
+            h_max[k] = fmaxf(h_max[k], m);
+            h_gmin[k] = min(h_gmin[k], min(__float_as_uint(m16) - 1u, __float_as_uint(mo16) - 1u));
+            int d = 0;
+            if (m > h_lim[k]) {  // the channel outgrew its exponent (all four threads of the quad take the branch together)
+                const int ne = gif::h2_exp_for(__float_as_uint(m), gif::kH2Target);
+                d = ne - h_ex[k];
+                h_ex[k] = ne;
+                h_sc[k] = gif::h2_pow2(ne);
+                h_lim[k] = ldexpf(gif::kH2Limit, -ne);
+                atomicOr(&flags[par], 1);
+            }
+            const int row = row0 + k;
+            if (po == 0) dexp[row] = d;
+            gif::u32x4_t hi4, lo4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned h, l;
+                gif::split_pair_h2_scalar(v[2 * e], v[2 * e + 1], h_sc[k], h, l);
+                hi4[e] = h; lo4[e] = l;
+            }
+            const int wsw = ((row >> 2) & 1) | ((((row >> 1) ^ (row >> 3)) & 1) << 1);  // v2's plane swizzle f(row)
+            unsigned short* const oprow = Op + row * 32 + ((po ^ wsw) << 3);
+            *reinterpret_cast<gif::u32x4_t*>(oprow) = hi4;
+            *reinterpret_cast<gif::u32x4_t*>(oprow + 256 * 32) = lo4;
+        }
+    };
+    // ---- product role (v2's)
+    const int rsw = ((li >> 2) & 1) | ((((li >> 1) ^ (li >> 3)) & 1) << 1);
+    auto products = [&](int par) __attribute__((always_inline)) {
+        if (flags[par] != 0) {
+            int dc[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) dc[j] = dexp[128 + wq0 + j * 32 + li];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dr = dexp[wp0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j][r] = ldexpf(acc[i][j][r], dr + dc[j]);
+                }
+        }
+        if (tid == 0) flags[par ^ 1] = 0;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            gif::u32x4_t sa[2][MT], sb[2][NT];
+            const int ch = ((2 * g + lh) ^ rsw) << 3;
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) sa[tt][i] = *reinterpret_cast<const gif::u32x4_t*>(Op + (tt * 256 + wp0 + i * 32 + li) * 32 + ch);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) sb[tt][j] = *reinterpret_cast<const gif::u32x4_t*>(Op + (tt * 256 + 128 + wq0 + j * 32 + li) * 32 + ch);
+            }
+            constexpr int TA3[3] = {1, 0, 0}, TB3[3] = {0, 1, 0};
+#pragma unroll
+            for (int t3 = 0; t3 < 3; ++t3)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gif::f16x8_t, sa[TA3[t3]][i]),
+                                                                           __builtin_bit_cast(gif::f16x8_t, sb[TB3[t3]][j]), acc[i][j], 0, 0, 0);
+        }
+    };
+
+    if (n_begin < n_end) {
+        __syncthreads();  // flags / Stab initialised
+        load_stage(std::integral_constant<int, 0>{});
+        int par = 0;
+        for (int n0 = n_begin; n0 < n_end; n0 += 2 * BKP) {
+            // stage n0 from raw[0]; its successor is requested first and stays in flight behind the conversion, the barrier and the products
+            if (n0 + BKP < n_end) {
+                load_stage(std::integral_constant<int, 1>{});
+#ifdef GIF_V3_DEBUG_WAIT0
+                asm_wait_vm<0>(raw[0]);
+#else
+                asm_wait_vm<8>(raw[0]);
+#endif
+            } else {
+                asm_wait_vm<0>(raw[0]);
+            }
+            convert(std::integral_constant<int, 0>{}, par);
+            __syncthreads();  // operand planes of this stage complete
+            products(par);
+            par ^= 1;
+            __syncthreads();  // every wave has read the planes: the next conversion may overwrite them
+            if (n0 + BKP < n_end) {
+                if (n0 + 2 * BKP < n_end) {
+                    load_stage(std::integral_constant<int, 0>{});
+#ifdef GIF_V3_DEBUG_WAIT0
+                    asm_wait_vm<0>(raw[1]);
+#else
+                    asm_wait_vm<8>(raw[1]);
+#endif
+                } else {
+                    asm_wait_vm<0>(raw[1]);
+                }
+                convert(std::integral_constant<int, 1>{}, par);
+                __syncthreads();
+                products(par);
+                par ^= 1;
+                __syncthreads();
+            }
+        }
+    }
+    // final exponents and the guard
+    __syncthreads();
+    if (po == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            fexp[row0 + k] = h_ex[k];
+            if ((int)(__float_as_uint(h_max[k]) >> 23) - (int)((h_gmin[k] + 1u) >> 23) > gif::kH2Window) atomicOr(&flags[is_q ? 3 : 2], 1);
+        }
+    }
+    __syncthreads();
+    if (tid == 0 && p.gate && flags[2] != 0 && flags[3] != 0) atomicMax(p.gate, p.gate_gen);
+    int ec[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) ec[j] = fexp[128 + wq0 + j * 32 + li];
+    float* out = p.ws + ((size_t)split * p.T + t) * p.RP * p.CP;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rl = wp0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int er = fexp[rl];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) out[(size_t)(r0 + rl) * p.CP + c0 + wq0 + j * 32 + li] = ldexpf(acc[i][j][r], -(er + ec[j]));
+        }
+}
+
 // buffer-addressed DMA of conv_wgrad_h2v2: both operands (per plane in planes mode) within 3.5 GiB; GIF_H2_WGRAD_BUF=0: the 64-bit form (A/B)
 inline bool h2v2_buf_ok(const WgradParams& p) {
     static const int off = gif::knob("GIF_H2_WGRAD_BUF") ? atoi(gif::knob("GIF_H2_WGRAD_BUF")) == 0 : 0;
@@ -992,7 +1315,29 @@ inline void wgrad_launch_v2_t(dim3 grid, size_t lds, hipStream_t s, const WgradP
         hipLaunchKernelGGL((conv_wgrad_h2v2<TAB, TAPS, false>), grid, dim3(256), lds, s, p);
     }
 }
+// conv_wgrad_h2v3 (operands prefetched into registers, no raw LDS stage): everything v2's buffer form takes except the grouped-tap thin
+// layers, with Ws >= 32 (one row wrap per 8 pixels / per stage).  OFF by default — GIF_H2_WGRAD_V3=1 (under GIF_EXPERIMENTAL=1) selects it:
+// +2-5 % per launch in isolation, nothing measurable in the step (178.7 / 179.1 ms with v2, 180.2 / 177.7 with v3, alternating arms:
+// profiles/r6_wgrad_v3_probe.txt), and v2 is the kernel every parity test of rounds 5-6 ran on.
+inline bool h2v3_ok(const WgradParams& p, bool taps) {
+    static const int on = gif::knob("GIF_H2_WGRAD_V3") ? atoi(gif::knob("GIF_H2_WGRAD_V3")) != 0 : 0;
+    return on && !taps && h2v2_buf_ok(p) && p.Ws >= 32;
+}
+// (measured, profiles/r6_wgrad_v3_probe.txt: +2-5 % on the un-modulated launches and the Winograd plane GEMMs, -2-3 % on the modulated ones,
+// whose per-sample scale multiplies sit in the conversion: those keep v2)
 inline void wgrad_launch_v2(bool tab, dim3 grid, hipStream_t s, const WgradParams& p, bool taps = false) {
+    if (!tab && h2v3_ok(p, taps)) {
+        static gif::LdsAttr attr3[2];
+        const size_t lds3 = (size_t)2 * 256 * 32 * 2 + (size_t)(512 + 8) * 4 + (size_t)(tab ? p.stab_nb * 256 : 0) * sizeof(float);
+        if (tab) {
+            attr3[1].ensure(reinterpret_cast<const void*>(conv_wgrad_h2v3<true>), lds3);
+            hipLaunchKernelGGL(conv_wgrad_h2v3<true>, grid, dim3(256), lds3, s, p);
+        } else {
+            attr3[0].ensure(reinterpret_cast<const void*>(conv_wgrad_h2v3<false>), lds3);
+            hipLaunchKernelGGL(conv_wgrad_h2v3<false>, grid, dim3(256), lds3, s, p);
+        }
+        return;
+    }
     const size_t lds = (size_t)32 * 256 * 4 + (size_t)2 * 256 * 32 * 2 + (size_t)(512 + 8) * 4 + (size_t)(tab ? p.stab_nb * 256 : 0) * sizeof(float);
     if (taps) wgrad_launch_v2_t<false, true>(grid, lds, s, p);
     else if (tab) wgrad_launch_v2_t<true, false>(grid, lds, s, p);

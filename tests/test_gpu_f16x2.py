@@ -413,6 +413,11 @@ WGRAD_CASES = [
     (32, 128, 128, 3, 1, 1, 32, False),   # batch 32
     (4, 128, 128, 3, 1, 1, 64, True),     # Winograd F(3x3,2x2): the 16 plane GEMMs on the same kernel
     (2, 256, 512, 3, 1, 1, 32, True),
+    # >= 512 workgroups = two per CU (round 6: the register-prefetch kernel's first version read operands ahead of their wait on one path
+    # — only visible once two workgroups shared a CU and the loads took longer)
+    (8, 128, 128, 3, 1, 1, 64, True),
+    (4, 256, 256, 3, 1, 1, 64, False),
+    (4, 128, 128, 3, 1, 1, 128, False),
 ]
 
 

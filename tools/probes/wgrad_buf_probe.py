@@ -50,10 +50,13 @@ def child():
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1:
+    if len(sys.argv) > 1 and sys.argv[1] == "child":
         child()
     else:
-        for arm, env in (("buffer-addressed DMA (default)", {}), ("64-bit addresses (GIF_H2_WGRAD_BUF=0)", {"GIF_H2_WGRAD_BUF": "0"}),
-                         ("buffer-addressed DMA (default), again", {})):
+        arms = (("v3: operands prefetched into registers (GIF_H2_WGRAD_V3=1)", {"GIF_H2_WGRAD_V3": "1"}), ("default: v2, buffer-addressed DMA", {}),
+                ("v2, 64-bit addresses (GIF_H2_WGRAD_BUF=0)", {"GIF_H2_WGRAD_BUF": "0"}), ("v3, again", {"GIF_H2_WGRAD_V3": "1"}))
+        if "--v3" in sys.argv:
+            arms = arms[:2] + arms[3:]
+        for arm, env in arms:
             print("== " + arm, flush=True)
             subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=dict(os.environ, GIF_EXPERIMENTAL="1", **env))
