@@ -2245,7 +2245,12 @@ static int conv2d_wgrad_f32_impl(const float* small, const float* big, float* ws
 #define GIF_WGRAD_LAUNCH(BP_, BQ_, WP_, WQ_, TH_)                                                                  \
     if (glds) wgrad_launch<float, BP_, BQ_, WP_, WQ_, true, 32>(grid, TH_, s, p);                                        \
     else wgrad_launch<float, BP_, BQ_, WP_, WQ_, false, 32>(grid, TH_, s, p)
-        const bool tab = (small_scale || big_scale) && (variant != 1 || x3) && tab_fits;
+        // Un-modulated f16x2 launches run the scale-table instantiation with unit scales (x 1.0f: bit-identical results) wherever it
+        // applies: that instantiation's instruction stream is 3-5 % faster than the plain one on every 128 x 128-tile shape — 3.02 -> 2.91 ms
+        // at 128@256^2, 2.92 -> 2.77 at 512@64^2, the modulated launches themselves 2.82 / 2.79 — for no reason visible in the source (the
+        // extra multiply moves hipcc's interleave of the conversion); -0.6 ms per step, three alternating pairs.  GIF_H2_WGRAD_PLAIN_TAB=0: A/B
+        static const int force_tab = gif::knob("GIF_H2_WGRAD_PLAIN_TAB") ? atoi(gif::knob("GIF_H2_WGRAD_PLAIN_TAB")) != 0 : 1;
+        const bool tab = ((small_scale || big_scale) || (force_tab && x3 && x3_mode == 2 && HWs % 32 == 0)) && (variant != 1 || x3) && tab_fits;
         static const int x3_simple = gif::knob("GIF_X3_WGRAD_SIMPLE") ? atoi(gif::knob("GIF_X3_WGRAD_SIMPLE")) : 0;  // A/B: 16-pixel stages, no pipeline
         // f16x2: the software-pipelined 32-pixel-stage instantiations; the launch is followed by its guarded bf16x3 twin
         const bool h2 = x3 && x3_mode == 2 && !x3_simple && (x3_thin || !tab || HWs % 32 == 0);
@@ -2391,7 +2396,13 @@ static int conv3x3_winograd_wgrad_impl(const float* x, const float* gy, float* V
         const gif::H2Gate gt = gif::h2_next_gate(s);
         if (gt.err) return gt.err;
         p.gate = gt.word; p.gate_gen = gt.gen; p.h2_stats = gif::h2_stats_words();
-        if (h2v2_on()) wgrad_launch_v2(false, grid, s, p);
+        if (h2v2_on()) {
+            // the plane GEMMs too run the scale-table instantiation with a one-row table of ones (see conv2d_wgrad_f32_impl: 3-5 % faster)
+            static const int plain_tab = gif::knob("GIF_H2_WGRAD_PLAIN_TAB") ? atoi(gif::knob("GIF_H2_WGRAD_PLAIN_TAB")) != 0 : 1;
+            WgradParams q = p;
+            q.stab_nb = 1;
+            wgrad_launch_v2(plain_tab != 0, grid, s, plain_tab ? q : p);
+        }
         else wgrad_launch<float, 128, 128, 2, 2, true, 32, false, 2>(grid, 256, s, p);
     }
     if (h2 && !p.gate) {}

@@ -55,6 +55,8 @@ if __name__ == "__main__":
     else:
         arms = (("v3: operands prefetched into registers (GIF_H2_WGRAD_V3=1)", {"GIF_H2_WGRAD_V3": "1"}), ("default: v2, buffer-addressed DMA", {}),
                 ("v2, 64-bit addresses (GIF_H2_WGRAD_BUF=0)", {"GIF_H2_WGRAD_BUF": "0"}), ("v3, again", {"GIF_H2_WGRAD_V3": "1"}))
+        if "--tab" in sys.argv:
+            arms = (("default (un-modulated launches on the scale-table kernel with unit scales)", {}), ("plain instantiation (GIF_H2_WGRAD_PLAIN_TAB=0)", {"GIF_H2_WGRAD_PLAIN_TAB": "0"}), ("default, again", {}))
         if "--v3" in sys.argv:
             arms = arms[:2] + arms[3:]
         for arm, env in arms:
