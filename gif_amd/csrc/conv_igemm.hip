@@ -33,13 +33,15 @@
 
 #ifdef GIF_X3_TIMING_PROBE
 // tools/probes/x3_sync_probe.sh: cycles the waves of the bf16x3 direct kernel spend at the mid-stage sync (own DMA wait, barrier), cycles in the K loop, waves
-__device__ unsigned long long g_x3_probe[4];
-extern "C" int gif_debug_x3_probe_read(unsigned long long* out4, int reset) {
+// [4] / [5]: cycles from kernel entry to the K loop (index tables, ring fill, first split) / from the K loop's end to the kernel's end (epilogue)
+// [6] scale-back + guard, [7] accumulators -> LDS incl. barriers, [8] entry -> first DMA issue (index tables), [9] first issue -> ring filled
+__device__ unsigned long long g_x3_probe[12];
+extern "C" int gif_debug_x3_probe_read(unsigned long long* out8, int reset) {
     hipDeviceSynchronize();
-    if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_x3_probe), 32) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_x3_probe), 96) != hipSuccess) return -1;
     if (reset) {
-        unsigned long long z[4] = {0, 0, 0, 0};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(g_x3_probe), z, 32) != hipSuccess) return -1;
+        unsigned long long z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_x3_probe), z, 96) != hipSuccess) return -1;
     }
     return 0;
 }
@@ -127,13 +129,21 @@ __device__ __forceinline__ void conv_epilogue(const GatherParams& p, f32x16 (&ac
     const T* const res = static_cast<const T*>(p.residual);
     T* const yout = static_cast<T*>(p.y);
     constexpr int LDC = BN + 4;
-    // the tile goes through LDS in EPI_CHUNKS row chunks so that it fits into the staging buffers' footprint
+    // the tile goes through LDS in EPI_CHUNKS row chunks so that it fits into the staging buffers' footprint.  Behind the chunk sits a row
+    // table (ROWTAB floats per row): the row's 64-bit output offset (or ~0: no such row) and its sample index, computed ONCE per row by one
+    // lane while the accumulators are written — the two integer divisions and the 64-bit multiply chain per row and LANE that the row loop
+    // carried before were ~50 of its ~85 VALU instructions, and the loop is 16 % of a 256 x 128 tile's life at 128 channels
+    // (profiles/r6_x3_life_probe.txt).  (Staging the three-stage ring's whole tile in ONE chunk — it fits — measured the same.)
+    constexpr int ROWTAB = 3;
     constexpr int STAGE_FLOATS = LDS_FLOATS ? LDS_FLOATS : 2 * (BM + BN) * LD;
-    constexpr int EPI_CHUNKS = (BM * LDC <= STAGE_FLOATS) ? 1 : (BM / 2 * LDC <= STAGE_FLOATS) ? 2
-                               : (BM / 4 * LDC <= STAGE_FLOATS) ? 4 : 8;
+    constexpr int EPI_CHUNKS = (BM * (LDC + ROWTAB) <= STAGE_FLOATS) ? 1 : (BM / 2 * (LDC + ROWTAB) <= STAGE_FLOATS) ? 2
+                               : (BM / 4 * (LDC + ROWTAB) <= STAGE_FLOATS) ? 4 : 8;
     constexpr int CR = BM / EPI_CHUNKS;  // rows per chunk
-    static_assert(CR % 32 == 0 && CR * LDC <= STAGE_FLOATS, "epilogue chunk must fit the staging LDS");
+    static_assert(CR % 32 == 0 && CR * (LDC + ROWTAB) <= STAGE_FLOATS && CR <= THREADS, "epilogue chunk must fit the staging LDS");
     float* Cs = smem;  // [CR][LDC]
+    unsigned long long* const roff = reinterpret_cast<unsigned long long*>(Cs + CR * LDC);  // [CR]
+    int* const rsmp = reinterpret_cast<int*>(roff + CR);                                    // [CR]
+    constexpr unsigned long long NO_ROW = ~0ull;
     constexpr int C4_ROW = BN / 4;           // float4 per tile row
     constexpr int EROWS = THREADS / C4_ROW;  // tile rows per pass
     constexpr int E_IT = CR / EROWS;
@@ -146,9 +156,41 @@ __device__ __forceinline__ void conv_epilogue(const GatherParams& p, f32x16 (&ac
     const T* const dsrc = static_cast<const T*>(p.dot_src);
     const bool fused = msk || dsrc || p.part_cs || p.part_dot;  // workgroup-uniform
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), ds = make_float4(0.f, 0.f, 0.f, 0.f);
+    // demodulation factors of this lane's four columns: a tile rarely spans more than two samples, so the first sample's and its successor's
+    // are loaded once (the row loop loaded them per row and waited for each: +11k cycles per tile on the generator's modulated convs)
+    int osb = 0;
+    // (ext-vector values, not float4 structs: hipcc kept the structs in stack slots and selected between their ADDRESSES per row)
+    f32x4 osc0 = {1.f, 1.f, 1.f, 1.f}, osc1 = osc0;
+    constexpr bool OSC = sizeof(T) == 4;  // (f16 kernels keep the per-row load: 8 more VGPRs cost them a wave per SIMD)
+    if (OSC && p.out_scale && n < p.Co) {
+        osb = T2D ? t2_b : (m0 < p.M ? m0 : p.M - 1) / HWp;  // workgroup-uniform
+        osc0 = *reinterpret_cast<const f32x4*>(p.out_scale + (size_t)osb * p.Co + n);
+        osc1 = *reinterpret_cast<const f32x4*>(p.out_scale + (size_t)(osb + 1 < p.B ? osb + 1 : osb) * p.Co + n);
+    }
 #pragma unroll
     for (int c = 0; c < EPI_CHUNKS; ++c) {
+#ifdef GIF_X3_TIMING_PROBE
+        const long long probe_c0 = clock64();
+#endif
         __syncthreads();  // staging buffers (c == 0) / previous chunk fully consumed
+        if (tid < CR) {  // row table of this chunk
+            int b, oy, ox;
+            bool okr;
+            if constexpr (T2D) {
+                const int r2 = c * CR + tid;
+                b = t2_b; oy = t2_oy0 + (r2 >> 4); ox = t2_ox0 + (r2 & 15);
+                okr = oy < p.Hp && ox < p.Wp;  // else: the patch overhangs the sub-grid
+            } else {
+                const int m = m0 + c * CR + tid;
+                okr = m < p.M;
+                const int mm = okr ? m : 0;
+                b = mm / HWp;
+                const int rr = mm - b * HWp;
+                oy = rr / p.Wp; ox = rr - oy * p.Wp;
+            }
+            roff[tid] = okr ? (unsigned long long)((((size_t)b * p.Ho + (oy * p.os + p.ooy)) * p.Wo + (ox * p.os + p.oox)) * p.Co) : NO_ROW;
+            rsmp[tid] = b;
+        }
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int rbase = wm0 + i * 32;           // wave-uniform
@@ -162,6 +204,9 @@ __device__ __forceinline__ void conv_epilogue(const GatherParams& p, f32x16 (&ac
                 }
         }
         __syncthreads();
+#ifdef GIF_X3_TIMING_PROBE
+        if ((tid & 63) == 0) atomicAdd(&g_x3_probe[7], (unsigned long long)(clock64() - probe_c0));
+#endif
         if (n < p.Co) {
             // two copies of the row loop: the plain one carries none of the gradient-producer work (measured on the f16 step, whose
             // MFMA phase is 8x shorter: the extra branches and the running sums cost 2 % of the whole step when they ran always)
@@ -174,33 +219,26 @@ __device__ __forceinline__ void conv_epilogue(const GatherParams& p, f32x16 (&ac
             // the f16 step 15 % SLOWER (occupancy; r4l).
             auto rows = [&](auto fused_tag) __attribute__((always_inline)) {
                 constexpr bool FUSED = decltype(fused_tag)::value;
-                constexpr int PF = FUSED ? (E_IT < PFMAX ? E_IT : PFMAX) : 1;
+                // (the plain loop batches its LDS reads the same way — row table and tile values of PF rows first: one at a time, every row
+                // paid two LDS round trips in sequence; its residual loads stay per row, see above)
+                constexpr int PF = (FUSED || sizeof(T) == 4) ? (E_IT < PFMAX ? E_IT : PFMAX) : 1;  // (f16 kernels: occupancy-bound, see above)
                 static_assert(E_IT % PF == 0, "epilogue batches");
                 const bool two_src = FUSED && msk && dsrc && msk != dsrc;
+                const f32x4 os0 = osc0, os1 = osc1;  // copies: a select between the by-reference captures is a select of stack addresses
 #pragma unroll 4
                 for (int it0 = 0; it0 < E_IT; it0 += PF) {
                     size_t off[PF];
                     int bs[PF];
                     bool ok[PF];
-                    float4 xa[PF], xb[PF];
+                    float4 xa[PF], xb[PF], vv[PF];
 #pragma unroll
                     for (int k = 0; k < PF; ++k) {
                         const int row = e_row0 + (it0 + k) * EROWS;
-                        int b, oy, ox;
-                        if constexpr (T2D) {
-                            const int r2 = c * CR + row;
-                            b = t2_b; oy = t2_oy0 + (r2 >> 4); ox = t2_ox0 + (r2 & 15);
-                            ok[k] = oy < p.Hp && ox < p.Wp;  // else: the patch overhangs the sub-grid
-                        } else {
-                            const int m = m0 + c * CR + row;
-                            ok[k] = m < p.M;
-                            const int mm = ok[k] ? m : 0;
-                            b = mm / HWp;
-                            const int rr = mm - b * HWp;
-                            oy = rr / p.Wp; ox = rr - oy * p.Wp;
-                        }
-                        bs[k] = b;
-                        off[k] = (((size_t)b * p.Ho + (oy * p.os + p.ooy)) * p.Wo + (ox * p.os + p.oox)) * p.Co + n;
+                        const unsigned long long o = roff[row];
+                        if constexpr (sizeof(T) == 4) vv[k] = *reinterpret_cast<const float4*>(Cs + row * LDC + e_c);
+                        ok[k] = o != NO_ROW;
+                        bs[k] = rsmp[row];
+                        off[k] = (size_t)o + n;
                         if constexpr (FUSED) {
                             xa[k] = xb[k] = make_float4(0.f, 0.f, 0.f, 0.f);
                             if (ok[k]) {
@@ -213,14 +251,16 @@ __device__ __forceinline__ void conv_epilogue(const GatherParams& p, f32x16 (&ac
 #pragma unroll
                     for (int k = 0; k < PF; ++k) {
                         if (!ok[k]) continue;
-                        const int row = e_row0 + (it0 + k) * EROWS;
-                        float4 v = *reinterpret_cast<const float4*>(Cs + row * LDC + e_c);
+                        float4 v = vv[k];
+                        if constexpr (sizeof(T) != 4) v = *reinterpret_cast<const float4*>(Cs + (e_row0 + (it0 + k) * EROWS) * LDC + e_c);
                         if (FUSED && dsrc) {  // modulation gradient: sum_pixels contraction * x
                             ds.x += v.x * xa[k].x; ds.y += v.y * xa[k].y; ds.z += v.z * xa[k].z; ds.w += v.w * xa[k].w;
                         }
                         if (p.out_scale) {
-                            float4 d = *reinterpret_cast<const float4*>(p.out_scale + (size_t)bs[k] * p.Co + n);
-                            v.x *= d.x; v.y *= d.y; v.z *= d.z; v.w *= d.w;
+                            f32x4 d = bs[k] == osb ? os0 : os1;
+                            if (!OSC || __builtin_expect(bs[k] > osb + 1, 0)) d = *reinterpret_cast<const f32x4*>(p.out_scale + (size_t)bs[k] * p.Co + n);
+                            const float dx = d[0], dy = d[1], dz = d[2], dw = d[3];
+                            v.x *= dx; v.y *= dy; v.z *= dz; v.w *= dw;
                         }
                         if (res) {
                             float4 rv = gif::load4(res + off[k]);
@@ -239,8 +279,13 @@ __device__ __forceinline__ void conv_epilogue(const GatherParams& p, f32x16 (&ac
                             }
                             cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
                         }
-                        if (sizeof(T) == 2 && p.out_f32) gif::store4(static_cast<float*>(p.y) + off[k], v);
-                        else gif::store4_flag(yout + off[k], v, p.sat_flag);
+#ifdef GIF_NOSTORE_PROBE  // timing probe (tools/probes/epilogue_probe.sh; results are WRONG): the row loop without its global stores
+                        if (p.M < 0)
+#endif
+                        {
+                            if (sizeof(T) == 2 && p.out_f32) gif::store4(static_cast<float*>(p.y) + off[k], v);
+                            else gif::store4_flag(yout + off[k], v, p.sat_flag);
+                        }
                     }
                 }
             };
@@ -513,6 +558,18 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
             if (bid == 0 && threadIdx.x == 0 && p.h2_stats && p.m_begin == 0) atomicAdd(p.h2_stats, 1u);  // (not the remainder launch)
         }
     }
+#ifdef GIF_DEPHASE_PROBE  // timing probe (tools/probes/dephase_probe.sh): the first round of workgroups starts in GIF_DEPHASE_PROBE phases, a K loop's
+    // 1/PHASES apart on neighbouring CUs of an XCD — do the launch-wide bursts of ring fills and tile stores (every CU at once) cost time?
+    if (X3 == 2 && bid < 256) {
+        const int ph = (bid >> 3) % GIF_DEPHASE_PROBE;
+        const long long d = (long long)(p.ntaps * (p.CP / BK)) * 4300 * ph / GIF_DEPHASE_PROBE, t0 = clock64();
+        while (clock64() - t0 < d) __builtin_amdgcn_s_sleep(32);
+    }
+#endif
+#ifdef GIF_X3_TIMING_PROBE
+    const long long probe_entry = clock64();
+    long long probe_loop_end = probe_entry;
+#endif
     extern __shared__ __attribute__((aligned(16))) float smem[];
     T* As = reinterpret_cast<T*>(smem);  // [NST][BM][LD]
     T* Bs = As + NST * BM * LD;          // [NST][BN][LD]
@@ -562,15 +619,37 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
         const int dyl = p.dy0 + (p.nky - 1) * p.ddy, dxl = p.dx0 + (p.nkx - 1) * p.ddx;
         min_off = (min(p.dy0, dyl) * p.Wi + min(p.dx0, dxl)) * p.Ci;
     }
+    // X3: the CH lanes of a row would each repeat the row's two integer divisions and tap tests, A_IT times: ONE lane per tile row does them
+    // and parks (byte offset, tap mask) in the ring's last stage, which no DMA touches before the K loop's first barrier (7.7k of a 256 x 128
+    // tile's 187k cycles went into these tables, profiles/r6_x3_life_probe.txt)
+    unsigned* const rtab = reinterpret_cast<unsigned*>(As + (NST - 1) * BM * LD);  // [BM][2]
+    if constexpr (X3 != 0) {
+        static_assert(BM <= THREADS, "row table: one lane per tile row");
+        if (tid < BM) {
+            const int m = m0 + tid;
+            const bool ok = m < p.M;
+            const int mm = ok ? m : 0;
+            const int b = mm / HWp;
+            const int r = mm - b * HWp;
+            const int oy = r / p.Wp, ox = r - oy * p.Wp;
+            const int iy0 = oy * p.is, ix0 = ox * p.is;
+            unsigned cm = 0, mk = 0;
+            for (int tb = 0; tb < p.nkx; ++tb) cm |= ((unsigned)(ix0 + p.dx0 + tb * p.ddx) < (unsigned)p.Wi ? 1u : 0u) << tb;
+            for (int ta = 0; ta < p.nky; ++ta)
+                mk |= (ok && (unsigned)(iy0 + p.dy0 + ta * p.ddy) < (unsigned)p.Hi ? cm : 0u) << (ta * p.nkx);
+            rtab[2 * tid] = (unsigned)(((b * p.Hi + iy0) * p.Wi + ix0) * p.Ci) * (unsigned)sizeof(T);
+            rtab[2 * tid + 1] = mk;
+        }
+    }
 #pragma unroll
-    for (int it = 0; it < A_IT; ++it) {
+    for (int it = 0; it < (X3 ? 0 : A_IT); ++it) {
         int m = m0 + t_row + it * RPP;
         bool ok = m < p.M;
         int mm = ok ? m : 0;
         int b = mm / HWp;
         int r = mm - b * HWp;
         int oy = r / p.Wp, ox = r - oy * p.Wp;
-        if constexpr (BUF) {
+        if constexpr (BUF && !X3) {
             const int iy0 = oy * p.is, ix0 = ox * p.is;
             a_voff[it] = (unsigned)(((b * p.Hi + iy0) * p.Wi + ix0) * p.Ci + src_c4) * (unsigned)sizeof(T);
             unsigned mk = 0;
@@ -608,7 +687,15 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
             if (m >= p.M) m = p.M - 1;
             s_row[i] = (m / HWp - b_first) * p.stab_stride + lh * EPC;
         }
-        __syncthreads();
+    }
+    if (SCALE || X3) __syncthreads();
+    if constexpr (X3 != 0) {
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const uint2 e = *reinterpret_cast<const uint2*>(rtab + 2 * (t_row + it * RPP));
+            a_voff[it] = e.x + (unsigned)src_c4 * (unsigned)sizeof(T);
+            a_mask[it] = e.y;
+        }
     }
     const int nsteps = dense_cpt ? (p.ntaps * dense_cpt + CH - 1) / CH : pair ? (p.ntaps + 1) / 2 : p.ntaps * (p.CP / BK);
     int ld_a = 0, ld_b = 0, ld_kc = 0;
@@ -995,6 +1082,9 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
         // DMA instructions per stage and wave (NST == 3: the newest stage stays in flight across the mid-stage sync)
         constexpr int DMA_PER_STAGE = A_IT + B3_IT;
         static_assert(NST == 2 || B3_BLK % NWAVES == 0, "three-stage ring: every wave issues the same number of pieces");
+#ifdef GIF_X3_TIMING_PROBE
+        const long long probe_i0 = clock64();
+#endif
         issue(0);
         if constexpr (NST == 3) {
             if (nsteps > 1) {
@@ -1003,6 +1093,12 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
             }
         }
         __syncthreads();
+#ifdef GIF_X3_TIMING_PROBE
+        if (lane == 0) {
+            atomicAdd(&g_x3_probe[8], (unsigned long long)(probe_i0 - probe_entry));
+            atomicAdd(&g_x3_probe[9], (unsigned long long)(clock64() - probe_i0));
+        }
+#endif
         read_raw(0, 0, 0, 0);
         track();  // (f16x2: first exponents; the accumulators are still zero)
 #pragma unroll
@@ -1091,7 +1187,9 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
             atomicAdd(&g_x3_probe[1], (unsigned long long)probe_sync);
             atomicAdd(&g_x3_probe[2], (unsigned long long)(clock64() - probe_t0));
             atomicAdd(&g_x3_probe[3], 1ull);
+            atomicAdd(&g_x3_probe[4], (unsigned long long)(probe_t0 - probe_entry));
         }
+        probe_loop_end = clock64();
 #endif
         if constexpr (H2) {
             // guard: a row one of whose 16-element K groups lies more than 2^kH2Window below the row maximum (the group's values no
@@ -1193,7 +1291,13 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
         mfma_group(g & 1);
     }
     }
+#ifdef GIF_X3_TIMING_PROBE
+    if (X3 && lane == 0) atomicAdd(&g_x3_probe[6], (unsigned long long)(clock64() - probe_loop_end));
+#endif
     conv_epilogue<BM, BN, 32, MT, NT, T, THREADS>(p, acc, smem, m0, n0, wm0, wn0, tid, li, lh, HWp);
+#ifdef GIF_X3_TIMING_PROBE
+    if (X3 && lane == 0) atomicAdd(&g_x3_probe[5], (unsigned long long)(clock64() - probe_loop_end));
+#endif
 }
 
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool SCALE, int BK, int X3 = 0, int NST = 2>
