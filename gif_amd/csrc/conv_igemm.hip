@@ -155,6 +155,20 @@ __device__ __forceinline__ void conv_epilogue(const GatherParams& p, f32x16 (&ac
     const T* const msk = static_cast<const T*>(p.mask_src);
     const T* const dsrc = static_cast<const T*>(p.dot_src);
     const bool fused = msk || dsrc || p.part_cs || p.part_dot;  // workgroup-uniform
+#if defined(GIF_EPI_PROBE) && GIF_EPI_PROBE == 3  // timing probe (tools/probes/epilogue_probe.sh; results are WRONG): NO epilogue — every lane
+    // stores the sum of its accumulators, one dword (keeps the K loop alive): the bound for any epilogue rewrite
+    {
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
+        if (m0 + wm0 < p.M) yout[(size_t)(m0 + wm0) * p.Co + n0 + wn0 + (tid & 63)] = (T)sacc;
+        return;
+    }
+#endif
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), ds = make_float4(0.f, 0.f, 0.f, 0.f);
     // demodulation factors of this lane's four columns: a tile rarely spans more than two samples, so the first sample's and its successor's
     // are loaded once (the row loop loaded them per row and waited for each: +11k cycles per tile on the generator's modulated convs)
@@ -1089,9 +1103,16 @@ __device__ __forceinline__ void glds_body(const GatherParams& p, const int bid, 
         if constexpr (NST == 3) {
             if (nsteps > 1) {
                 issue(1);
+#ifndef GIF_NOFILLWAIT_PROBE  // timing probe (tools/probes/epilogue_probe.sh; results are WRONG): the first stage is read before it has landed — what
+                // a first stage prefetched under the PREVIOUS tile's epilogue (a persistent workgroup) would save
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_STAGE) : "memory");
+#endif
             }
         }
+#ifdef GIF_NOFILLWAIT_PROBE
+        if (NST == 3 && nsteps > 1) __builtin_amdgcn_s_barrier();
+        else
+#endif
         __syncthreads();
 #ifdef GIF_X3_TIMING_PROBE
         if (lane == 0) {

@@ -267,11 +267,16 @@ struct WinoParams {
 // residual, bias, activation, leaky-ReLU-backward mask, running column sums.  Rows go in batches of PF: first every global load
 // of the batch, then the arithmetic and the stores — in one loop each row's loads would sit behind the previous row's store
 // (y may alias the sources as far as the compiler knows) and pay a full memory round trip on their own (conv_igemm.hip).
+// rtab != nullptr (wino_gemm_h2): the tile's row table in LDS — per GEMM row the 64-bit offset of its 2x2 output patch's first element (or ~0:
+// padding row) and its sample, filled once per tile by wino_row_table; without it every lane repeats two div/mod pairs and a 64-bit multiply
+// chain per row and output position (4 x E_IT times per tile).
 template <bool FUSED, int E_IT, int EROWS, int LDC, int PF>
 __device__ __forceinline__ void wino_epilogue_rows(const WinoParams& p, const float* Cs, int m0, int e_row0, int e_c, int n, int oa, int ob,
-                                                   const f32x4& bias4, f32x4& cs, f32x4& ds) {
+                                                   const f32x4& bias4, f32x4& cs, f32x4& ds, const unsigned long long* rtab = nullptr,
+                                                   const int* rsmp = nullptr) {
     static_assert(E_IT % PF == 0, "epilogue batches");
     const bool two_src = FUSED && p.mask_src && p.dot_src && p.mask_src != p.dot_src;
+    const size_t pos_off = ((size_t)oa * p.W + ob) * p.Co + n;
 #pragma unroll 1
     for (int it0 = 0; it0 < E_IT; it0 += PF) {
         size_t off[PF];
@@ -279,12 +284,22 @@ __device__ __forceinline__ void wino_epilogue_rows(const WinoParams& p, const fl
         f32x4 rv[PF], dv[PF], xa[PF], xb[PF];
 #pragma unroll
         for (int k = 0; k < PF; ++k) {
-            const int m = m0 + e_row0 + (it0 + k) * EROWS;
-            ok[k] = m < p.ntiles;
-            const int mm = ok[k] ? m : 0;
-            const int tx = mm % p.TW, t2 = mm / p.TW;
-            const int ty = t2 % p.TH, b = t2 / p.TH;
-            off[k] = (((size_t)b * p.H + 2 * ty + oa) * p.W + 2 * tx + ob) * p.Co + n;
+            int b;
+            if (rtab) {  // (compile-time per call site)
+                const int row = e_row0 + (it0 + k) * EROWS;
+                const unsigned long long o = rtab[row];
+                ok[k] = o != ~0ull;
+                b = rsmp[row];
+                off[k] = (size_t)o + pos_off;
+            } else {
+                const int m = m0 + e_row0 + (it0 + k) * EROWS;
+                ok[k] = m < p.ntiles;
+                const int mm = ok[k] ? m : 0;
+                const int tx = mm % p.TW, t2 = mm / p.TW;
+                const int ty = t2 % p.TH;
+                b = t2 / p.TH;
+                off[k] = (((size_t)b * p.H + 2 * ty + oa) * p.W + 2 * tx + ob) * p.Co + n;
+            }
             rv[k] = dv[k] = xa[k] = xb[k] = (f32x4)(0.f);
             if (ok[k]) {
                 if (p.residual) rv[k] = *reinterpret_cast<const f32x4*>(p.residual + off[k]);
@@ -1041,9 +1056,22 @@ __global__ void __launch_bounds__(512, 1) wino_gemm_h2(const WinoParams p) {
     if (p.bias && n < p.Co) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
     f32x4 cs = (f32x4)(0.f), ds = (f32x4)(0.f);
     const bool fused = p.mask_src || p.dot_src || p.part_cs || p.part_dot;  // workgroup-uniform
+    // row table behind the staging tile (the ring is larger): written between the first pair of barriers, read by all four positions
+    static_assert((BM * LDC + 3 * BM) * 4 <= NST * (BM * LD * 4 + 2 * BN * 64), "row table must fit the ring");
+    unsigned long long* const rtab = reinterpret_cast<unsigned long long*>(Cs + BM * LDC);  // [BM]
+    int* const rsmp = reinterpret_cast<int*>(rtab + BM);                                      // [BM]
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
         __syncthreads();
+        if (o == 0 && tid < BM) {
+            const int m = m0 + tid;
+            const bool okr = m < p.ntiles;
+            const int mm = okr ? m : 0;
+            const int tx = mm % p.TW, t2 = mm / p.TW;
+            const int ty = t2 % p.TH, b = t2 / p.TH;
+            rtab[tid] = okr ? (unsigned long long)((((size_t)b * p.H + 2 * ty) * p.W + 2 * tx) * p.Co) : ~0ull;
+            rsmp[tid] = b;
+        }
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -1053,8 +1081,8 @@ __global__ void __launch_bounds__(512, 1) wino_gemm_h2(const WinoParams p) {
             }
         __syncthreads();
         if (n < p.Co) {
-            if (fused) wino_epilogue_rows<true, E_IT, EROWS, LDC, (E_IT < 4 ? E_IT : 4)>(p, Cs, m0, e_row0, e_c, n, o >> 1, o & 1, bias4, cs, ds);
-            else wino_epilogue_rows<false, E_IT, EROWS, LDC, (E_IT < 4 ? E_IT : 4)>(p, Cs, m0, e_row0, e_c, n, o >> 1, o & 1, bias4, cs, ds);
+            if (fused) wino_epilogue_rows<true, E_IT, EROWS, LDC, (E_IT < 4 ? E_IT : 4)>(p, Cs, m0, e_row0, e_c, n, o >> 1, o & 1, bias4, cs, ds, rtab, rsmp);
+            else wino_epilogue_rows<false, E_IT, EROWS, LDC, (E_IT < 4 ? E_IT : 4)>(p, Cs, m0, e_row0, e_c, n, o >> 1, o & 1, bias4, cs, ds, rtab, rsmp);
         }
     }
     wino_write_partials<THREADS, C4_ROW, EROWS>(p, smem, tid, n, tm, cs, ds);

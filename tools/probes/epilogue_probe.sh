@@ -1,11 +1,13 @@
 #!/bin/bash
 # Timing probes (round 6) of the direct kernels' epilogue (results of the probe builds are WRONG):
 #   nostore : the row loop without its global stores (-DGIF_NOSTORE_PROBE) — what a free output write would give
+#   noepi   : no epilogue at all (-DGIF_EPI_PROBE=3): the bound for any rewrite
+#   nofillwait : the K loop starts without waiting for the first ring stage (-DGIF_NOFILLWAIT_PROBE): the bound for a cross-tile prefetch
 #   here:            bash tools/probes/epilogue_probe.sh build
 #   on the GPU box:  bash tools/probes/epilogue_probe.sh run
 set -eu
 cd "$(dirname "$0")/../.."
-VARIANTS="nostore:-DGIF_NOSTORE_PROBE nostore_life:-DGIF_NOSTORE_PROBE,-DGIF_X3_TIMING_PROBE"
+VARIANTS="nostore:-DGIF_NOSTORE_PROBE noepi:-DGIF_EPI_PROBE=3 nofillwait:-DGIF_NOFILLWAIT_PROBE"
 if [ "$1" = build ]; then
   make -s -j8 -C gif_amd/csrc ARCH=gfx950
   cd gif_amd/csrc; mkdir -p _probe
@@ -20,7 +22,10 @@ else
   echo "== normal library"; python tools/probes/kxshare_probe.py
   cp gif_amd/libgif_hip_nostore.so gif_amd/libgif_hip.so
   echo "== row loop without stores"; python tools/probes/kxshare_probe.py
-  cp gif_amd/libgif_hip_nostore_life.so gif_amd/libgif_hip.so
-  echo "== row loop without stores: wave life"; GIF_PROBE_MODE=f16x2 python tools/probes/x3_sync_probe.py
+  cp gif_amd/libgif_hip_noepi.so gif_amd/libgif_hip.so
+  echo "== no epilogue at all (one dword per lane)"; python tools/probes/kxshare_probe.py
+  cp gif_amd/libgif_hip_nofillwait.so gif_amd/libgif_hip.so
+  echo "== first ring stage read without waiting for it (three-stage kernels)"; python tools/probes/kxshare_probe.py
   cp /tmp/keep.so gif_amd/libgif_hip.so
+  echo "== normal library, again"; python tools/probes/kxshare_probe.py
 fi
