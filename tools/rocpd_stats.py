@@ -39,6 +39,24 @@ def main(path):
     for n, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         print(f"| `{n}` | {a[0]} | {a[1] / 1e3:.2f} | {a[1] / a[0]:.1f} | {a[2]:.1f} | {a[3]:.1f} | {100 * a[1] / total:.1f} |")
     print(f"\ntotal kernel time {total / 1e3:.1f} ms over {len(rows)} dispatches")
+    # how much of the trace's span the GPU had no kernel running (launch gaps, host stalls): union of the busy intervals against the span of
+    # the LAST 60 % of the dispatches (warm-up, allocator growth and the profiler's own start-up are in the first part)
+    iv = sorted((s, e) for _, s, e in rows)
+    iv = iv[int(len(iv) * 0.4):]
+    if iv:
+        busy, gaps, cur_s, cur_e = 0, [], iv[0][0], iv[0][1]
+        for s, e in iv[1:]:
+            if s > cur_e:
+                busy += cur_e - cur_s
+                gaps.append(s - cur_e)
+                cur_s, cur_e = s, e
+            else:
+                cur_e = max(cur_e, e)
+        busy += cur_e - cur_s
+        span = cur_e - iv[0][0]
+        big = [g for g in gaps if g > 20000]
+        print(f"idle inside the last 60 % of the trace: {(span - busy) / 1e6:.1f} ms of {span / 1e6:.1f} ms ({100.0 * (span - busy) / span:.1f} %), "
+              f"{len(gaps)} gaps, median {sorted(gaps)[len(gaps) // 2] / 1e3 if gaps else 0:.1f} us, {len(big)} gaps > 20 us totalling {sum(big) / 1e6:.1f} ms")
 
 
 if __name__ == "__main__":
