@@ -905,6 +905,12 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_h2v2(const WgradParams p) {
         for (int n0 = n_begin; n0 < n_end; n0 += BKP) {
             __syncthreads();  // the stage's fp32 tiles have landed (vmcnt(0) of every wave); the previous stage's operand reads are done
             convert(par);
+#ifdef GIF_WGRAD_KX3_PROBE  // timing probe (tools/probes/wgrad_kx3_probe.sh; results are WRONG): what a workgroup that forms the THREE dx taps of a
+            // kernel row from ONE staged pair of tiles would cost — a third of the operand traffic (19 GB through L2 per 128 -> 128 launch
+            // today), 512 channel rows converted per three taps instead of 768 (gy once, the activations at three shifts), 3 x 24 MFMAs
+            // per stage.  The host launches a third of the tap groups.
+            if (!TAPS) convert(par);
+#endif
             __syncthreads();  // operand planes complete; the raw buffer is free again
 #ifdef GIF_WGRAD_NO_DMA_PROBE  // timing probe (results wrong): the K loop on stale raw data — what the per-stage DMA issue + landing costs
             if (n0 == n_begin)
@@ -912,6 +918,9 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_h2v2(const WgradParams p) {
             if (n0 + BKP < n_end) load_global();
             __builtin_amdgcn_sched_barrier(0);
             products(par);
+#ifdef GIF_WGRAD_KX3_PROBE
+            if (!TAPS) { products(par); products(par); }
+#endif
             par ^= 1;
         }
     }
@@ -1339,6 +1348,16 @@ inline void wgrad_launch_v2(bool tab, dim3 grid, hipStream_t s, const WgradParam
         return;
     }
     const size_t lds = (size_t)32 * 256 * 4 + (size_t)2 * 256 * 32 * 2 + (size_t)(512 + 8) * 4 + (size_t)(tab ? p.stab_nb * 256 : 0) * sizeof(float);
+#ifdef GIF_WGRAD_KX3_PROBE
+    if (!taps && p.T == 9) {
+        WgradParams q = p;
+        q.T = 3;
+        grid = dim3(grid.x / 3);
+        if (tab) wgrad_launch_v2_t<true, false>(grid, lds, s, q);
+        else wgrad_launch_v2_t<false, false>(grid, lds, s, q);
+        return;
+    }
+#endif
     if (taps) wgrad_launch_v2_t<false, true>(grid, lds, s, p);
     else if (tab) wgrad_launch_v2_t<true, false>(grid, lds, s, p);
     else wgrad_launch_v2_t<false, false>(grid, lds, s, p);
@@ -2169,6 +2188,9 @@ int gif_conv2d_wgrad_splits(const gif_conv_geom* g) {
         thin_tap_tiles(g->Cb, g->KH * g->KW, &tpt, &tg);
         tiles = (long)(RP / 128) * tg;
     }
+#ifdef GIF_WGRAD_KX3_PROBE  // (timing probe: a third of the tap groups per split -> three times the splits)
+    else if (g->KH * g->KW == 9 && gif::fp32_mfma_mode() == GIF_FP32_MFMA_F16X2) tiles /= 3;
+#endif
     // 2 workgroups fit per CU (64 KB LDS each) => 512 concurrent slots on 256 CUs: fill k full rounds of 512
     // and never spill a few blocks into an extra, almost empty round (floor, not ceil)
     long want = tiles >= 1024 ? 1 : 1024 / tiles;
