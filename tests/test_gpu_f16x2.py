@@ -116,6 +116,34 @@ def test_f16x2_epilogue_and_determinism():
     assert _err(y1, ref) < 2e-6 and torch.equal(y1, y2)
 
 
+@pytest.mark.parametrize("mode", ["f16x2", "bf16x3", "native"])
+@pytest.mark.parametrize("case", [(48, 128, 128, 4, 1), (20, 128, 256, 8, 1), (5, 128, 128, 24, 1), (6, 128, 128, 17, 2), (3, 256, 128, 33, 1)])
+def test_epilogue_row_table_and_demodulation_cache(mode, case):
+    """conv_epilogue's per-tile row table and the per-tile cache of the demodulation factors: 256-row tiles that span up to
+    16 samples (4 x 4 .. 8 x 8 maps: every row beyond the tile's second sample takes the per-row load), ragged last tiles, strided
+    output geometry — modulated forward with bias + leaky ReLU, and the data gradient, against fp64."""
+    from gif_amd import ops
+    ops.set_fp32_mfma_mode(mode)
+    B, ci, co, h, stride = case
+    torch.manual_seed(sum(case))
+    spec = ops.ConvSpec(3, 3, stride, 1 if stride == 1 else 0)
+    x = _cl(torch.randn(B, ci, h, h, device="cuda"))
+    w = torch.randn(co, ci, 3, 3, device="cuda") / (ci * 9) ** 0.5
+    bias = torch.randn(co, device="cuda")
+    si, so = torch.rand(B, ci, device="cuda") + 0.5, torch.rand(B, co, device="cuda") + 0.5
+    pad = 1 if stride == 1 else 0
+    ref = 2 ** 0.5 * F.leaky_relu(F.conv2d(x.double() * si.double()[:, :, None, None], w.double(), stride=stride, padding=pad)
+                                  * so.double()[:, :, None, None] + bias.double()[None, :, None, None], 0.2)
+    y = ops.conv_fwd(x, w, spec, in_scale=si, out_scale=so, bias=bias, act=True, slope=0.2, gain=2 ** 0.5)
+    tol = 2e-6 if mode != "native" else 1e-5
+    assert _err(y[:, :co], ref) < tol
+    hs = ref.shape[-1]
+    gy = _cl(torch.randn(B, co, hs, hs, device="cuda"))
+    gref = F.conv_transpose2d(gy.double() * so.double()[:, :, None, None], w.double(), stride=stride, padding=pad) * si.double()[:, :, None, None]
+    gx = ops.conv_bwd_data(gy, w, spec, (h, h), in_scale=so, out_scale=si)
+    assert _err(gx[:, :ci, :gref.shape[-2], :gref.shape[-1]], gref) < tol
+
+
 # ------------------------------------------------------------------------------------------------ adversarial operands
 def _adv_scales(B, C, H, g):
     """per-channel magnitudes spanning 2^-20 .. 2^20 inside ONE reduction, random order: the row maximum sits ~2^20 above the small
