@@ -185,6 +185,81 @@ __global__ void __launch_bounds__(256) fir4x4_resample_kernel(const UpfirdnParam
     }
 }
 
+// Block form of the up = 2 kernel above (round 6).  One output pixel per lane loads 4 input pixels, 64 B for its 16: the launch moved 4 x its
+// OUTPUT through L1 / L2 and ran at 2.6 TB/s of in + out where the blur reaches 4.9 (profiles/r6_fir_block_probe.txt: 1.02 -> 0.49 ms for
+// 64 x 128 channels at 128^2 -> 256^2, 5.5 TB/s; f16 0.96 -> 0.42).
+// up = 2: the four output pixels (one of each parity phase) that read the SAME 2 x 2 input pixels are one lane's work — 4 loads per 4
+// outputs.  Output rows oy with (oy + pady0) odd open a block: oy_s = 2 m - 1 + (pady0 & 1), input rows r = (oy_s + 1 - pady0) / 2 and r + 1;
+// the block's first row takes kernel rows 1, 3, its second 0, 2 (columns alike).  Every output's sum runs over the same products in the same
+// order as fir4x4_resample_kernel's: bit-identical results.
+template <typename T>
+__global__ void __launch_bounds__(256) fir4x4_up2_block_kernel(const UpfirdnParams<T> p) {
+    __shared__ float kfs[16];
+    if (threadIdx.x < 16) {
+        int a = threadIdx.x >> 2, b = threadIdx.x & 3;
+        kfs[threadIdx.x] = p.k[p.flip ? (3 - a) * 4 + (3 - b) : a * 4 + b];
+    }
+    __syncthreads();
+    float kf[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) kf[i] = kfs[i];
+    const unsigned C4 = (unsigned)p.C >> 2;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int qy = p.pady0 & 1, qx = p.padx0 & 1;
+    const unsigned nby = (unsigned)(p.Ho + 2 - qy) >> 1, nbx = (unsigned)(p.Wo + 2 - qx) >> 1;
+    const unsigned row = blockIdx.y;
+    const int b = (int)(row / nby), m = (int)(row - (unsigned)b * nby);
+    const int oy_s = 2 * m - 1 + qy;
+    const int r = (oy_s + 1 - p.pady0) >> 1;  // (exact: the numerator is even)
+    float4 bias4 = zero4;
+    const unsigned row_items = nbx * C4;
+    for (unsigned it = blockIdx.x * blockDim.x + threadIdx.x; it < row_items; it += gridDim.x * blockDim.x) {
+        const int n = (int)(it / C4);
+        const int c4 = (int)(it - (unsigned)n * C4);
+        const int ox_s = 2 * n - 1 + qx;
+        const int c = (ox_s + 1 - p.padx0) >> 1;
+        const T* xb = p.x + (size_t)b * p.Hi * p.Wi * p.C + c4 * 4;
+        float4 xv[2][2];
+#pragma unroll
+        for (int ia = 0; ia < 2; ++ia)
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib) {
+                const int iy = r + ia, ix = c + ib;
+                const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+                xv[ia][ib] = gif::load4(xb + (ok ? ((size_t)iy * p.Wi + ix) * p.C : 0));
+                if (!ok) xv[ia][ib] = zero4;
+            }
+        if (p.bias) bias4 = *reinterpret_cast<const float4*>(p.bias + c4 * 4);
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            const int oy = oy_s + dy;
+            if ((unsigned)oy >= (unsigned)p.Ho) continue;
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int ox = ox_s + dx;
+                if ((unsigned)ox >= (unsigned)p.Wo) continue;
+                const int a0 = 1 - dy, b0 = 1 - dx;
+                float4 acc = zero4;
+#pragma unroll
+                for (int ia = 0; ia < 2; ++ia)
+#pragma unroll
+                    for (int ib = 0; ib < 2; ++ib) acc = f4fma(kf[(a0 + 2 * ia) * 4 + b0 + 2 * ib], xv[ia][ib], acc);
+                const size_t o = ((((size_t)b * p.Ho + oy) * p.Wo + ox) * C4 + c4) * 4;
+                if (p.residual) acc = f4add(acc, gif::load4(p.residual + o));
+                if (p.bias) acc = f4add(acc, bias4);
+                if (p.act) {
+                    acc.x = lrelu(acc.x, p.slope, p.gain); acc.y = lrelu(acc.y, p.slope, p.gain);
+                    acc.z = lrelu(acc.z, p.slope, p.gain); acc.w = lrelu(acc.w, p.slope, p.gain);
+                }
+                gif::store4_flag(p.y + o, acc, p.sat_flag);
+            }
+        }
+    }
+}
+
+// (down = 2 stays on the one-pixel-per-lane kernel: its 16 loads per output overlap in L1 — 4.8 TB/s of in + out; a 2 x 4-pixel block form with
+// 7.5 loads per output measured 13-18 % SLOWER, profiles/r6_fir_block_probe.txt.)
+
 // Fast path for the blur (up = down = 1, 4x4 FIR): one lane produces a TY x TX patch of output pixels for 4
 // channels, so every input float4 is loaded once per patch ((TY+3)*(TX+3) loads for TY*TX outputs: 4.4 loads
 // per output instead of 16).  Lanes are consecutive along the channel axis => fully coalesced 16-B accesses.
@@ -677,6 +752,16 @@ int upfirdn2d_impl(const T* x, const float* k, T* y, int B, int Hi, int Wi, int 
     }
     long total = (long)B * Ho * Wo * (C / 4);
     if (KH == 4 && KW == 4 && (long)B * Ho <= 65535 && ((up == 1 && down == 2) || (up == 2 && down == 1))) {
+        // GIF_FIR_BLOCK=0: the one-pixel-per-lane kernel for up = 2 as well (A/B; the block kernel gives the same bits)
+        static const int block_on = gif::knob("GIF_FIR_BLOCK") ? atoi(gif::knob("GIF_FIR_BLOCK")) != 0 : 1;
+        if (block_on && up == 2) {
+            const long nby = (Ho + 2 - (pady0 & 1)) / 2, nbx = (Wo + 2 - (padx0 & 1)) / 2;
+            long gx = (nbx * (C / 4) + 255) / 256;
+            if (gx > 64) gx = 64;
+            const dim3 grid((unsigned)gx, (unsigned)((long)B * nby));
+            fir4x4_up2_block_kernel<T><<<grid, 256, 0, gif::as_stream(stream)>>>(p);
+            return gif::check_launch("upfirdn2d(up 2, block)");
+        }
         const long row_items = (long)Wo * (C / 4);
         long gx = (row_items + 255) / 256;
         if (gx > 64) gx = 64;

@@ -95,3 +95,40 @@ def test_g_step_texture_interpolation_loss_vs_oracle(adaptive, mask_size):
         got.append(named[k].grad)
         want.append(v.grad)
     assert_grads_close(got, want, names, tight=1e-3, loose=2e-2, what=f"G grads with texture-interp loss (adaptive={adaptive})")
+
+
+_FIR_CHILD = r"""
+import hashlib, sys, torch
+sys.path.insert(0, %r)
+from gif_amd import ops
+k = torch.tensor([1.0, 3.0, 3.0, 1.0], device="cuda")
+k = (k[:, None] * k[None, :] / 16.0).contiguous()
+h = hashlib.sha1()
+for dt in (torch.float32, torch.float16):
+    for B, C, H, pad0, out in [(3, 8, 37, 2, 74), (3, 8, 37, 1, 73), (2, 16, 16, 2, 32), (2, 128, 33, 2, 67), (1, 8, 5, 3, 12), (4, 24, 64, 2, 128)]:
+        torch.manual_seed(H)
+        x = torch.randn(B, C, H, H, device="cuda").to(dt).contiguous(memory_format=torch.channels_last)
+        res = torch.randn(B, C, out, out, device="cuda").to(dt).contiguous(memory_format=torch.channels_last)
+        bias = torch.randn(C, device="cuda")
+        for flip in (True, False):
+            h.update(ops.upfirdn2d(x, k, 2, 1, pad0, (out, out), flip).cpu().numpy().tobytes())
+        h.update(ops.upfirdn2d(x, k, 2, 1, pad0, (out, out), True, bias=bias, residual=res, act=True).cpu().numpy().tobytes())
+print(h.hexdigest())
+"""
+
+
+@pytest.mark.gpu
+def test_fir_up2_block_kernel_gives_the_bits_of_the_per_pixel_kernel():
+    """fir4x4_up2_block_kernel (four output pixels of one 2 x 2 input block per lane) sums every output's products in the order of
+    fir4x4_resample_kernel<2, 1>: same bits, plain and with residual + bias + leaky ReLU, odd sizes, both pad parities, fp32 and f16.
+    GIF_FIR_BLOCK is read once per process: one child per kernel."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = []
+    for v in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", _FIR_CHILD % root], env=dict(os.environ, GIF_EXPERIMENTAL="1", GIF_FIR_BLOCK=v), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out.append(r.stdout.strip().splitlines()[-1])
+    assert out[0] == out[1] and len(out[0]) == 40
