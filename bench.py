@@ -325,6 +325,13 @@ def roofline_objects(ops, steps, wall_s):
                                    "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (2*FETCH + WRITE, gfx950 correction), "
                                            "family average over one profiled training iteration"
                                            + ("; STALE: the kernel sources changed since it was measured" if stale else "")}
+            # the same launches against the OTHER roof: measured HBM bytes per average launch over its average duration.  fp32 tensors make these
+            # kernels memory-heavy: for the f16x2 families the two floors (time at the MFMA ceiling, time at 8 TB/s) lie within ~10 % of each other
+            hbm_gbs = o["traffic"] / (o["avg_ms"] * 1e-3) / 1e9
+            o["hbm_view"] = {"achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm_gbs / PEAK_HBM_GBS,
+                             "floor_ms_at_hbm_peak": o["traffic"] / (PEAK_HBM_GBS * 1e9) * 1e3,
+                             "floor_ms_at_mfma_ceiling": o["algorithmic_flop_per_launch"] / (ceiling * 1e12) * 1e3,
+                             "note": "measured (PMC) HBM bytes of the family's average launch / its average duration; floors per average launch"}
         objs[fam] = o
     out = {}
     if objs:
